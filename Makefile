@@ -1,0 +1,29 @@
+# Builds libwdg_hip.so (gfx950 only) and the CPU oracle.  `python -c "import __graft_entry__ as g; g.build()"` calls this.
+PKG      := when-do-gnns-help_amd
+CSRC     := $(PKG)/csrc
+HIPCC    ?= /opt/rocm/bin/hipcc
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value
+SRCS     := $(wildcard $(CSRC)/*.hip)
+OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+LIB      := $(PKG)/lib/libwdg_hip.so
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/wdg_common.h include/wdg.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+oracle: oracle/_build/libwdg_oracle.so
+
+oracle/_build/libwdg_oracle.so: oracle/wdg_oracle.c
+	@mkdir -p oracle/_build
+	gcc -O2 -ffp-contract=off -shared -fPIC -o $@ $< -lm
+
+clean:
+	rm -rf build $(LIB) oracle/_build
+
+.PHONY: all oracle clean

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Headline benchmark: aggregation edges/s on the synthetic homophily sweep (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload per rank (weak scaling: fixed per-GPU work): the `data_synthesis/800`-equivalent sweep shard
+  10 homophily levels x `--seeds` seeds (default 10) = 100 graphs, N = 2000 nodes, k = 2, F = 500 fp32 features
+  (the directory name "800" is k*400, every graph has 2000 nodes - SURVEY G3).
+A step = one pass of the hot path over that batch with all inputs resident in HBM:
+  (1) A_hat X aggregation, A_hat = D^-1 (A + I) fused into the SpMM (one batched launch, csrc/spmm.hip)
+  (2) edge/label statistics pass (one batched launch, csrc/edge_stats.hip)
+`value` = stored entries of A+I aggregated per second over the whole job (all ranks); the dominant kernel's
+roofline is measured live with HIP events on the launch stream; a bounded CPU sample of the same workload,
+run the way the reference does it, is reported as `cpu_baseline` (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seeds", type=int, default=10, help="seeds per rank (x 10 homophily levels = graphs per step)")
+    ap.add_argument("--nodes", type=int, default=2000)
+    ap.add_argument("--feat", type=int, default=500)
+    ap.add_argument("--k", type=int, default=2, help="same-class out-neighbours per node (2 = `800` set, 10 = `4000` set)")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    from wdg_amd import sweep, synth
+    h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
+    # rank 0 defines the whole job list and broadcasts it; every rank takes its shard (whole seeds)
+    jobs = sweep.make_jobs(h_levels, range(args.seeds * world), k=args.k, n_nodes=args.nodes) if rank == 0 else []
+    jobs = sweep.broadcast_jobs(jobs, dev)
+    mine = sweep.shard_jobs(jobs, world, rank)
+    batch = sweep.SweepBatch(mine, n_feat=args.feat)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()           # torch's current stream == the stream the kernels are launched on
+        batch.spmm.launch()
+        ev[s][1].record()
+        batch.stats.launch()
+    rows = batch.results()
+    gathered = sweep.gather_results(rows, dev)  # the sweep's one exchange step: per-job metric rows (KBs)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        e = torch.tensor([batch.edges], dtype=torch.int64, device=dev)
+        dist.all_reduce(e)
+        total_edges = int(e.item())
+    else:
+        total_edges = batch.edges
+    n_graphs = sum(g.shape[0] for g in gathered)
+
+    if rank == 0:
+        spmm_ms = sorted(a.elapsed_time(b) for a, b in ev)
+        spmm_avg_ms = sum(spmm_ms) / len(spmm_ms)
+        alg = batch.spmm_algorithmic_bytes()
+        achieved = alg / (spmm_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch of the same command
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("graphs_per_launch") == len(mine) and tj.get("n_feat") == args.feat and tj.get("k") == args.k:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        fam, slab, threads = batch.ops.spmm_plan(args.nodes, args.nodes, args.feat)
+        out = {
+            "metric": "aggregation edges/sec (whole job; + %HBM roofline of the SpMM kernel)",
+            "value": total_edges * args.steps / elapsed,
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic homophily sweep (data_synthesis/{args.k * 400}-equivalent): "
+                                   f"{len(h_levels)} h-levels x {args.seeds} seeds = {len(mine)} graphs/GPU/step, "
+                                   f"N={args.nodes} nodes, k={args.k}, F={args.feat} fp32, C=5; step = batched "
+                                   f"D^-1(A+I)X aggregation + edge/label statistics pass",
+                       "graphs_per_step_per_gpu": len(mine), "edges_per_step_per_gpu": batch.edges,
+                       "parallelism": f"independent sweep shards x{world} (no data-path collective; job-table broadcast + result all_gather)"},
+            "graphs_per_s": n_graphs * args.steps / elapsed,
+            "edge_features_per_s": total_edges * args.feat * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": f"spmm_slab_kernel<{slab},{threads},float>" if fam == 0 else "spmm_gather_kernel",
+                         "avg_launch_us": spmm_avg_ms * 1e3, "median_launch_us": spmm_ms[len(spmm_ms) // 2] * 1e3,
+                         "algorithmic_bytes_per_launch": alg, "unique_bytes_per_launch": batch.spmm_unique_bytes(),
+                         "launches_timed": len(spmm_ms)},
+        }
+        if world == 1 and args.cpu_budget > 0:
+            from oracle import cpu_ref
+            sample = sweep.make_jobs(h_levels, [0], k=args.k, n_nodes=args.nodes)
+            cb = cpu_ref.time_sample(sample, args.feat, budget_s=args.cpu_budget)
+            out["cpu_baseline"] = {"value": cb["edges_per_s"], "unit": "edges/s", "cores": cb["cores"], "kind": "port",
+                                   "sample": f"{len(sample)} graphs (seed 0, {len(h_levels)} h-levels) x {cb['passes']} passes "
+                                             f"= {cb['graphs']} graph evaluations in {cb['seconds']:.1f} s; dense torch.spmm "
+                                             f"+ oracle edge metrics, the reference's call pattern (synthetic_plot.py:92-109)"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+/*
+ * wdg.h - C ABI of libwdg_hip.so: MI355X (gfx950) kernels for the aggregation /
+ * homophily-metric hot path of SitaoLuan/When-Do-GNNs-Help.
+ *
+ * The reference is pure Python and has no FFI layer; the narrowest seam it offers is
+ * the set of torch/scipy calls its metric code makes.  Each entry
+ * point below replaces one of those calls; the `replaces:` line cites it
+ * (paths are into the reference checkout).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - the caller owns all memory (outputs and workspaces are caller-allocated);
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work:
+ *     no allocation, no synchronisation, no host copies -> graph-capturable;
+ *   - return value: WDG_OK or a negative WDG_ERR_*; wdg_last_error() gives text;
+ *   - indices are int32 on the device (int64 only at the COO boundary, matching
+ *     torch's `indices()` dtype); sizes that can exceed 2^31 are int64.
+ */
+#ifndef WDG_H
+#define WDG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *wdg_stream_t; /* hipStream_t */
+
+#define WDG_OK 0
+#define WDG_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, ...)   */
+#define WDG_ERR_LAUNCH (-2)      /* the HIP runtime rejected a launch                  */
+#define WDG_ERR_WORKSPACE (-3)   /* workspace too small                                */
+#define WDG_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for      */
+
+int wdg_version(void);
+const char *wdg_last_error(void);
+/* number of CUs of the current device (host query, cached). */
+int wdg_device_cus(void);
+
+/* ------------------------------------------------------------------ graph construction */
+#define WDG_COO_SYMMETRISE 1      /* insert (dst,src) too           : to_undirected            */
+#define WDG_COO_BINARISE 2        /* merged value := 1              : to_undirected / (adj>0)  */
+#define WDG_COO_ADD_SELF_LOOPS 4  /* + I after merging (loop -> v+1): adj + eye                */
+#define WDG_COO_DROP_SELF_LOOPS 8 /* remove (i,i) of the input      : remove_self_loops        */
+#define WDG_COO_KEEP_DUPLICATES 16 /* sort only, no merging (edge-index inputs counted with multiplicity) */
+
+/*
+ * COO (int64 src/dst, optional fp32 val) -> CSR (int32 rowptr[N+1], col, fp32 val), rows sorted
+ * by column, duplicates summed in input order.
+ * replaces: torch `.coalesce()` utils/homophily_metrics.py:50,63,127;
+ *           `to_undirected` utils/util_funcs.py:225-283;
+ *           `adj + sp.eye` / `torch.eye + adj.to_dense()` utils/util_funcs.py:385,420, homophily_tests.py:83;
+ *           `sparse_mx_to_torch_sparse_tensor` utils/util_funcs.py:400-407 (index part).
+ * col/outval capacity: wdg_coo_to_csr_capacity(E, N, flags) entries.  *nnz_out (device int64) receives nnz.
+ * out-of-range indices set *nnz_out = -1 (checked by the host wrapper after the stream syncs).
+ */
+int64_t wdg_coo_to_csr_capacity(int64_t E, int32_t N, int flags);
+size_t wdg_coo_to_csr_workspace_bytes(int64_t E, int32_t N, int flags);
+int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val, int64_t E, int32_t N, int flags,
+                       int32_t *rowptr, int32_t *col, float *outval, int64_t *nnz_out, void *workspace,
+                       size_t workspace_bytes, wdg_stream_t stream);
+
+/*
+ * Dense [N,M] fp32 -> CSR of its non-zeros (the "plot" flavour hands dense adjacencies around).
+ * replaces: `A.nonzero()`, `A.to_sparse().coalesce()`, `(adj > 0)` utils/homophily_plot.py:48,85,133,151.
+ * Two calls: count (fills rowptr), then fill (needs col/val of rowptr[N] entries).
+ */
+int wdg_dense_to_csr_count(const float *A, int64_t lda, int32_t N, int32_t M, int32_t *rowptr, void *workspace,
+                           size_t workspace_bytes, wdg_stream_t stream);
+int wdg_dense_to_csr_fill(const float *A, int64_t lda, int32_t N, int32_t M, const int32_t *rowptr, int32_t *col,
+                          float *val, wdg_stream_t stream);
+size_t wdg_scan_workspace_bytes(int64_t n);
+
+/* ------------------------------------------------------------------ normalisation */
+#define WDG_NORM_RW 0  /* D^-1 A                                                              */
+#define WDG_NORM_SYM 1 /* D^-1/2 A D^-1/2 (row-sum degree on both sides)                       */
+#define WDG_PREC_F32 0 /* coefficient arithmetic in fp32: utils/util_funcs.py:29-36,365-380   */
+#define WDG_PREC_F64 1 /* in fp64, cast at the end: utils/util_funcs.py:383-390,418-426,:402  */
+
+/*
+ * Row sums / counts and the normalisation coefficient d_i (1/rowsum or rowsum^-1/2; inf -> 0; in the
+ * F64 path rowsum==0 -> 1).  Any of rowsum / cnt / dinv_f32 / dinv_f64 may be NULL.
+ * replaces: the degree part of normalize, normalize_tensor, row_normalized_adjacency,
+ *           sys_normalized_adjacency (utils/util_funcs.py:31-33,367-370,376-377,386,421-424).
+ */
+int wdg_degree_norm(const int32_t *rowptr, const float *val, int32_t N, int mode, int prec, float *rowsum,
+                    int32_t *cnt, float *dinv_f32, double *dinv_f64, wdg_stream_t stream);
+/* Materialise A_hat's values exactly as the reference would: out[p] = d_i * val[p] (* d_col[p] for SYM). */
+int wdg_normalise_values(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int mode, int prec,
+                         const float *dinv_f32, const double *dinv_f64, float *out, wdg_stream_t stream);
+/*
+ * Dense row scaling Y = X / rowsum(X) (inf -> 0), or with use_abs the torch F.normalize(p=1) form.
+ * replaces: preprocess_features utils/util_funcs.py:39-46; normalize_tensor(features) :365-373
+ *           (which the reference does as an O(N^2 F) diag matmul); f.normalize homophily_tests.py:94.
+ */
+int wdg_row_l1_normalise_f32(const float *X, int64_t ldx, float *Y, int64_t ldy, int32_t N, int32_t F, int use_abs,
+                             wdg_stream_t stream);
+
+/* ------------------------------------------------------------------ aggregation (SpMM) */
+/*
+ * One aggregation problem:  Y[i,:] = row_scale[i] * sum_p val[p] * col_scale[col[p]] * X[col[p],:]
+ * (val / row_scale / col_scale may each be NULL = 1).  rw: row_scale = d;  sym: row_scale = col_scale = d;
+ * explicit A_hat: val only.  X is [n_cols, F] row-major with leading dimension ldx (elements), Y [n_rows, F].
+ * replaces: torch.spmm / torch.mm(adj, X) - utils/homophily_metrics.py:192,199,200,234,235,299,315;
+ *           utils/homophily_plot.py:196,246,320,336.
+ */
+typedef struct wdg_spmm_job {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const float *val;
+    const float *row_scale;
+    const float *col_scale;
+    const void *X; /* fp32, or bf16 for the *_bf16 entry points */
+    float *Y;
+    int64_t ldx, ldy;
+    int32_t n_rows, n_cols, n_feat, reserved;
+} wdg_spmm_job;
+
+int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream);
+int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
+/*
+ * Many independent graphs in ONE launch (the homophily sweep, synthetic_plot.py:64-109).
+ * `jobs_dev` is a device array of n_jobs descriptors; max_rows/max_cols/max_feat bound the job shapes
+ * (needed on the host to size the grid and LDS without reading the table back).
+ */
+int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
+                         int32_t max_feat, wdg_stream_t stream);
+/* Which kernel family a shape dispatches to (0 = LDS column-slab, 1 = row gather, 2 = narrow); for tests/bench. */
+int wdg_spmm_plan(int32_t max_rows, int32_t max_cols, int32_t n_feat, int *slab_out, int *threads_out);
+
+/* ------------------------------------------------------------------ edge / label statistics */
+/*
+ * One pass over the stored pattern P of a CSR adjacency:
+ *   totals[0]=|P|  [1]=#{y_u==y_v}  [2]=#{y_u>=0,y_v>=0}  [3]=matches among [2]
+ *   totals[4]=|P'| (non-loop)  [5]=matches among P'
+ *   row_nnz[u]=|P_u|  row_nnz_noself[u]=|P'_u|  row_match_noself[u]=#{v in P'_u : y_v==y_u}
+ *   compat[i*C+j]=#{(u,v) in P' : y_u=i, y_v=j, both>=0}   classdeg[c]=sum_{y_u=c}(|P_u|-1)
+ * All outputs are exact integers (bit-exact parity).  Any per-row output may be NULL.
+ * replaces: utils/homophily_metrics.py:50-56 (edge), :73-78 (node), :89-101 (compat), :127-145
+ *           (class_distribution); dense twins utils/homophily_plot.py:48-51,85-99,111-122,151-170.
+ */
+int wdg_edge_label_stats(const int32_t *rowptr, const int32_t *col, const int32_t *labels, int32_t N, int32_t C,
+                         int64_t *totals, int32_t *row_nnz, int32_t *row_nnz_noself, int32_t *row_match_noself,
+                         int64_t *compat, int64_t *classdeg, wdg_stream_t stream);
+
+typedef struct wdg_stats_job {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const int32_t *labels;
+    int64_t *totals;   /* [6]   */
+    int64_t *compat;   /* [C*C] */
+    int64_t *classdeg; /* [C]   */
+    int32_t *row_nnz, *row_nnz_noself, *row_match_noself; /* [N] each, may be NULL */
+    int32_t n_rows, n_classes;
+} wdg_stats_job;
+/* Batched form: outputs must be zeroed by the caller (one memset over a pooled buffer). */
+int wdg_edge_label_stats_batched(const wdg_stats_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_classes,
+                                 wdg_stream_t stream);
+
+/* ------------------------------------------------------------------ label-aggregation similarity */
+/*
+ * W[i,c] = sum_{j: y_j=c} <H_i, H_j>  computed as H (H^T Y) with fp64 accumulation (never forms n x n),
+ * optionally restricted to the rows listed in `rows` (idx_train).  W_out is [n, C] fp64.
+ * Then counts: count_out[0] = #{i : soft LAS ratio >= 1}, count_out[1] = #{i : argmax_c W[i,c] == y_i}.
+ * replaces: utils/homophily_metrics.py:192-206,216-220,226; utils/homophily_plot.py:196-226,232.
+ * `labels` is indexed by node id (full length); `rows` (int32[n], may be NULL = identity) selects the sample.
+ * workspace: wdg_las_workspace_bytes(n, F, C).
+ */
+size_t wdg_las_workspace_bytes(int32_t n, int32_t F, int32_t C);
+int wdg_las_f32(const float *H, int64_t ldh, const int32_t *labels, const int32_t *rows, int32_t n, int32_t F,
+                int32_t C, double *W_out, int64_t *count_out, void *workspace, size_t workspace_bytes,
+                wdg_stream_t stream);
+
+/* ------------------------------------------------------------------ dense feature transform */
+#define WDG_ACT_NONE 0
+#define WDG_ACT_RELU 1
+/*
+ * C[M,N] = act(A[M,K] B[K,N] + bias[N]) in exact fp32 on the MFMA pipe (v_mfma_f32_32x32x2_f32).
+ * The reference has no X.W (its models live upstream, gnns_on_syn.py:1-249 holds only results);
+ * this is the build-defined SGC-1 / GCN-2 transform of SURVEY.md 7.3 (K10), and the Gram products of
+ * utils/homophily_metrics.py:234-235,246 (B = A^T via transb).
+ */
+int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, int act,
+                 float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, wdg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WDG_H */

@@ -25,7 +25,7 @@ _BUILD = os.path.join(_HERE, "_build")
 _SO = os.path.join(_BUILD, "libwdg_oracle.so")
 _SRC = os.path.join(_HERE, "wdg_oracle.c")
 
-SYMMETRISE, BINARISE, ADD_SELF_LOOPS, DROP_SELF_LOOPS = 1, 2, 4, 8
+SYMMETRISE, BINARISE, ADD_SELF_LOOPS, DROP_SELF_LOOPS, KEEP_DUPLICATES = 1, 2, 4, 8, 16
 NORM_RW, NORM_SYM = 0, 1
 PREC_F32, PREC_F64 = 0, 1
 

@@ -23,15 +23,18 @@
 #define ORC_BINARISE 2     /* merged value := 1 (pattern semantics, to_undirected) */
 #define ORC_ADD_SELF_LOOPS 4 /* add I AFTER merging: existing diagonal becomes v+1 */
 #define ORC_DROP_SELF_LOOPS 8 /* remove (i,i) entries of the input before anything */
+#define ORC_KEEP_DUPLICATES 16 /* sort only: every input entry stays its own CSR entry   */
 
 typedef struct {
     int64_t key;
+    int64_t seq; /* position in (input ++ mirrored input): ties keep input order */
     double val;
 } orc_entry;
 
 static int cmp_entry(const void *a, const void *b) {
-    int64_t ka = ((const orc_entry *)a)->key, kb = ((const orc_entry *)b)->key;
-    return (ka > kb) - (ka < kb);
+    const orc_entry *x = (const orc_entry *)a, *y = (const orc_entry *)b;
+    if (x->key != y->key) return (x->key > y->key) - (x->key < y->key);
+    return (x->seq > y->seq) - (x->seq < y->seq);
 }
 
 /*
@@ -59,17 +62,14 @@ int64_t orc_coo_to_csr(const int64_t *src, const int64_t *dst, const float *val,
         if ((flags & ORC_DROP_SELF_LOOPS) && s == d) continue;
         double v = val ? (double)val[i] : 1.0;
         e[n].key = s * (int64_t)N + d;
+        e[n].seq = i;
         e[n++].val = v;
-        if ((flags & ORC_SYMMETRISE) && s != d) {
+        /* mirrored copy; a loop's mirror is the loop again: the concatenation holds it twice (SUM
+           semantics) while to_undirected's unique keeps one copy (BINARISE) */
+        if ((flags & ORC_SYMMETRISE) && (s != d || !(flags & ORC_BINARISE))) {
             e[n].key = d * (int64_t)N + s;
+            e[n].seq = E + i;
             e[n++].val = v;
-        } else if ((flags & ORC_SYMMETRISE)) {
-            /* to_undirected keeps one copy of a loop after unique; under SUM semantics
-               the concatenation holds it twice */
-            if (!(flags & ORC_BINARISE)) {
-                e[n].key = e[n - 1].key;
-                e[n++].val = v;
-            }
         }
     }
     qsort(e, (size_t)n, sizeof(orc_entry), cmp_entry);
@@ -83,9 +83,10 @@ int64_t orc_coo_to_csr(const int64_t *src, const int64_t *dst, const float *val,
         int have_in = i < n, have_d = (flags & ORC_ADD_SELF_LOOPS) && next_diag < N;
         if (have_in && (!have_d || e[i].key <= dkey)) {
             key = e[i].key;
-            while (i < n && e[i].key == key) v += e[i++].val;
+            do v += e[i++].val;
+            while (!(flags & ORC_KEEP_DUPLICATES) && i < n && e[i].key == key);
             if (flags & ORC_BINARISE) v = 1.0;
-            if (have_d && key == dkey) {
+            if (have_d && key == dkey) { /* existing diagonal: + 1 (first such entry under KEEP_DUPLICATES) */
                 v += 1.0;
                 ++next_diag;
             }

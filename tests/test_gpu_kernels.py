@@ -1,0 +1,470 @@
+"""GPU parity tests, kernel level: every entry point of the C ABI (through wdg_amd.ops) against the CPU oracle
+on the same seeded inputs.  Integer / index outputs: bit exact.  fp32 aggregation: <= 1e-5 relative
+(north-star tolerance), measured against the oracle's fp32 result and its fp64-accumulated yardstick."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import REAL, SYN, dense_features, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from wdg_amd import ops as o
+    return o
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _rand_graph(rng, n, e, loops=True, dups=True):
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    if dups and e > 10:
+        src[: e // 10], dst[: e // 10] = src[-(e // 10):], dst[-(e // 10):]
+    if not loops:
+        dst = np.where(src == dst, (dst + 1) % n, dst)
+    return src.astype(np.int64), dst.astype(np.int64)
+
+
+def _assert_csr_equal(g, ref, val_exact=True):
+    rowptr, col, val = ref
+    np.testing.assert_array_equal(_np(g.rowptr), rowptr)
+    np.testing.assert_array_equal(_np(g.col), col)
+    if val_exact:
+        np.testing.assert_array_equal(_np(g.val), val)
+    else:
+        np.testing.assert_allclose(_np(g.val), val, rtol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------- graph build
+FLAG_SETS = [0, 1, 2, 4, 8, 16, 1 | 2, 1 | 2 | 4, 4 | 8, 1 | 4, 16 | 4, 1 | 16, 2 | 4]
+
+
+@pytest.mark.parametrize("flags", FLAG_SETS)
+def test_coo_to_csr_flags(ops, oracle, flags):
+    rng = np.random.default_rng(flags)
+    src, dst = _rand_graph(rng, 300, 4000)
+    val = rng.integers(1, 5, 4000).astype(np.float32)  # integer-valued: sums are exact, order irrelevant
+    g = ops.CsrGraph.from_coo(src, dst, 300, val, flags)
+    _assert_csr_equal(g, oracle.coo_to_csr(src, dst, 300, val, flags))
+    g = ops.CsrGraph.from_coo(src, dst, 300, None, flags)
+    _assert_csr_equal(g, oracle.coo_to_csr(src, dst, 300, None, flags))
+
+
+def test_coo_to_csr_float_values_sum_in_input_order(ops, oracle):
+    rng = np.random.default_rng(5)
+    src, dst = _rand_graph(rng, 50, 5000)
+    val = rng.random(5000, dtype=np.float32)
+    g = ops.CsrGraph.from_coo(src, dst, 50, val, 1)
+    _assert_csr_equal(g, oracle.coo_to_csr(src, dst, 50, val, 1))  # bit exact: same (col, input position) order
+
+
+@pytest.mark.parametrize("n,e", [(1, 0), (7, 0), (1, 5), (5, 1), (64, 64 * 64), (3, 70000)])
+def test_coo_to_csr_edge_cases(ops, oracle, n, e):
+    rng = np.random.default_rng(n * 31 + e)
+    src, dst = _rand_graph(rng, n, e)
+    for flags in (0, 4, 1 | 2 | 4, 16):
+        g = ops.CsrGraph.from_coo(src, dst, n, None, flags)
+        _assert_csr_equal(g, oracle.coo_to_csr(src, dst, n, None, flags))
+
+
+def test_coo_to_csr_long_and_skewed_rows(ops, oracle):
+    """rows of 65..16384 entries sort in LDS, longer ones in global memory (csrc/graph_build.hip)."""
+    rng = np.random.default_rng(11)
+    n = 40000
+    parts_s, parts_d = [], []
+    for row, deg in ((3, 65), (17, 1000), (100, 16384), (5000, 20000), (39999, 33000)):
+        parts_s.append(np.full(deg, row))
+        parts_d.append(rng.choice(n, deg, replace=False))
+    s2, d2 = _rand_graph(rng, n, 200000)
+    src, dst = np.concatenate(parts_s + [s2]), np.concatenate(parts_d + [d2])
+    perm = rng.permutation(src.shape[0])
+    src, dst = src[perm], dst[perm]
+    for flags in (0, 1 | 2 | 4):
+        g = ops.CsrGraph.from_coo(src, dst, n, None, flags)
+        _assert_csr_equal(g, oracle.coo_to_csr(src, dst, n, None, flags))
+
+
+def test_coo_to_csr_rejects_bad_index(ops):
+    with pytest.raises(IndexError):
+        ops.CsrGraph.from_coo([0, 5], [1, 0], 4)
+    with pytest.raises(IndexError):
+        ops.CsrGraph.from_coo([0, -1], [1, 0], 4)
+
+
+@pytest.mark.parametrize("name", REAL)
+def test_csr_build_matches_reference_golden(ops, name):
+    g0 = load("real_" + name)
+    n = int(g0["n_nodes"])
+    g = ops.CsrGraph.from_coo(g0["adj_row"], g0["adj_col"], n, g0["adj_val"], ops.COO_ADD_SELF_LOOPS)
+    np.testing.assert_array_equal(_np(g.row_indices()), g0["small_rw_row"])
+    np.testing.assert_array_equal(_np(g.col), g0["small_rw_col"])
+
+
+def test_dense_to_csr(ops):
+    rng = np.random.default_rng(2)
+    for n, m in ((1, 1), (37, 129), (300, 300), (5, 1000)):
+        a = (rng.random((n, m)) < 0.1) * rng.random((n, m))
+        a = a.astype(np.float32)
+        g = ops.CsrGraph.from_dense(torch.from_numpy(a))
+        r, c = np.nonzero(a)
+        np.testing.assert_array_equal(_np(g.row_indices()), r)
+        np.testing.assert_array_equal(_np(g.col), c)
+        np.testing.assert_array_equal(_np(g.val), a[r, c])
+
+
+def test_transpose_roundtrip(ops, oracle):
+    rng = np.random.default_rng(3)
+    src, dst = _rand_graph(rng, 200, 3000)
+    g = ops.CsrGraph.from_coo(src, dst, 200)
+    gt = g.transpose()
+    _assert_csr_equal(gt, oracle.coo_to_csr(dst, src, 200))
+    _assert_csr_equal(gt.transpose(), oracle.coo_to_csr(src, dst, 200))
+
+
+# --------------------------------------------------------------------------------------------- normalisation
+@pytest.mark.parametrize("name", REAL)
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_degree_and_normalised_values(ops, oracle, name, mode, prec):
+    g0 = load("real_" + name)
+    n = int(g0["n_nodes"])
+    g = ops.CsrGraph.from_coo(g0["adj_row"], g0["adj_col"], n, g0["adj_val"], ops.COO_ADD_SELF_LOOPS)
+    rowptr, col, val = oracle.coo_to_csr(g0["adj_row"], g0["adj_col"], n, g0["adj_val"], oracle.ADD_SELF_LOOPS)
+    d = ops.degree_norm(g, mode, prec)
+    rowsum, cnt, dinv = oracle.degree_norm(rowptr, val, mode, prec)
+    np.testing.assert_array_equal(_np(d["cnt"]), cnt)          # integer degree: bit exact
+    np.testing.assert_array_equal(_np(d["rowsum"]), rowsum)    # integer-valued fp32 sums: exact
+    np.testing.assert_allclose(_np(d["dinv64"]), dinv, rtol=2e-7 if prec == 0 else 1e-15)
+    gn = ops.normalise_values(g, mode, prec)
+    tag = "rw" if mode == 0 else "sym"
+    gold = g0[f"{'small' if prec == 0 else 'large'}_{tag}_val"]
+    np.testing.assert_allclose(_np(gn.val), gold, rtol=5e-7 if prec == 0 else 1.2e-7)
+
+
+def test_row_l1_normalise(ops, oracle):
+    for name in ("cora", "texas"):
+        g0 = load("real_" + name)
+        x = dense_features(g0)
+        y = _np(ops.row_l1_normalise(torch.from_numpy(x)))
+        np.testing.assert_allclose(y, oracle.row_l1_normalise(x), rtol=2e-7, atol=0)
+        ya = _np(ops.row_l1_normalise(torch.from_numpy(x - 0.5), use_abs=True))
+        np.testing.assert_allclose(ya, oracle.row_l1_normalise(x - 0.5, use_abs=True), rtol=1e-6, atol=0)
+    z = _np(ops.row_l1_normalise(torch.zeros(3, 5)))
+    assert (z == 0).all()  # inf -> 0 guard
+
+
+# --------------------------------------------------------------------------------------------- SpMM
+def _check_spmm(ops, oracle, rowptr, col, val, x, row_scale=None, col_scale=None, tol=1e-5, dtype=torch.float32):
+    n = rowptr.shape[0] - 1
+    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(),
+                     None if val is None else torch.from_numpy(val).cuda(), n, x.shape[0])
+    xt = torch.from_numpy(x).cuda().to(dtype)
+    rs = None if row_scale is None else torch.from_numpy(row_scale).cuda()
+    cs = None if col_scale is None else torch.from_numpy(col_scale).cuda()
+    y = _np(ops.spmm(g, xt, row_scale=rs, col_scale=cs))
+    xr = _np(xt.float())
+    v = np.ones(col.shape[0], np.float32) if val is None else val.copy()
+    if col_scale is not None:
+        v = v * col_scale[col]
+    y_ref = oracle.spmm_csr(rowptr, col, v, xr)
+    y64 = oracle.spmm_csr(rowptr, col, v, xr, f64acc=True)
+    if row_scale is not None:
+        y_ref, y64 = y_ref * row_scale[:, None], y64 * row_scale[:, None]
+    scale = np.abs(y64).max() + 1e-30
+    np.testing.assert_allclose(y, y_ref, rtol=tol, atol=tol * 0.1 * scale)
+    np.testing.assert_allclose(y, y64, rtol=tol, atol=tol * 0.1 * scale)
+    return y
+
+
+@pytest.mark.parametrize("n,f,e", [(2000, 500, 20000), (2000, 500, 82000), (2708, 1433, 13264), (500, 5, 3000),
+                                   (300, 64, 5000), (1200, 33, 9000), (4000, 128, 60000), (5201, 131, 50000),
+                                   (1, 1, 1), (64, 3, 0), (9000, 20, 40000)])
+def test_spmm_slab_family_shapes(ops, oracle, n, f, e):
+    rng = np.random.default_rng(n + f)
+    src, dst = _rand_graph(rng, n, e)
+    rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    assert ops.spmm_plan(n, n, f)[0] == 0
+    _check_spmm(ops, oracle, rowptr, col, val, x)
+    _check_spmm(ops, oracle, rowptr, col, None, x)
+    d = rng.random(n, dtype=np.float32)
+    _check_spmm(ops, oracle, rowptr, col, None, x, row_scale=d, col_scale=d)
+
+
+@pytest.mark.parametrize("slab", [4, 8, 16, 32])
+@pytest.mark.parametrize("threads", [512, 1024])
+def test_spmm_every_slab_variant(ops, oracle, slab, threads, monkeypatch):
+    monkeypatch.setenv("WDG_SPMM_SLAB", str(slab))
+    monkeypatch.setenv("WDG_SPMM_THREADS", str(threads))
+    rng = np.random.default_rng(slab)
+    n, f, e = 1100, 203, 15000
+    src, dst = _rand_graph(rng, n, e)
+    rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    assert ops.spmm_plan(n, n, f)[1:] == (slab, threads)
+    _check_spmm(ops, oracle, rowptr, col, val, x)
+    _check_spmm(ops, oracle, rowptr, col, None, x, row_scale=rng.random(n, dtype=np.float32))
+
+
+@pytest.mark.parametrize("n,f,e", [(60000, 7, 400000), (60000, 64, 300000), (50000, 300, 200000), (45000, 17, 100000),
+                                   (70000, 2, 500000), (41000, 130, 90000)])
+def test_spmm_gather_family(ops, oracle, n, f, e):
+    rng = np.random.default_rng(f)
+    src, dst = _rand_graph(rng, n, e)
+    rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    assert ops.spmm_plan(n, n, f)[0] == 1
+    _check_spmm(ops, oracle, rowptr, col, val, x)
+    d = rng.random(n, dtype=np.float32)
+    _check_spmm(ops, oracle, rowptr, col, None, x, row_scale=d, col_scale=d)
+
+
+def test_spmm_forced_gather_on_small_graph(ops, oracle, monkeypatch):
+    monkeypatch.setenv("WDG_SPMM_FORCE_GATHER", "1")
+    rng = np.random.default_rng(8)
+    for n, f, e in ((2000, 500, 30000), (700, 1433, 5000), (300, 9, 4000)):
+        src, dst = _rand_graph(rng, n, e)
+        rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
+        _check_spmm(ops, oracle, rowptr, col, val, rng.standard_normal((n, f)).astype(np.float32))
+
+
+def test_spmm_bf16_features(ops, oracle):
+    rng = np.random.default_rng(9)
+    for n, f, e in ((3000, 7, 40000), (60000, 7, 300000), (2000, 128, 20000)):
+        src, dst = _rand_graph(rng, n, e)
+        rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
+        x = rng.standard_normal((n, f)).astype(np.float32)
+        # bf16 inputs, fp32 accumulate: exact w.r.t. the bf16-rounded X, so the fp32 tolerance still applies
+        _check_spmm(ops, oracle, rowptr, col, val, x, dtype=torch.bfloat16)
+
+
+def test_spmm_strided_views_and_rectangular(ops, oracle):
+    rng = np.random.default_rng(10)
+    n_rows, n_cols, f = 700, 1300, 40
+    src, dst = rng.integers(0, n_rows, 6000), rng.integers(0, n_cols, 6000)
+    key = np.unique(src * n_cols + dst)
+    src, dst = key // n_cols, key % n_cols
+    rowptr = np.zeros(n_rows + 1, np.int32)
+    np.add.at(rowptr, src + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    col = dst.astype(np.int32)
+    val = rng.random(col.shape[0], dtype=np.float32)
+    big = torch.from_numpy(rng.standard_normal((n_cols, 100)).astype(np.float32)).cuda()
+    xv = big[:, 13:13 + f]  # ldx = 100, unaligned base
+    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(),
+                     n_rows, n_cols)
+    y = _np(ops.spmm(g, xv))
+    y_ref = oracle.spmm_csr(rowptr, col, val, _np(xv))
+    np.testing.assert_allclose(y, y_ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", REAL)
+@pytest.mark.parametrize("path,tag", [("small", "rw"), ("small", "sym"), ("large", "rw"), ("large", "sym")])
+def test_spmm_against_reference_golden(ops, name, path, tag):
+    """HIP result vs numbers the real reference produced (tests/golden), explicit A_hat values."""
+    g0 = load("real_" + name)
+    n = int(g0["n_nodes"])
+    x = dense_features(g0, "featn_data" if path == "small" else "featl1_data")
+    g = ops.CsrGraph.from_coo(g0[f"{path}_{tag}_row"], g0[f"{path}_{tag}_col"], n, g0[f"{path}_{tag}_val"])
+    y = _np(ops.spmm(g, torch.from_numpy(x)))
+    gold = g0[f"{path}_{tag}_y_rows"]
+    scale = np.abs(gold).max()
+    np.testing.assert_allclose(y[g0["sample_rows"]], gold, rtol=1e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(y.sum(1, dtype=np.float64), g0[f"{path}_{tag}_y_rowsum"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(np.linalg.norm(y.astype(np.float64)), g0[f"{path}_{tag}_y_fro"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", REAL)
+@pytest.mark.parametrize("sym", [0, 1])
+def test_spmm_fused_normalisation_end_to_end(ops, name, sym):
+    """raw COO -> +I -> degree -> fused-scale SpMM (no A_hat values materialised) vs the reference's Y."""
+    g0 = load("real_" + name)
+    n = int(g0["n_nodes"])
+    g = ops.CsrGraph.from_coo(g0["adj_row"], g0["adj_col"], n, g0["adj_val"], ops.COO_ADD_SELF_LOOPS)
+    d = ops.degree_norm(g, sym, ops.PREC_F32)
+    x = ops.row_l1_normalise(torch.from_numpy(dense_features(g0)))
+    y = _np(ops.spmm(g, x, row_scale=d["dinv"], col_scale=d["dinv"] if sym else None))
+    tag = "sym" if sym else "rw"
+    gold = g0[f"small_{tag}_y_rows"]
+    np.testing.assert_allclose(y[g0["sample_rows"]], gold, rtol=1e-5, atol=1e-6 * np.abs(gold).max())
+    np.testing.assert_allclose(np.linalg.norm(y.astype(np.float64)), g0[f"small_{tag}_y_fro"], rtol=2e-6)
+
+
+def test_spmm_batched_mixed_sizes(ops, oracle):
+    rng = np.random.default_rng(12)
+    entries, refs = [], []
+    for n, e in ((2000, 30000), (1500, 4000), (2000, 82000), (37, 100), (1999, 6000)):
+        src, dst = _rand_graph(rng, n, e)
+        rowptr, col, val = oracle.coo_to_csr(src, dst, n, None, oracle.ADD_SELF_LOOPS)
+        x = rng.random((n, 500), dtype=np.float32)
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, n)
+        d = ops.degree_norm(g, ops.NORM_RW, ops.PREC_F32)["dinv"]
+        y = torch.full((n, 500), float("nan"), device="cuda")
+        entries.append((g, torch.from_numpy(x).cuda(), y, d, None, True))
+        refs.append(oracle.spmm_csr(rowptr, col, val, x) * _np(d)[:, None])
+    batch = ops.SpmmBatch(entries)
+    batch.launch()
+    torch.cuda.synchronize()
+    for (g, x, y, *_), ref in zip(entries, refs):
+        np.testing.assert_allclose(_np(y), ref, rtol=1e-5, atol=1e-7)
+
+
+def test_spmm_full_size_properties(ops):
+    """BASELINE-size batch (100 graphs x N=2000 x F=500): size-independent checks instead of the oracle:
+    rows of D^-1(A+I) sum to one => A_hat 1 = 1; linearity; bitwise run-to-run reproducibility."""
+    from wdg_amd import synth
+    graphs = [synth.regular_graph(2000, 5, 2, h, seed) for seed in range(10) for h in synth.H_LEVELS_10]
+    entries = []
+    x1 = torch.ones((2000, 500), device="cuda")
+    xr = torch.rand((2000, 500), device="cuda")
+    for src, dst, _ in graphs:
+        g = ops.CsrGraph.from_coo(src, dst, 2000, None, ops.COO_ADD_SELF_LOOPS)
+        d = ops.degree_norm(g, ops.NORM_RW, ops.PREC_F32)["dinv"]
+        entries.append((g, x1, torch.empty((2000, 500), device="cuda"), d, None, False))
+        entries.append((g, xr, torch.empty((2000, 500), device="cuda"), d, None, False))
+        entries.append((g, xr + x1, torch.empty((2000, 500), device="cuda"), d, None, False))
+    batch = ops.SpmmBatch(entries)
+    batch.launch()
+    torch.cuda.synchronize()
+    first = [e[2].clone() for e in entries]
+    for i in range(0, len(entries), 3):
+        assert torch.allclose(entries[i][2], x1, rtol=0, atol=2e-6)
+        assert torch.allclose(entries[i + 2][2], entries[i + 1][2] + entries[i][2], rtol=1e-5, atol=1e-5)
+    batch.launch()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, e[2]) for a, e in zip(first, entries))
+
+
+# --------------------------------------------------------------------------------------------- edge / label stats
+STAT_KEYS = ("totals", "row_nnz", "row_nnz_noself", "row_match_noself", "compat", "classdeg")
+
+
+@pytest.mark.parametrize("name", REAL + SYN)
+def test_edge_label_stats_golden_graphs(ops, oracle, name):
+    g0 = load(name if name.startswith("syn") else "real_" + name)
+    n, labels = int(g0["n_nodes"]), g0["labels"]
+    c = int(labels.max()) + 1
+    if name.startswith("syn"):
+        src, dst = g0["norm_row"], g0["norm_col"]
+    else:
+        src, dst = g0["small_rw_row"], g0["small_rw_col"]
+    g = ops.CsrGraph.from_coo(src, dst, n)
+    rowptr, col, _ = oracle.coo_to_csr(src, dst, n)
+    st = ops.edge_label_stats(g, torch.from_numpy(labels))
+    ref = oracle.edge_label_stats(rowptr, col, labels, c)
+    for k in STAT_KEYS:
+        np.testing.assert_array_equal(_np(st[k]), ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize("n,e,c", [(1000, 20000, 3), (5000, 9000, 70), (300, 40000, 64), (2, 1, 2), (50000, 600000, 2)])
+def test_edge_label_stats_random(ops, oracle, n, e, c):
+    rng = np.random.default_rng(c)
+    src, dst = _rand_graph(rng, n, e)
+    labels = rng.integers(-1, c, n)  # -1 = unlabelled
+    labels[:c] = np.arange(c)
+    rowptr, col, _ = oracle.coo_to_csr(src, dst, n, None, oracle.ADD_SELF_LOOPS)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+    st = ops.edge_label_stats(g, torch.from_numpy(labels), c)
+    ref = oracle.edge_label_stats(rowptr, col, labels, c)
+    for k in STAT_KEYS:
+        np.testing.assert_array_equal(_np(st[k]), ref[k], err_msg=k)
+
+
+def test_edge_label_stats_batched(ops, oracle):
+    rng = np.random.default_rng(21)
+    graphs, labels, refs = [], [], []
+    for n, e in ((2000, 8000), (2000, 82000), (100, 50), (1500, 30000)):
+        src, dst = _rand_graph(rng, n, e)
+        lab = rng.integers(0, 5, n)
+        graphs.append(ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS))
+        labels.append(lab)
+        rowptr, col, _ = oracle.coo_to_csr(src, dst, n, None, oracle.ADD_SELF_LOOPS)
+        refs.append(oracle.edge_label_stats(rowptr, col, lab, 5))
+    b = ops.StatsBatch(graphs, labels, 5)
+    for _ in range(2):  # relaunch must re-zero
+        b.launch()
+    torch.cuda.synchronize()
+    for i, ref in enumerate(refs):
+        n = graphs[i].n_rows
+        np.testing.assert_array_equal(_np(b.totals[i]), ref["totals"])
+        np.testing.assert_array_equal(_np(b.compat[i]), ref["compat"])
+        np.testing.assert_array_equal(_np(b.classdeg[i]), ref["classdeg"])
+        np.testing.assert_array_equal(_np(b.rows[i, 0, :n]), ref["row_nnz"])
+        np.testing.assert_array_equal(_np(b.rows[i, 1, :n]), ref["row_nnz_noself"])
+        np.testing.assert_array_equal(_np(b.rows[i, 2, :n]), ref["row_match_noself"])
+
+
+# --------------------------------------------------------------------------------------------- LAS
+@pytest.mark.parametrize("name", ["cora", "citeseer", "texas"])
+def test_las_counts_and_weights(ops, oracle, name):
+    g0 = load("real_" + name)
+    n, labels = int(g0["n_nodes"]), g0["labels"]
+    c = int(labels.max()) + 1
+    onehot = np.eye(c, dtype=np.float32)[labels]
+    rowptr, col, val = oracle.coo_to_csr(g0["adj_row"], g0["adj_col"], n, g0["adj_val"])
+    h = oracle.spmm_csr(rowptr, col, val, onehot)
+    for rows in (None, np.nonzero(g0["las_mask"])[0].astype(np.int32)):
+        hs, ls = (h, labels) if rows is None else (h[rows], labels[rows])
+        w_ref = oracle.las_weights(hs, ls, c, f64=True)
+        cnt, nsel, w = ops.las(torch.from_numpy(h), torch.from_numpy(labels), c, rows=rows, want_weights=True)
+        assert nsel == hs.shape[0]
+        np.testing.assert_array_equal(_np(w), w_ref)  # integer-valued H: fp64 sums are exact in any order
+        soft = oracle.las_from_weights(w_ref, ls, hard=None)
+        hard = oracle.las_from_weights(w_ref, ls, hard=1)
+        assert int(cnt[0]) == round(soft * nsel) and int(cnt[1]) == round(hard * nsel)
+
+
+def test_las_real_valued(ops, oracle):
+    rng = np.random.default_rng(4)
+    n, f, c = 3000, 70, 6
+    h = rng.standard_normal((n, f)).astype(np.float32)
+    labels = rng.integers(0, c, n)
+    w_ref = oracle.las_weights(h, labels, c, f64=True)
+    cnt, _, w = ops.las(torch.from_numpy(h), torch.from_numpy(labels), c, want_weights=True)
+    np.testing.assert_allclose(_np(w), w_ref, rtol=1e-11, atol=1e-9)
+    assert abs(int(cnt[0]) - round(oracle.las_from_weights(w_ref, labels) * n)) <= 1
+    assert abs(int(cnt[1]) - round(oracle.las_from_weights(w_ref, labels, hard=1) * n)) <= 1
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(2000, 64, 500), (2708, 7, 1433), (300, 5, 64), (129, 33, 17), (1, 1, 1),
+                                   (4000, 64, 64), (257, 100, 300), (128, 32, 16)])
+def test_gemm_shapes(ops, oracle, m, n, k):
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    ref = oracle.gemm(a, b)
+    tol = dict(rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(_np(ops.gemm(torch.from_numpy(a), torch.from_numpy(b))), ref, **tol)
+    np.testing.assert_allclose(_np(ops.gemm(torch.from_numpy(a), torch.from_numpy(b), bias=torch.from_numpy(bias), relu=True)),
+                               oracle.gemm(a, b, bias, relu=True), **tol)
+    bt = np.ascontiguousarray(b.T)
+    np.testing.assert_allclose(_np(ops.gemm(torch.from_numpy(a), torch.from_numpy(bt), transb=True)), ref, **tol)
+
+
+def test_gemm_is_a_k_ordered_fp32_fma_chain(ops):
+    """fp32 MFMA = exact fp32 fma chain in k order: compare bitwise with an fma loop on the host."""
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((64, 40)).astype(np.float32)
+    b = rng.standard_normal((40, 32)).astype(np.float32)
+    out = _np(ops.gemm(torch.from_numpy(a), torch.from_numpy(b)))
+    ref = np.zeros((64, 32), np.float32)
+    for kk in range(40):  # fma(a, b, acc) with a single rounding == float64 product-sum rounded once
+        ref = (a[:, kk:kk + 1].astype(np.float64) * b[kk:kk + 1, :].astype(np.float64) + ref.astype(np.float64)).astype(np.float32)
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_gram_matches_oracle(ops, oracle):
+    g0 = load("real_cora")
+    x = dense_features(g0)
+    smp = g0["gntk_sample"]
+    gram = _np(ops.gemm(torch.from_numpy(x[smp]), torch.from_numpy(x[smp]), transb=True))
+    np.testing.assert_allclose(gram, oracle.gram(x, smp), rtol=1e-6, atol=1e-6)

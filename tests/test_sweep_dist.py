@@ -1,0 +1,70 @@
+"""CPU tests of the multi-process sweep logic (world_size 2, gloo): job-table broadcast, static sharding and
+result all_gather - the N>1 path of bench.py without a GPU.  The per-job evaluation is done by the oracle here
+(tests may use it); on a GPU node the same driver code runs the HIP batch instead."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from wdg_amd import sweep, synth
+
+
+def test_shard_jobs_partitions_whole_seeds():
+    jobs = sweep.make_jobs(synth.H_LEVELS_10, range(7))
+    for ws in (1, 2, 3, 8):
+        shards = [sweep.shard_jobs(jobs, ws, r) for r in range(ws)]
+        flat = [j for s in shards for j in s]
+        assert sorted(flat, key=lambda j: (j.seed, j.h)) == sorted(jobs, key=lambda j: (j.seed, j.h))
+        for s in shards:
+            seeds = {j.seed for j in s}
+            assert all(len([j for j in s if j.seed == sd]) == 10 for sd in seeds)  # a seed never splits
+        loads = [sum(j.nnz for j in s) for s in shards]
+        assert max(loads) - min(loads) <= max(j.nnz for j in jobs) * 10
+    assert sweep.decode_jobs(sweep.encode_jobs(jobs)) == jobs
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    dev = torch.device("cpu")
+    jobs = sweep.make_jobs([0.1, 0.5, 0.9], range(4), n_nodes=200) if rank == 0 else []
+    jobs = sweep.broadcast_jobs(jobs, dev)
+    mine = sweep.shard_jobs(jobs, world, rank)
+    rows = []
+    for j in mine:  # stand-in evaluator: oracle metrics per job, keyed so the gather can be checked
+        src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+        rowptr, col, _ = orc.coo_to_csr(src, dst, j.n_nodes, None, orc.ADD_SELF_LOOPS)
+        st = orc.edge_label_stats(rowptr, col, lab, j.n_classes)
+        rows.append([j.seed, j.h, orc.edge_homophily_dense(st), orc.node_homophily_dense(st)])
+    local = torch.tensor(rows, dtype=torch.float64).reshape(-1, 4)
+    gathered = sweep.gather_results(local, dev)
+    torch.save(dict(jobs=len(jobs), mine=len(mine), gathered=[g.clone() for g in gathered]),
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sweep_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    assert res[0]["jobs"] == res[1]["jobs"] == 12
+    assert res[0]["mine"] + res[1]["mine"] == 12 and res[0]["mine"] == 6
+    for r in range(world):  # every rank holds everybody's rows after the all_gather
+        g = torch.cat(res[r]["gathered"])
+        assert g.shape == (12, 4)
+        assert sorted((int(a), float(b)) for a, b in g[:, :2].tolist()) == sorted((s, h) for s in range(4) for h in (0.1, 0.5, 0.9))
+        for seed, h, eh, nh in g.tolist():
+            d = int(2 / h)
+            assert abs(eh - 2 / d) < 1e-12 and abs(nh - 3 / (d + 1)) < 1e-6  # generator's known answers
+    assert torch.equal(torch.cat(res[0]["gathered"]), torch.cat(res[1]["gathered"]))

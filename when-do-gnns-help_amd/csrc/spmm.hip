@@ -1,0 +1,401 @@
+// Neighbour aggregation Y = diag(r) A diag(c) X  (CSR, fp32 accumulate) for MI355X / gfx950.
+//
+// replaces: torch.spmm / torch.mm(adj, X) at utils/homophily_metrics.py:192,199,200,234,235,299,315 and
+//           utils/homophily_plot.py:196,246,320,336 of the reference.
+//
+// Two kernel families, chosen by wdg_spmm_plan():
+//
+//  (1) LDS column-slab kernel  - for graphs whose column count fits an LDS-resident feature slab
+//      ((n_cols+1) * SLAB * 4 B <= LDS).  A workgroup owns one (graph, slab-of-SLAB-features) item: it streams
+//      the slab X[:, s*SLAB:(s+1)*SLAB] from HBM/L2 into LDS ONCE (pre-multiplied by the column scale), then
+//      every destination row is produced by a group of SLAB/4 lanes that walks the row's CSR segment and
+//      accumulates 16-byte LDS reads in registers.  No atomics, fixed summation order (CSR order) ->
+//      bitwise reproducible.  X is read once and Y written once from HBM; the E*F gather traffic that a
+//      row-gather SpMM pushes through L2 stays inside the CU.  Items are laid out so that each XCD walks a
+//      contiguous (graph, slab) range: adjacent slabs of a graph complete each other's 128-B lines in one L2.
+//      Many graphs are processed by one launch (job table in device memory).
+//
+//  (2) row-gather kernel       - any size: a group of GL lanes owns (row, chunk of GL*VEC features) and gathers
+//      whole row segments of X straight into registers.  Used when the slab would not fit LDS (large graphs).
+//
+// Normalisation is fused: the caller passes d = D^-1 or D^-1/2 as row_scale / col_scale instead of
+// materialising A_hat's values (K2 fused into K1); an explicit `val` array is honoured too.
+#include "wdg_common.h"
+
+namespace {
+
+using namespace wdg;
+
+struct bf16_t {
+    unsigned short bits;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float(static_cast<unsigned>(v.bits) << 16); }
+
+// broadcast lane J of each G-lane group to the whole group (G in {1,2,4}: DPP quad_perm, no LDS traffic)
+template <int G, int J>
+__device__ __forceinline__ int group_bcast(int v) {
+    if constexpr (G == 1) {
+        return v;
+    } else if constexpr (G == 2) {
+        constexpr int ctrl = J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6);
+        return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
+    } else if constexpr (G == 4) {
+        constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
+        return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true);
+    } else {
+        return __shfl(v, J, G);
+    }
+}
+
+template <bool HAS_VAL>
+__device__ __forceinline__ void fma4(float4 &acc, const float4 x, float w) {
+    if constexpr (HAS_VAL) {
+        acc.x = fmaf(w, x.x, acc.x);
+        acc.y = fmaf(w, x.y, acc.y);
+        acc.z = fmaf(w, x.z, acc.z);
+        acc.w = fmaf(w, x.w, acc.w);
+    } else {
+        acc.x += x.x;
+        acc.y += x.y;
+        acc.z += x.z;
+        acc.w += x.w;
+    }
+}
+
+template <int G, int J, bool HAS_VAL>
+__device__ __forceinline__ void accumulate_edges(float4 &acc, const float4 *xs, int idx, float w, int q) {
+    if constexpr (J < G) {
+        const int c = group_bcast<G, J>(idx);
+        float wj = 1.0f;
+        if constexpr (HAS_VAL) wj = __int_as_float(group_bcast<G, J>(__float_as_int(w)));
+        fma4<HAS_VAL>(acc, xs[c * G + q], wj);
+        accumulate_edges<G, J + 1, HAS_VAL>(acc, xs, idx, w, q);
+    }
+}
+
+// One destination row, produced by a G-lane group (lane q of the group owns features 4q..4q+3 of the slab).
+template <int G, bool HAS_VAL>
+__device__ __forceinline__ float4 aggregate_row(const float4 *xs, const int32_t *__restrict__ col,
+                                                const float *__restrict__ val, int start, int end, int q,
+                                                int zero_row) {
+    constexpr int UNR = (G >= 4) ? 1 : 4 / G;  // edges per iteration = G*UNR >= 4
+    constexpr int EPI = G * UNR;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int idx[UNR];
+    float w[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int pp = start + u * G + q;
+        const bool ok = pp < end;
+        idx[u] = ok ? col[pp] : zero_row;
+        w[u] = (HAS_VAL && ok) ? val[pp] : 0.f;
+    }
+    for (int p = start; p < end; p += EPI) {
+        int nidx[UNR];
+        float nw[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {  // prefetch the next group of indices while this one hits LDS
+            const int pp = p + EPI + u * G + q;
+            const bool ok = pp < end;
+            nidx[u] = ok ? col[pp] : zero_row;
+            nw[u] = (HAS_VAL && ok) ? val[pp] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) accumulate_edges<G, 0, HAS_VAL>(acc, xs, idx[u], w[u], q);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            idx[u] = nidx[u];
+            w[u] = nw[u];
+        }
+    }
+    return acc;
+}
+
+template <int SLAB, int THREADS, typename TIN>
+__global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *__restrict__ jobs,
+                                                            const wdg_spmm_job inline_job, int n_slabs,
+                                                            long long n_items) {
+    constexpr int G = SLAB / 4;             // lanes per destination row
+    constexpr int GROUPS = THREADS / G;     // destination rows in flight per workgroup
+    extern __shared__ float4 xs[];          // [(n_cols + 1) * G] float4; last row = zeros
+
+    const long long item = xcd_contiguous_item(blockIdx.x, n_items);
+    if (item >= n_items) return;
+    const int job_id = static_cast<int>(item / n_slabs);
+    const int slab = static_cast<int>(item % n_slabs);
+    const wdg_spmm_job job = jobs ? jobs[job_id] : inline_job;  // single-graph calls pass the descriptor by value
+    const int f0 = slab * SLAB;
+    if (f0 >= job.n_feat) return;
+    const int n_cols = job.n_cols, n_rows = job.n_rows, F = job.n_feat;
+    const TIN *__restrict__ X = static_cast<const TIN *>(job.X);
+    const int tid = threadIdx.x;
+
+    // ---- stage 1: X[:, f0:f0+SLAB] -> LDS, pre-multiplied by the column scale
+    const bool full = (f0 + SLAB <= F);
+    const bool vec_ok = full && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    for (int i = tid; i < (n_cols + 1) * G; i += THREADS) {
+        const int r = i / G, q = i % G;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n_cols) {
+            const TIN *src = X + static_cast<int64_t>(r) * job.ldx + f0 + q * 4;
+            if (vec_ok) {
+                v = *reinterpret_cast<const float4 *>(src);
+            } else {
+                const int f = f0 + q * 4;
+                if (f + 0 < F) v.x = to_f32(src[0]);
+                if (f + 1 < F) v.y = to_f32(src[1]);
+                if (f + 2 < F) v.z = to_f32(src[2]);
+                if (f + 3 < F) v.w = to_f32(src[3]);
+            }
+            if (job.col_scale) {
+                const float s = job.col_scale[r];
+                v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            }
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+
+    // ---- stage 2: every destination row = CSR-ordered sum of LDS rows
+    const int q = tid % G;
+    const bool y_vec = full && (job.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.Y) & 15) == 0);
+    for (int row = tid / G; row < n_rows; row += GROUPS) {
+        const int start = job.rowptr[row], end = job.rowptr[row + 1];
+        float4 acc = job.val ? aggregate_row<G, true>(xs, job.col, job.val, start, end, q, n_cols)
+                             : aggregate_row<G, false>(xs, job.col, nullptr, start, end, q, n_cols);
+        if (job.row_scale) {
+            const float s = job.row_scale[row];
+            acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
+        }
+        float *dst = job.Y + static_cast<int64_t>(row) * job.ldy + f0 + q * 4;
+        if (y_vec) {
+            *reinterpret_cast<float4 *>(dst) = acc;
+        } else {
+            const int f = f0 + q * 4;
+            if (f + 0 < F) dst[0] = acc.x;
+            if (f + 1 < F) dst[1] = acc.y;
+            if (f + 2 < F) dst[2] = acc.z;
+            if (f + 3 < F) dst[3] = acc.w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-gather kernel: group of GL lanes x VEC floats per lane = one (row, feature chunk) task.
+template <int GL, int VEC, typename TIN>
+__global__ __launch_bounds__(256) void spmm_gather_kernel(const wdg_spmm_job *__restrict__ jobs,
+                                                          const wdg_spmm_job inline_job, int n_chunks,
+                                                          long long tasks_per_job, long long n_tasks) {
+    constexpr int CH = GL * VEC;
+    const long long gtask = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) / GL;
+    if (gtask >= n_tasks) return;
+    const int job_id = static_cast<int>(gtask / tasks_per_job);
+    const long long t = gtask % tasks_per_job;
+    const wdg_spmm_job job = jobs ? jobs[job_id] : inline_job;
+    const int row = static_cast<int>(t / n_chunks), chunk = static_cast<int>(t % n_chunks);
+    if (row >= job.n_rows) return;
+    const int F = job.n_feat;
+    const int f = chunk * CH + (threadIdx.x % GL) * VEC;
+    if (chunk * CH >= F) return;
+    const TIN *__restrict__ X = static_cast<const TIN *>(job.X);
+    const int start = job.rowptr[row], end = job.rowptr[row + 1];
+    const bool vec_ok = VEC == 4 && sizeof(TIN) == 4 && (f + VEC <= F) && (job.ldx % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    constexpr int U = 4;
+    int p = start;
+    for (; p + U <= end; p += U) {
+        int c[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c[u] = job.col[p + u];
+            w[u] = job.val ? job.val[p + u] : 1.f;
+        }
+        if (job.col_scale) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] *= job.col_scale[c[u]];
+        }
+        float x[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const TIN *src = X + static_cast<int64_t>(c[u]) * job.ldx + f;
+            if (vec_ok) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                x[u][0] = t4.x;
+                if constexpr (VEC == 4) { x[u][1] = t4.y; x[u][2] = t4.z; x[u][3] = t4.w; }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) x[u][v] = (f + v < F) ? to_f32(src[v]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+    }
+    for (; p < end; ++p) {
+        const int c = job.col[p];
+        float w = job.val ? job.val[p] : 1.f;
+        if (job.col_scale) w *= job.col_scale[c];
+        const TIN *src = X + static_cast<int64_t>(c) * job.ldx + f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            if (f + v < F) acc[v] = fmaf(w, to_f32(src[v]), acc[v]);
+    }
+    const float rs = job.row_scale ? job.row_scale[row] : 1.f;
+    float *dst = job.Y + static_cast<int64_t>(row) * job.ldy + f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        if (f + v < F) dst[v] = rs * acc[v];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Plan {
+    int family;   // 0 slab, 1 gather
+    int slab;     // slab family: floats per LDS row; gather family: GL
+    int threads;  // slab family: workgroup size; gather: VEC
+};
+
+int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
+Plan make_plan(int max_rows, int max_cols, int n_feat, int n_jobs) {
+    Plan p{};
+    const int64_t budget_two = 80 * 1024 - 256;   // two workgroups per CU
+    const int64_t budget_one = kLdsBytes - 512;   // one workgroup per CU
+    const int64_t rows = static_cast<int64_t>(max_cols) + 1;
+    const int forced = env_int("WDG_SPMM_SLAB", 0);
+    if (rows * 16 <= budget_one && env_int("WDG_SPMM_FORCE_GATHER", 0) == 0) {
+        p.family = 0;
+        int slab = 4;
+        const int cus = 256;
+        for (int s : {32, 16, 8}) {
+            if (rows * s * 4 > budget_one) continue;
+            if (s / 2 >= n_feat && s > 4) continue;                       // do not pad tiny F beyond need
+            const int64_t items = static_cast<int64_t>(n_jobs) * ceil_div(n_feat, s);
+            if (items < 2 * cus && s > 4) continue;                       // keep the chip filled
+            if (rows * s * 4 > budget_two && rows * (s / 2) * 4 <= budget_two) continue;  // prefer 2 WG / CU
+            slab = s;
+            break;
+        }
+        if (forced == 4 || forced == 8 || forced == 16 || forced == 32)
+            if (rows * forced * 4 <= budget_one) slab = forced;
+        p.slab = slab;
+        p.threads = (rows * slab * 4 <= budget_two) ? 512 : 1024;
+        const int ft = env_int("WDG_SPMM_THREADS", 0);
+        if (ft == 512 || ft == 1024) p.threads = ft;
+        return p;
+    }
+    p.family = 1;
+    if (n_feat >= 256) { p.slab = 64; p.threads = 4; }
+    else if (n_feat >= 128) { p.slab = 32; p.threads = 4; }
+    else if (n_feat >= 64) { p.slab = 16; p.threads = 4; }
+    else if (n_feat >= 32) { p.slab = 32; p.threads = 1; }
+    else if (n_feat >= 16) { p.slab = 16; p.threads = 1; }
+    else if (n_feat >= 8) { p.slab = 8; p.threads = 1; }
+    else { p.slab = 4; p.threads = 1; }
+    return p;
+}
+
+template <int SLAB, int THREADS, typename TIN>
+int launch_slab(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_cols, int max_feat,
+                hipStream_t st) {
+    const int n_slabs = static_cast<int>(ceil_div(max_feat, SLAB));
+    const int64_t n_items = static_cast<int64_t>(n_jobs) * n_slabs;
+    const size_t lds = static_cast<size_t>(max_cols + 1) * SLAB * 4;
+    auto kern = spmm_slab_kernel<SLAB, THREADS, TIN>;
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(kLdsBytes - 256)) != hipSuccess)
+            return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+        configured = kLdsBytes;
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(xcd_grid_size(n_items))), dim3(THREADS), lds, st, jobs,
+                       inl, n_slabs, static_cast<long long>(n_items));
+    return check_launch("spmm_slab_kernel");
+}
+
+template <int GL, int VEC, typename TIN>
+int launch_gather(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_feat,
+                  hipStream_t st) {
+    const int n_chunks = static_cast<int>(ceil_div(max_feat, GL * VEC));
+    const long long tasks_per_job = static_cast<long long>(max_rows) * n_chunks;
+    const long long n_tasks = tasks_per_job * n_jobs;
+    const long long blocks = ceil_div(n_tasks * GL, 256);
+    if (blocks > 0x7fffffffLL) return fail(WDG_ERR_UNSUPPORTED, "spmm: grid too large");
+    hipLaunchKernelGGL((spmm_gather_kernel<GL, VEC, TIN>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, jobs,
+                       inl, n_chunks, tasks_per_job, n_tasks);
+    return check_launch("spmm_gather_kernel");
+}
+
+template <typename TIN>
+int dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols, int max_feat,
+             hipStream_t st) {
+    if (n_jobs == 0 || max_rows == 0 || max_feat == 0) return WDG_OK;
+    const Plan p = make_plan(max_rows, max_cols, max_feat, n_jobs);
+    if (p.family == 0) {
+#define WDG_SLAB_CASE(S, T) \
+    if (p.slab == S && p.threads == T) return launch_slab<S, T, TIN>(jobs, inl, n_jobs, max_cols, max_feat, st);
+        WDG_SLAB_CASE(4, 512) WDG_SLAB_CASE(4, 1024) WDG_SLAB_CASE(8, 512) WDG_SLAB_CASE(8, 1024)
+        WDG_SLAB_CASE(16, 512) WDG_SLAB_CASE(16, 1024) WDG_SLAB_CASE(32, 512) WDG_SLAB_CASE(32, 1024)
+#undef WDG_SLAB_CASE
+        return fail(WDG_ERR_UNSUPPORTED, "spmm: no slab kernel for slab=%d threads=%d", p.slab, p.threads);
+    }
+#define WDG_GATHER_CASE(GL, V) \
+    if (p.slab == GL && p.threads == V) return launch_gather<GL, V, TIN>(jobs, inl, n_jobs, max_rows, max_feat, st);
+    WDG_GATHER_CASE(64, 4) WDG_GATHER_CASE(32, 4) WDG_GATHER_CASE(16, 4) WDG_GATHER_CASE(32, 1)
+    WDG_GATHER_CASE(16, 1) WDG_GATHER_CASE(8, 1) WDG_GATHER_CASE(4, 1)
+#undef WDG_GATHER_CASE
+    return fail(WDG_ERR_UNSUPPORTED, "spmm: no gather kernel for GL=%d VEC=%d", p.slab, p.threads);
+}
+
+int validate_job(const wdg_spmm_job *j) {
+    WDG_REQUIRE(j != nullptr, "spmm: null job");
+    WDG_REQUIRE(j->n_rows >= 0 && j->n_cols >= 0 && j->n_feat >= 0, "spmm: negative size");
+    if (j->n_rows == 0 || j->n_feat == 0) return WDG_OK;
+    WDG_REQUIRE(j->rowptr && j->Y, "spmm: null rowptr / Y");
+    WDG_REQUIRE(j->ldx >= j->n_feat && j->ldy >= j->n_feat, "spmm: leading dimension smaller than n_feat");
+    return WDG_OK;
+}
+
+// single-graph entry points pass the descriptor BY VALUE as a kernel argument: no upload, no allocation,
+// graph-capturable.
+template <typename TIN>
+int single(const wdg_spmm_job *job_host, wdg_stream_t stream) {
+    if (int e = validate_job(job_host)) return e;
+    if (job_host->n_rows == 0 || job_host->n_feat == 0) return WDG_OK;
+    return dispatch<TIN>(nullptr, *job_host, 1, job_host->n_rows, job_host->n_cols, job_host->n_feat,
+                         as_stream(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream) { return single<float>(job_host, stream); }
+
+int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream) { return single<bf16_t>(job_host, stream); }
+
+int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
+                         int32_t max_feat, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_cols >= 0 && max_feat >= 0, "spmm_batched: negative size");
+    WDG_REQUIRE(n_jobs == 0 || jobs_dev != nullptr, "spmm_batched: null job table");
+    return dispatch<float>(jobs_dev, wdg_spmm_job{}, n_jobs, max_rows, max_cols, max_feat, as_stream(stream));
+}
+
+int wdg_spmm_plan(int32_t max_rows, int32_t max_cols, int32_t n_feat, int *slab_out, int *threads_out) {
+    const Plan p = make_plan(max_rows, max_cols, n_feat, 1);
+    if (slab_out) *slab_out = p.slab;
+    if (threads_out) *threads_out = p.threads;
+    return p.family;
+}
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+"""Torch-tensor front end of the C ABI (include/wdg.h): device CSR container + one Python function per kernel.
+
+PyTorch is plumbing here (device memory, the current HIP stream); every computation below is a hand-written
+gfx950 kernel in csrc/.  Nothing in this file runs on the CPU, and nothing falls back.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SpmmJob, StatsJob, c_void_p, check, lib, require_gpu, stream_handle
+
+# flags / modes of include/wdg.h
+COO_SYMMETRISE, COO_BINARISE, COO_ADD_SELF_LOOPS, COO_DROP_SELF_LOOPS, COO_KEEP_DUPLICATES = 1, 2, 4, 8, 16
+NORM_RW, NORM_SYM = 0, 1
+PREC_F32, PREC_F64 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+
+
+def _ptr(t):
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dev(t, dtype, dev):
+    """tensor / ndarray / list -> contiguous device tensor of `dtype` (no copy when already there)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=dev, dtype=dtype).contiguous()
+
+
+class CsrGraph:
+    """Device-resident CSR adjacency: int32 rowptr[n_rows+1], int32 col[nnz], optional fp32 val[nnz].
+
+    The layout every kernel consumes: row-major sorted, duplicates already merged - what the
+    reference gets from `.coalesce()` on a torch COO tensor, with 4-byte instead of 8-byte indices.
+    """
+
+    def __init__(self, rowptr, col, val, n_rows, n_cols):
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+
+    @property
+    def nnz(self):
+        return int(self.col.shape[0])
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    # -- constructors ---------------------------------------------------------------------------
+    @staticmethod
+    def from_coo(src, dst, n, val=None, flags=0):
+        """COO edge list (any integer dtype, host or device) -> CSR on the GPU via wdg_coo_to_csr_i32."""
+        dev = require_gpu()
+        src, dst = _dev(src, torch.int64, dev), _dev(dst, torch.int64, dev)
+        val = _dev(val, torch.float32, dev)
+        e, n = int(src.shape[0]), int(n)
+        cap = lib.wdg_coo_to_csr_capacity(e, n, flags)
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(cap, dtype=torch.int32, device=dev)
+        out = torch.empty(cap, dtype=torch.float32, device=dev)
+        nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws_bytes = lib.wdg_coo_to_csr_workspace_bytes(e, n, flags)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.wdg_coo_to_csr_i32(_ptr(src), _ptr(dst), _ptr(val), e, n, flags, _ptr(rowptr), _ptr(col), _ptr(out),
+                                     _ptr(nnz), _ptr(ws), ws_bytes, stream_handle()), "wdg_coo_to_csr_i32")
+        k = int(nnz.item())  # the one host sync of graph construction
+        if k < 0:
+            raise IndexError("edge index out of range for a graph of %d nodes" % n)
+        return CsrGraph(rowptr, col[:k], out[:k], n, n)
+
+    @staticmethod
+    def from_torch_sparse(a, flags=0):
+        """torch sparse COO (coalesced or not; fp32/fp64 values) -> CSR.  Duplicates are summed like `.coalesce()`."""
+        idx = a._indices()
+        return CsrGraph.from_coo(idx[0], idx[1], a.shape[0], a._values(), flags)
+
+    @staticmethod
+    def from_dense(a):
+        """Dense [N,M] fp32 -> CSR of its non-zero entries (wdg_dense_to_csr_*)."""
+        dev = require_gpu()
+        a = _dev(a, torch.float32, dev)
+        n, m = a.shape
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.wdg_scan_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.wdg_dense_to_csr_count(_ptr(a), a.stride(0), n, m, _ptr(rowptr), _ptr(ws), ws_bytes,
+                                         stream_handle()), "wdg_dense_to_csr_count")
+        nnz = int(rowptr[-1].item())
+        col = torch.empty(nnz, dtype=torch.int32, device=dev)
+        val = torch.empty(nnz, dtype=torch.float32, device=dev)
+        check(lib.wdg_dense_to_csr_fill(_ptr(a), a.stride(0), n, m, _ptr(rowptr), _ptr(col), _ptr(val),
+                                        stream_handle()), "wdg_dense_to_csr_fill")
+        return CsrGraph(rowptr, col, val, n, m)
+
+    @staticmethod
+    def from_scipy(mx, flags=0):
+        coo = mx.tocoo()
+        return CsrGraph.from_coo(coo.row, coo.col, coo.shape[0], coo.data, flags)
+
+    @staticmethod
+    def from_any(a, flags=0):
+        """Accept what the reference's functions are handed: torch sparse / dense tensors, scipy matrices, CsrGraph."""
+        if isinstance(a, CsrGraph):
+            return a
+        if isinstance(a, torch.Tensor):
+            if a.layout == torch.sparse_coo:
+                return CsrGraph.from_torch_sparse(a, flags)
+            if a.dim() == 2 and a.shape[0] == 2 and not a.is_floating_point():
+                raise TypeError("edge-index tensors need an explicit node count: use CsrGraph.from_coo")
+            g = CsrGraph.from_dense(a)
+            return g if flags == 0 else g.rebuild(flags)
+        if hasattr(a, "tocoo"):
+            return CsrGraph.from_scipy(a, flags)
+        raise TypeError(f"cannot build a CSR graph from {type(a)}")
+
+    # -- views ------------------------------------------------------------------------------------
+    def row_indices(self):
+        """int64 row id of every stored entry (device), i.e. COO row vector in coalesced order."""
+        counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        return torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), counts)
+
+    def rebuild(self, flags):
+        return CsrGraph.from_coo(self.row_indices(), self.col, self.n_rows, self.val, flags)
+
+    def transpose(self):
+        """A^T as CSR (the backward pass of a directed graph needs it)."""
+        g = CsrGraph.from_coo(self.col, self.row_indices(), self.n_cols, self.val, 0)
+        g.n_cols = self.n_rows
+        return g
+
+    def to_torch_sparse(self):
+        idx = torch.stack([self.row_indices(), self.col.to(torch.int64)])
+        val = self.val if self.val is not None else torch.ones(self.nnz, device=self.device)
+        return torch.sparse_coo_tensor(idx, val, (self.n_rows, self.n_cols)).coalesce()
+
+    def with_values(self, val):
+        return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)
+
+
+# ------------------------------------------------------------------------------------------- normalisation
+def degree_norm(g, mode=NORM_RW, prec=PREC_F32, use_values=True):
+    """-> dict(rowsum fp32[N], cnt int32[N], dinv fp32[N], dinv64 fp64[N]) ; wdg_degree_norm."""
+    dev = g.device
+    n = g.n_rows
+    out = dict(rowsum=torch.empty(n, dtype=torch.float32, device=dev), cnt=torch.empty(n, dtype=torch.int32, device=dev),
+               dinv=torch.empty(n, dtype=torch.float32, device=dev), dinv64=torch.empty(n, dtype=torch.float64, device=dev))
+    val = g.val if use_values else None
+    check(lib.wdg_degree_norm(_ptr(g.rowptr), _ptr(val), n, mode, prec, _ptr(out["rowsum"]), _ptr(out["cnt"]),
+                              _ptr(out["dinv"]), _ptr(out["dinv64"]), stream_handle()), "wdg_degree_norm")
+    return out
+
+
+def normalise_values(g, mode=NORM_RW, prec=PREC_F32):
+    """A_hat's stored values as the reference materialises them (D^-1 A or D^-1/2 A D^-1/2) -> new CsrGraph."""
+    d = degree_norm(g, mode, prec)
+    out = torch.empty(g.nnz, dtype=torch.float32, device=g.device)
+    check(lib.wdg_normalise_values(_ptr(g.rowptr), _ptr(g.col), _ptr(g.val), g.n_rows, mode, prec, _ptr(d["dinv"]),
+                                   _ptr(d["dinv64"]), _ptr(out), stream_handle()), "wdg_normalise_values")
+    return g.with_values(out)
+
+
+def row_l1_normalise(x, use_abs=False):
+    dev = require_gpu()
+    x = _dev(x, torch.float32, dev)
+    y = torch.empty_like(x)
+    check(lib.wdg_row_l1_normalise_f32(_ptr(x), x.stride(0), _ptr(y), y.stride(0), x.shape[0], x.shape[1],
+                                       int(use_abs), stream_handle()), "wdg_row_l1_normalise_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------------------- aggregation
+def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
+    job.rowptr, job.col = g.rowptr.data_ptr(), g.col.data_ptr()
+    job.val = g.val.data_ptr() if (use_values and g.val is not None) else 0
+    job.row_scale = 0 if row_scale is None else row_scale.data_ptr()
+    job.col_scale = 0 if col_scale is None else col_scale.data_ptr()
+    job.X, job.Y = x.data_ptr(), y.data_ptr()
+    job.ldx, job.ldy = x.stride(0), y.stride(0)
+    job.n_rows, job.n_cols, job.n_feat = g.n_rows, g.n_cols, x.shape[1]
+    job.reserved = 0
+    return job
+
+
+def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
+    """Y = diag(row_scale) A diag(col_scale) X on the GPU (wdg_spmm_csr_f32 / _bf16 by x.dtype)."""
+    dev = require_gpu()
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.to(torch.float32)
+    x = x.to(dev)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    if x.shape[0] != g.n_cols:
+        raise ValueError(f"spmm: X has {x.shape[0]} rows, adjacency has {g.n_cols} columns")
+    y = out if out is not None else torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=dev)
+    row_scale, col_scale = _dev(row_scale, torch.float32, dev), _dev(col_scale, torch.float32, dev)
+    job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values)
+    fn = lib.wdg_spmm_csr_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_csr_f32
+    check(fn(ctypes.byref(job), stream_handle()), "wdg_spmm_csr")
+    return y
+
+
+class SpmmBatch:
+    """Job table for wdg_spmm_batched_f32: many graphs, one launch.  Built once, launched many times."""
+
+    def __init__(self, entries):
+        """entries: list of (CsrGraph, X, Y, row_scale|None, col_scale|None, use_values)."""
+        dev = require_gpu()
+        self.keep = entries  # tensors must outlive the table
+        arr = (SpmmJob * len(entries))()
+        self.max_rows = self.max_cols = self.max_feat = 0
+        for job, (g, x, y, rs, cs, uv) in zip(arr, entries):
+            if x.dtype != torch.float32 or x.stride(1) != 1:
+                raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
+            _fill_job(job, g, x, y, rs, cs, uv)
+            self.max_rows, self.max_cols = max(self.max_rows, g.n_rows), max(self.max_cols, g.n_cols)
+            self.max_feat = max(self.max_feat, x.shape[1])
+        self.n_jobs = len(entries)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
+        self.table = host.to(dev)
+        self.edges = sum(e[0].nnz for e in entries)
+
+    def launch(self):
+        check(lib.wdg_spmm_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, self.max_cols, self.max_feat,
+                                       stream_handle()), "wdg_spmm_batched_f32")
+
+
+def spmm_plan(n_rows, n_cols, n_feat):
+    slab, threads = ctypes.c_int(0), ctypes.c_int(0)
+    fam = lib.wdg_spmm_plan(n_rows, n_cols, n_feat, ctypes.byref(slab), ctypes.byref(threads))
+    return fam, slab.value, threads.value
+
+
+# ------------------------------------------------------------------------------------------- edge/label stats
+def edge_label_stats(g, labels, n_classes=None, per_row=True):
+    """One pass over the pattern -> dict of exact integer tensors (see wdg_edge_label_stats)."""
+    dev = g.device
+    labels = _dev(labels, torch.int32, dev)
+    if labels.shape[0] != g.n_rows:
+        raise ValueError("edge_label_stats: one label per node expected")
+    c = int(n_classes) if n_classes is not None else (int(labels.max().item()) + 1 if labels.numel() else 0)
+    n = g.n_rows
+    st = dict(totals=torch.empty(6, dtype=torch.int64, device=dev),
+              compat=torch.empty((c, c), dtype=torch.int64, device=dev),
+              classdeg=torch.empty(c, dtype=torch.int64, device=dev))
+    if per_row:
+        for k in ("row_nnz", "row_nnz_noself", "row_match_noself"):
+            st[k] = torch.empty(n, dtype=torch.int32, device=dev)
+    check(lib.wdg_edge_label_stats(_ptr(g.rowptr), _ptr(g.col), _ptr(labels), n, c, _ptr(st["totals"]),
+                                   _ptr(st.get("row_nnz")), _ptr(st.get("row_nnz_noself")),
+                                   _ptr(st.get("row_match_noself")), _ptr(st["compat"]), _ptr(st["classdeg"]),
+                                   stream_handle()), "wdg_edge_label_stats")
+    st["n_classes"] = c
+    return st
+
+
+class StatsBatch:
+    """Job table for wdg_edge_label_stats_batched; outputs live in pooled tensors zeroed by one memset."""
+
+    def __init__(self, graphs, labels_list, n_classes):
+        dev = require_gpu()
+        self.n_jobs, self.c = len(graphs), int(n_classes)
+        c = self.c
+        self.totals = torch.zeros((self.n_jobs, 6), dtype=torch.int64, device=dev)
+        self.compat = torch.zeros((self.n_jobs, c, c), dtype=torch.int64, device=dev)
+        self.classdeg = torch.zeros((self.n_jobs, c), dtype=torch.int64, device=dev)
+        self.max_rows = max([g.n_rows for g in graphs], default=0)
+        self.rows = torch.zeros((self.n_jobs, 3, max(self.max_rows, 1)), dtype=torch.int32, device=dev)
+        self.labels = [_dev(l, torch.int32, dev) for l in labels_list]
+        self.keep = graphs
+        arr = (StatsJob * self.n_jobs)()
+        for i, (job, g) in enumerate(zip(arr, graphs)):
+            job.rowptr, job.col, job.labels = g.rowptr.data_ptr(), g.col.data_ptr(), self.labels[i].data_ptr()
+            job.totals, job.compat, job.classdeg = (self.totals[i].data_ptr(), self.compat[i].data_ptr(),
+                                                    self.classdeg[i].data_ptr())
+            job.row_nnz, job.row_nnz_noself, job.row_match_noself = (self.rows[i, 0].data_ptr(), self.rows[i, 1].data_ptr(),
+                                                                     self.rows[i, 2].data_ptr())
+            job.n_rows, job.n_classes = g.n_rows, c
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
+        self.table = host.to(dev)
+
+    def launch(self):
+        self.totals.zero_()
+        self.compat.zero_()
+        self.classdeg.zero_()
+        check(lib.wdg_edge_label_stats_batched(_ptr(self.table), self.n_jobs, self.max_rows, self.c, stream_handle()),
+              "wdg_edge_label_stats_batched")
+
+
+# ------------------------------------------------------------------------------------------- LAS
+def las(h, labels, n_classes, rows=None, want_weights=False):
+    """-> (soft_count, hard_count, n, W|None): device-side label-aggregation similarity (wdg_las_f32)."""
+    dev = require_gpu()
+    h = _dev(h, torch.float32, dev)
+    labels = _dev(labels, torch.int32, dev)
+    rows = _dev(rows, torch.int32, dev)
+    n = int(rows.shape[0]) if rows is not None else int(h.shape[0])
+    f, c = int(h.shape[1]), int(n_classes)
+    w = torch.empty((n, c), dtype=torch.float64, device=dev) if want_weights else None
+    cnt = torch.empty(2, dtype=torch.int64, device=dev)
+    ws_bytes = lib.wdg_las_workspace_bytes(n, f, c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.wdg_las_f32(_ptr(h), h.stride(0), _ptr(labels), _ptr(rows), n, f, c, _ptr(w), _ptr(cnt), _ptr(ws), ws_bytes,
+                          stream_handle()), "wdg_las_f32")
+    return cnt, n, w
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def gemm(a, b, bias=None, relu=False, transb=False, out=None):
+    """act(A @ B + bias) (or A @ B^T with transb) in exact fp32 on the MFMA pipe (wdg_gemm_f32)."""
+    dev = require_gpu()
+    a, b, bias = _dev(a, torch.float32, dev), _dev(b, torch.float32, dev), _dev(bias, torch.float32, dev)
+    m, k = a.shape
+    n = b.shape[0] if transb else b.shape[1]
+    if (b.shape[1] if transb else b.shape[0]) != k:
+        raise ValueError("gemm: inner dimensions differ")
+    c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
+    check(lib.wdg_gemm_f32(_ptr(a), a.stride(0), _ptr(b), b.stride(0), int(transb), _ptr(bias),
+                           ACT_RELU if relu else ACT_NONE, _ptr(c), c.stride(0), m, n, k, stream_handle()),
+          "wdg_gemm_f32")
+    return c

@@ -1,0 +1,168 @@
+"""Homophily sweep driver: many independent (h, seed) graphs per launch, sharded over GPUs.
+
+Counterpart of the loop body of the reference's `synthetic_plot.py:64-137`: a job is
+one synthetic graph (homophily level h, seed s) with the feature matrix of its seed; the per-job work is
+  degree / normalisation -> A_hat X aggregation -> edge/label statistics -> metric scalars.
+The reference runs the jobs one after another in one Python process; here every stage is ONE batched kernel
+launch over all jobs resident on the GPU (job tables in device memory), and the job list is sharded statically
+over ranks (one process per GPU).  Jobs are independent, so the data path has no collective; ranks exchange
+only the job table (broadcast from rank 0) and the per-job result rows (all_gather) through torch.distributed
+(RCCL over xGMI on a GPU node, gloo in the CPU tests).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import synth
+
+METRIC_NAMES = ("edge_homo", "node_homo", "class_homo", "adj_homo", "label_info")
+
+
+@dataclass(frozen=True)
+class Job:
+    h: float
+    seed: int
+    k: int = 2
+    n_nodes: int = 2000
+    n_classes: int = 5
+
+    @property
+    def nnz(self):  # stored entries of A + I
+        return self.n_nodes * (synth.out_degree(self.k, self.h) + 1)
+
+
+def make_jobs(h_levels, seeds, k=2, n_nodes=2000, n_classes=5):
+    """seed-major order: the jobs of one seed (which share a feature matrix) are adjacent."""
+    return [Job(float(h), int(s), k, n_nodes, n_classes) for s in seeds for h in h_levels]
+
+
+def shard_jobs(jobs, world_size, rank):
+    """Static partition: whole seeds (= groups sharing X) are dealt to the least-loaded rank by stored entries
+    (longest-processing-time first); deterministic, identical on every rank."""
+    groups = {}
+    for j in jobs:
+        groups.setdefault(j.seed, []).append(j)
+    order = sorted(groups, key=lambda s: (-sum(j.nnz for j in groups[s]), s))
+    load = [0] * world_size
+    mine = []
+    for s in order:
+        r = min(range(world_size), key=lambda i: (load[i], i))
+        load[r] += sum(j.nnz for j in groups[s])
+        if r == rank:
+            mine.extend(groups[s])
+    return sorted(mine, key=lambda j: (j.seed, jobs.index(j)))
+
+
+def encode_jobs(jobs):
+    return torch.tensor([[j.h, j.seed, j.k, j.n_nodes, j.n_classes] for j in jobs], dtype=torch.float64).reshape(-1, 5)
+
+
+def decode_jobs(t):
+    return [Job(float(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4])) for r in t.tolist()]
+
+
+def broadcast_jobs(jobs, device):
+    """rank 0's job list -> every rank (one small broadcast; RCCL on GPUs, gloo on CPU)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return jobs
+    n = torch.tensor([len(jobs) if dist.get_rank() == 0 else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, 0)
+    table = encode_jobs(jobs).to(device) if dist.get_rank() == 0 else torch.empty((int(n.item()), 5), dtype=torch.float64, device=device)
+    dist.broadcast(table, 0)
+    return decode_jobs(table.cpu())
+
+
+def gather_results(local_rows, device):
+    """[jobs_local, M] result rows of every rank -> list of per-rank tensors on every rank (all_gather, KBs)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local_rows]
+    ws = dist.get_world_size()
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(ws)]
+    dist.all_gather(counts, torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=device))
+    m = max(int(c.item()) for c in counts)
+    pad = torch.zeros((m, local_rows.shape[1]), dtype=local_rows.dtype, device=device)
+    pad[: local_rows.shape[0]] = local_rows.to(device)
+    out = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(out, pad)
+    return [o[: int(c.item())] for o, c in zip(out, counts)]
+
+
+class SweepBatch:
+    """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
+
+    def __init__(self, jobs, n_feat=500, symmetric=0):
+        from . import ops
+        self.ops = ops
+        self.jobs = list(jobs)
+        dev = ops.require_gpu()
+        self.n_feat = n_feat
+        feats, self.graphs, self.dinv, self.labels, self.y = {}, [], [], [], []
+        for j in self.jobs:
+            if j.seed not in feats:
+                feats[j.seed] = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed)).to(dev)
+            src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+            g = ops.CsrGraph.from_coo(src, dst, j.n_nodes, None, ops.COO_ADD_SELF_LOOPS)  # A + I (synthetic_plot.py:92)
+            d = ops.degree_norm(g, ops.NORM_SYM if symmetric else ops.NORM_RW, ops.PREC_F32, use_values=True)["dinv"]
+            self.graphs.append(g)
+            self.dinv.append(d)
+            self.labels.append(torch.from_numpy(lab).to(dev).to(torch.int32))
+            self.y.append(torch.empty((j.n_nodes, n_feat), dtype=torch.float32, device=dev))
+        self.x = feats
+        # A + I has unit values except a doubled pre-existing loop; the generator emits no loops -> pattern only
+        entries = [(g, self.x[j.seed], y, d, d if symmetric else None, False)
+                   for j, g, y, d in zip(self.jobs, self.graphs, self.y, self.dinv)]
+        self.spmm = ops.SpmmBatch(entries)
+        n_classes = max([j.n_classes for j in self.jobs], default=0)
+        self.stats = ops.StatsBatch(self.graphs, self.labels, n_classes)
+        self.edges = sum(g.nnz for g in self.graphs)
+
+    # -- bytes the aggregation must move (fused normalisation: no `val`, + dinv) ---------------
+    def spmm_algorithmic_bytes(self):
+        tot = 0
+        for g in self.graphs:
+            n, e, f = g.n_rows, g.nnz, self.n_feat
+            tot += 4 * (n + 1) + 4 * e + 4 * n + 4 * n * f + 4 * n * f
+        return tot
+
+    def spmm_unique_bytes(self):
+        """same, counting each distinct feature matrix once (graphs of one seed share X)"""
+        tot = sum(4 * x.numel() for x in self.x.values())
+        for g in self.graphs:
+            tot += 4 * (g.n_rows + 1) + 4 * g.nnz + 4 * g.n_rows + 4 * g.n_rows * self.n_feat
+        return tot
+
+    def step(self):
+        """one pass of the hot path over the batch: aggregation, then the integer edge/label pass"""
+        self.spmm.launch()
+        self.stats.launch()
+
+    def results(self):
+        """[jobs, len(METRIC_NAMES)] fp32: dense-flavour metric scalars (utils/homophily_plot.py) from the counters."""
+        st = self.stats
+        tot = st.totals.to(torch.float32)
+        edge = tot[:, 5] / tot[:, 4]
+        n = st.max_rows
+        nnz, noself, match = (st.rows[:, i, :].to(torch.float32) for i in range(3))
+        hs = (match + (nnz - noself)) / nnz
+        valid = nnz != 0
+        node = torch.where(valid, hs, torch.zeros_like(hs)).sum(1) / valid.sum(1)
+        k = st.compat.to(torch.float32)
+        c = k.shape[1]
+        hmat = k / k.sum(2, keepdim=True)
+        lab = torch.stack([torch.nn.functional.pad(l, (0, n - l.shape[0]), value=-1) for l in st.labels]) if st.n_jobs else torch.zeros((0, n))
+        counts = torch.stack([(lab == i).sum(1) for i in range(c)], 1).to(torch.float32)
+        prop = counts / counts.sum(1, keepdim=True)
+        terms = torch.clamp(torch.diagonal(hmat, dim1=1, dim2=2) - prop, min=0)
+        cls = torch.where(torch.isnan(terms), torch.zeros_like(terms), terms).sum(1) / (c - 1)
+        degsum = st.classdeg.sum(1, keepdim=True).to(torch.float32)
+        p_bar = st.classdeg.to(torch.float32) / degsum
+        pc = k / degsum[:, :, None]
+        p_bar = torch.where(p_bar == 0, torch.full_like(p_bar, 1e-8), p_bar)
+        pc = torch.where(pc == 0, torch.full_like(pc, 1e-8), pc)
+        s2 = (p_bar ** 2).sum(1)
+        adj = (edge - s2) / (1 - s2)
+        li = 2 - (pc * torch.log(pc)).sum((1, 2)) / (p_bar * torch.log(p_bar)).sum(1)
+        return torch.stack([edge, node, cls, adj, li], 1)
