@@ -71,7 +71,8 @@ def main():
 
     for _ in range(args.warmup):
         batch.step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sweep.gather_results(batch.results(), dev)  # untimed: first use of the tail ops loads their code objects
+    ev =[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -108,7 +109,7 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        fam, slab, threads = batch.ops.spmm_plan(args.nodes, args.nodes, args.feat)
+        fam, slab, threads = batch.ops.spmm_plan(args.nodes, args.nodes, args.feat, len(mine))
         out = {
             "metric": "aggregation edges/sec (whole job; + %HBM roofline of the SpMM kernel)",
             "value": total_edges * args.steps / elapsed,

@@ -128,8 +128,8 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
  */
 int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
                          int32_t max_feat, wdg_stream_t stream);
-/* Which kernel family a shape dispatches to (0 = LDS column-slab, 1 = row gather, 2 = narrow); for tests/bench. */
-int wdg_spmm_plan(int32_t max_rows, int32_t max_cols, int32_t n_feat, int *slab_out, int *threads_out);
+/* Which kernel family a batch of n_jobs such shapes dispatches to (0 = LDS column-slab, 1 = row gather); for tests/bench. */
+int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int *slab_out, int *threads_out);
 
 /* ------------------------------------------------------------------ edge / label statistics */
 /*

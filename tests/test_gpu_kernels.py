@@ -204,7 +204,7 @@ def test_spmm_every_slab_variant(ops, oracle, slab, threads, monkeypatch):
     monkeypatch.setenv("WDG_SPMM_SLAB", str(slab))
     monkeypatch.setenv("WDG_SPMM_THREADS", str(threads))
     rng = np.random.default_rng(slab)
-    n, f, e = 1100, 203, 15000
+    n, f, e = 900, 203, 15000  # 900 x 32 floats still fits the LDS next to the index staging buffers
     src, dst = _rand_graph(rng, n, e)
     rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
     x = rng.standard_normal((n, f)).astype(np.float32)

@@ -55,7 +55,7 @@ SIGNATURES = {
     "wdg_spmm_csr_f32": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
     "wdg_spmm_csr_bf16": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
     "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, c_int32, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "wdg_edge_label_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "wdg_edge_label_stats_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

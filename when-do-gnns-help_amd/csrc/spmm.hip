@@ -26,6 +26,23 @@ namespace {
 
 using namespace wdg;
 
+#ifdef WDG_STAMPS  // diagnostic build only (make STAMPS=1): per-workgroup phase timestamps, never in the product
+__device__ unsigned long long wdg_stamp_buf[8192 * 8];
+#define WDG_STAMP(k)                                                                        \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                        \
+            __builtin_amdgcn_s_waitcnt(0);                                                  \
+            wdg_stamp_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();         \
+        }                                                                                   \
+    } while (0)
+#else
+#define WDG_STAMP(k) do { } while (0)
+#endif
+
+#ifndef WDG_PREFETCH_DEPTH
+#define WDG_PREFETCH_DEPTH 2
+#endif
+
 struct bf16_t {
     unsigned short bits;
 };
@@ -64,53 +81,137 @@ __device__ __forceinline__ void fma4(float4 &acc, const float4 x, float w) {
     }
 }
 
-template <int G, int J, bool HAS_VAL>
-__device__ __forceinline__ void accumulate_edges(float4 &acc, const float4 *xs, int idx, float w, int q) {
-    if constexpr (J < G) {
-        const int c = group_bcast<G, J>(idx);
-        float wj = 1.0f;
-        if constexpr (HAS_VAL) wj = __int_as_float(group_bcast<G, J>(__float_as_int(w)));
-        fma4<HAS_VAL>(acc, xs[c * G + q], wj);
-        accumulate_edges<G, J + 1, HAS_VAL>(acc, xs, idx, w, q);
+// same with the source lane given as a loop variable of a fully unrolled loop (folds to one DPP move)
+template <int G>
+__device__ __forceinline__ int group_bcast_dyn(int v, int j) {
+    if constexpr (G == 1) {
+        return v;
+    } else if constexpr (G == 2) {
+        return j == 0 ? group_bcast<2, 0>(v) : group_bcast<2, 1>(v);
+    } else if constexpr (G == 4) {
+        switch (j) {
+            case 0: return group_bcast<4, 0>(v);
+            case 1: return group_bcast<4, 1>(v);
+            case 2: return group_bcast<4, 2>(v);
+            default: return group_bcast<4, 3>(v);
+        }
+    } else {
+        return __shfl(v, j, G);
     }
 }
 
-// One destination row, produced by a G-lane group (lane q of the group owns features 4q..4q+3 of the slab).
-template <int G, bool HAS_VAL>
-__device__ __forceinline__ float4 aggregate_row(const float4 *xs, const int32_t *__restrict__ col,
-                                                const float *__restrict__ val, int start, int end, int q,
-                                                int zero_row) {
-    constexpr int UNR = (G >= 4) ? 1 : 4 / G;  // edges per iteration = G*UNR >= 4
-    constexpr int EPI = G * UNR;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int idx[UNR];
-    float w[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-        const int pp = start + u * G + q;
-        const bool ok = pp < end;
-        idx[u] = ok ? col[pp] : zero_row;
-        w[u] = (HAS_VAL && ok) ? val[pp] : 0.f;
-    }
-    for (int p = start; p < end; p += EPI) {
-        int nidx[UNR];
-        float nw[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {  // prefetch the next group of indices while this one hits LDS
-            const int pp = p + EPI + u * G + q;
-            const bool ok = pp < end;
-            nidx[u] = ok ? col[pp] : zero_row;
-            nw[u] = (HAS_VAL && ok) ? val[pp] : 0.f;
+int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
+// Where a finished row goes: scale, then one 16-byte store per lane (or guarded scalar stores on ragged tails).
+struct RowSink {
+    float *Y;
+    const float *row_scale;  // LDS copy (n_rows floats) or nullptr
+    int64_t ldy;
+    int f, F;
+    bool vec;
+    float4 *stage;  // experiment: finished rows parked in LDS, stored after the stream (no store in the load stream)
+    int gq;         // G-relative position of this lane: stage index = row * G + q
+    int G_;
+    __device__ __forceinline__ void put(int row, float4 acc) const {
+        if (row_scale) {
+            const float s = row_scale[row];
+            acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
         }
+        if (stage) {
+            stage[row * G_ + gq] = acc;
+            return;
+        }
+        float *dst = Y + static_cast<int64_t>(row) * ldy + f;
+        if (vec) {
+            *reinterpret_cast<float4 *>(dst) = acc;
+        } else {
+            if (f + 0 < F) dst[0] = acc.x;
+            if (f + 1 < F) dst[1] = acc.y;
+            if (f + 2 < F) dst[2] = acc.z;
+            if (f + 3 < F) dst[3] = acc.w;
+        }
+    }
+};
+
+// A G-lane group (lane q owns features 4q..4q+3 of the slab) produces the CONSECUTIVE rows [row, row_last).
+// Their CSR segments form one contiguous index stream [rp[row], rp[row_last]): the group walks it in steps of
+// EPI entries with the next two steps' indices already in flight, and emits a row whenever the stream crosses a
+// row boundary (row pointers come from LDS).  The dependent chain rowptr -> col -> LDS -> store is thus paid once
+// per group instead of once per row - the kernel is latency-bound otherwise (72 % of wave cycles in s_waitcnt).
+template <int G, bool HAS_VAL>
+__device__ __forceinline__ void aggregate_rows(const float4 *xs, const int *rp, const int32_t *__restrict__ col,
+                                               const float *__restrict__ val, int row, int row_last, int q,
+                                               int zero_row, const RowSink &sink) {
+    constexpr int UNR = (G >= 4) ? 1 : 4 / G;  // entries per step = G*UNR >= 4
+    constexpr int EPI = G * UNR;
+    if (row >= row_last) return;
+    int p = rp[row];
+    const int p_end = rp[row_last];
+    int row_end = rp[row + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int D = WDG_PREFETCH_DEPTH;  // steps of indices in flight ahead of the one being consumed
+    int ring[D][UNR];
+    float wring[D][UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) accumulate_edges<G, 0, HAS_VAL>(acc, xs, idx[u], w[u], q);
+    for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            idx[u] = nidx[u];
-            w[u] = nw[u];
+            const int pp = p + d * EPI + u * G + q;
+            ring[d][u] = pp < p_end ? col[pp] : zero_row;
+            wring[d][u] = (HAS_VAL && pp < p_end) ? val[pp] : 0.f;
+        }
+    while (p < p_end) {
+        int inew[UNR];
+        float wnew[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {  // D steps ahead
+            const int pc = p + D * EPI + u * G + q;
+            inew[u] = pc < p_end ? col[pc] : zero_row;
+            wnew[u] = (HAS_VAL && pc < p_end) ? val[pc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int cj[G];
+            float wj[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                cj[j] = group_bcast_dyn<G>(ring[0][u], j);
+                wj[j] = HAS_VAL ? __int_as_float(group_bcast_dyn<G>(__float_as_int(wring[0][u]), j)) : 1.f;
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int e = p + u * G + j;
+                while (e == row_end && row < row_last) {  // row boundary (loops over empty rows)
+                    sink.put(row, acc);
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ++row;
+                    row_end = rp[min(row + 1, row_last)];
+                }
+                fma4<HAS_VAL>(acc, xs[cj[j] * G + q], wj[j]);  // entries past p_end hit the zero row
+            }
+        }
+        p += EPI;
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                ring[d][u] = ring[d + 1][u];
+                wring[d][u] = wring[d + 1][u];
+            }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            ring[D - 1][u] = inew[u];
+            wring[D - 1][u] = wnew[u];
         }
     }
-    return acc;
+    while (row < row_last) {  // last row of the stream, and any empty rows behind it
+        sink.put(row, acc);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        ++row;
+    }
 }
 
 template <int SLAB, int THREADS, typename TIN>
@@ -119,8 +220,9 @@ __global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *
                                                             long long n_items) {
     constexpr int G = SLAB / 4;             // lanes per destination row
     constexpr int GROUPS = THREADS / G;     // destination rows in flight per workgroup
-    extern __shared__ float4 xs[];          // [(n_cols + 1) * G] float4; last row = zeros
+    extern __shared__ float4 xs[];          // [(n_cols + 1) * G] float4 (last row = zeros), then int rp[n_rows + 1]
 
+    WDG_STAMP(0);
     const long long item = xcd_contiguous_item(blockIdx.x, n_items);
     if (item >= n_items) return;
     const int job_id = static_cast<int>(item / n_slabs);
@@ -138,7 +240,7 @@ __global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *
     for (int i = tid; i < (n_cols + 1) * G; i += THREADS) {
         const int r = i / G, q = i % G;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < n_cols) {
+        if (r < n_cols && !(job.reserved & 2)) {  // reserved bits: timing-only ablation switches (diagnostics)
             const TIN *src = X + static_cast<int64_t>(r) * job.ldx + f0 + q * 4;
             if (vec_ok) {
                 v = *reinterpret_cast<const float4 *>(src);
@@ -156,28 +258,46 @@ __global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *
         }
         xs[i] = v;
     }
+    int *rp = reinterpret_cast<int *>(xs + static_cast<size_t>(n_cols + 1) * G);  // row pointers, [n_rows + 1]
+    for (int i = tid; i <= n_rows; i += THREADS) rp[i] = job.rowptr[i];
+    // row scale staged too: a global load per finished row would sit in the stream's dependency chain
+    float *rs = reinterpret_cast<float *>(rp + ((n_rows + 1 + 3) & ~3));
+    if (job.row_scale)
+        for (int i = tid; i < n_rows; i += THREADS) rs[i] = job.row_scale[i];
+    WDG_STAMP(1);
     __syncthreads();
+    WDG_STAMP(2);
 
-    // ---- stage 2: every destination row = CSR-ordered sum of LDS rows
-    const int q = tid % G;
-    const bool y_vec = full && (job.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.Y) & 15) == 0);
-    for (int row = tid / G; row < n_rows; row += GROUPS) {
-        const int start = job.rowptr[row], end = job.rowptr[row + 1];
-        float4 acc = job.val ? aggregate_row<G, true>(xs, job.col, job.val, start, end, q, n_cols)
-                             : aggregate_row<G, false>(xs, job.col, nullptr, start, end, q, n_cols);
-        if (job.row_scale) {
-            const float s = job.row_scale[row];
-            acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
-        }
-        float *dst = job.Y + static_cast<int64_t>(row) * job.ldy + f0 + q * 4;
-        if (y_vec) {
-            *reinterpret_cast<float4 *>(dst) = acc;
-        } else {
-            const int f = f0 + q * 4;
-            if (f + 0 < F) dst[0] = acc.x;
-            if (f + 1 < F) dst[1] = acc.y;
-            if (f + 2 < F) dst[2] = acc.z;
-            if (f + 3 < F) dst[3] = acc.w;
+    // ---- stage 2: every destination row = CSR-ordered sum of LDS rows; a group owns a run of consecutive rows
+    const int q = tid % G, grp = tid / G;
+    const int rows_per_group = (n_rows + GROUPS - 1) / GROUPS;
+    const int row0 = min(grp * rows_per_group, n_rows), row1 = min(row0 + rows_per_group, n_rows);
+    RowSink sink;
+    sink.Y = job.Y;
+    sink.row_scale = job.row_scale ? rs : nullptr;
+    sink.ldy = job.ldy;
+    sink.f = f0 + q * 4;
+    sink.F = F;
+    sink.vec = full && (job.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.Y) & 15) == 0);
+    const bool defer = (job.reserved & 8) != 0;  // experiment switch: needs LDS room for n_rows * SLAB * 4 more bytes
+    float4 *ystage = reinterpret_cast<float4 *>(rs + ((n_rows + 3) & ~3));
+    sink.stage = defer ? ystage : nullptr;
+    sink.gq = q;
+    sink.G_ = G;
+    if (job.val) aggregate_rows<G, true>(xs, rp, job.col, job.val, row0, row1, q, n_cols, sink);
+    else aggregate_rows<G, false>(xs, rp, job.col, nullptr, row0, row1, q, n_cols, sink);
+    WDG_STAMP(3);
+#ifdef WDG_STAMPS
+    __syncthreads();
+    WDG_STAMP(4);
+#endif
+    if (defer) {
+        __syncthreads();
+        sink.stage = nullptr;
+        sink.row_scale = nullptr;
+        for (int i = tid; i < n_rows * G; i += THREADS) {
+            sink.f = f0 + (i % G) * 4;
+            sink.put(i / G, ystage[i]);
         }
     }
 }
@@ -261,15 +381,13 @@ struct Plan {
     int threads;  // slab family: workgroup size; gather: VEC
 };
 
-int env_int(const char *name, int dflt) {
-    const char *s = getenv(name);
-    return s ? atoi(s) : dflt;
-}
 
 Plan make_plan(int max_rows, int max_cols, int n_feat, int n_jobs) {
     Plan p{};
-    const int64_t budget_two = 80 * 1024 - 256;   // two workgroups per CU
-    const int64_t budget_one = kLdsBytes - 512;   // one workgroup per CU
+    // LDS per workgroup = feature slab + the graph's row pointers
+    const int64_t rp_bytes = (static_cast<int64_t>(max_rows) + 1) * 8 + 32;  // row pointers + row scales
+    const int64_t budget_two = 80 * 1024 - 256 - rp_bytes;   // two workgroups per CU
+    const int64_t budget_one = kLdsBytes - 512 - rp_bytes;   // one workgroup per CU
     const int64_t rows = static_cast<int64_t>(max_cols) + 1;
     const int forced = env_int("WDG_SPMM_SLAB", 0);
     if (rows * 16 <= budget_one && env_int("WDG_SPMM_FORCE_GATHER", 0) == 0) {
@@ -305,11 +423,12 @@ Plan make_plan(int max_rows, int max_cols, int n_feat, int n_jobs) {
 }
 
 template <int SLAB, int THREADS, typename TIN>
-int launch_slab(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_cols, int max_feat,
-                hipStream_t st) {
+int launch_slab(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
+                int max_feat, hipStream_t st) {
     const int n_slabs = static_cast<int>(ceil_div(max_feat, SLAB));
     const int64_t n_items = static_cast<int64_t>(n_jobs) * n_slabs;
-    const size_t lds = static_cast<size_t>(max_cols + 1) * SLAB * 4;
+    size_t lds = static_cast<size_t>(max_cols + 1) * SLAB * 4 + (static_cast<size_t>(max_rows) + 1) * 8 + 32;
+    if (env_int("WDG_SPMM_ABLATE", 0) & 8) lds += static_cast<size_t>(max_rows) * SLAB * 4 + 16;  // experiment: Y staging
     auto kern = spmm_slab_kernel<SLAB, THREADS, TIN>;
     static thread_local size_t configured = 0;
     if (lds > configured) {
@@ -343,7 +462,7 @@ int dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int 
     const Plan p = make_plan(max_rows, max_cols, max_feat, n_jobs);
     if (p.family == 0) {
 #define WDG_SLAB_CASE(S, T) \
-    if (p.slab == S && p.threads == T) return launch_slab<S, T, TIN>(jobs, inl, n_jobs, max_cols, max_feat, st);
+    if (p.slab == S && p.threads == T) return launch_slab<S, T, TIN>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, st);
         WDG_SLAB_CASE(4, 512) WDG_SLAB_CASE(4, 1024) WDG_SLAB_CASE(8, 512) WDG_SLAB_CASE(8, 1024)
         WDG_SLAB_CASE(16, 512) WDG_SLAB_CASE(16, 1024) WDG_SLAB_CASE(32, 512) WDG_SLAB_CASE(32, 1024)
 #undef WDG_SLAB_CASE
@@ -380,6 +499,12 @@ int single(const wdg_spmm_job *job_host, wdg_stream_t stream) {
 
 extern "C" {
 
+#ifdef WDG_STAMPS
+int wdg_debug_stamps(unsigned long long *host_out, int n_blocks) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wdg_stamp_buf), sizeof(unsigned long long) * 8 * n_blocks) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream) { return single<float>(job_host, stream); }
 
 int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream) { return single<bf16_t>(job_host, stream); }
@@ -391,8 +516,9 @@ int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t m
     return dispatch<float>(jobs_dev, wdg_spmm_job{}, n_jobs, max_rows, max_cols, max_feat, as_stream(stream));
 }
 
-int wdg_spmm_plan(int32_t max_rows, int32_t max_cols, int32_t n_feat, int *slab_out, int *threads_out) {
-    const Plan p = make_plan(max_rows, max_cols, n_feat, 1);
+int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int *slab_out,
+                  int *threads_out) {
+    const Plan p = make_plan(max_rows, max_cols, n_feat, n_jobs > 0 ? n_jobs : 1);
     if (slab_out) *slab_out = p.slab;
     if (threads_out) *threads_out = p.threads;
     return p.family;

@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, the current HIP stream); every computat
 gfx950 kernel in csrc/.  Nothing in this file runs on the CPU, and nothing falls back.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -181,7 +182,7 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     job.X, job.Y = x.data_ptr(), y.data_ptr()
     job.ldx, job.ldy = x.stride(0), y.stride(0)
     job.n_rows, job.n_cols, job.n_feat = g.n_rows, g.n_cols, x.shape[1]
-    job.reserved = 0
+    job.reserved = int(os.environ.get("WDG_SPMM_ABLATE", "0"))  # diagnostics only (timing ablations)
     return job
 
 
@@ -228,9 +229,9 @@ class SpmmBatch:
                                        stream_handle()), "wdg_spmm_batched_f32")
 
 
-def spmm_plan(n_rows, n_cols, n_feat):
+def spmm_plan(n_rows, n_cols, n_feat, n_jobs=1):
     slab, threads = ctypes.c_int(0), ctypes.c_int(0)
-    fam = lib.wdg_spmm_plan(n_rows, n_cols, n_feat, ctypes.byref(slab), ctypes.byref(threads))
+    fam = lib.wdg_spmm_plan(n_jobs, n_rows, n_cols, n_feat, ctypes.byref(slab), ctypes.byref(threads))
     return fam, slab.value, threads.value
 
 
