@@ -109,7 +109,9 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        fam, slab, threads = batch.ops.spmm_plan(args.nodes, args.nodes, args.feat, len(mine))
+        fam, slab, threads = batch.spmm.plan()
+        kernel_name = {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
+                       2: f"spmm_rowlane_kernel<{slab // 4},{(args.nodes + 1023) // 1024},float,false>"}[fam]
         out = {
             "metric": "aggregation edges/sec (whole job; + %HBM roofline of the SpMM kernel)",
             "value": total_edges * args.steps / elapsed,
@@ -128,7 +130,7 @@ def main():
             "edge_features_per_s": total_edges * args.feat * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"spmm_slab_kernel<{slab},{threads},float>" if fam == 0 else "spmm_gather_kernel",
+                         "kernel": kernel_name,
                          "avg_launch_us": spmm_avg_ms * 1e3, "median_launch_us": spmm_ms[len(spmm_ms) // 2] * 1e3,
                          "algorithmic_bytes_per_launch": alg, "unique_bytes_per_launch": batch.spmm_unique_bytes(),
                          "launches_timed": len(spmm_ms)},

@@ -42,14 +42,14 @@ def test_host_side_queries_need_no_gpu():
     assert L.lib.wdg_coo_to_csr_workspace_bytes(1000, 100, 0) > 1000 * 8
     assert L.lib.wdg_las_workspace_bytes(1000, 5, 5) > 0
     slab, thr = ctypes.c_int(), ctypes.c_int()
-    assert L.lib.wdg_spmm_plan(1, 2000, 2000, 500, ctypes.byref(slab), ctypes.byref(thr)) == 0  # LDS slab family
+    assert L.lib.wdg_spmm_plan(1, 2000, 2000, 500, 0, ctypes.byref(slab), ctypes.byref(thr)) == 0  # LDS slab family
     assert slab.value in (4, 8, 16, 32) and thr.value in (512, 1024)
-    assert L.lib.wdg_spmm_plan(1, 200000, 200000, 7, ctypes.byref(slab), ctypes.byref(thr)) == 1  # row gather
+    assert L.lib.wdg_spmm_plan(1, 200000, 200000, 7, 0, ctypes.byref(slab), ctypes.byref(thr)) == 1  # row gather
 
 
 def test_struct_layout_matches_header():
     import wdg_amd._lib as L
-    assert ctypes.sizeof(L.SpmmJob) == 7 * 8 + 2 * 8 + 4 * 4
+    assert ctypes.sizeof(L.SpmmJob) == 7 * 8 + 2 * 8 + 4 * 4 + 3 * 8 + 2 * 4
     assert ctypes.sizeof(L.StatsJob) == 9 * 8 + 2 * 4
 
 

@@ -185,8 +185,9 @@ def _check_spmm(ops, oracle, rowptr, col, val, x, row_scale=None, col_scale=None
 
 @pytest.mark.parametrize("n,f,e", [(2000, 500, 20000), (2000, 500, 82000), (2708, 1433, 13264), (500, 5, 3000),
                                    (300, 64, 5000), (1200, 33, 9000), (4000, 128, 60000), (5201, 131, 50000),
-                                   (1, 1, 1), (64, 3, 0), (9000, 20, 40000)])
-def test_spmm_slab_family_shapes(ops, oracle, n, f, e):
+                                   (1, 1, 1), (64, 3, 0), (5000, 20, 40000)])
+def test_spmm_slab_family_shapes(ops, oracle, n, f, e, monkeypatch):
+    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")  # keep the column-slab kernel covered
     rng = np.random.default_rng(n + f)
     src, dst = _rand_graph(rng, n, e)
     rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
@@ -201,6 +202,7 @@ def test_spmm_slab_family_shapes(ops, oracle, n, f, e):
 @pytest.mark.parametrize("slab", [4, 8, 16, 32])
 @pytest.mark.parametrize("threads", [512, 1024])
 def test_spmm_every_slab_variant(ops, oracle, slab, threads, monkeypatch):
+    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")
     monkeypatch.setenv("WDG_SPMM_SLAB", str(slab))
     monkeypatch.setenv("WDG_SPMM_THREADS", str(threads))
     rng = np.random.default_rng(slab)
@@ -342,8 +344,91 @@ def test_spmm_full_size_properties(ops):
     assert all(torch.equal(a, e[2]) for a, e in zip(first, entries))
 
 
+# --------------------------------------------------------------------------------------------- SELL-64 + row-lane kernel
+def test_sell_layout_matches_csr(ops, oracle):
+    rng = np.random.default_rng(31)
+    for n, e in ((1, 1), (64, 500), (65, 700), (2000, 20000), (4096, 9000), (130, 0)):
+        src, dst = _rand_graph(rng, n, e)
+        rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, n)
+        if not g.ensure_sell(max_padding=1e9):
+            assert col.shape[0] == 0
+            continue
+        sp, sc, sv = (_np(t) for t in g.sell[:3])
+        bc, nb = g.sell[3], g.sell[4]
+        assert nb == (n + bc - 1) // bc and bc * 128 <= 160 * 1024
+        n_slices = (n + 63) // 64
+        for b in range(nb):
+            for s in range(n_slices):
+                t = b * n_slices + s
+                rows = np.arange(s * 64, min(n, s * 64 + 64))
+                width = (sp[t + 1] - sp[t]) // 64
+                blk_c = sc[sp[t]:sp[t + 1]].reshape(width, 64)
+                blk_v = sv[sp[t]:sp[t + 1]].reshape(width, 64)
+                longest = 0
+                for r in rows:
+                    cr, vr = col[rowptr[r]:rowptr[r + 1]], val[rowptr[r]:rowptr[r + 1]]
+                    sel = (cr >= b * bc) & (cr < (b + 1) * bc)
+                    l = int(sel.sum())
+                    longest = max(longest, l)
+                    np.testing.assert_array_equal(blk_c[:l, r - s * 64], cr[sel])
+                    np.testing.assert_array_equal(blk_v[:l, r - s * 64], vr[sel])
+                    assert (blk_c[l:, r - s * 64] == 0x7fffffff).all() and (blk_v[l:, r - s * 64] == 0).all()
+                assert width == longest
+                assert (blk_c[:, rows.size:] == 0x7fffffff).all()
+
+
+@pytest.mark.parametrize("n,f,e", [(2000, 500, 20000), (2000, 500, 82000), (2708, 1433, 13264), (1000, 32, 6000),
+                                   (4096, 64, 30000), (3000, 17, 20000), (100, 8, 300), (2048, 100, 2048), (1025, 33, 9000),
+                                   (4000, 500, 100000), (64, 129, 64)])
+def test_spmm_rowlane_family_shapes(ops, oracle, n, f, e):
+    rng = np.random.default_rng(n * 7 + f)
+    src, dst = _rand_graph(rng, n, e)
+    rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, n)
+    assert g.ensure_sell(max_padding=1e9)
+    assert ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL)[0] == 2
+
+    def run(use_values, rs, cs, dtype=torch.float32):
+        xt = torch.from_numpy(x).cuda().to(dtype)
+        y = _np(ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
+                         col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values))
+        v = val.copy() if use_values else np.ones_like(val)
+        if cs is not None:
+            v = v * cs[col]
+        xr = _np(xt.float())
+        ref, ref64 = oracle.spmm_csr(rowptr, col, v, xr), oracle.spmm_csr(rowptr, col, v, xr, f64acc=True)
+        if rs is not None:
+            ref, ref64 = ref * rs[:, None], ref64 * rs[:, None]
+        scale = np.abs(ref64).max() + 1e-30
+        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(y, ref64, rtol=1e-5, atol=1e-6 * scale)
+
+    d = rng.random(n, dtype=np.float32)
+    run(True, None, None)
+    run(False, d, None)
+    run(False, d, d)
+    run(True, d, d, torch.bfloat16)
+
+
+def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch):
+    """Both LDS kernels sum a row in CSR column order: results must be bit-identical."""
+    rng = np.random.default_rng(77)
+    n, f, e = 2000, 500, 40000
+    src, dst = _rand_graph(rng, n, e)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+    x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
+    d = ops.degree_norm(g, ops.NORM_SYM)["dinv"]
+    y_rl = ops.spmm(g, x, row_scale=d, col_scale=d).clone()
+    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")
+    y_slab = ops.spmm(g, x, row_scale=d, col_scale=d)
+    assert ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL)[0] == 0
+    assert torch.equal(y_rl, y_slab)
+
+
 # --------------------------------------------------------------------------------------------- edge / label stats
-STAT_KEYS = ("totals", "row_nnz", "row_nnz_noself", "row_match_noself", "compat", "classdeg")
+STAT_KEYS =("totals", "row_nnz", "row_nnz_noself", "row_match_noself", "compat", "classdeg")
 
 
 @pytest.mark.parametrize("name", REAL + SYN)

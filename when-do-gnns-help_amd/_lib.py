@@ -25,7 +25,9 @@ class SpmmJob(ctypes.Structure):
     """mirror of `wdg_spmm_job` (include/wdg.h)"""
     _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p),
                 ("col_scale", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("ldx", c_int64), ("ldy", c_int64),
-                ("n_rows", c_int32), ("n_cols", c_int32), ("n_feat", c_int32), ("reserved", c_int32)]
+                ("n_rows", c_int32), ("n_cols", c_int32), ("n_feat", c_int32), ("reserved", c_int32),
+                ("sell_ptr", c_void_p), ("sell_col", c_void_p), ("sell_val", c_void_p),
+                ("sell_block_cols", c_int32), ("sell_n_blocks", c_int32)]
 
 
 class StatsJob(ctypes.Structure):
@@ -54,8 +56,13 @@ SIGNATURES = {
     "wdg_row_l1_normalise_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
     "wdg_spmm_csr_f32": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
     "wdg_spmm_csr_bf16": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
-    "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, c_int32, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "wdg_sell_block_cols": (c_int32, [c_int32]),
+    "wdg_sell_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "wdg_csr_to_sell_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wdg_csr_to_sell_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "wdg_edge_label_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "wdg_edge_label_stats_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

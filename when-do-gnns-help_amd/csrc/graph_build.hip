@@ -434,6 +434,13 @@ inline unsigned wave_rows_grid(int32_t N) { return static_cast<unsigned>(ceil_di
 
 }  // namespace
 
+namespace wdg {
+int exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int64_t *total64, void *ws, hipStream_t st) {
+    return exclusive_scan(in, n, out, total64, ws, st);
+}
+size_t exclusive_scan_ws_bytes(int64_t n) { return scan_ws_bytes(n); }
+}  // namespace wdg
+
 extern "C" {
 
 size_t wdg_scan_workspace_bytes(int64_t n) { return scan_ws_bytes(n + 1) + 256; }

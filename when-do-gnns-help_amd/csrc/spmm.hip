@@ -22,6 +22,12 @@
 // materialising A_hat's values (K2 fused into K1); an explicit `val` array is honoured too.
 #include "wdg_common.h"
 
+namespace wdg {  // row-lane family (spmm_rowlane.hip)
+bool rowlane_eligible(int max_rows, int max_cols, int max_feat);
+int rowlane_dispatch_f32(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
+int rowlane_dispatch_bf16(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
+}  // namespace wdg
+
 namespace {
 
 using namespace wdg;
@@ -457,8 +463,13 @@ int launch_gather(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs,
 
 template <typename TIN>
 int dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols, int max_feat,
-             hipStream_t st) {
+             int flags, hipStream_t st) {
     if (n_jobs == 0 || max_rows == 0 || max_feat == 0) return WDG_OK;
+    if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, max_feat)) {
+        const bool has_val = (flags & WDG_SPMM_ANY_VAL) != 0;
+        if (sizeof(TIN) == 4) return rowlane_dispatch_f32(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
+        return rowlane_dispatch_bf16(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
+    }
     const Plan p = make_plan(max_rows, max_cols, max_feat, n_jobs);
     if (p.family == 0) {
 #define WDG_SLAB_CASE(S, T) \
@@ -491,7 +502,10 @@ template <typename TIN>
 int single(const wdg_spmm_job *job_host, wdg_stream_t stream) {
     if (int e = validate_job(job_host)) return e;
     if (job_host->n_rows == 0 || job_host->n_feat == 0) return WDG_OK;
-    return dispatch<TIN>(nullptr, *job_host, 1, job_host->n_rows, job_host->n_cols, job_host->n_feat,
+    int flags = 0;
+    if (job_host->sell_ptr && job_host->sell_col && (!job_host->val || job_host->sell_val)) flags |= WDG_SPMM_ALL_SELL;
+    if (job_host->val) flags |= WDG_SPMM_ANY_VAL;
+    return dispatch<TIN>(nullptr, *job_host, 1, job_host->n_rows, job_host->n_cols, job_host->n_feat, flags,
                          as_stream(stream));
 }
 
@@ -510,14 +524,20 @@ int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream) { return
 int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream) { return single<bf16_t>(job_host, stream); }
 
 int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
-                         int32_t max_feat, wdg_stream_t stream) {
+                         int32_t max_feat, int flags, wdg_stream_t stream) {
     WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_cols >= 0 && max_feat >= 0, "spmm_batched: negative size");
     WDG_REQUIRE(n_jobs == 0 || jobs_dev != nullptr, "spmm_batched: null job table");
-    return dispatch<float>(jobs_dev, wdg_spmm_job{}, n_jobs, max_rows, max_cols, max_feat, as_stream(stream));
+    return dispatch<float>(jobs_dev, wdg_spmm_job{}, n_jobs, max_rows, max_cols, max_feat, flags, as_stream(stream));
 }
 
-int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int *slab_out,
+int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int flags, int *slab_out,
                   int *threads_out) {
+    if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, n_feat)) {
+        const int rpt = (max_rows + 1023) / 1024;
+        if (slab_out) *slab_out = ((rpt <= 2) && n_feat > 16) ? 32 : 16;  // features per item
+        if (threads_out) *threads_out = 1024;
+        return 2;
+    }
     const Plan p = make_plan(max_rows, max_cols, n_feat, n_jobs > 0 ? n_jobs : 1);
     if (slab_out) *slab_out = p.slab;
     if (threads_out) *threads_out = p.threads;

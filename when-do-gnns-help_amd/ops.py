@@ -39,9 +39,39 @@ class CsrGraph:
     reference gets from `.coalesce()` on a torch COO tensor, with 4-byte instead of 8-byte indices.
     """
 
+    SELL_MAX_ROWS = 4096  # the row-lane kernel keeps every row of a graph in one workgroup's registers
+
     def __init__(self, rowptr, col, val, n_rows, n_cols):
         self.rowptr, self.col, self.val = rowptr, col, val
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.sell = None  # (sell_ptr, sell_col, sell_val|None): SELL-64 copy of the pattern, built on demand
+
+    def ensure_sell(self, max_padding=3.0):
+        """Build the SELL-64 copy (wdg_csr_to_sell_*) that the row-lane SpMM consumes.  One-time per graph.
+        Skipped (returns False) for graphs too large for that kernel or whose slices would pad too much."""
+        if self.sell is not None:
+            return True
+        if self.n_rows == 0 or self.n_rows > self.SELL_MAX_ROWS or self.nnz == 0:
+            return False
+        dev = self.device
+        n_slices = (self.n_rows + 63) // 64
+        block_cols = lib.wdg_sell_block_cols(self.n_cols)
+        n_blocks = (self.n_cols + block_cols - 1) // block_cols
+        sell_ptr = torch.empty(n_slices * n_blocks + 1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.wdg_sell_workspace_bytes(self.n_rows, self.n_cols)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.wdg_csr_to_sell_count(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, _ptr(sell_ptr), _ptr(ws),
+                                        ws_bytes, stream_handle()), "wdg_csr_to_sell_count")
+        total = int(sell_ptr[-1].item())
+        if total > max_padding * self.nnz + 64 * 64 * n_blocks:
+            return False  # very skewed rows: the CSR kernels are the better fit
+        sell_col = torch.empty(total, dtype=torch.int32, device=dev)
+        sell_val = torch.empty(total, dtype=torch.float32, device=dev) if self.val is not None else None
+        check(lib.wdg_csr_to_sell_fill(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), self.n_rows, self.n_cols,
+                                       _ptr(sell_ptr), _ptr(sell_col), _ptr(sell_val), stream_handle()),
+              "wdg_csr_to_sell_fill")
+        self.sell = (sell_ptr, sell_col, sell_val, block_cols, n_blocks)
+        return True
 
     @property
     def nnz(self):
@@ -139,7 +169,7 @@ class CsrGraph:
         return torch.sparse_coo_tensor(idx, val, (self.n_rows, self.n_cols)).coalesce()
 
     def with_values(self, val):
-        return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)
+        return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)  # SELL copy (holds values) not shared
 
 
 # ------------------------------------------------------------------------------------------- normalisation
@@ -183,6 +213,14 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     job.ldx, job.ldy = x.stride(0), y.stride(0)
     job.n_rows, job.n_cols, job.n_feat = g.n_rows, g.n_cols, x.shape[1]
     job.reserved = int(os.environ.get("WDG_SPMM_ABLATE", "0"))  # diagnostics only (timing ablations)
+    wants_val = bool(job.val)
+    if g.sell is not None and (not wants_val or g.sell[2] is not None):
+        job.sell_ptr, job.sell_col = g.sell[0].data_ptr(), g.sell[1].data_ptr()
+        job.sell_val = g.sell[2].data_ptr() if (wants_val and g.sell[2] is not None) else 0
+        job.sell_block_cols, job.sell_n_blocks = g.sell[3], g.sell[4]
+    else:
+        job.sell_ptr = job.sell_col = job.sell_val = 0
+        job.sell_block_cols = job.sell_n_blocks = 0
     return job
 
 
@@ -198,6 +236,8 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
         raise ValueError(f"spmm: X has {x.shape[0]} rows, adjacency has {g.n_cols} columns")
     y = out if out is not None else torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=dev)
     row_scale, col_scale = _dev(row_scale, torch.float32, dev), _dev(col_scale, torch.float32, dev)
+    if x.shape[1] >= 8:
+        g.ensure_sell()  # one-time SELL-64 copy -> row-lane kernel for graphs of <= 4096 rows
     job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values)
     fn = lib.wdg_spmm_csr_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_csr_f32
     check(fn(ctypes.byref(job), stream_handle()), "wdg_spmm_csr")
@@ -213,25 +253,38 @@ class SpmmBatch:
         self.keep = entries  # tensors must outlive the table
         arr = (SpmmJob * len(entries))()
         self.max_rows = self.max_cols = self.max_feat = 0
+        all_sell, any_val = len(entries) > 0, False
         for job, (g, x, y, rs, cs, uv) in zip(arr, entries):
             if x.dtype != torch.float32 or x.stride(1) != 1:
                 raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
+            if x.shape[1] >= 8:
+                g.ensure_sell()
             _fill_job(job, g, x, y, rs, cs, uv)
+            all_sell = all_sell and bool(job.sell_ptr)
+            any_val = any_val or bool(job.val)
             self.max_rows, self.max_cols = max(self.max_rows, g.n_rows), max(self.max_cols, g.n_cols)
             self.max_feat = max(self.max_feat, x.shape[1])
         self.n_jobs = len(entries)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
         self.table = host.to(dev)
         self.edges = sum(e[0].nnz for e in entries)
+        self.flags = (SPMM_ALL_SELL if all_sell else 0) | (SPMM_ANY_VAL if any_val else 0)
 
     def launch(self):
         check(lib.wdg_spmm_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, self.max_cols, self.max_feat,
-                                       stream_handle()), "wdg_spmm_batched_f32")
+                                       self.flags, stream_handle()), "wdg_spmm_batched_f32")
+
+    def plan(self):
+        return spmm_plan(self.max_rows, self.max_cols, self.max_feat, self.n_jobs, self.flags)
 
 
-def spmm_plan(n_rows, n_cols, n_feat, n_jobs=1):
+SPMM_ALL_SELL, SPMM_ANY_VAL = 1, 2
+
+
+def spmm_plan(n_rows, n_cols, n_feat, n_jobs=1, flags=0):
+    """(family, width, threads): 0 = LDS column slab, 1 = row gather, 2 = row-lane (needs SPMM_ALL_SELL)."""
     slab, threads = ctypes.c_int(0), ctypes.c_int(0)
-    fam = lib.wdg_spmm_plan(n_jobs, n_rows, n_cols, n_feat, ctypes.byref(slab), ctypes.byref(threads))
+    fam = lib.wdg_spmm_plan(n_jobs, n_rows, n_cols, n_feat, flags, ctypes.byref(slab), ctypes.byref(threads))
     return fam, slab.value, threads.value
 
 
