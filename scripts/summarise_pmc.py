@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 out_dir = sys.argv[1]
-want = ("spmm_slab", "spmm_gather", "edge_stats", "gemm_f32", "las_")
+want = ("spmm_rowlane", "spmm_slab", "spmm_gather", "edge_stats", "gemm_f32", "las_")
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(out_dir, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
@@ -16,7 +16,7 @@ for path in glob.glob(os.path.join(out_dir, "*", "**", "*counter_collection.csv"
         key = next((w for w in want if w in name), None)
         if key is None:
             continue
-        short = name.split("(")[0].replace("void (anonymous namespace)::", "")
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, counters in acc.items():
