@@ -185,6 +185,17 @@ typedef struct wdg_stats_job {
 int wdg_edge_label_stats_batched(const wdg_stats_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_classes,
                                  wdg_stream_t stream);
 
+/* ------------------------------------------------------------------ per-edge cosine (SDDMM) */
+/*
+ * out[i] = cos(x_u, x_v) for stored entry e_i = (u, v) (e_i = entries[i], or i when entries == NULL); NaN -> 0;
+ * self loops give 0 when skip_self.  Replaces the dense N x N sklearn cosine matrix masked by the adjacency in
+ * generalized_edge_homophily (utils/homophily_metrics.py:164-187, utils/homophily_plot.py:56-78): only the pairs
+ * that are edges get computed.
+ */
+int wdg_edge_cosine_f32(const int32_t *rowptr, const int32_t *col, const int32_t *entries, int64_t n_entries,
+                        const float *X, int64_t ldx, int32_t N, int32_t F, int skip_self, float *out,
+                        wdg_stream_t stream);
+
 /* ------------------------------------------------------------------ label-aggregation similarity */
 /*
  * W[i,c] = sum_{j: y_j=c} <H_i, H_j>  computed as H (H^T Y) with fp64 accumulation (never forms n x n),

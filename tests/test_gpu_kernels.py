@@ -547,6 +547,28 @@ def test_gemm_is_a_k_ordered_fp32_fma_chain(ops):
     np.testing.assert_array_equal(out, ref)
 
 
+def test_edge_cosine_sddmm(ops, oracle):
+    rng = np.random.default_rng(41)
+    for n, f, e in ((500, 37, 6000), (2708, 1433, 13000), (30, 3, 200)):
+        src, dst = _rand_graph(rng, n, e)
+        rowptr, col, _ = oracle.coo_to_csr(src, dst, n)
+        x = rng.standard_normal((n, f)).astype(np.float32)
+        x[::7] = 0  # zero rows -> NaN -> 0 (utils/homophily_metrics.py:168)
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), None, n, n)
+        rows = np.repeat(np.arange(n), np.diff(rowptr))
+        xd = x.astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ref = (xd[rows] * xd[col]).sum(1) / (np.linalg.norm(xd[rows], axis=1) * np.linalg.norm(xd[col], axis=1))
+        ref[np.isnan(ref)] = 0
+        got = _np(ops.edge_cosine(g, torch.from_numpy(x), skip_self=False))
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+        got = _np(ops.edge_cosine(g, torch.from_numpy(x), skip_self=True))
+        np.testing.assert_allclose(got, np.where(rows == col, 0, ref), rtol=2e-5, atol=2e-6)
+        ent = rng.choice(col.shape[0], min(100, col.shape[0]), replace=False).astype(np.int32)
+        got = _np(ops.edge_cosine(g, torch.from_numpy(x), entries=ent, skip_self=False))
+        np.testing.assert_allclose(got, ref[ent], rtol=2e-5, atol=2e-6)
+
+
 def test_gram_matches_oracle(ops, oracle):
     g0 = load("real_cora")
     x = dense_features(g0)

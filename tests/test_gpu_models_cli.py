@@ -1,0 +1,101 @@
+"""GPU tests: SGC-1 / GCN-2 (forward vs oracle, gradients vs a dense torch reference, a short training run whose
+outcome follows the published U-shape) and the `homophily_tests.py` CLI counterpart vs golden scalars."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import dense_features, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available()
+    from wdg_amd import models, ops, synth
+    return models, ops, synth
+
+
+def _graph(synth, h, seed=0, n=2000, k=2):
+    src, dst, lab = synth.regular_graph(n, 5, k, h, seed)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([src, dst])), torch.ones(src.shape[0]), (n, n))
+    return adj, src, dst, lab
+
+
+@pytest.mark.parametrize("symmetric", [0, 1])
+def test_forward_matches_oracle(env, oracle, symmetric):
+    models, ops, synth = env
+    adj_t, src, dst, lab = _graph(synth, 0.3)
+    n, f, c = 2000, 500, 5
+    x = synth.features(n, f, 0)
+    adj = models.NormAdj(adj_t, symmetric=symmetric)
+    rowptr, col, val = oracle.coo_to_csr(src, dst, n, None, oracle.ADD_SELF_LOOPS)
+    vhat = oracle.normalised_csr(rowptr, col, val, symmetric, oracle.PREC_F32)
+    torch.manual_seed(0)
+    sgc, gcn = models.SGC1(f, c).cuda(), models.GCN2(f, c, nhid=64, dropout=0.0).cuda().eval()
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        out_sgc, out_gcn = sgc(adj, xt).cpu().numpy(), gcn(adj, xt).cpu().numpy()
+    agg = oracle.spmm_csr(rowptr, col, vhat, x)
+    ref_sgc = oracle.gemm(agg, sgc.weight.detach().cpu().numpy())
+    h1 = np.maximum(oracle.spmm_csr(rowptr, col, vhat, oracle.gemm(x, gcn.w0.detach().cpu().numpy())), 0)
+    ref_gcn = oracle.spmm_csr(rowptr, col, vhat, oracle.gemm(h1, gcn.w1.detach().cpu().numpy()))
+    for got, ref in ((out_sgc, ref_sgc), (out_gcn, ref_gcn)):
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())  # north-star logits tolerance
+
+
+def test_gradients_match_dense_autograd(env):
+    models, ops, synth = env
+    n, f, c = 300, 40, 5
+    adj_t, src, dst, lab = _graph(synth, 0.4, n=n)
+    x = torch.from_numpy(synth.features(n, f, 1)).cuda()
+    labels = torch.from_numpy(lab).cuda()
+    for symmetric in (0, 1):
+        adj = models.NormAdj(adj_t, symmetric=symmetric)
+        dense = adj.graph.to_torch_sparse().to_dense()
+        r = adj.row_scale[:, None]
+        a_hat = r * dense * (adj.col_scale[None, :] if adj.col_scale is not None else 1.0)
+        torch.manual_seed(1)
+        gcn = models.GCN2(f, c, nhid=16, dropout=0.0).cuda()
+        loss = torch.nn.functional.cross_entropy(gcn(adj, x), labels)
+        loss.backward()
+        w0, w1 = gcn.w0.detach().clone().requires_grad_(), gcn.w1.detach().clone().requires_grad_()
+        ref = torch.nn.functional.cross_entropy(a_hat @ (torch.relu(a_hat @ (x @ w0)) @ w1), labels)
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < 1e-5
+        for got, want in ((gcn.w0.grad, w0.grad), (gcn.w1.grad, w1.grad)):
+            torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-6)
+
+
+def test_training_follows_published_u_shape(env):
+    """gnns_on_syn.py: GCN / SGC are near-perfect at high homophily and collapse in the middle of the range."""
+    models, ops, synth = env
+    torch.manual_seed(0)
+    res = {}
+    for h in (0.9, 0.2):  # h = 0.2 = 1/C: neighbourhoods are class-uniform, aggregation washes the signal out
+        adj_t, src, dst, lab = _graph(synth, h, seed=1, k=10)
+        adj = models.NormAdj(adj_t, symmetric=0)
+        x = torch.from_numpy(synth.features(2000, 128, 1, labels=lab, signal=0.5))
+        for name, mk in (("sgc", lambda: models.SGC1(128, 5)), ("gcn", lambda: models.GCN2(128, 5, nhid=32, dropout=0.2))):
+            res[name, h] = models.train_eval(mk(), adj, x, torch.from_numpy(lab), epochs=80, lr=0.05)["test_acc"]
+    assert res["sgc", 0.9] > 0.9 and res["gcn", 0.9] > 0.9, res
+    assert res["sgc", 0.2] < res["sgc", 0.9] - 0.3 and res["gcn", 0.2] < res["gcn", 0.9] - 0.3, res
+
+
+@pytest.mark.parametrize("name", ["cora", "texas"])
+def test_cli_counterpart_matches_golden(name):
+    from wdg_amd import homophily_tests as cli
+    g0 = load("real_" + name)
+    n = int(g0["n_nodes"])
+    pairs = [("node_homo", "m_node_homo", 1e-6), ("edge_homo", "m_edge_homo_onehot_quirk", 1e-6),
+             ("class_homo", "m_class_homo", 1e-5), ("adj_homo", "m_adj_homo", 1e-5), ("label_info", "m_label_info", 1e-3),
+             ("node_hom_generalized", "m_ge_homo", 1e-4)]
+    for metric, key, tol in pairs:
+        got = float(cli.main(["--dataset_name", name, "--homophily_metric", metric]))
+        assert got == pytest.approx(float(g0[key]), rel=tol, abs=1e-6), metric
+    for metric, key in (("agg_homo_soft", "m_agg_soft"), ("agg_homo_hard", "m_agg_hard")):
+        got = float(cli.main(["--dataset_name", name, "--homophily_metric", metric]))
+        assert abs(got - float(g0[key])) <= 2 * 1.01 / n, metric
+    assert set(cli.METRIC_LIST) == {"node_homo", "edge_homo", "class_homo", "node_hom_generalized", "agg_homo_soft",
+                                    "agg_homo_hard", "adj_homo", "label_info", "kernel_reg0_based_homo",
+                                    "kernel_reg1_based_homo", "gnb_based_homo"}

@@ -344,6 +344,19 @@ class StatsBatch:
               "wdg_edge_label_stats_batched")
 
 
+# ------------------------------------------------------------------------------------------- per-edge cosine
+def edge_cosine(g, x, entries=None, skip_self=True):
+    """fp32 cosine similarity of the endpoints of every stored entry (or of the listed entry ids); wdg_edge_cosine_f32."""
+    dev = g.device
+    x = _dev(x, torch.float32, dev)
+    entries = _dev(entries, torch.int32, dev)
+    n = int(entries.shape[0]) if entries is not None else g.nnz
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    check(lib.wdg_edge_cosine_f32(_ptr(g.rowptr), _ptr(g.col), _ptr(entries), n, _ptr(x), x.stride(0), g.n_rows,
+                                  x.shape[1], int(skip_self), _ptr(out), stream_handle()), "wdg_edge_cosine_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- LAS
 def las(h, labels, n_classes, rows=None, want_weights=False):
     """-> (soft_count, hard_count, n, W|None): device-side label-aggregation similarity (wdg_las_f32)."""

@@ -49,11 +49,20 @@ def regular_graph(n, n_classes, k, h, seed):
     return src.astype(np.int64), dst.reshape(-1).astype(np.int64), labels.astype(np.int64)
 
 
-def features(n, f, seed, density=0.1):
-    """Row-L1-normalised sparse-ish dense features, fp32 [n, f]."""
+def features(n, f, seed, density=0.1, labels=None, signal=1.0):
+    """Row-L1-normalised sparse-ish dense features, fp32 [n, f].
+
+    With `labels`, the features carry class information the way the reference's do (its synthetic features are
+    sampled from real nodes of the same class): class c switches features of "its" block of columns on with
+    twice the base density, the others with less, keeping the mean density."""
     rng = np.random.default_rng([int(seed), n, f, 77])
     x = rng.random((n, f), dtype=np.float32) * np.float32(0.33)
-    x *= rng.random((n, f), dtype=np.float32) < density
+    dens = np.full((n, f), density, np.float32)
+    if labels is not None:
+        c = int(np.max(labels)) + 1
+        block = (np.arange(f) * c // f)[None, :] == np.asarray(labels)[:, None]
+        dens = np.where(block, density * (1 + signal), density * (1 - signal / max(c - 1, 1))).astype(np.float32)
+    x *= rng.random((n, f), dtype=np.float32) < dens
     x[np.arange(n), rng.integers(0, f, n)] += np.float32(0.01)  # no empty rows
     return (x / x.sum(1, keepdims=True)).astype(np.float32)
 

@@ -140,22 +140,12 @@ def label_informativeness(A, label):
 def _edge_cosine_sum(g, features, entries=None):
     """sum over stored non-loop entries (or the listed entry ids) of cos(x_u, x_v); NaN -> 0."""
     x = features.to(g.device, torch.float32)
-    nrm = torch.linalg.norm(x, dim=1)
-    rows, cols = g.row_indices(), g.col.to(torch.int64)
-    if entries is not None:
-        rows, cols = rows[entries], cols[entries]
-        keep = torch.ones_like(rows, dtype=torch.bool)
-    else:
-        keep = rows != cols
-    total = torch.zeros((), dtype=torch.float32, device=g.device)
-    per_edge = []
-    for s in range(0, rows.shape[0], 1 << 18):  # bounded temporary: chunk x F floats
-        r, c, k = rows[s:s + (1 << 18)], cols[s:s + (1 << 18)], keep[s:s + (1 << 18)]
-        sim = (x[r] * x[c]).sum(1) / (nrm[r] * nrm[c])
-        sim = torch.where(torch.isnan(sim), torch.zeros_like(sim), sim)
-        per_edge.append(sim * k)
-        total = total + (sim * k).sum()
-    return total, keep.sum(), per_edge
+    if entries is not None:  # sampled entries: loops are kept, as the reference's sampling branch does
+        sim = ops.edge_cosine(g, x, entries=entries, skip_self=False)
+        return sim.double().sum().float(), torch.tensor(sim.shape[0], device=g.device), sim
+    sim = ops.edge_cosine(g, x, skip_self=True)  # csrc/edge_cosine.hip: one wave per stored entry
+    n_noself = (g.row_indices() != g.col.to(torch.int64)).sum()
+    return sim.double().sum().float(), n_noself, sim
 
 
 def generalized_edge_homophily(adj, features, label, sample_max=75000, iteration=10):
