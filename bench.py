@@ -79,7 +79,7 @@ def main():
         ev[s][0].record()           # torch's current stream == the stream the kernels are launched on
         batch.spmm.launch()
         ev[s][1].record()
-        batch.stats.launch()
+        batch.step_rest()
     rows = batch.results()
     gathered = sweep.gather_results(rows, dev)  # the sweep's one exchange step: per-job metric rows (KBs)
     sync_all()
@@ -123,7 +123,8 @@ def main():
             "config": {"workload": f"synthetic homophily sweep (data_synthesis/{args.k * 400}-equivalent): "
                                    f"{len(h_levels)} h-levels x {args.seeds} seeds = {len(mine)} graphs/GPU/step, "
                                    f"N={args.nodes} nodes, k={args.k}, F={args.feat} fp32, C=5; step = batched "
-                                   f"D^-1(A+I)X aggregation + edge/label statistics pass",
+                                   f"D^-1(A+I)X aggregation + edge/label statistics + label aggregation & LAS + "
+                                   f"GCN-2 forward (hidden 64, per-graph weights), 7 launches",
                        "graphs_per_step_per_gpu": len(mine), "edges_per_step_per_gpu": batch.edges,
                        "parallelism": f"independent sweep shards x{world} (no data-path collective; job-table broadcast + result all_gather)"},
             "graphs_per_s": n_graphs * args.steps / elapsed,

@@ -210,6 +210,20 @@ int wdg_las_f32(const float *H, int64_t ldh, const int32_t *labels, const int32_
                 int32_t C, double *W_out, int64_t *count_out, void *workspace, size_t workspace_bytes,
                 wdg_stream_t stream);
 
+/* Many problems in one launch (every graph of a sweep batch); count_out is reset by the call itself. */
+typedef struct wdg_las_job {
+    const float *H;
+    const int32_t *labels;
+    const int32_t *rows;  /* NULL = identity */
+    double *W_out;        /* [n, C] or NULL */
+    int64_t *count_out;   /* [2] */
+    void *workspace;      /* wdg_las_workspace_bytes(n, F, C) bytes, private to this job */
+    int64_t ldh;
+    int32_t n, F, C, reserved;
+} wdg_las_job;
+int wdg_las_batched_f32(const wdg_las_job *jobs_dev, int32_t n_jobs, int32_t max_n, int32_t max_F, int32_t max_C,
+                        wdg_stream_t stream);
+
 /* ------------------------------------------------------------------ dense feature transform */
 #define WDG_ACT_NONE 0
 #define WDG_ACT_RELU 1
@@ -221,6 +235,18 @@ int wdg_las_f32(const float *H, int64_t ldh, const int32_t *labels, const int32_
  */
 int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, int act,
                  float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, wdg_stream_t stream);
+
+/* Many independent products in one launch (every graph of a sweep batch with its own weights); B is [K,N]. */
+typedef struct wdg_gemm_job {
+    const float *A;
+    const float *B;
+    const float *bias; /* [N] or NULL */
+    float *C;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K, act; /* act: WDG_ACT_* */
+} wdg_gemm_job;
+int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
+                         wdg_stream_t stream);
 
 #ifdef __cplusplus
 }

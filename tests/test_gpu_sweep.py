@@ -1,0 +1,70 @@
+"""GPU parity of the batched sweep step (wdg_amd.sweep.SweepBatch = loop body of synthetic_plot.py:81-109 without
+the kernel-regression metric, plus the GCN-2 forward): every stage of one step against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("symmetric", [0, 1])
+def test_sweep_step_against_oracle(oracle, symmetric):
+    from wdg_amd import sweep, synth
+    jobs = sweep.make_jobs([0.1, 0.5, 0.9], [0, 1], k=2, n_nodes=1000) + sweep.make_jobs([0.2, 0.4], [2], k=10, n_nodes=1000)
+    batch = sweep.SweepBatch(jobs, n_feat=96, symmetric=symmetric, gcn_hidden=32)
+    batch.step()
+    batch.step()  # relaunch must give the same answers (counters re-zeroed)
+    torch.cuda.synchronize()
+    rows = batch.results().cpu().numpy()
+    assert rows.shape == (len(jobs), len(sweep.METRIC_NAMES))
+    for i, j in enumerate(jobs):
+        src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+        x = synth.features(j.n_nodes, 96, j.seed)
+        rowptr, col, val = oracle.coo_to_csr(src, dst, j.n_nodes, None, oracle.ADD_SELF_LOOPS)
+        vhat = oracle.normalised_csr(rowptr, col, val, symmetric, oracle.PREC_F32)
+        y = oracle.spmm_csr(rowptr, col, vhat, x)
+        np.testing.assert_allclose(batch.y[i].cpu().numpy(), y, rtol=1e-5, atol=1e-6 * np.abs(y).max())
+        st = oracle.edge_label_stats(rowptr, col, lab, j.n_classes)
+        want = [oracle.edge_homophily_dense(st), oracle.node_homophily_dense(st), oracle.class_homophily_dense(st, lab),
+                oracle.adjusted_homophily_dense(st, lab), oracle.label_informativeness(st, lab)]
+        np.testing.assert_allclose(rows[i, :5], want, rtol=2e-4, atol=3e-6)
+        onehot = np.eye(j.n_classes, dtype=np.float32)[lab]
+        soft = oracle.similarity(onehot, rowptr, col, vhat, onehot, f64=True)
+        assert abs(rows[i, 5] - soft) <= 2.01 / j.n_nodes
+        g = batch.gcn
+        hid = oracle.gemm(y, g["w0"][i].cpu().numpy(), relu=True)
+        np.testing.assert_allclose(g["hid"][i].cpu().numpy(), hid, rtol=1e-5, atol=1e-5 * np.abs(hid).max())
+        logits = oracle.spmm_csr(rowptr, col, vhat, oracle.gemm(hid, g["w1"][i].cpu().numpy()))
+        np.testing.assert_allclose(g["logits"][i].cpu().numpy(), logits, rtol=1e-5, atol=1e-5 * np.abs(logits).max())
+
+
+def test_batched_gemm_and_las_mixed_shapes(oracle):
+    from wdg_amd import ops
+    rng = np.random.default_rng(3)
+    ent, refs = [], []
+    for m, k, n in ((300, 40, 64), (2000, 500, 64), (17, 3, 5), (129, 64, 33)):
+        a, b = rng.standard_normal((m, k)).astype(np.float32), rng.standard_normal((k, n)).astype(np.float32)
+        bias = rng.standard_normal(n).astype(np.float32)
+        ent.append((torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.empty((m, n), device="cuda"),
+                    torch.from_numpy(bias).cuda()))
+        refs.append(oracle.gemm(a, b, bias, relu=True))
+    gb = ops.GemmBatch(ent, relu=True)
+    gb.launch()
+    torch.cuda.synchronize()
+    for (_, _, c, _), ref in zip(ent, refs):
+        np.testing.assert_allclose(c.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    las_ent, want = [], []
+    for n, f, c in ((500, 5, 5), (1300, 17, 3), (64, 5, 5)):
+        h = rng.random((n, f), dtype=np.float32)
+        lab = rng.integers(0, c, n)
+        lab[:c] = np.arange(c)
+        las_ent.append((torch.from_numpy(h).cuda(), torch.from_numpy(lab).cuda().to(torch.int32)))
+        w = oracle.las_weights(h, lab, 5, f64=True)
+        want.append((round(oracle.las_from_weights(w, lab) * n), round(oracle.las_from_weights(w, lab, hard=1) * n)))
+    lb = ops.LasBatch(las_ent, 5)
+    lb.launch()
+    lb.launch()
+    torch.cuda.synchronize()
+    got = lb.counts.cpu().numpy()
+    for i, (s, hd) in enumerate(want):
+        assert abs(int(got[i, 0]) - s) <= 1 and abs(int(got[i, 1]) - hd) <= 1

@@ -73,7 +73,22 @@ SIGNATURES = {
                             c_void_p, c_size_t, c_void_p]),
     "wdg_gemm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64,
                              c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_gemm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_las_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
 }
+
+
+class LasJob(ctypes.Structure):
+    """mirror of `wdg_las_job` (include/wdg.h)"""
+    _fields_ = [("H", c_void_p), ("labels", c_void_p), ("rows", c_void_p), ("W_out", c_void_p), ("count_out", c_void_p),
+                ("workspace", c_void_p), ("ldh", c_int64), ("n", c_int32), ("F", c_int32), ("C", c_int32),
+                ("reserved", c_int32)]
+
+
+class GemmJob(ctypes.Structure):
+    """mirror of `wdg_gemm_job` (include/wdg.h)"""
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("lda", c_int64), ("ldb", c_int64),
+                ("ldc", c_int64), ("M", c_int32), ("N", c_int32), ("K", c_int32), ("act", c_int32)]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -20,18 +20,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BK = 16, THREADS = 256;
 constexpr int LDA_S = BK + 1;  // As[m][k], odd stride -> lanes m=0..31 hit distinct banks
 
+// One launch serves a single problem (descriptor by value) or a table of independent problems (blockIdx.z = job):
+// the sweep transforms every graph's features with that graph's own weights in one go.
 template <int NT, bool TRANSB>
-__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const float *__restrict__ A, int64_t lda,
-                                                           const float *__restrict__ B, int64_t ldb,
-                                                           const float *__restrict__ bias, int act,
-                                                           float *__restrict__ C, int64_t ldc, int M, int N, int K) {
+__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *__restrict__ jobs,
+                                                           const wdg_gemm_job inline_job) {
     constexpr int BN = 32 * NT;
     constexpr int LDB_S = TRANSB ? (BK + 1) : (BN + 1);  // Bs[n][k] (transb) or Bs[k][n]
     __shared__ float As[BM * LDA_S];
     __shared__ float Bs[TRANSB ? BN * LDB_S : BK * LDB_S];
 
+    const wdg_gemm_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const float *__restrict__ A = job.A, *__restrict__ B = job.B, *__restrict__ bias = job.bias;
+    float *__restrict__ C = job.C;
+    const int64_t lda = job.lda, ldb = job.ldb, ldc = job.ldc;
+    const int M = job.M, N = job.N, K = job.K, act = job.act;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M || n0 >= N) return;  // table entries smaller than the launch bounds
 
     constexpr int A_PER = BM * BK / THREADS;  // 8
     constexpr int B_PER = BN * BK / THREADS;  // 2 or 4
@@ -135,14 +141,33 @@ int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int t
     hipStream_t st = wdg::as_stream(stream);
     const bool wide = N > 32;
     const dim3 grid(static_cast<unsigned>(wdg::ceil_div(M, BM)), static_cast<unsigned>(wdg::ceil_div(N, wide ? 64 : 32)));
+    wdg_gemm_job j{};
+    j.A = A; j.B = B; j.bias = bias; j.C = C;
+    j.lda = lda; j.ldb = ldb; j.ldc = ldc;
+    j.M = M; j.N = N; j.K = K; j.act = act;
+    const wdg_gemm_job *none = nullptr;
     if (wide) {
-        if (transb) hipLaunchKernelGGL((gemm_f32_kernel<2, true>), grid, dim3(THREADS), 0, st, A, lda, B, ldb, bias, act, C, ldc, M, N, K);
-        else hipLaunchKernelGGL((gemm_f32_kernel<2, false>), grid, dim3(THREADS), 0, st, A, lda, B, ldb, bias, act, C, ldc, M, N, K);
+        if (transb) hipLaunchKernelGGL((gemm_f32_kernel<2, true>), grid, dim3(THREADS), 0, st, none, j);
+        else hipLaunchKernelGGL((gemm_f32_kernel<2, false>), grid, dim3(THREADS), 0, st, none, j);
     } else {
-        if (transb) hipLaunchKernelGGL((gemm_f32_kernel<1, true>), grid, dim3(THREADS), 0, st, A, lda, B, ldb, bias, act, C, ldc, M, N, K);
-        else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), grid, dim3(THREADS), 0, st, A, lda, B, ldb, bias, act, C, ldc, M, N, K);
+        if (transb) hipLaunchKernelGGL((gemm_f32_kernel<1, true>), grid, dim3(THREADS), 0, st, none, j);
+        else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), grid, dim3(THREADS), 0, st, none, j);
     }
     return wdg::check_launch("gemm_f32_kernel");
+}
+
+int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
+                         wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_M >= 0 && max_N >= 0, "gemm_batched: negative size");
+    if (n_jobs == 0 || max_M == 0 || max_N == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "gemm_batched: null job table");
+    WDG_REQUIRE(n_jobs <= 65535, "gemm_batched: more than 65535 jobs per launch");
+    const bool wide = max_N > 32;
+    const dim3 grid(static_cast<unsigned>(wdg::ceil_div(max_M, BM)), static_cast<unsigned>(wdg::ceil_div(max_N, wide ? 64 : 32)),
+                    static_cast<unsigned>(n_jobs));
+    if (wide) hipLaunchKernelGGL((gemm_f32_kernel<2, false>), grid, dim3(THREADS), 0, wdg::as_stream(stream), jobs_dev, wdg_gemm_job{});
+    else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), grid, dim3(THREADS), 0, wdg::as_stream(stream), jobs_dev, wdg_gemm_job{});
+    return wdg::check_launch("gemm_f32_kernel (batched)");
 }
 
 }  // extern "C"

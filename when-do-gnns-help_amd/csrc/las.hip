@@ -6,6 +6,8 @@
 //
 // Everything accumulates in fp64 in a FIXED order (row tiles summed in tile order), so the result is bitwise
 // reproducible; with one-hot features and an un-normalised adjacency H holds integer counts and W is exact.
+// One launch serves one problem (descriptor by value) or a table of problems (blockIdx.z = job): the sweep scores
+// every graph of a batch at once.
 #include "wdg_common.h"
 
 namespace {
@@ -15,66 +17,101 @@ using u64 = unsigned long long;
 
 constexpr int TILE_ROWS = 128;
 
+struct LasWs {
+    double *partial;   // [n_tiles][C][F]
+    int *cnt_partial;  // [n_tiles][C]
+    double *M;         // [C][F]
+    long long *cls_cnt;  // [C]
+};
+
+__host__ __device__ inline size_t las_align(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+__host__ __device__ inline size_t las_layout(int n_tiles, int F, int C, char *base, LasWs *ws) {
+    size_t off = 0;
+    LasWs w;
+    w.partial = reinterpret_cast<double *>(base + off);
+    off += las_align(sizeof(double) * static_cast<size_t>(n_tiles) * F * C);
+    w.cnt_partial = reinterpret_cast<int *>(base + off);
+    off += las_align(sizeof(int) * static_cast<size_t>(n_tiles) * C);
+    w.M = reinterpret_cast<double *>(base + off);
+    off += las_align(sizeof(double) * static_cast<size_t>(F) * C);
+    w.cls_cnt = reinterpret_cast<long long *>(base + off);
+    off += las_align(sizeof(long long) * static_cast<size_t>(C));
+    if (ws) *ws = w;
+    return off;
+}
+
+__device__ __forceinline__ LasWs job_ws(const wdg_las_job &j) {
+    LasWs ws;
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(j.workspace) + 255) & ~static_cast<uintptr_t>(255));
+    las_layout((j.n + TILE_ROWS - 1) / TILE_ROWS, j.F, j.C, base, &ws);
+    return ws;
+}
+
 // partial[t][c][f] = sum over rows j of tile t with label c of H[row_j, f]; cnt_partial[t][c] = #rows
-__global__ __launch_bounds__(64) void las_middle_partial(const float *__restrict__ H, int64_t ldh,
-                                                         const int32_t *__restrict__ labels,
-                                                         const int32_t *__restrict__ rows, int n, int F, int C,
-                                                         double *__restrict__ partial, int *__restrict__ cnt_partial) {
+__global__ __launch_bounds__(64) void las_middle_partial(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
+    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const int n = job.n, F = job.F, C = job.C;
     const int tile = blockIdx.x, f = blockIdx.y * 64 + threadIdx.x;
+    if (tile * TILE_ROWS >= n || (blockIdx.y * 64 >= F && blockIdx.y > 0)) return;
+    const LasWs ws = job_ws(job);
     const int j0 = tile * TILE_ROWS, j1 = min(n, j0 + TILE_ROWS);
-    double *out = partial + static_cast<int64_t>(tile) * C * F;
+    double *out = ws.partial + static_cast<int64_t>(tile) * C * F;
     // walk the tile once per class: C is small (2..7 on every reference dataset); rows stay in L1/L2
     for (int c = 0; c < C; ++c) {
         double acc = 0.0;
         int cnt = 0;
         for (int j = j0; j < j1; ++j) {
-            const int r = rows ? rows[j] : j;
-            if (labels[r] == c) {
+            const int r = job.rows ? job.rows[j] : j;
+            if (job.labels[r] == c) {
                 ++cnt;
-                if (f < F) acc += static_cast<double>(H[static_cast<int64_t>(r) * ldh + f]);
+                if (f < F) acc += static_cast<double>(job.H[static_cast<int64_t>(r) * job.ldh + f]);
             }
         }
         if (f < F) out[static_cast<int64_t>(c) * F + f] = acc;
-        if (blockIdx.y == 0 && threadIdx.x == 0) cnt_partial[tile * C + c] = cnt;
+        if (blockIdx.y == 0 && threadIdx.x == 0) ws.cnt_partial[tile * C + c] = cnt;
     }
 }
 
-// M[f][c] (stored [c][f]) = sum_t partial[t][c][f] in tile order; class counts likewise
-__global__ void las_middle_reduce(const double *__restrict__ partial, const int *__restrict__ cnt_partial,
-                                  int n_tiles, int F, int C, double *__restrict__ M, long long *__restrict__ cls_cnt) {
+// M[c][f] = sum_t partial[t][c][f] in tile order; class counts likewise; the job's counters are reset here
+__global__ void las_middle_reduce(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
+    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const int n = job.n, F = job.F, C = job.C;
+    if (n <= 0 || C <= 0) return;
+    const int n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+    const LasWs ws = job_ws(job);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C * F) {
         double acc = 0.0;
-        for (int t = 0; t < n_tiles; ++t) acc += partial[static_cast<int64_t>(t) * C * F + i];
-        M[i] = acc;
+        for (int t = 0; t < n_tiles; ++t) acc += ws.partial[static_cast<int64_t>(t) * C * F + i];
+        ws.M[i] = acc;
     }
     if (i < C) {
         long long s = 0;
-        for (int t = 0; t < n_tiles; ++t) s += cnt_partial[t * C + i];
-        cls_cnt[i] = s;
+        for (int t = 0; t < n_tiles; ++t) s += ws.cnt_partial[t * C + i];
+        ws.cls_cnt[i] = s;
     }
+    if (i < 2) job.count_out[i] = 0;
 }
 
 // one wave per selected row: W[i,c] = sum_f H[i,f] M[c][f]; then the two LAS decisions
-__global__ __launch_bounds__(256) void las_weights_kernel(const float *__restrict__ H, int64_t ldh,
-                                                          const int32_t *__restrict__ labels,
-                                                          const int32_t *__restrict__ rows, int n, int F, int C,
-                                                          const double *__restrict__ M,
-                                                          const long long *__restrict__ cls_cnt,
-                                                          double *__restrict__ W_out, long long *__restrict__ count_out) {
+__global__ __launch_bounds__(256) void las_weights_kernel(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
+    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const int n = job.n, F = job.F, C = job.C;
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= n) return;
-    const int r = rows ? rows[i] : i;
-    const float *h = H + static_cast<int64_t>(r) * ldh;
-    const int y = labels[r];
+    const LasWs ws = job_ws(job);
+    const int r = job.rows ? job.rows[i] : i;
+    const float *h = job.H + static_cast<int64_t>(r) * job.ldh;
+    const int y = job.labels[r];
     double own = 0.0, tot = 0.0, best = 0.0;
     int best_c = -1;
     for (int c = 0; c < C; ++c) {
         double acc = 0.0;
-        for (int f = lane; f < F; f += 64) acc += static_cast<double>(h[f]) * M[static_cast<int64_t>(c) * F + f];
-        // fixed-shape butterfly: every lane ends with the same, order-independent-of-scheduling sum
+        for (int f = lane; f < F; f += 64) acc += static_cast<double>(h[f]) * ws.M[static_cast<int64_t>(c) * F + f];
+        // fixed-shape butterfly: every lane ends with the same sum, independent of scheduling
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (W_out && lane == 0) W_out[static_cast<int64_t>(i) * C + c] = acc;
+        if (job.W_out && lane == 0) job.W_out[static_cast<int64_t>(i) * C + c] = acc;
         tot += acc;
         if (c == y) own = acc;
         if (best_c < 0 || acc > best) {  // first maximum wins, as torch.argmax on CPU
@@ -83,35 +120,110 @@ __global__ __launch_bounds__(256) void las_weights_kernel(const float *__restric
         }
     }
     if (lane != 0) return;
-    const double ny = (y >= 0 && y < C) ? static_cast<double>(cls_cnt[y]) : 0.0;
+    const double ny = (y >= 0 && y < C) ? static_cast<double>(ws.cls_cnt[y]) : 0.0;
     // (W_iy / n_y) / ((sum_c W_ic - W_iy) / (n - n_y)); NaN -> 0 (utils/homophily_metrics.py:216-220)
     const double ratio = (own / ny) / ((tot - own) / (static_cast<double>(n) - ny));
     const bool soft = !(ratio != ratio) && ratio >= 1.0;
-    if (soft) atomicAdd(reinterpret_cast<u64 *>(&count_out[0]), 1ull);
-    if (best_c == y) atomicAdd(reinterpret_cast<u64 *>(&count_out[1]), 1ull);
+    if (soft) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[0]), 1ull);
+    if (best_c == y) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[1]), 1ull);
 }
 
-struct LasWs {
-    double *partial;
-    int *cnt_partial;
-    double *M;
-    long long *cls_cnt;
-};
+// ---- narrow-feature path (F <= 16: label propagation, F = C): rows on lanes instead of features on lanes.
+constexpr int SMALL_F = 16;
 
-size_t las_layout(int n_tiles, int F, int C, char *base, LasWs *ws) {
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        char *p = base ? base + off : nullptr;
-        off += (bytes + 255) & ~static_cast<size_t>(255);
-        return p;
-    };
-    LasWs w;
-    w.partial = reinterpret_cast<double *>(take(sizeof(double) * static_cast<size_t>(n_tiles) * F * C));
-    w.cnt_partial = reinterpret_cast<int *>(take(sizeof(int) * static_cast<size_t>(n_tiles) * C));
-    w.M = reinterpret_cast<double *>(take(sizeof(double) * static_cast<size_t>(F) * C));
-    w.cls_cnt = reinterpret_cast<long long *>(take(sizeof(long long) * static_cast<size_t>(C)));
-    if (ws) *ws = w;
-    return off;
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);  // fixed butterfly -> scheduling-independent
+    return v;
+}
+
+__global__ __launch_bounds__(64) void las_middle_partial_small(const wdg_las_job *__restrict__ jobs,
+                                                               const wdg_las_job inline_job) {
+    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const int n = job.n, F = job.F, C = job.C, tile = blockIdx.x, lane = threadIdx.x;
+    if (tile * TILE_ROWS >= n) return;
+    const LasWs ws = job_ws(job);
+    float h[TILE_ROWS / 64][SMALL_F];
+    int lab[TILE_ROWS / 64];
+#pragma unroll
+    for (int s = 0; s < TILE_ROWS / 64; ++s) {
+        const int j = tile * TILE_ROWS + s * 64 + lane;
+        lab[s] = -1;
+        if (j < n) {
+            const int r = job.rows ? job.rows[j] : j;
+            lab[s] = job.labels[r];
+#pragma unroll
+            for (int f = 0; f < SMALL_F; ++f) h[s][f] = (f < F) ? job.H[static_cast<int64_t>(r) * job.ldh + f] : 0.f;
+        }
+    }
+    double *out = ws.partial + static_cast<int64_t>(tile) * C * F;
+    for (int c = 0; c < C; ++c) {
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < TILE_ROWS / 64; ++s) cnt += (lab[s] == c);
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) ws.cnt_partial[tile * C + c] = cnt;
+#pragma unroll
+        for (int f = 0; f < SMALL_F; ++f) {
+            if (f >= F) break;
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < TILE_ROWS / 64; ++s) v += (lab[s] == c) ? static_cast<double>(h[s][f]) : 0.0;  // row order
+            v = wave_sum(v);
+            if (lane == 0) out[static_cast<int64_t>(c) * F + f] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void las_weights_small(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
+    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const int n = job.n, F = job.F, C = job.C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const LasWs ws = job_ws(job);
+    const int r = job.rows ? job.rows[i] : i;
+    const float *hp = job.H + static_cast<int64_t>(r) * job.ldh;
+    float h[SMALL_F];
+#pragma unroll
+    for (int f = 0; f < SMALL_F; ++f) h[f] = (f < F) ? hp[f] : 0.f;
+    const int y = job.labels[r];
+    double own = 0.0, tot = 0.0, best = 0.0;
+    int best_c = -1;
+    for (int c = 0; c < C; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int f = 0; f < SMALL_F; ++f)
+            if (f < F) acc += static_cast<double>(h[f]) * ws.M[static_cast<int64_t>(c) * F + f];
+        if (job.W_out) job.W_out[static_cast<int64_t>(i) * C + c] = acc;
+        tot += acc;
+        if (c == y) own = acc;
+        if (best_c < 0 || acc > best) {
+            best = acc;
+            best_c = c;
+        }
+    }
+    const double ny = (y >= 0 && y < C) ? static_cast<double>(ws.cls_cnt[y]) : 0.0;
+    const double ratio = (own / ny) / ((tot - own) / (static_cast<double>(n) - ny));
+    const bool soft = !(ratio != ratio) && ratio >= 1.0;
+    // one 64-bit atomic per wave instead of per row
+    const unsigned long long ms = __ballot(soft), mh = __ballot(best_c == y);
+    if ((threadIdx.x & 63) == 0) {
+        if (ms) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[0]), static_cast<u64>(__popcll(ms)));
+        if (mh) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[1]), static_cast<u64>(__popcll(mh)));
+    }
+}
+
+int launch_las(const wdg_las_job *jobs, const wdg_las_job &inl, int n_jobs, int max_n, int max_F, int max_C, hipStream_t st) {
+    const int n_tiles = static_cast<int>(ceil_div(max_n, TILE_ROWS));
+    const int fchunks = static_cast<int>(ceil_div(max_F > 0 ? max_F : 1, 64));
+    const int cf = max_C * (max_F > 0 ? max_F : 1);
+    const bool small = max_F <= SMALL_F;
+    if (small) hipLaunchKernelGGL(las_middle_partial_small, dim3(n_tiles, 1, n_jobs), dim3(64), 0, st, jobs, inl);
+    else hipLaunchKernelGGL(las_middle_partial, dim3(n_tiles, fchunks, n_jobs), dim3(64), 0, st, jobs, inl);
+    hipLaunchKernelGGL(las_middle_reduce, dim3(ceil_div(cf > max_C ? cf : max_C, 256), 1, n_jobs), dim3(256), 0, st, jobs, inl);
+    if (small) hipLaunchKernelGGL(las_weights_small, dim3(ceil_div(max_n, 256), 1, n_jobs), dim3(256), 0, st, jobs, inl);
+    else hipLaunchKernelGGL(las_weights_kernel, dim3(ceil_div(static_cast<int64_t>(max_n) * 64, 256), 1, n_jobs), dim3(256), 0,
+                            st, jobs, inl);
+    return check_launch("las");
 }
 
 }  // namespace
@@ -119,7 +231,7 @@ size_t las_layout(int n_tiles, int F, int C, char *base, LasWs *ws) {
 extern "C" {
 
 size_t wdg_las_workspace_bytes(int32_t n, int32_t F, int32_t C) {
-    return las_layout(static_cast<int>(wdg::ceil_div(n > 0 ? n : 1, TILE_ROWS)), F, C, nullptr, nullptr) + 256;
+    return las_layout(static_cast<int>(wdg::ceil_div(n > 0 ? n : 1, TILE_ROWS)), F, C, nullptr, nullptr) + 512;
 }
 
 int wdg_las_f32(const float *H, int64_t ldh, const int32_t *labels, const int32_t *rows, int32_t n, int32_t F,
@@ -128,24 +240,21 @@ int wdg_las_f32(const float *H, int64_t ldh, const int32_t *labels, const int32_
     WDG_REQUIRE(n >= 0 && F >= 0 && C >= 0, "las: negative size");
     WDG_REQUIRE(count_out, "las: null count_out");
     hipStream_t st = as_stream(stream);
-    hipMemsetAsync(count_out, 0, sizeof(int64_t) * 2, st);
-    if (n == 0 || C == 0) return WDG_OK;
+    if (n == 0 || C == 0) return hipMemsetAsync(count_out, 0, sizeof(int64_t) * 2, st) == hipSuccess ? WDG_OK : WDG_ERR_LAUNCH;
     WDG_REQUIRE(H && labels && ldh >= F, "las: bad input");
-    const int n_tiles = static_cast<int>(ceil_div(n, TILE_ROWS));
-    if (!workspace || workspace_bytes < wdg_las_workspace_bytes(n, F, C))
-        return fail(WDG_ERR_WORKSPACE, "las: workspace too small");
-    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
-    LasWs ws;
-    las_layout(n_tiles, F, C, base, &ws);
-    const int fchunks = static_cast<int>(ceil_div(F > 0 ? F : 1, 64));
-    hipLaunchKernelGGL(las_middle_partial, dim3(n_tiles, fchunks), dim3(64), 0, st, H, ldh, labels, rows, n, F, C,
-                       ws.partial, ws.cnt_partial);
-    const int cf = C * (F > 0 ? F : 1);
-    hipLaunchKernelGGL(las_middle_reduce, dim3(ceil_div(cf > C ? cf : C, 256)), dim3(256), 0, st, ws.partial,
-                       ws.cnt_partial, n_tiles, F, C, ws.M, ws.cls_cnt);
-    hipLaunchKernelGGL(las_weights_kernel, dim3(ceil_div(static_cast<int64_t>(n) * 64, 256)), dim3(256), 0, st, H, ldh,
-                       labels, rows, n, F, C, ws.M, ws.cls_cnt, W_out, reinterpret_cast<long long *>(count_out));
-    return check_launch("las");
+    if (!workspace || workspace_bytes < wdg_las_workspace_bytes(n, F, C)) return fail(WDG_ERR_WORKSPACE, "las: workspace too small");
+    wdg_las_job j{};
+    j.H = H; j.labels = labels; j.rows = rows; j.W_out = W_out; j.count_out = count_out; j.workspace = workspace;
+    j.ldh = ldh; j.n = n; j.F = F; j.C = C;
+    return launch_las(nullptr, j, 1, n, F, C, st);
+}
+
+int wdg_las_batched_f32(const wdg_las_job *jobs_dev, int32_t n_jobs, int32_t max_n, int32_t max_F, int32_t max_C,
+                        wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_n >= 0 && max_F >= 0 && max_C >= 0, "las_batched: negative size");
+    if (n_jobs == 0 || max_n == 0 || max_C == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr && n_jobs <= 65535, "las_batched: bad job table");
+    return launch_las(jobs_dev, wdg_las_job{}, n_jobs, max_n, max_F, max_C, as_stream(stream));
 }
 
 }  // extern "C"

@@ -344,6 +344,64 @@ class StatsBatch:
               "wdg_edge_label_stats_batched")
 
 
+class LasBatch:
+    """Job table for wdg_las_batched_f32: soft / hard LAS counts of many graphs in one launch (3 kernels)."""
+
+    def __init__(self, entries, n_classes):
+        """entries: list of (H [n,F] fp32 device, labels int32 device [n])."""
+        dev = require_gpu()
+        self.keep = entries
+        self.n_jobs, self.c = len(entries), int(n_classes)
+        self.counts = torch.zeros((self.n_jobs, 2), dtype=torch.int64, device=dev)
+        self.n = torch.tensor([h.shape[0] for h, _ in entries], dtype=torch.float32, device=dev)
+        sizes = [lib.wdg_las_workspace_bytes(h.shape[0], h.shape[1], self.c) for h, _ in entries]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.ws = torch.empty(int(offs[-1]) + 256, dtype=torch.uint8, device=dev)
+        arr = (_lib.LasJob * self.n_jobs)()
+        self.max_n = self.max_f = 0
+        for i, (job, (h, lab)) in enumerate(zip(arr, entries)):
+            job.H, job.labels, job.rows, job.W_out = h.data_ptr(), lab.data_ptr(), 0, 0
+            job.count_out, job.workspace = self.counts[i].data_ptr(), self.ws.data_ptr() + int(offs[i])
+            job.ldh, job.n, job.F, job.C = h.stride(0), h.shape[0], h.shape[1], self.c
+            self.max_n, self.max_f = max(self.max_n, h.shape[0]), max(self.max_f, h.shape[1])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
+        self.table = host.to(dev)
+
+    def launch(self):
+        check(lib.wdg_las_batched_f32(_ptr(self.table), self.n_jobs, self.max_n, self.max_f, self.c, stream_handle()),
+              "wdg_las_batched_f32")
+
+
+class GemmBatch:
+    """Job table for wdg_gemm_batched_f32: C_i = act(A_i @ B_i + bias_i), one launch."""
+
+    def __init__(self, entries, relu=False):
+        """entries: list of (A [M,K], B [K,N], C [M,N], bias|None) fp32 device tensors (unit inner stride)."""
+        dev = require_gpu()
+        self.keep = entries
+        arr = (_lib.GemmJob * len(entries))()
+        self.max_m = self.max_n = 0
+        self.flops = 0
+        for job, (a, b, c, bias) in zip(arr, entries):
+            m, k = a.shape
+            n = b.shape[1]
+            if b.shape[0] != k or tuple(c.shape) != (m, n) or any(t.stride(1) != 1 or t.dtype != torch.float32 for t in (a, b, c)):
+                raise ValueError("GemmBatch: shape / layout mismatch")
+            job.A, job.B, job.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
+            job.bias = 0 if bias is None else bias.data_ptr()
+            job.lda, job.ldb, job.ldc = a.stride(0), b.stride(0), c.stride(0)
+            job.M, job.N, job.K, job.act = m, n, k, (ACT_RELU if relu else ACT_NONE)
+            self.max_m, self.max_n = max(self.max_m, m), max(self.max_n, n)
+            self.flops += 2 * m * n * k
+        self.n_jobs = len(entries)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
+        self.table = host.to(dev)
+
+    def launch(self):
+        check(lib.wdg_gemm_batched_f32(_ptr(self.table), self.n_jobs, self.max_m, self.max_n, stream_handle()),
+              "wdg_gemm_batched_f32")
+
+
 # ------------------------------------------------------------------------------------------- per-edge cosine
 def edge_cosine(g, x, entries=None, skip_self=True):
     """fp32 cosine similarity of the endpoints of every stored entry (or of the listed entry ids); wdg_edge_cosine_f32."""

@@ -16,7 +16,7 @@ import torch
 
 from . import synth
 
-METRIC_NAMES = ("edge_homo", "node_homo", "class_homo", "adj_homo", "label_info")
+METRIC_NAMES = ("edge_homo", "node_homo", "class_homo", "adj_homo", "label_info", "soft_las")
 
 
 @dataclass(frozen=True)
@@ -93,7 +93,7 @@ def gather_results(local_rows, device):
 class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
-    def __init__(self, jobs, n_feat=500, symmetric=0):
+    def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64):
         from . import ops
         self.ops = ops
         self.jobs = list(jobs)
@@ -116,8 +116,40 @@ class SweepBatch:
                    for j, g, y, d in zip(self.jobs, self.graphs, self.y, self.dinv)]
         self.spmm = ops.SpmmBatch(entries)
         n_classes = max([j.n_classes for j in self.jobs], default=0)
+        self.n_classes = n_classes
         self.stats = ops.StatsBatch(self.graphs, self.labels, n_classes)
         self.edges = sum(g.nnz for g in self.graphs)
+
+        def scale(d):
+            return d if symmetric else None
+
+        # aggregation homophily (soft LAS, synthetic_plot.py:106): H = A_hat Z with one-hot Z, then W = H (H^T Y)
+        onehot = {}
+        self.h_las = []
+        las_entries = []
+        for j, lab in zip(self.jobs, self.labels):
+            key = (j.n_nodes, j.n_classes)
+            if key not in onehot:
+                onehot[key] = torch.eye(n_classes, device=dev)[lab.long()].contiguous()
+            self.h_las.append(torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev))
+            las_entries.append((self.graphs[len(las_entries)], onehot[key], self.h_las[-1]))
+        self.spmm_las = ops.SpmmBatch([(g, z, h, d, scale(d), False) for (g, z, h), d in zip(las_entries, self.dinv)])
+        self.las = ops.LasBatch(list(zip(self.h_las, self.labels)), n_classes)
+
+        # GCN-2 forward (build-defined model, models.py): logits = A_hat relu((A_hat X) W0) W1, every job its own weights
+        self.gcn = None
+        if gcn_hidden:
+            gen = torch.Generator(device="cpu").manual_seed(1234)
+            w0 = [(torch.randn((n_feat, gcn_hidden), generator=gen) * (2.0 / (n_feat + gcn_hidden)) ** 0.5).to(dev) for _ in self.jobs]
+            w1 = [(torch.randn((gcn_hidden, n_classes), generator=gen) * (2.0 / (gcn_hidden + n_classes)) ** 0.5).to(dev) for _ in self.jobs]
+            hid = [torch.empty((j.n_nodes, gcn_hidden), dtype=torch.float32, device=dev) for j in self.jobs]
+            z2 = [torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev) for j in self.jobs]
+            out = [torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev) for j in self.jobs]
+            self.gcn = dict(w0=w0, w1=w1, hid=hid, z2=z2, logits=out,
+                            gemm1=ops.GemmBatch([(y, a, h, None) for y, a, h in zip(self.y, w0, hid)], relu=True),
+                            gemm2=ops.GemmBatch([(h, b, z, None) for h, b, z in zip(hid, w1, z2)]),
+                            spmm=ops.SpmmBatch([(g, z, o, d, scale(d), False)
+                                                for g, z, o, d in zip(self.graphs, z2, out, self.dinv)]))
 
     # -- bytes the aggregation must move (fused normalisation: no `val`, + dinv) ---------------
     def spmm_algorithmic_bytes(self):
@@ -135,9 +167,20 @@ class SweepBatch:
         return tot
 
     def step(self):
-        """one pass of the hot path over the batch: aggregation, then the integer edge/label pass"""
-        self.spmm.launch()
-        self.stats.launch()
+        """one pass of the hot path over the batch (synthetic_plot.py:92-108 minus the kernel-regression metric):
+        feature aggregation, integer edge/label pass, label aggregation + LAS, GCN-2 forward"""
+        self.spmm.launch()        # Y = A_hat X                       (F = n_feat)   dominant kernel
+        self.step_rest()
+
+    def step_rest(self):
+        """everything of a step after the feature aggregation (bench.py times that launch separately)"""
+        self.stats.launch()       # edge / node / class / adjusted homophily, label informativeness counters
+        self.spmm_las.launch()    # H = A_hat onehot(labels)          (F = C)
+        self.las.launch()         # soft / hard LAS counts
+        if self.gcn:
+            self.gcn["gemm1"].launch()  # relu(Y W0)                  fp32 MFMA
+            self.gcn["gemm2"].launch()  # (.) W1
+            self.gcn["spmm"].launch()   # logits = A_hat (.)           (F = C)
 
     def results(self):
         """[jobs, len(METRIC_NAMES)] fp32: dense-flavour metric scalars (utils/homophily_plot.py) from the counters."""
@@ -165,4 +208,5 @@ class SweepBatch:
         s2 = (p_bar ** 2).sum(1)
         adj = (edge - s2) / (1 - s2)
         li = 2 - (pc * torch.log(pc)).sum((1, 2)) / (p_bar * torch.log(p_bar)).sum(1)
-        return torch.stack([edge, node, cls, adj, li], 1)
+        soft_las = self.las.counts[:, 0].to(torch.float32) / self.las.n
+        return torch.stack([edge, node, cls, adj, li, soft_las], 1)
