@@ -116,7 +116,8 @@ typedef struct wdg_spmm_job {
     const void *X; /* fp32, or bf16 for the *_bf16 entry points */
     float *Y;
     int64_t ldx, ldy;
-    int32_t n_rows, n_cols, n_feat, reserved;
+    int32_t n_rows, n_cols, n_feat;
+    int32_t reserved; /* must be 0 (bits 0 / 2 are timing-only ablation switches of the diagnostics scripts: results are wrong when set) */
     /* optional column-blocked SELL-64 copy of the same pattern (wdg_csr_to_sell_*): enables the row-lane
        kernel for graphs of <= 4096 rows; NULL = CSR kernels only */
     const int32_t *sell_ptr; /* [n_blocks * ceil(n_rows/64) + 1] entry offsets, block-major                */

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
             if (slice >= n_slices) continue;  // wave-uniform
             const int task = blk * n_slices + slice;
             const int base = job.sell_ptr[task];
-            const int width = (job.sell_ptr[task + 1] - base) >> 6;  // wave-uniform trip count
+            const int width = (job.reserved & 4) ? 0 : (job.sell_ptr[task + 1] - base) >> 6;  // wave-uniform trip count (reserved bit 2: timing ablation)
             const int32_t *sc = job.sell_col + base + lane;
             const float *sv = HAS_VAL ? job.sell_val + base + lane : nullptr;
             int c[U], cn[U];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
             const int rl = it * ROWS_PER_IT + lane / QUADS, qd = lane % QUADS;
             const float4 a = tr[rl * QUADS + qd];
             const int grow = slice * 64 + rl;
-            if (grow < n_rows) {
+            if (grow < n_rows && !((job.reserved & 1) && a.x != 12345.678f)) {  // reserved bit 0: timing ablation
                 float *dst = job.Y + static_cast<int64_t>(grow) * job.ldy + f0 + qd * 4;
                 if (y_vec) {
                     *reinterpret_cast<float4 *>(dst) = a;
