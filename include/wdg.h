@@ -119,12 +119,13 @@ typedef struct wdg_spmm_job {
     int32_t n_rows, n_cols, n_feat;
     int32_t reserved; /* must be 0 (bits 0 / 2 are timing-only ablation switches of the diagnostics scripts: results are wrong when set) */
     /* optional column-blocked SELL-64 copy of the same pattern (wdg_csr_to_sell_*): enables the row-lane
-       kernel for graphs of <= 4096 rows; NULL = CSR kernels only */
+       kernel for graphs of <= 6144 rows; NULL = CSR kernels only */
     const int32_t *sell_ptr; /* [n_blocks * ceil(n_rows/64) + 1] entry offsets, block-major                */
     const int32_t *sell_col; /* (block b, slice s): entry e of row 64 s + l at sell_ptr[b*S + s] + 64 e + l */
     const float *sell_val;   /* same layout, needed when `val` is given                                    */
     int32_t sell_block_cols; /* columns per block = wdg_sell_block_cols(n_cols)                            */
     int32_t sell_n_blocks;   /* ceil(n_cols / sell_block_cols)                                             */
+    const int32_t *sell_perm; /* [n_rows] SELL slot -> row (rows sorted by length, longest first); NULL = identity */
 } wdg_spmm_job;
 
 int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream);
@@ -133,6 +134,8 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
  * Many independent graphs in ONE launch (the homophily sweep, synthetic_plot.py:64-109).
  * `jobs_dev` is a device array of n_jobs descriptors; max_rows/max_cols/max_feat bound the job shapes
  * (needed on the host to size the grid and LDS without reading the table back).
+ * Jobs are started in table order by persistent workgroups: put the jobs with the most stored entries first
+ * so that no long job starts last (results do not depend on the order).
  */
 #define WDG_SPMM_ALL_SELL 1 /* every job of the table carries sell_ptr / sell_col            */
 #define WDG_SPMM_ANY_VAL 2  /* some job has explicit values (then sell_val must be set too) */
@@ -147,15 +150,19 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
  * CSR -> column-blocked SELL-64: the columns are cut into ceil(n_cols / B) blocks of B = wdg_sell_block_cols(n_cols)
  * (what one LDS pass of the row-lane kernel can stage); inside a block the rows are grouped in slices of 64, stored
  * entry-major, padded with 0x7fffffff / value 0.  Column indices stay global, order inside a row is preserved.
+ * Rows are first sorted (sell_perm[slot] = row, ties by row id) so that a slice holds rows of similar length and
+ * pads by percents instead of multiples: by total length, longest first, for skewed graphs (longest row > 4x the
+ * mean) or more than 4 column blocks; otherwise lexicographically by the per-block lengths (block 0 first).
  * Two calls: count fills sell_ptr (entry offsets; the last one = padded entry count, read it back to size
  * sell_col / sell_val), then fill.  One-time per graph, like the CSR build.
  */
 int32_t wdg_sell_block_cols(int32_t n_cols);
 size_t wdg_sell_workspace_bytes(int32_t N, int32_t n_cols);
-int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *sell_ptr,
-                          void *workspace, size_t workspace_bytes, wdg_stream_t stream);
+int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *sell_perm,
+                          int32_t *sell_ptr, void *workspace, size_t workspace_bytes, wdg_stream_t stream);
 int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
-                         const int32_t *sell_ptr, int32_t *sell_col, float *sell_val, wdg_stream_t stream);
+                         const int32_t *sell_perm, const int32_t *sell_ptr, int32_t *sell_col, float *sell_val,
+                         wdg_stream_t stream);
 
 /* ------------------------------------------------------------------ edge / label statistics */
 /*

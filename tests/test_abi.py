@@ -49,7 +49,7 @@ def test_host_side_queries_need_no_gpu():
 
 def test_struct_layout_matches_header():
     import wdg_amd._lib as L
-    assert ctypes.sizeof(L.SpmmJob) == 7 * 8 + 2 * 8 + 4 * 4 + 3 * 8 + 2 * 4
+    assert ctypes.sizeof(L.SpmmJob) == 7 * 8 + 2 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8
     assert ctypes.sizeof(L.StatsJob) == 9 * 8 + 2 * 4
 
 

@@ -1,0 +1,110 @@
+"""GPU parity at the sizes of BASELINE configs C4 (squirrel + chameleon real topology, heterophilous, skewed degrees)
+and C5 (twitch-gamers scale: 168 114 nodes, ~13.8 M stored entries, F = 7 bf16 features, C = 2).
+Real node features / the twitch csv are absent from the reference checkout, so features and labels are
+synthetic of the right shape; the topology of C4 is the real one (tests/golden/topo_*.npz)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name,f", [("squirrel", 2089), ("chameleon", 2325)])
+def test_c4_real_topology(oracle, name, f):
+    from wdg_amd import models, ops
+    g0 = load("topo_" + name)
+    n = int(g0["n_nodes"])
+    rng = np.random.default_rng(17)
+    x = (rng.random((n, f), dtype=np.float32) < 0.02) * rng.random((n, f), dtype=np.float32)
+    x[np.arange(n), rng.integers(0, f, n)] = 1.0
+    labels = rng.integers(0, 5, n)
+    g = ops.CsrGraph.from_coo(g0["adj_row"], g0["adj_col"], n, None, ops.COO_ADD_SELF_LOOPS)
+    rowptr, col, val = oracle.coo_to_csr(g0["adj_row"], g0["adj_col"], n, None, oracle.ADD_SELF_LOOPS)
+    np.testing.assert_array_equal(_np(g.rowptr), rowptr)
+    np.testing.assert_array_equal(_np(g.col), col)
+    np.testing.assert_array_equal(_np(g.val), val)  # pre-existing loops doubled by A + I
+    assert int((val == 2).sum()) == int((g0["adj_row"] == g0["adj_col"]).sum())
+    st = ops.edge_label_stats(g, torch.from_numpy(labels))
+    ref = oracle.edge_label_stats(rowptr, col, labels, 5)
+    for k in ("totals", "row_nnz", "row_nnz_noself", "row_match_noself", "compat", "classdeg"):
+        np.testing.assert_array_equal(_np(st[k]), ref[k], err_msg=k)
+    xt = torch.from_numpy(x).cuda()
+    for mode in (0, 1):
+        d = ops.degree_norm(g, mode, ops.PREC_F32)["dinv"]
+        y = ops.spmm(g, xt, row_scale=d, col_scale=d if mode else None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ops.spmm(g, xt, row_scale=d, col_scale=d if mode else None, out=y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        vhat = oracle.normalised_csr(rowptr, col, val, mode, oracle.PREC_F32)
+        want = oracle.spmm_csr(rowptr, col, vhat, x)
+        np.testing.assert_allclose(_np(y), want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+        print(f"[C4 {name} mode={mode}] {col.shape[0] / dt / 1e6:.0f} M edges/s, {dt * 1e6:.0f} us "
+              f"(plan {ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL if g.sell else 0)})")
+    # GCN-2 vs SGC-1 forward on this topology (config C4): finite, and SGC equals the oracle chain
+    adj = models.NormAdj(g, symmetric=1, add_self_loops=False)  # g already holds A + I
+    torch.manual_seed(0)
+    sgc, gcn = models.SGC1(f, 5).cuda(), models.GCN2(f, 5, nhid=64, dropout=0.0).cuda().eval()
+    with torch.no_grad():
+        a, b = sgc(adj, xt), gcn(adj, xt)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    vhat = oracle.normalised_csr(rowptr, col, val, 1, oracle.PREC_F32)
+    want = oracle.gemm(oracle.spmm_csr(rowptr, col, vhat, x), _np(sgc.weight))
+    np.testing.assert_allclose(_np(a), want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+
+
+def test_c5_twitch_scale(oracle):
+    from wdg_amd import ops, synth
+    from wdg_amd.utils import homophily_metrics as hm
+    from wdg_amd.utils.util_funcs import random_disassortative_splits
+    n, e_und, f = 168114, 6797557, 7
+    src, dst = synth.random_graph(n, e_und, seed=5)
+    flags = ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_ADD_SELF_LOOPS  # to_undirected, then + I
+    g = ops.CsrGraph.from_coo(src, dst, n, None, flags)
+    rowptr, col, val = oracle.coo_to_csr(src, dst, n, None, oracle.SYMMETRISE | oracle.BINARISE | oracle.ADD_SELF_LOOPS)
+    np.testing.assert_array_equal(_np(g.rowptr), rowptr)
+    np.testing.assert_array_equal(_np(g.col), col)
+    np.testing.assert_array_equal(_np(g.val), val)
+    rng = np.random.default_rng(6)
+    labels = rng.integers(0, 2, n)
+    st = ops.edge_label_stats(g, torch.from_numpy(labels), per_row=False)
+    ref = oracle.edge_label_stats(rowptr, col, labels, 2)
+    for k in ("totals", "compat", "classdeg"):
+        np.testing.assert_array_equal(_np(st[k]), ref[k], err_msg=k)
+    # SGC-1 aggregation with bf16 features, fp32 accumulation (config C5)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    xb = torch.from_numpy(x).cuda().to(torch.bfloat16)
+    d = ops.degree_norm(g, ops.NORM_SYM, ops.PREC_F32)["dinv"]
+    assert ops.spmm_plan(n, n, f)[0] == 1  # row-gather family
+    y = ops.spmm(g, xb, row_scale=d, col_scale=d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ops.spmm(g, xb, row_scale=d, col_scale=d, out=y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"[C5 twitch-scale] nnz={col.shape[0]} bf16 F=7: {col.shape[0] / dt / 1e9:.2f} G edges/s, {dt * 1e6:.0f} us")
+    vhat = oracle.normalised_csr(rowptr, col, val, 1, oracle.PREC_F32)
+    want = oracle.spmm_csr(rowptr, col, vhat, _np(xb.float()))
+    np.testing.assert_allclose(_np(y), want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+    # aggregation homophily with the 10 000-node class-balanced sample (homophily_tests.py:124-131)
+    lab_t = torch.from_numpy(labels)
+    onehot = torch.eye(2)[lab_t]
+    torch.manual_seed(3)
+    mask, _, _ = random_disassortative_splits(lab_t, lab_t.max() + 1, 10000 / n)
+    adj_raw = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE)
+    r2, c2, v2 = oracle.coo_to_csr(src, dst, n, None, oracle.SYMMETRISE | oracle.BINARISE)
+    for hard in (None, 1):
+        got = float(hm.similarity(onehot, adj_raw, onehot, hard=hard, LP=1, idx_train=mask))
+        want = oracle.similarity(_np(onehot), r2, c2, v2, _np(onehot), hard=hard, idx_train=_np(mask), f64=True)
+        assert abs(got - want) <= 1.01 / int(mask.sum())

@@ -347,7 +347,7 @@ def test_spmm_full_size_properties(ops):
 # --------------------------------------------------------------------------------------------- SELL-64 + row-lane kernel
 def test_sell_layout_matches_csr(ops, oracle):
     rng = np.random.default_rng(31)
-    for n, e in ((1, 1), (64, 500), (65, 700), (2000, 20000), (4096, 9000), (130, 0)):
+    for n, e in ((1, 1), (64, 500), (65, 700), (2000, 20000), (4096, 9000), (130, 0), (5201, 40000), (6144, 7000)):
         src, dst = _rand_graph(rng, n, e)
         rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
         g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, n)
@@ -358,22 +358,32 @@ def test_sell_layout_matches_csr(ops, oracle):
         bc, nb = g.sell[3], g.sell[4]
         assert nb == (n + bc - 1) // bc and bc * 128 <= 160 * 1024
         n_slices = (n + 63) // 64
+        perm = _np(g.sell[5])  # slot -> row (see sell_sort_rows: by total length if skewed, else by block lengths)
+        lens = np.diff(rowptr)
+        skewed = int(lens.max()) * n > 4 * int(lens.sum())
+        if skewed or nb < 2 or nb > 4:
+            want_perm = np.argsort(-lens, kind="stable")
+        else:
+            rows_of = np.repeat(np.arange(n), lens)
+            per_block = [np.bincount(rows_of[col // bc == b], minlength=n) for b in range(nb)]
+            want_perm = np.lexsort([np.arange(n)] + [-per_block[b] for b in reversed(range(nb))])
+        np.testing.assert_array_equal(perm, want_perm)
         for b in range(nb):
             for s in range(n_slices):
                 t = b * n_slices + s
-                rows = np.arange(s * 64, min(n, s * 64 + 64))
+                rows = perm[s * 64:min(n, s * 64 + 64)]
                 width = (sp[t + 1] - sp[t]) // 64
                 blk_c = sc[sp[t]:sp[t + 1]].reshape(width, 64)
                 blk_v = sv[sp[t]:sp[t + 1]].reshape(width, 64)
                 longest = 0
-                for r in rows:
+                for lane, r in enumerate(rows):
                     cr, vr = col[rowptr[r]:rowptr[r + 1]], val[rowptr[r]:rowptr[r + 1]]
                     sel = (cr >= b * bc) & (cr < (b + 1) * bc)
                     l = int(sel.sum())
                     longest = max(longest, l)
-                    np.testing.assert_array_equal(blk_c[:l, r - s * 64], cr[sel])
-                    np.testing.assert_array_equal(blk_v[:l, r - s * 64], vr[sel])
-                    assert (blk_c[l:, r - s * 64] == 0x7fffffff).all() and (blk_v[l:, r - s * 64] == 0).all()
+                    np.testing.assert_array_equal(blk_c[:l, lane], cr[sel])
+                    np.testing.assert_array_equal(blk_v[:l, lane], vr[sel])
+                    assert (blk_c[l:, lane] == 0x7fffffff).all() and (blk_v[l:, lane] == 0).all()
                 assert width == longest
                 assert (blk_c[:, rows.size:] == 0x7fffffff).all()
 

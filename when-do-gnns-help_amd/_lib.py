@@ -27,7 +27,7 @@ class SpmmJob(ctypes.Structure):
                 ("col_scale", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("ldx", c_int64), ("ldy", c_int64),
                 ("n_rows", c_int32), ("n_cols", c_int32), ("n_feat", c_int32), ("reserved", c_int32),
                 ("sell_ptr", c_void_p), ("sell_col", c_void_p), ("sell_val", c_void_p),
-                ("sell_block_cols", c_int32), ("sell_n_blocks", c_int32)]
+                ("sell_block_cols", c_int32), ("sell_n_blocks", c_int32), ("sell_perm", c_void_p)]
 
 
 class StatsJob(ctypes.Structure):
@@ -60,9 +60,10 @@ SIGNATURES = {
     "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "wdg_sell_block_cols": (c_int32, [c_int32]),
     "wdg_sell_workspace_bytes": (c_size_t, [c_int32, c_int32]),
-    "wdg_csr_to_sell_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wdg_csr_to_sell_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
     "wdg_csr_to_sell_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                     c_void_p]),
+                                     c_void_p, c_void_p]),
     "wdg_edge_label_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "wdg_edge_label_stats_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

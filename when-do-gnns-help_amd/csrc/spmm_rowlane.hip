@@ -24,6 +24,8 @@
 //     128 bytes: Y leaves the CU in whole lines as well.
 // Summation order per row = column order of the CSR row (blocks ascend, entries ascend inside a block) ->
 // bitwise reproducible, the order a sequential CPU sweep over the coalesced COO uses.
+#include <atomic>
+
 #include "wdg_common.h"
 
 namespace wdg {
@@ -37,20 +39,26 @@ using namespace wdg;
 
 constexpr int RL_THREADS = 1024;
 constexpr int RL_WAVES = RL_THREADS / 64;
-constexpr int RL_MAX_ROWS = 4 * RL_THREADS;
+constexpr int RL_MAX_ROWS = 6 * RL_THREADS;  // 6 rows per thread at 4 float4 accumulators each
 constexpr int SELL_SENTINEL = 0x7fffffff;  // padding entry
 constexpr int RL_LDS_ROW_BYTES = 128;      // the block size is chosen for 32-feature (128-B) staged rows
 
-#ifdef WDG_STAMPS  // diagnostic build only (make STAMPS=1)
+#ifdef WDG_STAMPS  // diagnostic build only (make STAMPS=1): wave 0's clock at phase boundaries, one 16-slot record per
+                   // (workgroup, item iteration); the s_waitcnt(0) makes wave 0 drain its queues, so timings are perturbed
 __device__ unsigned long long wdg_rl_stamp_buf[4096 * 16];
+#define RL_STAMP_ITER int rl_iter = 0
+#define RL_STAMP_NEXT ++rl_iter
 #define RL_STAMP(k)                                                                          \
     do {                                                                                     \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                         \
+        const int rl_slot = rl_iter * gridDim.x + blockIdx.x;                                \
+        if (threadIdx.x == 0 && rl_slot < 4096 && (k) < 16) {                                \
             __builtin_amdgcn_s_waitcnt(0);                                                   \
-            wdg_rl_stamp_buf[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();      \
+            wdg_rl_stamp_buf[rl_slot * 16 + (k)] = __builtin_amdgcn_s_memrealtime();         \
         }                                                                                    \
     } while (0)
 #else
+#define RL_STAMP_ITER do { } while (0)
+#define RL_STAMP_NEXT do { } while (0)
 #define RL_STAMP(k) do { } while (0)
 #endif
 
@@ -70,14 +78,89 @@ __device__ __forceinline__ int lower_bound_col(const int32_t *col, int lo, int h
     return lo;
 }
 
+// Row order of the SELL copy (SELL-C-sigma with sigma = the whole graph): perm[slot] = original row of slot.
+//   * skewed graphs (longest row > 4x the mean; squirrel: max degree 1904, mean 76) or > 4 column blocks: rows by
+//     total length, longest first - slices hold rows of similar length and pad by percents instead of 25x;
+//   * otherwise lexicographically by the per-column-block lengths (block 0 first, longest first): a slice's rows
+//     then agree in EVERY block, where sorting by the total leaves the binomial split between blocks as padding
+//     (N = 2000, degree 10, 2 blocks: 2.2x padded entries in row order, 1.7x by total, ~1.1x by block lengths).
+// Ties keep row order.  Padding costs LDS issue slots in the sweep, which is LDS-bound.
+constexpr int SORT_MAX_ROWS = 8192;  // 13 bits of row id in the packed key
+constexpr int SORT_MAX_BLOCKS = 4;   // 4 x 12 bits of block length (a block has <= 1272 columns)
+
+__global__ __launch_bounds__(1024) void sell_sort_rows(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                       int32_t N, int32_t n_blocks, int32_t block_cols,
+                                                       int32_t *__restrict__ perm) {
+    __shared__ unsigned long long keys[SORT_MAX_ROWS - 8];
+    __shared__ int longest;
+    if (N > SORT_MAX_ROWS - 8) {  // such graphs never take the row-lane path: identity
+        for (int i = threadIdx.x; i < N; i += 1024) perm[i] = i;
+        return;
+    }
+    if (threadIdx.x == 0) longest = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < N; i += 1024) mine = max(mine, rowptr[i + 1] - rowptr[i]);
+    if (mine > 0) atomicMax(&longest, mine);
+    __syncthreads();
+    const bool skewed = static_cast<long long>(longest) * N > 4ll * (rowptr[N] - rowptr[0]);
+    const bool by_block = !skewed && n_blocks >= 2 && n_blocks <= SORT_MAX_BLOCKS;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const int s = rowptr[i], e = rowptr[i + 1];
+        unsigned long long key;
+        if (by_block) {
+            key = 0;
+            int a = s;
+            for (int b = 0; b < n_blocks; ++b) {
+                const int nxt = (b + 1 == n_blocks) ? e : lower_bound_col(col, a, e, (b + 1) * block_cols);
+                key = (key << 12) | static_cast<unsigned>(4095 - min(nxt - a, 4095));
+                a = nxt;
+            }
+            key = (key << 13) | static_cast<unsigned>(i);
+        } else {
+            key = (static_cast<unsigned long long>(0x7fffffffu - static_cast<unsigned>(e - s)) << 32) | static_cast<unsigned>(i);
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    int P = 1;
+    while (P < N) P <<= 1;
+    for (int k = 2; k <= P; k <<= 1) {  // comparator network, all ascending, virtual +inf padding (any N)
+        for (int i = threadIdx.x; i < N; i += 1024) {
+            const int l = i ^ (k - 1);
+            if (l > i && l < N && keys[i] > keys[l]) {
+                const unsigned long long t = keys[i];
+                keys[i] = keys[l];
+                keys[l] = t;
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < N; i += 1024) {
+                const int l = i ^ j;
+                if (l > i && l < N && keys[i] > keys[l]) {
+                    const unsigned long long t = keys[i];
+                    keys[i] = keys[l];
+                    keys[l] = t;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned long long row_mask = by_block ? 0x1fffull : 0xffffffffull;
+    for (int i = threadIdx.x; i < N; i += 1024) perm[i] = static_cast<int32_t>(keys[i] & row_mask);
+}
+
 // one wave per (column block, slice): width = longest in-block row segment of the slice
 __global__ __launch_bounds__(256) void sell_widths(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                   int32_t N, int32_t n_slices, int32_t n_blocks, int32_t block_cols,
+                                                   const int32_t *__restrict__ perm, int32_t N, int32_t n_slices,
+                                                   int32_t n_blocks, int32_t block_cols,
                                                    int32_t *__restrict__ width64) {
     const int task = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (task >= n_slices * n_blocks) return;
     const int blk = task / n_slices, slice = task % n_slices;
-    const int row = slice * 64 + lane;
+    const int slot = slice * 64 + lane;
+    const int row = slot < N ? perm[slot] : N;
     int len = 0;
     if (row < N) {
         const int s = rowptr[row], e = rowptr[row + 1];
@@ -90,14 +173,15 @@ __global__ __launch_bounds__(256) void sell_widths(const int32_t *__restrict__ r
 }
 
 __global__ __launch_bounds__(256) void sell_fill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                 const float *__restrict__ val, int32_t N, int32_t n_slices,
-                                                 int32_t n_blocks, int32_t block_cols,
+                                                 const float *__restrict__ val, const int32_t *__restrict__ perm,
+                                                 int32_t N, int32_t n_slices, int32_t n_blocks, int32_t block_cols,
                                                  const int32_t *__restrict__ sell_ptr, int32_t *__restrict__ sell_col,
                                                  float *__restrict__ sell_val) {
     const int task = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (task >= n_slices * n_blocks) return;
     const int blk = task / n_slices, slice = task % n_slices;
-    const int row = slice * 64 + lane;
+    const int slot = slice * 64 + lane;
+    const int row = slot < N ? perm[slot] : N;
     const int base = sell_ptr[task], width = (sell_ptr[task + 1] - base) >> 6;
     int a = 0, len = 0;
     if (row < N) {
@@ -114,6 +198,18 @@ __global__ __launch_bounds__(256) void sell_fill(const int32_t *__restrict__ row
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
+// work-queue counters, one slot per launch in flight (slots are handed out round-robin by the launcher and re-armed by
+// the last workgroup of the launch that used them)
+constexpr int RL_QUEUE_SLOTS = 256;
+__device__ unsigned int rl_queue_next[RL_QUEUE_SLOTS * kXcds];
+__device__ unsigned int rl_queue_done[RL_QUEUE_SLOTS];
+
+// workgroup barrier that waits for this wave's LDS traffic only: global stores and loads stay in flight across it
+// (__syncthreads() would drain vmcnt as well, i.e. wait for the previous item's row stores to be acknowledged)
+__device__ __forceinline__ void rl_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int QUADS, bool HAS_VAL>
 __device__ __forceinline__ void rl_accumulate(float4 (&acc)[QUADS], const float4 *xs, int c, float w, int lane) {
     const float4 *src = xs + c * QUADS;
@@ -134,27 +230,62 @@ __device__ __forceinline__ void rl_accumulate(float4 (&acc)[QUADS], const float4
 template <int QUADS, int RPT, typename TIN, bool HAS_VAL>
 __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm_job *__restrict__ jobs,
                                                                    const wdg_spmm_job inline_job, int n_groups,
-                                                                   long long n_items) {
+                                                                   long long n_items, int queue_slot) {
     constexpr int FG = QUADS * 4;  // features per item
-    constexpr int NL = 8;          // staged X loads in flight per thread
-    constexpr int U = 8;           // index entries per step (next step's loads are issued before this one is used)
+    constexpr int NL = 4;                // register-staged X loads in flight per thread (the LDS-DMA path needs no registers)
+    constexpr int U = RPT > 4 ? 4 : 8;   // index entries per step (next step's loads are issued before this one is used)
     extern __shared__ float4 xs[];
 
+    RL_STAMP_ITER;
+    // Persistent workgroups over per-XCD work queues.  Job j belongs to XCD j % 8 (queue j % n_queues; callers put the expensive jobs first, so
+    // the deal is balanced); all feature groups of a job run on that XCD, back to back: the 128-B lines they write are
+    // neighbours in Y's rows and leave one L2 together (write-backs that stay in one DRAM page; spread over the 8 L2s the
+    // same stores ran at 3 instead of 5 TB/s), and the SELL indices are fetched into one L2 only.  A workgroup's first
+    // item is static, the following ones come from its XCD's atomic counter, requested one item ahead so the round trip
+    // hides behind the current item; a workgroup whose queue is empty steals from the next XCD's.  A finished item's row
+    // stores drain while the next item's staging loads are already queued (the barriers below wait for LDS traffic only).
+    __shared__ int next_item[2];
+    __shared__ int stolen_item;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ng = n_groups;
+    const int n_jobs = static_cast<int>(n_items / ng);
+    const int wgs_per_xcd = gridDim.x / kXcds, xcd = blockIdx.x % kXcds;
+    const int n_queues = n_jobs >= 8 ? 8 : n_jobs >= 4 ? 4 : n_jobs >= 2 ? 2 : 1;  // fewer jobs than XCDs: XCDs share queues
+    const int first_claim = wgs_per_xcd * (kXcds / n_queues);                      // static items per queue
+    const unsigned *queues = rl_queue_next + queue_slot * kXcds;
+    int victim = 0, q = xcd % n_queues;  // q = (xcd + victim) % n_queues: the queue this workgroup currently draws from
+    int t = (xcd / n_queues) * wgs_per_xcd + blockIdx.x / kXcds;  // item index in queue q: job (t / ng) * n_queues + q, group t % ng
+    for (int round = 0;;) {
+    const int q_items = ((n_jobs - q + n_queues - 1) / n_queues) * ng;
+    if (t >= q_items) {              // queue q is drained: move on to the next one, claiming synchronously (rare)
+        if (++victim == n_queues) break;
+        q = (xcd + victim) % n_queues;
+        if (threadIdx.x == 0) stolen_item = static_cast<int>(first_claim + atomicAdd(const_cast<unsigned *>(&queues[q]), 1u));
+        rl_barrier_lds();
+        t = __builtin_amdgcn_readfirstlane(stolen_item);
+        rl_barrier_lds();
+        continue;
+    }
+    unsigned claimed = 0;  // thread 0 keeps the reply in a register until the item is done: nothing waits for it
+    if (threadIdx.x == 0) claimed = atomicAdd(const_cast<unsigned *>(&queues[q]), 1u);
+    do {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // opaque per item: keeps per-thread address arithmetic from being hoisted out of the
+                                   // item loop into registers the accumulators need
+    const int lane = tid & 63;
     RL_STAMP(0);
-    const long long item = xcd_contiguous_item(blockIdx.x, n_items);
-    if (item >= n_items) return;
-    const int job_id = static_cast<int>(item / n_groups), group = static_cast<int>(item % n_groups);
+    const int job_id = __builtin_amdgcn_readfirstlane((t / ng) * n_queues + q);  // uniform: the descriptor stays in SGPRs
+    const int group = __builtin_amdgcn_readfirstlane(t % ng);
     const wdg_spmm_job job = jobs ? jobs[job_id] : inline_job;
     const int f0 = group * FG;
-    if (f0 >= job.n_feat) return;
+    if (f0 >= job.n_feat) break;  // workgroup-uniform: this job has fewer feature groups than the widest one
     const int n_cols = job.n_cols, n_rows = job.n_rows, F = job.n_feat;
     const int block_cols = job.sell_block_cols, n_blocks = job.sell_n_blocks;
     const TIN *__restrict__ X = static_cast<const TIN *>(job.X);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool full = (f0 + FG <= F);
     const bool x_vec = full && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     const int n_slices = (n_rows + 63) >> 6;
+    const bool dma = x_vec && !job.col_scale && !(job.reserved & 8);  // reserved bit 3: diagnostic, forces register staging
 
     float4 acc[RPT][QUADS];
 #pragma unroll
@@ -162,12 +293,59 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
 #pragma unroll
         for (int h = 0; h < QUADS; ++h) acc[k][h] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    int out_row[RPT];
+    float out_scale[RPT];
     for (int blk = 0; blk < n_blocks; ++blk) {
         const int begin = blk * block_cols, end = min(begin + block_cols, n_cols);
-        const int n_stage = (end - begin) * QUADS;  // float4 slots to fill
-        RL_STAMP(3 + (blk - 1) * 3 + (blk == 0 ? 100 : 0) > 15 ? 15 : 3 + (blk - 1) * 3);
-        if (blk > 0) __syncthreads();               // previous block's readers are done
-        // ---- stage X[begin:end, f0:f0+FG] -> LDS: whole 128-B row segments, NL loads in flight per thread
+        const int n_stage = (job.reserved & 2) ? 0 : (end - begin) * QUADS;  // float4 slots to fill (reserved bit 1: timing ablation)
+        // ---- everything the sweep and the epilogue will wait for is requested BEFORE the staging, so its latency
+        //      hides behind the staging loads: the extents of this wave's slices (wave-uniform -> scalar loads), the
+        //      first index chunk, and (last block) the destination rows and their scales
+        int base[RPT], width[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int slice = wave + k * RL_WAVES;
+            base[k] = width[k] = 0;
+            if (slice < n_slices && !(job.reserved & 4)) {  // reserved bit 2: timing ablation (no sweep)
+                const int task = blk * n_slices + slice;
+                base[k] = job.sell_ptr[task];
+                width[k] = (job.sell_ptr[task + 1] - base[k]) >> 6;  // wave-uniform trip count
+            }
+        }
+        int c[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c[u] = (u < width[0]) ? job.sell_col[base[0] + lane + u * 64] : SELL_SENTINEL;
+            w[u] = (HAS_VAL && u < width[0]) ? job.sell_val[base[0] + lane + u * 64] : 0.f;
+        }
+        if (blk + 1 == n_blocks) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int slot = (wave + k * RL_WAVES) * 64 + lane;  // SELL slot -> original row (length-sort permutation)
+                out_row[k] = (slot < n_rows) ? (job.sell_perm ? job.sell_perm[slot] : slot) : n_rows;
+                out_scale[k] = (job.row_scale && out_row[k] < n_rows) ? job.row_scale[out_row[k]] : 1.f;
+            }
+        }
+        RL_STAMP(1 + blk * 4);  // extents, first chunk (and epilogue operands) landed
+        if (blk > 0) rl_barrier_lds();              // previous block's readers are done
+        // ---- stage X[begin:end, f0:f0+FG] -> LDS in whole 128-B row segments.  fp32, aligned, unscaled rows go by
+        //      LDS-DMA (global_load_lds_dwordx4: a wave-instruction fills 1 KiB = 8 staged rows, no data registers, every
+        //      load of the block in flight at once); the rest through registers, NL loads in flight per thread
+        if (dma) {
+            if constexpr (sizeof(TIN) == 4) {
+                for (int i0 = wave * 64; i0 < n_stage; i0 += RL_THREADS) {  // wave-uniform LDS destination xs[i0 + lane]
+                    const int i = i0 + lane;
+                    if (i < n_stage) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
+                        const int r = begin + i / QUADS, qd = i % QUADS;
+                        __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(r) * job.ldx + f0 + qd * 4,
+                                                         (__attribute__((address_space(3))) void *)(xs + i0), 16, 0, 0);
+#endif
+                    }
+                }
+            }
+        } else
         for (int i0 = 0; i0 < n_stage; i0 += RL_THREADS * NL) {
             float4 v[NL];
 #pragma unroll
@@ -198,33 +376,33 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
                 if (i < n_stage) xs[i] = v[j];
             }
         }
-        RL_STAMP(1 + blk * 3);
+        RL_STAMP(2 + blk * 4);  // staged
         __syncthreads();
-        RL_STAMP(2 + blk * 3);
+        RL_STAMP(3 + blk * 4);  // barrier
 
-        // ---- SELL sweep of this column block: counted loop, indices one step (U entries) ahead of their use
+        // ---- SELL sweep of this column block: counted loops; the indices of the NEXT step (the slice's next U entries,
+        //      or the first U of the wave's next slice) are requested before the current U entries are consumed
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int slice = wave + k * RL_WAVES;
-            if (slice >= n_slices) continue;  // wave-uniform
-            const int task = blk * n_slices + slice;
-            const int base = job.sell_ptr[task];
-            const int width = (job.reserved & 4) ? 0 : (job.sell_ptr[task + 1] - base) >> 6;  // wave-uniform trip count (reserved bit 2: timing ablation)
-            const int32_t *sc = job.sell_col + base + lane;
-            const float *sv = HAS_VAL ? job.sell_val + base + lane : nullptr;
-            int c[U], cn[U];
-            float w[U], wn[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                c[u] = (u < width) ? sc[u * 64] : SELL_SENTINEL;
-                w[u] = (HAS_VAL && u < width) ? sv[u * 64] : 0.f;
-            }
-            for (int e0 = 0; e0 < width; e0 += U) {
+            const int nbase = (k + 1 < RPT) ? base[k + 1 < RPT ? k + 1 : k] : 0;
+            const int nwidth = (k + 1 < RPT) ? width[k + 1 < RPT ? k + 1 : k] : 0;
+            if (width[k] == 0 && k + 1 < RPT) {  // empty slice: nothing ran that could have prefetched the next one
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int e = e0 + U + u;
-                    cn[u] = (e < width) ? sc[e * 64] : SELL_SENTINEL;
-                    wn[u] = (HAS_VAL && e < width) ? sv[e * 64] : 0.f;
+                    c[u] = (u < nwidth) ? job.sell_col[nbase + lane + u * 64] : SELL_SENTINEL;
+                    w[u] = (HAS_VAL && u < nwidth) ? job.sell_val[nbase + lane + u * 64] : 0.f;
+                }
+            }
+            for (int e0 = 0; e0 < width[k]; e0 += U) {
+                const bool more = e0 + U < width[k];  // wave-uniform
+                const int pf = (more ? base[k] + (e0 + U) * 64 : nbase) + lane;
+                const int left = more ? width[k] - (e0 + U) : nwidth;
+                int cn[U];
+                float wn[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    cn[u] = (u < left) ? job.sell_col[pf + u * 64] : SELL_SENTINEL;
+                    wn[u] = (HAS_VAL && u < left) ? job.sell_val[pf + u * 64] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -236,11 +414,12 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
                 }
             }
         }
+        RL_STAMP(4 + blk * 4);  // swept
     }
 
     // ---- epilogue: scale, transpose through LDS (64 rows x FG floats per wave), whole-line stores
     RL_STAMP(12);
-    __syncthreads();
+    rl_barrier_lds();  // every wave has finished sweeping: the staged block may be overwritten by the transpose tiles
     RL_STAMP(13);
     float4 *tr = xs + wave * 64 * QUADS;
     const bool y_vec = full && (job.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.Y) & 15) == 0);
@@ -249,8 +428,8 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     for (int k = 0; k < RPT; ++k) {
         const int slice = wave + k * RL_WAVES;
         if (slice >= n_slices) continue;
-        const int row = slice * 64 + lane;
-        const float rs = (job.row_scale && row < n_rows) ? job.row_scale[row] : 1.f;
+        const int row = out_row[k];
+        const float rs = out_scale[k];
 #pragma unroll
         for (int h = 0; h < QUADS; ++h) {
             float4 a = acc[k][h];
@@ -262,7 +441,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
         for (int it = 0; it < QUADS; ++it) {
             const int rl = it * ROWS_PER_IT + lane / QUADS, qd = lane % QUADS;
             const float4 a = tr[rl * QUADS + qd];
-            const int grow = slice * 64 + rl;
+            const int grow = __shfl(row, rl);  // destination row of slot slice * 64 + rl (n_rows = none)
             if (grow < n_rows && !((job.reserved & 1) && a.x != 12345.678f)) {  // reserved bit 0: timing ablation
                 float *dst = job.Y + static_cast<int64_t>(grow) * job.ldy + f0 + qd * 4;
                 if (y_vec) {
@@ -279,6 +458,23 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
         __builtin_amdgcn_wave_barrier();
     }
     RL_STAMP(14);
+    } while (0);
+    if (threadIdx.x == 0) next_item[round & 1] = static_cast<int>(first_claim + claimed);
+    rl_barrier_lds();  // the transpose tiles are read (the row stores may still be in flight); next_item[] is visible
+    t = __builtin_amdgcn_readfirstlane(next_item[round & 1]);
+    ++round;
+    RL_STAMP(15);
+    RL_STAMP_NEXT;
+    }  // item loop
+    // the last workgroup to leave re-arms the queue slot for a later launch
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&rl_queue_done[queue_slot], 1u) == gridDim.x - 1) {
+            for (int x = 0; x < kXcds; ++x) rl_queue_next[queue_slot * kXcds + x] = 0;
+            rl_queue_done[queue_slot] = 0;
+            __threadfence();
+        }
+    }
 }
 
 int sell_block_cols_for(int n_cols) {
@@ -292,6 +488,7 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
                    bool has_val, hipStream_t st) {
     const int n_groups = static_cast<int>(ceil_div(max_feat, QUADS * 4));
     const int64_t n_items = static_cast<int64_t>(n_jobs) * n_groups;
+    if (n_items >= (1ll << 31) - 4096) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: too many work items");
     size_t lds = static_cast<size_t>(sell_block_cols_for(max_cols)) * QUADS * 16;  // jobs were blocked with this rule
     const size_t tr_bytes = static_cast<size_t>(RL_WAVES) * 64 * QUADS * 16;
     if (lds < tr_bytes) lds = tr_bytes;
@@ -300,13 +497,16 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
     static thread_local bool configured = false;
     if (!configured) {
         for (const void *k : {reinterpret_cast<const void *>(kv), reinterpret_cast<const void *>(kn)})
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes)) != hipSuccess)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes) - 1024) != hipSuccess)  // 1 KiB left for static LDS
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
         configured = true;
     }
-    const dim3 grid(static_cast<unsigned>(xcd_grid_size(n_items)));
-    if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items));
-    else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items));
+    const int64_t resident = static_cast<int64_t>(std::max(wdg_device_cus(), 8));  // 1 workgroup per CU (LDS), persistent over items
+    const dim3 grid(static_cast<unsigned>(std::min(xcd_grid_size(n_items), ceil_div(resident, kXcds) * kXcds)));
+    static std::atomic<unsigned> launches{0};
+    const int slot = static_cast<int>(launches.fetch_add(1) % RL_QUEUE_SLOTS);
+    if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items), slot);
+    else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items), slot);
     return check_launch("spmm_rowlane_kernel");
 }
 
@@ -318,6 +518,7 @@ int rowlane_dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jo
 #define WDG_RL_CASE(Q, R) \
     if ((wide ? 8 : 4) == Q && rpt == R) return launch_rowlane<Q, R, TIN>(jobs, inl, n_jobs, max_cols, max_feat, has_val, st);
     WDG_RL_CASE(8, 1) WDG_RL_CASE(8, 2) WDG_RL_CASE(4, 1) WDG_RL_CASE(4, 2) WDG_RL_CASE(4, 3) WDG_RL_CASE(4, 4)
+    WDG_RL_CASE(4, 5) WDG_RL_CASE(4, 6)
 #undef WDG_RL_CASE
     return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: no kernel for rows=%d feat=%d", max_rows, max_feat);
 }
@@ -358,9 +559,9 @@ size_t wdg_sell_workspace_bytes(int32_t N, int32_t n_cols) {
     return wdg::exclusive_scan_ws_bytes(tasks + 1) + 256;
 }
 
-int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *sell_ptr,
-                          void *workspace, size_t workspace_bytes, wdg_stream_t stream) {
-    WDG_REQUIRE(N >= 0 && n_cols >= 0 && sell_ptr && (N == 0 || rowptr), "csr_to_sell_count: bad arguments");
+int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *sell_perm,
+                          int32_t *sell_ptr, void *workspace, size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && n_cols >= 0 && sell_ptr && (N == 0 || (rowptr && sell_perm)), "csr_to_sell_count: bad arguments");
     if (!workspace || workspace_bytes < wdg_sell_workspace_bytes(N, n_cols))
         return wdg::fail(WDG_ERR_WORKSPACE, "csr_to_sell: workspace too small");
     hipStream_t st = wdg::as_stream(stream);
@@ -369,15 +570,18 @@ int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, 
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
     const int64_t tasks = static_cast<int64_t>(n_slices) * n_blocks;
     void *ws = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
-    if (tasks > 0)
-        hipLaunchKernelGGL(sell_widths, dim3(wdg::ceil_div(tasks * 64, 256)), dim3(256), 0, st, rowptr, col, N, n_slices,
-                           n_blocks, block_cols, sell_ptr);
+    if (tasks > 0) {
+        hipLaunchKernelGGL(sell_sort_rows, dim3(1), dim3(1024), 0, st, rowptr, col, N, n_blocks, block_cols, sell_perm);
+        hipLaunchKernelGGL(sell_widths, dim3(wdg::ceil_div(tasks * 64, 256)), dim3(256), 0, st, rowptr, col, sell_perm, N,
+                           n_slices, n_blocks, block_cols, sell_ptr);
+    }
     return wdg::exclusive_scan_i32(sell_ptr, tasks, sell_ptr, nullptr, ws, st);
 }
 
 int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
-                         const int32_t *sell_ptr, int32_t *sell_col, float *sell_val, wdg_stream_t stream) {
-    WDG_REQUIRE(N >= 0 && n_cols >= 0 && sell_ptr, "csr_to_sell_fill: bad arguments");
+                         const int32_t *sell_perm, const int32_t *sell_ptr, int32_t *sell_col, float *sell_val,
+                         wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && n_cols >= 0 && sell_ptr && (N == 0 || sell_perm), "csr_to_sell_fill: bad arguments");
     const int n_slices = (N + 63) / 64;
     const int block_cols = sell_block_cols_for(n_cols);
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
@@ -385,7 +589,7 @@ int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float 
     if (tasks == 0) return WDG_OK;
     WDG_REQUIRE(rowptr, "csr_to_sell_fill: null rowptr");
     hipLaunchKernelGGL(sell_fill, dim3(wdg::ceil_div(tasks * 64, 256)), dim3(256), 0, wdg::as_stream(stream), rowptr, col,
-                       val, N, n_slices, n_blocks, block_cols, sell_ptr, sell_col, sell_val);
+                       val, sell_perm, N, n_slices, n_blocks, block_cols, sell_ptr, sell_col, sell_val);
     return wdg::check_launch("csr_to_sell_fill");
 }
 

@@ -39,7 +39,7 @@ class CsrGraph:
     reference gets from `.coalesce()` on a torch COO tensor, with 4-byte instead of 8-byte indices.
     """
 
-    SELL_MAX_ROWS = 4096  # the row-lane kernel keeps every row of a graph in one workgroup's registers
+    SELL_MAX_ROWS = 6144  # the row-lane kernel keeps every row of a graph in one workgroup's registers
 
     def __init__(self, rowptr, col, val, n_rows, n_cols):
         self.rowptr, self.col, self.val = rowptr, col, val
@@ -58,19 +58,20 @@ class CsrGraph:
         block_cols = lib.wdg_sell_block_cols(self.n_cols)
         n_blocks = (self.n_cols + block_cols - 1) // block_cols
         sell_ptr = torch.empty(n_slices * n_blocks + 1, dtype=torch.int32, device=dev)
+        sell_perm = torch.empty(self.n_rows, dtype=torch.int32, device=dev)
         ws_bytes = lib.wdg_sell_workspace_bytes(self.n_rows, self.n_cols)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        check(lib.wdg_csr_to_sell_count(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, _ptr(sell_ptr), _ptr(ws),
-                                        ws_bytes, stream_handle()), "wdg_csr_to_sell_count")
+        check(lib.wdg_csr_to_sell_count(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, _ptr(sell_perm),
+                                        _ptr(sell_ptr), _ptr(ws), ws_bytes, stream_handle()), "wdg_csr_to_sell_count")
         total = int(sell_ptr[-1].item())
         if total > max_padding * self.nnz + 64 * 64 * n_blocks:
             return False  # very skewed rows: the CSR kernels are the better fit
         sell_col = torch.empty(total, dtype=torch.int32, device=dev)
         sell_val = torch.empty(total, dtype=torch.float32, device=dev) if self.val is not None else None
         check(lib.wdg_csr_to_sell_fill(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), self.n_rows, self.n_cols,
-                                       _ptr(sell_ptr), _ptr(sell_col), _ptr(sell_val), stream_handle()),
+                                       _ptr(sell_perm), _ptr(sell_ptr), _ptr(sell_col), _ptr(sell_val), stream_handle()),
               "wdg_csr_to_sell_fill")
-        self.sell = (sell_ptr, sell_col, sell_val, block_cols, n_blocks)
+        self.sell = (sell_ptr, sell_col, sell_val, block_cols, n_blocks, sell_perm)
         return True
 
     @property
@@ -218,8 +219,9 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
         job.sell_ptr, job.sell_col = g.sell[0].data_ptr(), g.sell[1].data_ptr()
         job.sell_val = g.sell[2].data_ptr() if (wants_val and g.sell[2] is not None) else 0
         job.sell_block_cols, job.sell_n_blocks = g.sell[3], g.sell[4]
+        job.sell_perm = g.sell[5].data_ptr()
     else:
-        job.sell_ptr = job.sell_col = job.sell_val = 0
+        job.sell_ptr = job.sell_col = job.sell_val = job.sell_perm = 0
         job.sell_block_cols = job.sell_n_blocks = 0
     return job
 
@@ -254,7 +256,11 @@ class SpmmBatch:
         arr = (SpmmJob * len(entries))()
         self.max_rows = self.max_cols = self.max_feat = 0
         all_sell, any_val = len(entries) > 0, False
-        for job, (g, x, y, rs, cs, uv) in zip(arr, entries):
+        # the kernels start jobs in table order: most stored entries first, so the long jobs do not end up in the tail
+        order = sorted(range(len(entries)), key=lambda i: -entries[i][0].nnz)
+        if os.environ.get("WDG_SPMM_ORDER") == "0":
+            order = list(range(len(entries)))
+        for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
             if x.dtype != torch.float32 or x.stride(1) != 1:
                 raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
             if x.shape[1] >= 8:
