@@ -123,7 +123,7 @@ typedef struct wdg_spmm_job {
     const int32_t *sell_ptr; /* [n_blocks * ceil(n_rows/64) + 1] entry offsets, block-major                */
     const int32_t *sell_col; /* (block b, slice s): entry e of row 64 s + l at sell_ptr[b*S + s] + 64 e + l */
     const float *sell_val;   /* same layout, needed when `val` is given                                    */
-    int32_t sell_block_cols; /* columns per block = wdg_sell_block_cols(n_cols)                            */
+    int32_t sell_block_cols; /* columns per block = wdg_sell_block_cols(n_rows, n_cols)                          */
     int32_t sell_n_blocks;   /* ceil(n_cols / sell_block_cols)                                             */
     const int32_t *sell_perm; /* [n_rows] SELL slot -> row (rows sorted by length, longest first); NULL = identity */
 } wdg_spmm_job;
@@ -139,15 +139,18 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
  */
 #define WDG_SPMM_ALL_SELL 1 /* every job of the table carries sell_ptr / sell_col            */
 #define WDG_SPMM_ANY_VAL 2  /* some job has explicit values (then sell_val must be set too) */
+#define WDG_SPMM_DMA_OK 4   /* every job: X and Y 16-byte aligned, ldx, ldy and n_feat multiples of 4, col_scale NULL:
+                               X rows may be staged by LDS-DMA -> the pipelined row-lane kernel (family 3) */
 int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
                          int32_t max_feat, int flags, wdg_stream_t stream);
 /* Which kernel family a batch of n_jobs such shapes dispatches to (0 = LDS column-slab, 1 = row gather,
- * 2 = row-lane when `flags` has WDG_SPMM_ALL_SELL); for tests/bench. */
+ * 2 = row-lane when `flags` has WDG_SPMM_ALL_SELL, 3 = pipelined row-lane when it also has WDG_SPMM_DMA_OK);
+ * for tests/bench. */
 int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int flags, int *slab_out,
                   int *threads_out);
 
 /*
- * CSR -> column-blocked SELL-64: the columns are cut into ceil(n_cols / B) blocks of B = wdg_sell_block_cols(n_cols)
+ * CSR -> column-blocked SELL-64: the columns are cut into ceil(n_cols / B) blocks of B = wdg_sell_block_cols(n_rows, n_cols)
  * (what one LDS pass of the row-lane kernel can stage); inside a block the rows are grouped in slices of 64, stored
  * entry-major, padded with 0x7fffffff / value 0.  Column indices stay global, order inside a row is preserved.
  * Rows are first sorted (sell_perm[slot] = row, ties by row id) so that a slice holds rows of similar length and
@@ -156,7 +159,7 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
  * Two calls: count fills sell_ptr (entry offsets; the last one = padded entry count, read it back to size
  * sell_col / sell_val), then fill.  One-time per graph, like the CSR build.
  */
-int32_t wdg_sell_block_cols(int32_t n_cols);
+int32_t wdg_sell_block_cols(int32_t n_rows, int32_t n_cols);
 size_t wdg_sell_workspace_bytes(int32_t N, int32_t n_cols);
 int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *sell_perm,
                           int32_t *sell_ptr, void *workspace, size_t workspace_bytes, wdg_stream_t stream);

@@ -58,7 +58,7 @@ SIGNATURES = {
     "wdg_spmm_csr_bf16": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
     "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
-    "wdg_sell_block_cols": (c_int32, [c_int32]),
+    "wdg_sell_block_cols": (c_int32, [c_int32, c_int32]),
     "wdg_sell_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "wdg_csr_to_sell_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
                                       c_void_p]),

@@ -24,7 +24,7 @@
 
 namespace wdg {  // row-lane family (spmm_rowlane.hip)
 bool rowlane_eligible(int max_rows, int max_cols, int max_feat);
-int rowlane_dispatch_f32(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
+int rowlane_dispatch_f32(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, bool, hipStream_t);
 int rowlane_dispatch_bf16(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
 }  // namespace wdg
 
@@ -467,7 +467,8 @@ int dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int 
     if (n_jobs == 0 || max_rows == 0 || max_feat == 0) return WDG_OK;
     if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, max_feat)) {
         const bool has_val = (flags & WDG_SPMM_ANY_VAL) != 0;
-        if (sizeof(TIN) == 4) return rowlane_dispatch_f32(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
+        if (sizeof(TIN) == 4)
+            return rowlane_dispatch_f32(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, (flags & WDG_SPMM_DMA_OK) != 0, st);
         return rowlane_dispatch_bf16(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
     }
     const Plan p = make_plan(max_rows, max_cols, max_feat, n_jobs);
@@ -505,6 +506,10 @@ int single(const wdg_spmm_job *job_host, wdg_stream_t stream) {
     int flags = 0;
     if (job_host->sell_ptr && job_host->sell_col && (!job_host->val || job_host->sell_val)) flags |= WDG_SPMM_ALL_SELL;
     if (job_host->val) flags |= WDG_SPMM_ANY_VAL;
+    const auto aligned16 = [](const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    if (sizeof(TIN) == 4 && !job_host->col_scale && aligned16(job_host->X) && aligned16(job_host->Y) &&
+        job_host->ldx % 4 == 0 && job_host->ldy % 4 == 0 && job_host->n_feat % 4 == 0)
+        flags |= WDG_SPMM_DMA_OK;
     return dispatch<TIN>(nullptr, *job_host, 1, job_host->n_rows, job_host->n_cols, job_host->n_feat, flags,
                          as_stream(stream));
 }
@@ -534,9 +539,9 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
                   int *threads_out) {
     if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, n_feat)) {
         const int rpt = (max_rows + 1023) / 1024;
-        if (slab_out) *slab_out = ((rpt <= 2) && n_feat > 16) ? 32 : 16;  // features per item
+        if (slab_out) *slab_out = ((rpt <= 2) && n_feat > 16 && !((flags & WDG_SPMM_DMA_OK) && rpt <= 4)) ? 32 : 16;  // features per item
         if (threads_out) *threads_out = 1024;
-        return 2;
+        return ((flags & WDG_SPMM_DMA_OK) && rpt <= 4) ? 3 : 2;
     }
     const Plan p = make_plan(max_rows, max_cols, n_feat, n_jobs > 0 ? n_jobs : 1);
     if (slab_out) *slab_out = p.slab;

@@ -62,11 +62,9 @@ __device__ unsigned long long wdg_rl_stamp_buf[4096 * 16];
 #define RL_STAMP(k) do { } while (0)
 #endif
 
-struct bf16r_t {
-    unsigned short bits;
-};
+using bf16r_t = unsigned short;  // raw bf16 bits (a builtin type: loadable through address-space-qualified pointers)
 __device__ __forceinline__ float rl_f32(float v) { return v; }
-__device__ __forceinline__ float rl_f32(bf16r_t v) { return __uint_as_float(static_cast<unsigned>(v.bits) << 16); }
+__device__ __forceinline__ float rl_f32(bf16r_t v) { return __uint_as_float(static_cast<unsigned>(v) << 16); }
 
 // ------------------------------------------------------------------------------------------------ CSR -> blocked SELL-64
 __device__ __forceinline__ int lower_bound_col(const int32_t *col, int lo, int hi, int key) {
@@ -198,16 +196,82 @@ __global__ __launch_bounds__(256) void sell_fill(const int32_t *__restrict__ row
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
+// A job descriptor as the kernels use it: scalars plus GLOBAL-address-space pointers (see wdg_common.h, global_ptr).
+struct JobView {
+    global_ptr<const int32_t> sell_ptr, sell_col, sell_perm;
+    global_ptr<const float> sell_val, row_scale, col_scale;
+    global_ptr<const void> X;
+    global_ptr<float> Y;
+    int64_t ldx, ldy;
+    int32_t n_rows, n_cols, n_feat, reserved, sell_block_cols, sell_n_blocks;
+};
+// job `id` of the table, or the by-value descriptor of a single-graph launch.  Both live at wave-uniform addresses that
+// are only read: viewed through the constant address space the fields arrive by scalar loads (a generic pointer that may
+// be either would be read with flat vector loads)
+__device__ __forceinline__ JobView load_job(const wdg_spmm_job *__restrict__ jobs, const wdg_spmm_job &inline_job, int id) {
+    typedef const wdg_spmm_job __attribute__((address_space(4))) *desc_ptr;
+    const desc_ptr j = jobs ? (desc_ptr)(jobs + id) : (desc_ptr)(&inline_job);
+    JobView v;
+    v.sell_ptr = to_global(j->sell_ptr); v.sell_col = to_global(j->sell_col); v.sell_perm = to_global(j->sell_perm);
+    v.sell_val = to_global(j->sell_val); v.row_scale = to_global(j->row_scale); v.col_scale = to_global(j->col_scale);
+    v.X = to_global(j->X); v.Y = to_global(j->Y);
+    v.ldx = j->ldx; v.ldy = j->ldy;
+    v.n_rows = j->n_rows; v.n_cols = j->n_cols; v.n_feat = j->n_feat; v.reserved = j->reserved;
+    v.sell_block_cols = j->sell_block_cols; v.sell_n_blocks = j->sell_n_blocks;
+    return v;
+}
+
 // work-queue counters, one slot per launch in flight (slots are handed out round-robin by the launcher and re-armed by
 // the last workgroup of the launch that used them)
 constexpr int RL_QUEUE_SLOTS = 256;
 __device__ unsigned int rl_queue_next[RL_QUEUE_SLOTS * kXcds];
 __device__ unsigned int rl_queue_done[RL_QUEUE_SLOTS];
 
+// The k-th slice of a wave: boustrophedon over the length-sorted slices (wave w: w, 31 - w, 32 + w, ...), so that every wave
+// gets long and short slices alike - with w, 16 + w, ... wave 0 would hold the longest slice of every round and every
+// barrier would wait for it (measured: +45 % sweep time on the by-block sorted sweep graphs)
+__device__ __forceinline__ int rl_slice(int wave, int k) {
+    return k * RL_WAVES + ((k & 1) ? RL_WAVES - 1 - wave : wave);
+}
+
 // workgroup barrier that waits for this wave's LDS traffic only: global stores and loads stay in flight across it
 // (__syncthreads() would drain vmcnt as well, i.e. wait for the previous item's row stores to be acknowledged)
 __device__ __forceinline__ void rl_barrier_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// A workgroup whose queue is drained looks at the other queues' counters first (plain loads, one round trip) and claims
+// two consecutive items from the first one that still has work; `found` < 0: every queue is drained.
+struct RlSteal {
+    int queue, t, t_next;
+};
+__device__ __forceinline__ RlSteal rl_steal(unsigned *queues, int xcd, int n_queues, int n_jobs, int ng, int first_claim,
+                                            int *mailbox /* LDS, 3 ints */) {
+    if (threadIdx.x == 0) {
+        unsigned seen[kXcds];
+#pragma unroll
+        for (int s = 0; s < kXcds; ++s) seen[s] = (s < n_queues) ? __hip_atomic_load(&queues[(xcd + s) % n_queues], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        int found = -1;
+#pragma unroll
+        for (int s = kXcds - 1; s >= 0; --s) {
+            const int qq = (xcd + s) % n_queues;
+            const long long items = static_cast<long long>((n_jobs - qq + n_queues - 1) / n_queues) * ng;
+            if (s < n_queues && static_cast<long long>(first_claim) + seen[s] < items) found = qq;
+        }
+        mailbox[0] = found;
+        if (found >= 0) {
+            const unsigned a = atomicAdd(&queues[found], 2u);
+            mailbox[1] = static_cast<int>(first_claim + a);
+            mailbox[2] = static_cast<int>(first_claim + a + 1);
+        }
+    }
+    rl_barrier_lds();
+    RlSteal r;
+    r.queue = __builtin_amdgcn_readfirstlane(mailbox[0]);
+    r.t = __builtin_amdgcn_readfirstlane(mailbox[1]);
+    r.t_next = __builtin_amdgcn_readfirstlane(mailbox[2]);
+    rl_barrier_lds();
+    return r;
 }
 
 template <int QUADS, bool HAS_VAL>
@@ -245,7 +309,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     // hides behind the current item; a workgroup whose queue is empty steals from the next XCD's.  A finished item's row
     // stores drain while the next item's staging loads are already queued (the barriers below wait for LDS traffic only).
     __shared__ int next_item[2];
-    __shared__ int stolen_item;
+    __shared__ int steal_box[3];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ng = n_groups;
     const int n_jobs = static_cast<int>(n_items / ng);
@@ -253,17 +317,15 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     const int n_queues = n_jobs >= 8 ? 8 : n_jobs >= 4 ? 4 : n_jobs >= 2 ? 2 : 1;  // fewer jobs than XCDs: XCDs share queues
     const int first_claim = wgs_per_xcd * (kXcds / n_queues);                      // static items per queue
     const unsigned *queues = rl_queue_next + queue_slot * kXcds;
-    int victim = 0, q = xcd % n_queues;  // q = (xcd + victim) % n_queues: the queue this workgroup currently draws from
+    int q = xcd % n_queues;  // the queue this workgroup currently draws from
     int t = (xcd / n_queues) * wgs_per_xcd + blockIdx.x / kXcds;  // item index in queue q: job (t / ng) * n_queues + q, group t % ng
     for (int round = 0;;) {
     const int q_items = ((n_jobs - q + n_queues - 1) / n_queues) * ng;
-    if (t >= q_items) {              // queue q is drained: move on to the next one, claiming synchronously (rare)
-        if (++victim == n_queues) break;
-        q = (xcd + victim) % n_queues;
-        if (threadIdx.x == 0) stolen_item = static_cast<int>(first_claim + atomicAdd(const_cast<unsigned *>(&queues[q]), 1u));
-        rl_barrier_lds();
-        t = __builtin_amdgcn_readfirstlane(stolen_item);
-        rl_barrier_lds();
+    if (t >= q_items) {              // queue q is drained: take over a queue that still has work, or leave
+        const RlSteal st = rl_steal(const_cast<unsigned *>(queues), xcd, n_queues, n_jobs, ng, first_claim, steal_box);
+        if (st.queue < 0) break;
+        q = st.queue;
+        t = st.t;  // (st.t_next stays unused here: this kernel claims one item ahead, asynchronously)
         continue;
     }
     unsigned claimed = 0;  // thread 0 keeps the reply in a register until the item is done: nothing waits for it
@@ -276,14 +338,14 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     RL_STAMP(0);
     const int job_id = __builtin_amdgcn_readfirstlane((t / ng) * n_queues + q);  // uniform: the descriptor stays in SGPRs
     const int group = __builtin_amdgcn_readfirstlane(t % ng);
-    const wdg_spmm_job job = jobs ? jobs[job_id] : inline_job;
+    const JobView job = load_job(jobs, inline_job, job_id);
     const int f0 = group * FG;
     if (f0 >= job.n_feat) break;  // workgroup-uniform: this job has fewer feature groups than the widest one
     const int n_cols = job.n_cols, n_rows = job.n_rows, F = job.n_feat;
     const int block_cols = job.sell_block_cols, n_blocks = job.sell_n_blocks;
-    const TIN *__restrict__ X = static_cast<const TIN *>(job.X);
+    const global_ptr<const TIN> X = (global_ptr<const TIN>)job.X;
     const bool full = (f0 + FG <= F);
-    const bool x_vec = full && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool x_vec = full && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
     const int n_slices = (n_rows + 63) >> 6;
     const bool dma = x_vec && !job.col_scale && !(job.reserved & 8);  // reserved bit 3: diagnostic, forces register staging
 
@@ -304,7 +366,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
         int base[RPT], width[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int slice = wave + k * RL_WAVES;
+            const int slice = rl_slice(wave, k);
             base[k] = width[k] = 0;
             if (slice < n_slices && !(job.reserved & 4)) {  // reserved bit 2: timing ablation (no sweep)
                 const int task = blk * n_slices + slice;
@@ -322,7 +384,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
         if (blk + 1 == n_blocks) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const int slot = (wave + k * RL_WAVES) * 64 + lane;  // SELL slot -> original row (length-sort permutation)
+                const int slot = rl_slice(wave, k) * 64 + lane;  // SELL slot -> original row (length-sort permutation)
                 out_row[k] = (slot < n_rows) ? (job.sell_perm ? job.sell_perm[slot] : slot) : n_rows;
                 out_scale[k] = (job.row_scale && out_row[k] < n_rows) ? job.row_scale[out_row[k]] : 1.f;
             }
@@ -354,9 +416,9 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
                 v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (i < n_stage) {
                     const int r = begin + i / QUADS, qd = i % QUADS;
-                    const TIN *src = X + static_cast<int64_t>(r) * job.ldx + f0 + qd * 4;
+                    const global_ptr<const TIN> src = X + static_cast<int64_t>(r) * job.ldx + f0 + qd * 4;
                     if (x_vec) {
-                        v[j] = *reinterpret_cast<const float4 *>(src);
+                        v[j] = load_f32x4((global_ptr<const float>)src);
                     } else {
                         const int f = f0 + qd * 4;
                         if (f + 0 < F) v[j].x = rl_f32(src[0]);
@@ -422,11 +484,11 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     rl_barrier_lds();  // every wave has finished sweeping: the staged block may be overwritten by the transpose tiles
     RL_STAMP(13);
     float4 *tr = xs + wave * 64 * QUADS;
-    const bool y_vec = full && (job.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.Y) & 15) == 0);
+    const bool y_vec = full && (job.ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
     constexpr int ROWS_PER_IT = 64 / QUADS;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int slice = wave + k * RL_WAVES;
+        const int slice = rl_slice(wave, k);
         if (slice >= n_slices) continue;
         const int row = out_row[k];
         const float rs = out_scale[k];
@@ -443,9 +505,9 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
             const float4 a = tr[rl * QUADS + qd];
             const int grow = __shfl(row, rl);  // destination row of slot slice * 64 + rl (n_rows = none)
             if (grow < n_rows && !((job.reserved & 1) && a.x != 12345.678f)) {  // reserved bit 0: timing ablation
-                float *dst = job.Y + static_cast<int64_t>(grow) * job.ldy + f0 + qd * 4;
+                const global_ptr<float> dst = job.Y + static_cast<int64_t>(grow) * job.ldy + f0 + qd * 4;
                 if (y_vec) {
-                    *reinterpret_cast<float4 *>(dst) = a;
+                    store_f32x4(dst, a);
                 } else {
                     const int f = f0 + qd * 4;
                     if (f + 0 < F) dst[0] = a.x;
@@ -477,19 +539,433 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     }
 }
 
-int sell_block_cols_for(int n_cols) {
-    const int cap = (kLdsBytes - 1024) / RL_LDS_ROW_BYTES;  // source rows one pass can stage at 128 B each
+// ------------------------------------------------------------------------------------------------ the pipelined kernel
+// Same item, same arithmetic, same summation order as spmm_rowlane_kernel, for jobs whose X rows can go by LDS-DMA
+// (WDG_SPMM_DMA_OK: fp32 X, X/Y 16-byte aligned, ldx/ldy/n_feat multiples of 4, no col_scale).  What changes is the
+// schedule - with one workgroup per CU every exposed latency is lost time, so the memory phases move behind the sweeps:
+//   * the LDS holds TWO column-block buffers (blocks of <= 512 source rows, 64 KiB each): while block b is swept, block
+//     b+1 lands in the other buffer by LDS-DMA (no registers); after an item's last sweep the NEXT item's block 0, slice
+//     extents and first index chunk are requested, then the rows are transposed (through the buffer just swept) and
+//     stored, and the next sweep starts while those stores drain;
+//   * a wave waits for its DMA pieces (vmcnt(0)) BEFORE it issues its row stores: vmcnt retires in order, so any wait
+//     placed after the stores would wait for the stores' acknowledgements too;
+//   * every wave reads the extents of all its (block, slice) pairs with one vector load per item (lane = pair) and
+//     picks them up with v_readlane: no scalar loads inside the block loop.
+// index-chunk length of the pipelined kernel: accumulators (16 RPT) + head/current chunks of every slice + the two in-sweep
+// chunks of a wide slice must stay clear of the 128-VGPR ceiling of a 1024-thread workgroup
+constexpr int rl_pipe_chunk(int rpt, bool has_val) {
+    const int room = (96 - 16 * rpt) / ((2 * rpt + 2) * (has_val ? 2 : 1));
+    return room >= 8 ? 8 : room >= 4 ? 4 : room >= 2 ? 2 : 1;
+}
+
+template <int QUADS, int RPT, bool HAS_VAL>
+__global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg_spmm_job *__restrict__ jobs,
+                                                                        const wdg_spmm_job inline_job, int n_groups,
+                                                                        int n_jobs, int queue_slot, int buf_slots) {
+    constexpr int FG = QUADS * 4;
+    constexpr int U = rl_pipe_chunk(RPT, HAS_VAL);  // index entries per register chunk
+    constexpr int ROWS_PASS = 256 / QUADS;        // rows a wave transposes at a time through its 4 KiB of LDS
+    constexpr int PASSES = 64 / ROWS_PASS;
+    constexpr int READS = ROWS_PASS * QUADS / 64;  // float4 a lane reads back (and stores) per pass
+    constexpr int ROWS_PER_READ = 64 / QUADS;
+    extern __shared__ float4 lds[];
+    __shared__ int next_item[2];
+    __shared__ int steal_box[3];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ng = n_groups;
+    const int wgs_per_xcd = gridDim.x / kXcds, xcd = blockIdx.x % kXcds;
+    const int n_queues = n_jobs >= 8 ? 8 : n_jobs >= 4 ? 4 : n_jobs >= 2 ? 2 : 1;
+    const int first_claim = wgs_per_xcd * (kXcds / n_queues);
+    unsigned *queues = rl_queue_next + queue_slot * kXcds;
+
+    auto claim_sync = [&](int queue) -> int {  // exposed round trip: once, at kernel start
+        if (threadIdx.x == 0) steal_box[0] = static_cast<int>(first_claim + atomicAdd(&queues[queue], 1u));
+        rl_barrier_lds();
+        const int v = __builtin_amdgcn_readfirstlane(steal_box[0]);
+        rl_barrier_lds();
+        return v;
+    };
+    // X[begin:end, f0:f0+FG] of `j` -> dst, one 1-KiB wave-instruction per 8 (QUADS = 8) or 16 staged rows
+    auto stage = [&](const JobView &j, int f0, int blk, float4 *dst, int lane) {
+        const int begin = blk * j.sell_block_cols, end = min(begin + j.sell_block_cols, j.n_cols);
+        const int n_stage = (j.reserved & 2) ? 0 : (end - begin) * QUADS;  // reserved bit 1: timing ablation
+        const global_ptr<const float> X = (global_ptr<const float>)j.X;
+        for (int i0 = wave * 64; i0 < n_stage; i0 += RL_THREADS) {
+            const int i = i0 + lane;
+            const int r = begin + i / QUADS, qd = i % QUADS;
+            if (i < n_stage && f0 + qd * 4 < j.n_feat) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(r) * j.ldx + f0 + qd * 4,
+                                                 (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
+#endif
+            }
+        }
+    };
+    // extents of this wave's (block, slice) pairs: lane b * RPT + k holds sell_ptr[b * S + slice] and its successor
+    auto load_extents = [&](const JobView &j, int lane, int &lo, int &hi) {
+        const int n_slices = (j.n_rows + 63) >> 6;
+        lo = hi = 0;
+        if (lane < j.sell_n_blocks * RPT) {
+            const int slice = rl_slice(wave, lane % RPT);
+            if (slice < n_slices && !(j.reserved & 4)) {  // reserved bit 2: timing ablation (no sweep)
+                const int task = (lane / RPT) * n_slices + slice;
+                lo = j.sell_ptr[task];
+                hi = j.sell_ptr[task + 1];
+            }
+        }
+    };
+
+    RL_STAMP_ITER;
+    int q = xcd % n_queues;
+    int t = (xcd / n_queues) * wgs_per_xcd + blockIdx.x / kXcds;
+    int t_next = claim_sync(q);
+    int p = 0;            // buffer that holds (or will hold) block 0 of item t
+    bool primed = false;  // item t's block 0, extents and head chunks were requested during the previous item
+    int ext_lo = 0, ext_hi = 0;
+    // Index registers.  vmcnt retires in order, so an index load issued AFTER a block's DMA cannot be consumed before that
+    // DMA has landed: a sweep that fetched its indices as it went would run at the DMA's latency, not the LDS's.  The
+    // first U entries of EVERY slice of block b+1 are therefore requested at the top of block b, BEFORE block b+1's DMA
+    // is issued (head[][], copied to cur[][] at the top of block b+1); slices wider than U fetch the rest in-sweep and
+    // pay that wait once per block.
+    int head[RPT][U];
+    float headw[RPT][U];
+
+    for (int round = 0;;) {
+        const int q_items = ((n_jobs - q + n_queues - 1) / n_queues) * ng;
+        if (t >= q_items) {  // queue drained: take over a queue that still has work, or leave
+            const RlSteal st = rl_steal(queues, xcd, n_queues, n_jobs, ng, first_claim, steal_box);
+            if (st.queue < 0) break;
+            q = st.queue;
+            t = st.t;
+            t_next = st.t_next;
+            primed = false;
+            continue;
+        }
+        unsigned claimed = 0;  // the item after next; thread 0 keeps the reply in a register until the epilogue
+        if (threadIdx.x == 0) claimed = atomicAdd(&queues[q], 1u);
+        RL_STAMP(0);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // opaque per item: no hoisting of per-thread address arithmetic out of the item loop
+        int lane = tid & 63;  // re-made opaque at phase boundaries (below): address arithmetic stays inside its phase
+
+        const int job_id = __builtin_amdgcn_readfirstlane((t / ng) * n_queues + q);
+        const int f0 = __builtin_amdgcn_readfirstlane(t % ng) * FG;
+        const JobView job = load_job(jobs, inline_job, job_id);  // uniform: SGPRs (the line is warm: it was `nxt` before)
+        const bool live = f0 < job.n_feat;  // a job with fewer feature groups than the widest one: nothing to do
+        const int n_rows = job.n_rows, F = job.n_feat, n_blocks = job.sell_n_blocks, block_cols = job.sell_block_cols;
+        const int n_slices = (n_rows + 63) >> 6;
+        const bool ext_vec = n_blocks * RPT <= 64;
+        float4 *const buf0 = lds, *const buf1 = lds + buf_slots;
+
+        // the item after this one (same queue)
+        const bool next_in_queue = t_next < q_items;
+        const int next_job_id = __builtin_amdgcn_readfirstlane((t_next / ng) * n_queues + q);
+        const int next_f0 = __builtin_amdgcn_readfirstlane(t_next % ng) * FG;
+        const JobView nxt = load_job(next_in_queue ? jobs : nullptr, inline_job, next_job_id);
+        const bool next_live = next_in_queue && next_f0 < nxt.n_feat;
+        const bool next_ext_vec = nxt.sell_n_blocks * RPT <= 64;
+        const int next_slices = (nxt.n_rows + 63) >> 6;
+        int next_lo = 0, next_hi = 0;  // its extents: requested now, read at the top of this item's last block
+        if (next_live && next_ext_vec) load_extents(nxt, lane, next_lo, next_hi);
+        bool next_staged = false;
+
+        float4 acc[RPT][QUADS];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+#pragma unroll
+            for (int h = 0; h < QUADS; ++h) acc[k][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int out_row[RPT];
+        float out_scale[RPT];
+
+        auto extent = [&](int blk, int k, int &base, int &width) {  // wave-uniform
+            if (ext_vec) {
+                base = __builtin_amdgcn_readlane(ext_lo, blk * RPT + k);
+                width = (__builtin_amdgcn_readlane(ext_hi, blk * RPT + k) - base) >> 6;
+            } else {
+                const int slice = rl_slice(wave, k);
+                base = width = 0;
+                if (slice < n_slices && !(job.reserved & 4)) {
+                    base = job.sell_ptr[blk * n_slices + slice];
+                    width = (job.sell_ptr[blk * n_slices + slice + 1] - base) >> 6;
+                }
+            }
+        };
+        auto next_extent = [&](int k, int &base, int &width) {  // block 0 of the next item
+            if (next_ext_vec) {
+                base = __builtin_amdgcn_readlane(next_lo, k);
+                width = (__builtin_amdgcn_readlane(next_hi, k) - base) >> 6;
+            } else {
+                const int slice = rl_slice(wave, k);
+                base = width = 0;
+                if (slice < next_slices && !(nxt.reserved & 4)) {
+                    base = nxt.sell_ptr[slice];
+                    width = (nxt.sell_ptr[slice + 1] - base) >> 6;
+                }
+            }
+        };
+        // head[][] <- the first U entries of every slice of block `blk` of this item / of block 0 of the next item
+        auto load_heads = [&](int blk) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                int base, width;
+                extent(blk, k, base, width);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    head[k][u] = (u < width) ? job.sell_col[base + lane + u * 64] : SELL_SENTINEL;
+                    headw[k][u] = (HAS_VAL && u < width) ? job.sell_val[base + lane + u * 64] : 0.f;
+                }
+            }
+        };
+        auto load_next_heads = [&]() {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                int base, width;
+                next_extent(k, base, width);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    head[k][u] = (u < width) ? nxt.sell_col[base + lane + u * 64] : SELL_SENTINEL;
+                    headw[k][u] = (HAS_VAL && u < width) ? nxt.sell_val[base + lane + u * 64] : 0.f;
+                }
+            }
+        };
+
+        if (live && !primed) {  // first item of the workgroup / after a queue switch: nothing was requested ahead
+            if (ext_vec) load_extents(job, lane, ext_lo, ext_hi);
+            load_heads(0);
+            stage(job, f0, 0, p ? buf1 : buf0, lane);
+        }
+
+        int last = p;
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {  // destination rows of this wave's slots (the length-sort permutation)
+                const int slot = rl_slice(wave, k) * 64 + lane;
+                out_row[k] = (slot < n_rows) ? (job.sell_perm ? job.sell_perm[slot] : slot) : n_rows;
+            }
+            for (int blk = 0; blk < n_blocks; ++blk) {
+                const int begin = blk * block_cols;
+                asm volatile("" : "+v"(lane));
+                const int cur_i = p ^ (blk & 1);
+                float4 *const cur = cur_i ? buf1 : buf0, *const oth = cur_i ? buf0 : buf1;
+                last = cur_i;
+                // this wave's pieces of block blk and its head chunks have landed (for a primed block 0 that was waited
+                // for before the previous item's stores), then: everyone's pieces have, and everyone is done reading `oth`
+                if (blk > 0 || !primed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                rl_barrier_lds();
+                RL_STAMP(1 + (blk < 4 ? blk : 3) * 2);  // block's data complete for all waves
+                int c[RPT][U];
+                float w[RPT][U];
+#pragma unroll
+                for (int k = 0; k < RPT; ++k)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        c[k][u] = head[k][u];
+                        w[k][u] = headw[k][u];
+                    }
+                // requests for the block after this one: head chunks FIRST, then the DMA (see head[][])
+                if (blk + 1 < n_blocks) {
+                    load_heads(blk + 1);
+                    stage(job, f0, blk + 1, oth, lane);
+                } else if (next_live) {  // last block: the other buffer is free for the NEXT item's block 0
+                    load_next_heads();
+                    stage(nxt, next_f0, 0, oth, lane);
+                    next_staged = true;
+                }
+                // ---- sweep
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    int base, width;
+                    extent(blk, k, base, width);
+                    int cx[U];  // entries U .. 2U-1 of a wide slice, requested before the head chunk is consumed
+                    float wx[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        cx[u] = (U + u < width) ? job.sell_col[base + lane + (U + u) * 64] : SELL_SENTINEL;
+                        wx[u] = (HAS_VAL && U + u < width) ? job.sell_val[base + lane + (U + u) * 64] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (c[k][u] != SELL_SENTINEL) rl_accumulate<QUADS, HAS_VAL>(acc[k], cur, c[k][u] - begin, w[k][u], lane);
+                        __builtin_amdgcn_sched_barrier(0);  // one entry's LDS reads in flight per wave (16 waves fill the pipe)
+                    }
+                    for (int e0 = U; e0 < width; e0 += U) {
+                        const int left = width - (e0 + U);  // wave-uniform
+                        int cy[U];
+                        float wy[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            cy[u] = (u < left) ? job.sell_col[base + lane + (e0 + U + u) * 64] : SELL_SENTINEL;
+                            wy[u] = (HAS_VAL && u < left) ? job.sell_val[base + lane + (e0 + U + u) * 64] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (cx[u] != SELL_SENTINEL) rl_accumulate<QUADS, HAS_VAL>(acc[k], cur, cx[u] - begin, wx[u], lane);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            cx[u] = cy[u];
+                            wx[u] = wy[u];
+                        }
+                    }
+                }
+                RL_STAMP(2 + (blk < 4 ? blk : 3) * 2);  // block swept (wave 0)
+            }
+        }
+
+        // ---- tail: the next item's head if the block loop did not request it (dead current item), the row scales
+        asm volatile("" : "+v"(lane));
+        const int next_p = live ? (last ^ 1) : p;
+        if (next_live && !next_staged) {
+            load_next_heads();
+            stage(nxt, next_f0, 0, next_p ? buf1 : buf0, lane);
+        }
+        if (next_live) {
+            ext_lo = next_lo;
+            ext_hi = next_hi;
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k)
+                out_scale[k] = (job.row_scale && out_row[k] < n_rows) ? job.row_scale[out_row[k]] : 1.f;
+        }
+        RL_STAMP(9);
+        if (threadIdx.x == 0) next_item[round & 1] = static_cast<int>(first_claim + claimed);
+        rl_barrier_lds();  // every wave has finished the last sweep: its buffer is free for the transposes
+        const int t_after = __builtin_amdgcn_readfirstlane(next_item[round & 1]);
+        RL_STAMP(10);
+
+        asm volatile("" : "+v"(lane));
+        bool settled = !next_live;  // the next item's head has been waited for
+        if (live) {
+            // ---- epilogue: scale, transpose through LDS (ROWS_PASS rows per wave at a time), whole-line stores
+            float4 *tr = (last ? buf1 : buf0) + wave * 256;
+            const bool y_ok = !(job.reserved & 1);  // reserved bit 0: timing ablation (no stores)
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                if (rl_slice(wave, k) >= n_slices) continue;  // wave-uniform
+                const int row = out_row[k];
+                const float rs = out_scale[k];
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps) {
+                    if (lane / ROWS_PASS == ps) {
+#pragma unroll
+                        for (int h = 0; h < QUADS; ++h) {
+                            float4 a = acc[k][h];
+                            a.x *= rs; a.y *= rs; a.z *= rs; a.w *= rs;
+                            tr[(lane % ROWS_PASS) * QUADS + ((h + lane) & (QUADS - 1))] = a;  // acc[k][h] = chunk (h + lane) % QUADS
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (k == 0 && ps == 0 && !settled) {
+                        // the next item's head (block 0, head chunks) must have landed before anything is queued behind
+                        // it: a wait placed after the stores would cover them too
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int kk = 0; kk < RPT; ++kk)
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {  // arrived: the compiler need not wait for them again
+                                asm volatile("" : "+v"(head[kk][u]));
+                                if (HAS_VAL) asm volatile("" : "+v"(headw[kk][u]));
+                            }
+                        settled = true;
+                    }
+#pragma unroll
+                    for (int it = 0; it < READS; ++it) {
+                        const float4 a = tr[it * 64 + lane];
+                        const int grow = __shfl(row, ps * ROWS_PASS + it * ROWS_PER_READ + lane / QUADS);
+                        const int qd = lane % QUADS;
+                        if (grow < n_rows && f0 + qd * 4 < F && y_ok)
+                            store_f32x4(job.Y + static_cast<int64_t>(grow) * job.ldy + f0 + qd * 4, a);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (!settled) {  // this wave stored nothing: same wait, no stores behind it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < RPT; ++kk)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    asm volatile("" : "+v"(head[kk][u]));
+                    if (HAS_VAL) asm volatile("" : "+v"(headw[kk][u]));
+                }
+        }
+        RL_STAMP(11);  // epilogue done (stores complete: the stamp drains them)
+        RL_STAMP_NEXT;
+        // ---- advance
+        p = next_p;
+        primed = next_live;
+        t = t_next;
+        t_next = t_after;
+        ++round;
+    }
+    if (threadIdx.x == 0) {  // the last workgroup to leave re-arms the queue slot for a later launch
+        __threadfence();
+        if (atomicAdd(&rl_queue_done[queue_slot], 1u) == gridDim.x - 1) {
+            for (int x = 0; x < kXcds; ++x) rl_queue_next[queue_slot * kXcds + x] = 0;
+            rl_queue_done[queue_slot] = 0;
+            __threadfence();
+        }
+    }
+}
+
+// Column-block size of a graph's SELL copy: two blocks must fit the LDS side by side (the pipelined kernel sweeps one while
+// the next lands): it runs 16-feature items, 64-B staged rows, 1024 rows = 64 KiB per block.  (32-feature items would need
+// 512-row blocks; every extra block adds padding - a slice runs as long as its longest row IN THAT BLOCK - and the sweep is
+// LDS-bound: N = 2000, degree 10: 4 blocks pad 2.5x, 2 blocks ~1.2x with the by-block row sort.)  The single-buffer kernel
+// stages one 1024-row block of 128-B rows at a time.  Blocks are balanced: N = 2000 -> 2 x 1000.
+int sell_block_cap(int /*n_rows*/) { return 1024; }
+int sell_block_cols_for(int n_rows, int n_cols) {
+    const int cap = sell_block_cap(n_rows);
     const int blocks = static_cast<int>(ceil_div(n_cols > 0 ? n_cols : 1, cap));
     return static_cast<int>(ceil_div(n_cols > 0 ? n_cols : 1, blocks));
 }
 
+unsigned next_queue_slot() {
+    static std::atomic<unsigned> launches{0};
+    return launches.fetch_add(1) % RL_QUEUE_SLOTS;
+}
+
+int64_t resident_grid(int64_t n_items) {  // 1 workgroup per CU (LDS), persistent over items
+    const int64_t resident = static_cast<int64_t>(std::max(wdg_device_cus(), 8));
+    return std::min(xcd_grid_size(n_items), ceil_div(resident, kXcds) * kXcds);
+}
+
+template <int QUADS, int RPT>
+int launch_rowlane_pipe(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
+                        int max_feat, bool has_val, hipStream_t st) {
+    const int n_groups = static_cast<int>(ceil_div(max_feat, QUADS * 4));
+    const int64_t n_items = static_cast<int64_t>(n_jobs) * n_groups;
+    if (n_items >= (1ll << 31) - 4096) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: too many work items");
+    // two block buffers; a buffer also serves the 16 waves' 4-KiB transpose tiles (64 KiB)
+    const int buf_slots = std::max(std::min(sell_block_cap(max_rows), max_cols) * QUADS, RL_WAVES * 256);
+    const size_t lds = static_cast<size_t>(buf_slots) * 2 * 16;
+    auto kv = spmm_rowlane_pipe_kernel<QUADS, RPT, true>;
+    auto kn = spmm_rowlane_pipe_kernel<QUADS, RPT, false>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        for (const void *k : {reinterpret_cast<const void *>(kv), reinterpret_cast<const void *>(kn)})
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes) - 1024) != hipSuccess)
+                return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+        configured = true;
+    }
+    const dim3 grid(static_cast<unsigned>(resident_grid(n_items)));
+    const int slot = static_cast<int>(next_queue_slot());
+    if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, n_jobs, slot, buf_slots);
+    else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, n_jobs, slot, buf_slots);
+    return check_launch("spmm_rowlane_pipe_kernel");
+}
+
 template <int QUADS, int RPT, typename TIN>
-int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_cols, int max_feat,
+int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols, int max_feat,
                    bool has_val, hipStream_t st) {
     const int n_groups = static_cast<int>(ceil_div(max_feat, QUADS * 4));
     const int64_t n_items = static_cast<int64_t>(n_jobs) * n_groups;
     if (n_items >= (1ll << 31) - 4096) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: too many work items");
-    size_t lds = static_cast<size_t>(sell_block_cols_for(max_cols)) * QUADS * 16;  // jobs were blocked with this rule
+    size_t lds = static_cast<size_t>(std::min(sell_block_cap(max_rows), max_cols)) * QUADS * 16;  // bound of the jobs' block sizes
     const size_t tr_bytes = static_cast<size_t>(RL_WAVES) * 64 * QUADS * 16;
     if (lds < tr_bytes) lds = tr_bytes;
     auto kv = spmm_rowlane_kernel<QUADS, RPT, TIN, true>;
@@ -501,10 +977,8 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
         configured = true;
     }
-    const int64_t resident = static_cast<int64_t>(std::max(wdg_device_cus(), 8));  // 1 workgroup per CU (LDS), persistent over items
-    const dim3 grid(static_cast<unsigned>(std::min(xcd_grid_size(n_items), ceil_div(resident, kXcds) * kXcds)));
-    static std::atomic<unsigned> launches{0};
-    const int slot = static_cast<int>(launches.fetch_add(1) % RL_QUEUE_SLOTS);
+    const dim3 grid(static_cast<unsigned>(resident_grid(n_items)));
+    const int slot = static_cast<int>(next_queue_slot());
     if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items), slot);
     else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items), slot);
     return check_launch("spmm_rowlane_kernel");
@@ -512,11 +986,19 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
 
 template <typename TIN>
 int rowlane_dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
-                     int max_feat, bool has_val, hipStream_t st) {
+                     int max_feat, bool has_val, bool dma_ok, hipStream_t st) {
     const int rpt = static_cast<int>(ceil_div(max_rows, RL_THREADS));
     const bool wide = (rpt <= 2) && max_feat > 16;  // 32-feature items need 8 float4 accumulators per row
+    if (const char *e = getenv("WDG_SPMM_NO_PIPE"))
+        if (atoi(e)) dma_ok = false;
+    if (dma_ok && sizeof(TIN) == 4) {
+#define WDG_RL_PIPE_CASE(R) \
+    if (rpt == R) return launch_rowlane_pipe<4, R>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
+        WDG_RL_PIPE_CASE(1) WDG_RL_PIPE_CASE(2) WDG_RL_PIPE_CASE(3) WDG_RL_PIPE_CASE(4)  // more rows per thread: no room
+#undef WDG_RL_PIPE_CASE
+    }
 #define WDG_RL_CASE(Q, R) \
-    if ((wide ? 8 : 4) == Q && rpt == R) return launch_rowlane<Q, R, TIN>(jobs, inl, n_jobs, max_cols, max_feat, has_val, st);
+    if ((wide ? 8 : 4) == Q && rpt == R) return launch_rowlane<Q, R, TIN>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
     WDG_RL_CASE(8, 1) WDG_RL_CASE(8, 2) WDG_RL_CASE(4, 1) WDG_RL_CASE(4, 2) WDG_RL_CASE(4, 3) WDG_RL_CASE(4, 4)
     WDG_RL_CASE(4, 5) WDG_RL_CASE(4, 6)
 #undef WDG_RL_CASE
@@ -535,11 +1017,11 @@ bool rowlane_eligible(int max_rows, int max_cols, int max_feat) {
 
 int rowlane_dispatch_bf16(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
                           int max_feat, bool has_val, hipStream_t st) {
-    return rowlane_dispatch<bf16r_t>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
+    return rowlane_dispatch<bf16r_t>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, false, st);
 }
 int rowlane_dispatch_f32(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
-                         int max_feat, bool has_val, hipStream_t st) {
-    return rowlane_dispatch<float>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
+                         int max_feat, bool has_val, bool dma_ok, hipStream_t st) {
+    return rowlane_dispatch<float>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, dma_ok, st);
 }
 
 }  // namespace wdg
@@ -552,10 +1034,10 @@ int wdg_debug_rl_stamps(unsigned long long *host_out, int n_blocks) {
 }
 #endif
 
-int32_t wdg_sell_block_cols(int32_t n_cols) { return sell_block_cols_for(n_cols); }
+int32_t wdg_sell_block_cols(int32_t n_rows, int32_t n_cols) { return sell_block_cols_for(n_rows, n_cols); }
 
 size_t wdg_sell_workspace_bytes(int32_t N, int32_t n_cols) {
-    const int64_t tasks = ((static_cast<int64_t>(N) + 63) / 64) * wdg::ceil_div(n_cols > 0 ? n_cols : 1, sell_block_cols_for(n_cols));
+    const int64_t tasks = ((static_cast<int64_t>(N) + 63) / 64) * wdg::ceil_div(n_cols > 0 ? n_cols : 1, sell_block_cols_for(N, n_cols));
     return wdg::exclusive_scan_ws_bytes(tasks + 1) + 256;
 }
 
@@ -566,7 +1048,7 @@ int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, 
         return wdg::fail(WDG_ERR_WORKSPACE, "csr_to_sell: workspace too small");
     hipStream_t st = wdg::as_stream(stream);
     const int n_slices = (N + 63) / 64;
-    const int block_cols = sell_block_cols_for(n_cols);
+    const int block_cols = sell_block_cols_for(N, n_cols);
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
     const int64_t tasks = static_cast<int64_t>(n_slices) * n_blocks;
     void *ws = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
@@ -583,7 +1065,7 @@ int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float 
                          wdg_stream_t stream) {
     WDG_REQUIRE(N >= 0 && n_cols >= 0 && sell_ptr && (N == 0 || sell_perm), "csr_to_sell_fill: bad arguments");
     const int n_slices = (N + 63) / 64;
-    const int block_cols = sell_block_cols_for(n_cols);
+    const int block_cols = sell_block_cols_for(N, n_cols);
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
     const int64_t tasks = static_cast<int64_t>(n_slices) * n_blocks;
     if (tasks == 0) return WDG_OK;

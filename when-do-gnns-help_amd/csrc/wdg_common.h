@@ -35,6 +35,24 @@ __device__ __forceinline__ int64_t xcd_contiguous_item(int64_t block, int64_t n_
 }
 inline int64_t xcd_grid_size(int64_t n_items) { return ceil_div(n_items, kXcds) * kXcds; }
 
+// Pointers that kernels read out of job tables are generic to the compiler (only kernel ARGUMENTS are inferred to be
+// global), and generic accesses compile to flat_load/flat_store: those count on lgkmcnt as well as vmcnt, so every LDS
+// wait in a loop also waits for the outstanding index prefetches.  Kernels therefore convert table pointers once:
+template <typename T>
+using global_ptr = T __attribute__((address_space(1))) *;
+template <typename T>
+__device__ __forceinline__ global_ptr<T> to_global(T *p) {
+    return (global_ptr<T>)p;
+}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_f32x4(global_ptr<const float> p) {
+    const f32x4_t v = *(global_ptr<const f32x4_t>)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_f32x4(global_ptr<float> p, const float4 &a) {
+    *(global_ptr<f32x4_t>)p = f32x4_t{a.x, a.y, a.z, a.w};
+}
+
 }  // namespace wdg
 
 #define WDG_REQUIRE(cond, ...)                                  \

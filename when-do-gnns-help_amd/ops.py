@@ -55,7 +55,7 @@ class CsrGraph:
             return False
         dev = self.device
         n_slices = (self.n_rows + 63) // 64
-        block_cols = lib.wdg_sell_block_cols(self.n_cols)
+        block_cols = lib.wdg_sell_block_cols(self.n_rows, self.n_cols)
         n_blocks = (self.n_cols + block_cols - 1) // block_cols
         sell_ptr = torch.empty(n_slices * n_blocks + 1, dtype=torch.int32, device=dev)
         sell_perm = torch.empty(self.n_rows, dtype=torch.int32, device=dev)
@@ -226,6 +226,12 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     return job
 
 
+def _dma_ok(job):
+    """WDG_SPMM_DMA_OK contract of include/wdg.h for one job descriptor."""
+    return (not job.col_scale and (job.X or 0) % 16 == 0 and (job.Y or 0) % 16 == 0 and job.ldx % 4 == 0
+            and job.ldy % 4 == 0 and job.n_feat % 4 == 0)
+
+
 def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
     """Y = diag(row_scale) A diag(col_scale) X on the GPU (wdg_spmm_csr_f32 / _bf16 by x.dtype)."""
     dev = require_gpu()
@@ -255,7 +261,7 @@ class SpmmBatch:
         self.keep = entries  # tensors must outlive the table
         arr = (SpmmJob * len(entries))()
         self.max_rows = self.max_cols = self.max_feat = 0
-        all_sell, any_val = len(entries) > 0, False
+        all_sell, any_val, dma_ok = len(entries) > 0, False, len(entries) > 0
         # the kernels start jobs in table order: most stored entries first, so the long jobs do not end up in the tail
         order = sorted(range(len(entries)), key=lambda i: -entries[i][0].nnz)
         if os.environ.get("WDG_SPMM_ORDER") == "0":
@@ -268,13 +274,14 @@ class SpmmBatch:
             _fill_job(job, g, x, y, rs, cs, uv)
             all_sell = all_sell and bool(job.sell_ptr)
             any_val = any_val or bool(job.val)
+            dma_ok = dma_ok and _dma_ok(job)
             self.max_rows, self.max_cols = max(self.max_rows, g.n_rows), max(self.max_cols, g.n_cols)
             self.max_feat = max(self.max_feat, x.shape[1])
         self.n_jobs = len(entries)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
         self.table = host.to(dev)
         self.edges = sum(e[0].nnz for e in entries)
-        self.flags = (SPMM_ALL_SELL if all_sell else 0) | (SPMM_ANY_VAL if any_val else 0)
+        self.flags = (SPMM_ALL_SELL if all_sell else 0) | (SPMM_ANY_VAL if any_val else 0) | (SPMM_DMA_OK if dma_ok else 0)
 
     def launch(self):
         check(lib.wdg_spmm_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, self.max_cols, self.max_feat,
@@ -284,11 +291,12 @@ class SpmmBatch:
         return spmm_plan(self.max_rows, self.max_cols, self.max_feat, self.n_jobs, self.flags)
 
 
-SPMM_ALL_SELL, SPMM_ANY_VAL = 1, 2
+SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK = 1, 2, 4
 
 
 def spmm_plan(n_rows, n_cols, n_feat, n_jobs=1, flags=0):
-    """(family, width, threads): 0 = LDS column slab, 1 = row gather, 2 = row-lane (needs SPMM_ALL_SELL)."""
+    """(family, width, threads): 0 = LDS column slab, 1 = row gather, 2 = row-lane (needs SPMM_ALL_SELL),
+    3 = pipelined row-lane (SPMM_ALL_SELL | SPMM_DMA_OK)."""
     slab, threads = ctypes.c_int(0), ctypes.c_int(0)
     fam = lib.wdg_spmm_plan(n_jobs, n_rows, n_cols, n_feat, flags, ctypes.byref(slab), ctypes.byref(threads))
     return fam, slab.value, threads.value
