@@ -140,7 +140,8 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
 #define WDG_SPMM_ALL_SELL 1 /* every job of the table carries sell_ptr / sell_col            */
 #define WDG_SPMM_ANY_VAL 2  /* some job has explicit values (then sell_val must be set too) */
 #define WDG_SPMM_DMA_OK 4   /* every job: X and Y 16-byte aligned, ldx, ldy and n_feat multiples of 4, col_scale NULL:
-                               X rows may be staged by LDS-DMA -> the pipelined row-lane kernel (family 3) */
+                               X rows may be staged by LDS-DMA; with WDG_SPMM_PIPELINED=1 in the environment such
+                               batches run the pipelined row-lane kernel (family 3), an opt-in schedule */
 int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
                          int32_t max_feat, int flags, wdg_stream_t stream);
 /* Which kernel family a batch of n_jobs such shapes dispatches to (0 = LDS column-slab, 1 = row gather,

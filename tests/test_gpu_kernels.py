@@ -437,6 +437,38 @@ def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch):
     assert torch.equal(y_rl, y_slab)
 
 
+@pytest.mark.parametrize("n,f,e,power_law", [(2000, 500, 20000, False), (1000, 64, 9000, False), (3000, 100, 30000, False),
+                                              (4096, 36, 50000, True), (700, 16, 0, False), (2277, 2324, 60000, True)])
+def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power_law):
+    """The opt-in pipelined schedule (WDG_SPMM_PIPELINED=1, family 3) sums in the same order as the default row-lane
+    kernel: bit-identical results, single-graph and batched, with and without explicit values."""
+    from wdg_amd import synth
+    rng = np.random.default_rng(n + f)
+    src, dst = synth.random_graph(n, max(e, 1), seed=n, power_law=power_law)
+    src, dst = src[:e], dst[:e]
+    g = ops.CsrGraph.from_coo(src, dst, n, rng.random(e, dtype=np.float32) if e else None, ops.COO_ADD_SELF_LOOPS)
+    x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
+    d = ops.degree_norm(g, ops.NORM_RW)["dinv"]
+    assert g.ensure_sell(max_padding=1e9)  # keep the skewed cases on the row-lane family whatever they pad
+    for use_values in (False, True):
+        monkeypatch.delenv("WDG_SPMM_PIPELINED", raising=False)
+        y0 = ops.spmm(g, x, row_scale=d, use_values=use_values).clone()
+        monkeypatch.setenv("WDG_SPMM_PIPELINED", "1")
+        assert ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL | ops.SPMM_DMA_OK)[0] == 3
+        y1 = ops.spmm(g, x, row_scale=d, use_values=use_values).clone()
+        ys = [torch.empty_like(y0) for _ in range(3)]
+        batch = ops.SpmmBatch([(g, x, y, d, None, use_values) for y in ys])
+        assert batch.plan()[0] == 3
+        batch.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+        for y in ys:
+            assert torch.equal(y0, y)
+    rowptr, col, val = (_np(t) for t in (g.rowptr, g.col, g.val))
+    want = oracle.spmm_csr(rowptr, col, val * _np(d)[np.repeat(np.arange(n), np.diff(rowptr))], _np(x))
+    np.testing.assert_allclose(_np(y1), want, rtol=1e-5, atol=1e-6 * max(np.abs(want).max(), 1e-30))
+
+
 # --------------------------------------------------------------------------------------------- edge / label stats
 STAT_KEYS =("totals", "row_nnz", "row_nnz_noself", "row_match_noself", "compat", "classdeg")
 

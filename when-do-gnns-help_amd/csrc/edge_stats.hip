@@ -29,8 +29,12 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
     __shared__ int tot[6];
 
     const int job_id = blockIdx.x / tiles_per_job, tile = blockIdx.x % tiles_per_job;
-    const wdg_stats_job job = jobs ? jobs[job_id] : inline_job;
-    const int N = job.n_rows, C = job.n_classes;
+    const desc_ptr<wdg_stats_job> d = descriptor(jobs, inline_job, job_id);
+    const global_ptr<const int32_t> rowptr = to_global(d->rowptr), col = to_global(d->col), labels = to_global(d->labels);
+    const global_ptr<int64_t> totals = to_global(d->totals), compat = to_global(d->compat), classdeg = to_global(d->classdeg);
+    const global_ptr<int32_t> row_nnz = to_global(d->row_nnz), row_nnz_noself = to_global(d->row_nnz_noself),
+                              row_match_noself = to_global(d->row_match_noself);
+    const int N = d->n_rows, C = d->n_classes;
     if (tile * ROWS_PER_BLOCK >= N) return;
     const bool lds_hist = C <= MAX_LDS_CLASSES;
     if (lds_hist) {
@@ -44,12 +48,12 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
     int nn = 0, ns = 0, ms = 0, m_all = 0, lab = 0, lab_m = 0;
     int yu = -1;
     if (row < N) {
-        const int s = job.rowptr[row], e = job.rowptr[row + 1];
-        yu = job.labels[row];
+        const int s = rowptr[row], e = rowptr[row + 1];
+        yu = labels[row];
         nn = e - s;
         for (int p = s + q; p < e; p += GL) {
-            const int v = job.col[p];
-            const int yv = job.labels[v];
+            const int v = col[p];
+            const int yv = labels[v];
             const int match = (yu == yv);
             const int both = (yu >= 0 && yv >= 0);
             m_all += match;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
                 ms += match;
                 if (both && yu < C && yv < C) {
                     if (lds_hist) atomicAdd(&hist[yu * C + yv], 1);
-                    else atomicAdd(reinterpret_cast<u64 *>(&job.compat[static_cast<int64_t>(yu) * C + yv]), 1ull);
+                    else atomicAdd((u64 *)(&compat[static_cast<int64_t>(yu) * C + yv]), 1ull);
                 }
             }
         }
@@ -74,9 +78,9 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
         lab_m += __shfl_xor(lab_m, o);
     }
     if (row < N && q == 0) {
-        if (job.row_nnz) job.row_nnz[row] = nn;
-        if (job.row_nnz_noself) job.row_nnz_noself[row] = ns;
-        if (job.row_match_noself) job.row_match_noself[row] = ms;
+        if (row_nnz) row_nnz[row] = nn;
+        if (row_nnz_noself) row_nnz_noself[row] = ns;
+        if (row_match_noself) row_match_noself[row] = ms;
         atomicAdd(&tot[0], nn);
         atomicAdd(&tot[1], m_all);
         atomicAdd(&tot[2], lab);
@@ -85,17 +89,17 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
         atomicAdd(&tot[5], ms);
         if (yu >= 0 && yu < C) {
             if (lds_hist) atomicAdd(reinterpret_cast<u64 *>(&cdeg[yu]), static_cast<u64>(static_cast<long long>(nn) - 1));
-            else atomicAdd(reinterpret_cast<u64 *>(&job.classdeg[yu]), static_cast<u64>(static_cast<long long>(nn) - 1));
+            else atomicAdd((u64 *)(&classdeg[yu]), static_cast<u64>(static_cast<long long>(nn) - 1));
         }
     }
     __syncthreads();
     if (threadIdx.x < 6 && tot[threadIdx.x] != 0)
-        atomicAdd(reinterpret_cast<u64 *>(&job.totals[threadIdx.x]), static_cast<u64>(tot[threadIdx.x]));
+        atomicAdd((u64 *)(&totals[threadIdx.x]), static_cast<u64>(tot[threadIdx.x]));
     if (lds_hist) {
         for (int i = threadIdx.x; i < C * C; i += THREADS)
-            if (hist[i] != 0) atomicAdd(reinterpret_cast<u64 *>(&job.compat[i]), static_cast<u64>(hist[i]));
+            if (hist[i] != 0) atomicAdd((u64 *)(&compat[i]), static_cast<u64>(hist[i]));
         for (int i = threadIdx.x; i < C; i += THREADS)
-            if (cdeg[i] != 0) atomicAdd(reinterpret_cast<u64 *>(&job.classdeg[i]), static_cast<u64>(cdeg[i]));
+            if (cdeg[i] != 0) atomicAdd((u64 *)(&classdeg[i]), static_cast<u64>(cdeg[i]));
     }
 }
 

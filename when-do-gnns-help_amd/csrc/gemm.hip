@@ -30,11 +30,11 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
     __shared__ float As[BM * LDA_S];
     __shared__ float Bs[TRANSB ? BN * LDB_S : BK * LDB_S];
 
-    const wdg_gemm_job job = jobs ? jobs[blockIdx.z] : inline_job;
-    const float *__restrict__ A = job.A, *__restrict__ B = job.B, *__restrict__ bias = job.bias;
-    float *__restrict__ C = job.C;
-    const int64_t lda = job.lda, ldb = job.ldb, ldc = job.ldc;
-    const int M = job.M, N = job.N, K = job.K, act = job.act;
+    const desc_ptr<wdg_gemm_job> job = descriptor(jobs, inline_job, blockIdx.z);
+    const global_ptr<const float> A = to_global(job->A), B = to_global(job->B), bias = to_global(job->bias);
+    const global_ptr<float> C = to_global(job->C);
+    const int64_t lda = job->lda, ldb = job->ldb, ldc = job->ldc;
+    const int M = job->M, N = job->N, K = job->K, act = job->act;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     if (m0 >= M || n0 >= N) return;  // table entries smaller than the launch bounds

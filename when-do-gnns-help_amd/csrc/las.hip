@@ -41,22 +41,48 @@ __host__ __device__ inline size_t las_layout(int n_tiles, int F, int C, char *ba
     return off;
 }
 
-__device__ __forceinline__ LasWs job_ws(const wdg_las_job &j) {
+// a job as the kernels use it: scalars + global-address-space pointers (wdg_common.h: global_ptr, descriptor)
+struct LasView {
+    global_ptr<const float> H;
+    global_ptr<const int32_t> labels, rows;
+    global_ptr<double> W_out;
+    global_ptr<int64_t> count_out;
+    void *workspace;
+    int64_t ldh;
+    int32_t n, F, C;
+};
+__device__ __forceinline__ LasView las_view(const wdg_las_job *jobs, const wdg_las_job &inline_job, int id) {
+    const desc_ptr<wdg_las_job> d = descriptor(jobs, inline_job, id);
+    LasView v;
+    v.H = to_global(d->H); v.labels = to_global(d->labels); v.rows = to_global(d->rows);
+    v.W_out = to_global(d->W_out); v.count_out = to_global(d->count_out);
+    v.workspace = d->workspace; v.ldh = d->ldh; v.n = d->n; v.F = d->F; v.C = d->C;
+    return v;
+}
+struct LasWsView {
+    global_ptr<double> partial, M;
+    global_ptr<int> cnt_partial;
+    global_ptr<long long> cls_cnt;
+};
+__device__ __forceinline__ LasWsView job_ws(const LasView &j) {
     LasWs ws;
     char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(j.workspace) + 255) & ~static_cast<uintptr_t>(255));
     las_layout((j.n + TILE_ROWS - 1) / TILE_ROWS, j.F, j.C, base, &ws);
-    return ws;
+    LasWsView v;
+    v.partial = to_global(ws.partial); v.M = to_global(ws.M); v.cnt_partial = to_global(ws.cnt_partial);
+    v.cls_cnt = to_global(ws.cls_cnt);
+    return v;
 }
 
 // partial[t][c][f] = sum over rows j of tile t with label c of H[row_j, f]; cnt_partial[t][c] = #rows
 __global__ __launch_bounds__(64) void las_middle_partial(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
-    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const LasView job = las_view(jobs, inline_job, blockIdx.z);
     const int n = job.n, F = job.F, C = job.C;
     const int tile = blockIdx.x, f = blockIdx.y * 64 + threadIdx.x;
     if (tile * TILE_ROWS >= n || (blockIdx.y * 64 >= F && blockIdx.y > 0)) return;
-    const LasWs ws = job_ws(job);
+    const LasWsView ws = job_ws(job);
     const int j0 = tile * TILE_ROWS, j1 = min(n, j0 + TILE_ROWS);
-    double *out = ws.partial + static_cast<int64_t>(tile) * C * F;
+    const global_ptr<double> out = ws.partial + static_cast<int64_t>(tile) * C * F;
     // walk the tile once per class: C is small (2..7 on every reference dataset); rows stay in L1/L2
     for (int c = 0; c < C; ++c) {
         double acc = 0.0;
@@ -75,11 +101,11 @@ __global__ __launch_bounds__(64) void las_middle_partial(const wdg_las_job *__re
 
 // M[c][f] = sum_t partial[t][c][f] in tile order; class counts likewise; the job's counters are reset here
 __global__ void las_middle_reduce(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
-    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const LasView job = las_view(jobs, inline_job, blockIdx.z);
     const int n = job.n, F = job.F, C = job.C;
     if (n <= 0 || C <= 0) return;
     const int n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
-    const LasWs ws = job_ws(job);
+    const LasWsView ws = job_ws(job);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C * F) {
         double acc = 0.0;
@@ -96,13 +122,13 @@ __global__ void las_middle_reduce(const wdg_las_job *__restrict__ jobs, const wd
 
 // one wave per selected row: W[i,c] = sum_f H[i,f] M[c][f]; then the two LAS decisions
 __global__ __launch_bounds__(256) void las_weights_kernel(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
-    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const LasView job = las_view(jobs, inline_job, blockIdx.z);
     const int n = job.n, F = job.F, C = job.C;
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= n) return;
-    const LasWs ws = job_ws(job);
+    const LasWsView ws = job_ws(job);
     const int r = job.rows ? job.rows[i] : i;
-    const float *h = job.H + static_cast<int64_t>(r) * job.ldh;
+    const global_ptr<const float> h = job.H + static_cast<int64_t>(r) * job.ldh;
     const int y = job.labels[r];
     double own = 0.0, tot = 0.0, best = 0.0;
     int best_c = -1;
@@ -124,8 +150,8 @@ __global__ __launch_bounds__(256) void las_weights_kernel(const wdg_las_job *__r
     // (W_iy / n_y) / ((sum_c W_ic - W_iy) / (n - n_y)); NaN -> 0 (utils/homophily_metrics.py:216-220)
     const double ratio = (own / ny) / ((tot - own) / (static_cast<double>(n) - ny));
     const bool soft = !(ratio != ratio) && ratio >= 1.0;
-    if (soft) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[0]), 1ull);
-    if (best_c == y) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[1]), 1ull);
+    if (soft) atomicAdd((u64 *)(&job.count_out[0]), 1ull);
+    if (best_c == y) atomicAdd((u64 *)(&job.count_out[1]), 1ull);
 }
 
 // ---- narrow-feature path (F <= 16: label propagation, F = C): rows on lanes instead of features on lanes.
@@ -138,10 +164,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __global__ __launch_bounds__(64) void las_middle_partial_small(const wdg_las_job *__restrict__ jobs,
                                                                const wdg_las_job inline_job) {
-    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const LasView job = las_view(jobs, inline_job, blockIdx.z);
     const int n = job.n, F = job.F, C = job.C, tile = blockIdx.x, lane = threadIdx.x;
     if (tile * TILE_ROWS >= n) return;
-    const LasWs ws = job_ws(job);
+    const LasWsView ws = job_ws(job);
     float h[TILE_ROWS / 64][SMALL_F];
     int lab[TILE_ROWS / 64];
 #pragma unroll
@@ -155,7 +181,7 @@ __global__ __launch_bounds__(64) void las_middle_partial_small(const wdg_las_job
             for (int f = 0; f < SMALL_F; ++f) h[s][f] = (f < F) ? job.H[static_cast<int64_t>(r) * job.ldh + f] : 0.f;
         }
     }
-    double *out = ws.partial + static_cast<int64_t>(tile) * C * F;
+    const global_ptr<double> out = ws.partial + static_cast<int64_t>(tile) * C * F;
     for (int c = 0; c < C; ++c) {
         int cnt = 0;
 #pragma unroll
@@ -175,13 +201,13 @@ __global__ __launch_bounds__(64) void las_middle_partial_small(const wdg_las_job
 }
 
 __global__ __launch_bounds__(256) void las_weights_small(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
-    const wdg_las_job job = jobs ? jobs[blockIdx.z] : inline_job;
+    const LasView job = las_view(jobs, inline_job, blockIdx.z);
     const int n = job.n, F = job.F, C = job.C;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const LasWs ws = job_ws(job);
+    const LasWsView ws = job_ws(job);
     const int r = job.rows ? job.rows[i] : i;
-    const float *hp = job.H + static_cast<int64_t>(r) * job.ldh;
+    const global_ptr<const float> hp = job.H + static_cast<int64_t>(r) * job.ldh;
     float h[SMALL_F];
 #pragma unroll
     for (int f = 0; f < SMALL_F; ++f) h[f] = (f < F) ? hp[f] : 0.f;
@@ -207,8 +233,8 @@ __global__ __launch_bounds__(256) void las_weights_small(const wdg_las_job *__re
     // one 64-bit atomic per wave instead of per row
     const unsigned long long ms = __ballot(soft), mh = __ballot(best_c == y);
     if ((threadIdx.x & 63) == 0) {
-        if (ms) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[0]), static_cast<u64>(__popcll(ms)));
-        if (mh) atomicAdd(reinterpret_cast<u64 *>(&job.count_out[1]), static_cast<u64>(__popcll(mh)));
+        if (ms) atomicAdd((u64 *)(&job.count_out[0]), static_cast<u64>(__popcll(ms)));
+        if (mh) atomicAdd((u64 *)(&job.count_out[1]), static_cast<u64>(__popcll(mh)));
     }
 }
 

@@ -21,9 +21,11 @@
 // Normalisation is fused: the caller passes d = D^-1 or D^-1/2 as row_scale / col_scale instead of
 // materialising A_hat's values (K2 fused into K1); an explicit `val` array is honoured too.
 #include "wdg_common.h"
+#include "spmm_job_view.h"
 
 namespace wdg {  // row-lane family (spmm_rowlane.hip)
 bool rowlane_eligible(int max_rows, int max_cols, int max_feat);
+bool rowlane_pipelined(int max_rows, int flags);
 int rowlane_dispatch_f32(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, bool, hipStream_t);
 int rowlane_dispatch_bf16(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
 }  // namespace wdg
@@ -49,12 +51,10 @@ __device__ unsigned long long wdg_stamp_buf[8192 * 8];
 #define WDG_PREFETCH_DEPTH 2
 #endif
 
-struct bf16_t {
-    unsigned short bits;
-};
+using bf16_t = unsigned short;  // raw bf16 bits (a builtin type: loadable through address-space-qualified pointers)
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
-__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float(static_cast<unsigned>(v.bits) << 16); }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float(static_cast<unsigned>(v) << 16); }
 
 // broadcast lane J of each G-lane group to the whole group (G in {1,2,4}: DPP quad_perm, no LDS traffic)
 template <int G, int J>
@@ -113,7 +113,7 @@ int env_int(const char *name, int dflt) {
 
 // Where a finished row goes: scale, then one 16-byte store per lane (or guarded scalar stores on ragged tails).
 struct RowSink {
-    float *Y;
+    global_ptr<float> Y;
     const float *row_scale;  // LDS copy (n_rows floats) or nullptr
     int64_t ldy;
     int f, F;
@@ -130,9 +130,9 @@ struct RowSink {
             stage[row * G_ + gq] = acc;
             return;
         }
-        float *dst = Y + static_cast<int64_t>(row) * ldy + f;
+        const global_ptr<float> dst = Y + static_cast<int64_t>(row) * ldy + f;
         if (vec) {
-            *reinterpret_cast<float4 *>(dst) = acc;
+            store_f32x4(dst, acc);
         } else {
             if (f + 0 < F) dst[0] = acc.x;
             if (f + 1 < F) dst[1] = acc.y;
@@ -148,8 +148,8 @@ struct RowSink {
 // row boundary (row pointers come from LDS).  The dependent chain rowptr -> col -> LDS -> store is thus paid once
 // per group instead of once per row - the kernel is latency-bound otherwise (72 % of wave cycles in s_waitcnt).
 template <int G, bool HAS_VAL>
-__device__ __forceinline__ void aggregate_rows(const float4 *xs, const int *rp, const int32_t *__restrict__ col,
-                                               const float *__restrict__ val, int row, int row_last, int q,
+__device__ __forceinline__ void aggregate_rows(const float4 *xs, const int *rp, global_ptr<const int32_t> col,
+                                               global_ptr<const float> val, int row, int row_last, int q,
                                                int zero_row, const RowSink &sink) {
     constexpr int UNR = (G >= 4) ? 1 : 4 / G;  // entries per step = G*UNR >= 4
     constexpr int EPI = G * UNR;
@@ -233,23 +233,23 @@ __global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *
     if (item >= n_items) return;
     const int job_id = static_cast<int>(item / n_slabs);
     const int slab = static_cast<int>(item % n_slabs);
-    const wdg_spmm_job job = jobs ? jobs[job_id] : inline_job;  // single-graph calls pass the descriptor by value
+    const JobView job = load_job(jobs, inline_job, job_id);  // single-graph calls pass the descriptor by value
     const int f0 = slab * SLAB;
     if (f0 >= job.n_feat) return;
     const int n_cols = job.n_cols, n_rows = job.n_rows, F = job.n_feat;
-    const TIN *__restrict__ X = static_cast<const TIN *>(job.X);
+    const global_ptr<const TIN> X = (global_ptr<const TIN>)job.X;
     const int tid = threadIdx.x;
 
     // ---- stage 1: X[:, f0:f0+SLAB] -> LDS, pre-multiplied by the column scale
     const bool full = (f0 + SLAB <= F);
-    const bool vec_ok = full && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool vec_ok = full && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
     for (int i = tid; i < (n_cols + 1) * G; i += THREADS) {
         const int r = i / G, q = i % G;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < n_cols && !(job.reserved & 2)) {  // reserved bits: timing-only ablation switches (diagnostics)
-            const TIN *src = X + static_cast<int64_t>(r) * job.ldx + f0 + q * 4;
+            const global_ptr<const TIN> src = X + static_cast<int64_t>(r) * job.ldx + f0 + q * 4;
             if (vec_ok) {
-                v = *reinterpret_cast<const float4 *>(src);
+                v = load_f32x4((global_ptr<const float>)src);
             } else {
                 const int f = f0 + q * 4;
                 if (f + 0 < F) v.x = to_f32(src[0]);
@@ -284,14 +284,14 @@ __global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *
     sink.ldy = job.ldy;
     sink.f = f0 + q * 4;
     sink.F = F;
-    sink.vec = full && (job.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.Y) & 15) == 0);
+    sink.vec = full && (job.ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
     const bool defer = (job.reserved & 8) != 0;  // experiment switch: needs LDS room for n_rows * SLAB * 4 more bytes
     float4 *ystage = reinterpret_cast<float4 *>(rs + ((n_rows + 3) & ~3));
     sink.stage = defer ? ystage : nullptr;
     sink.gq = q;
     sink.G_ = G;
     if (job.val) aggregate_rows<G, true>(xs, rp, job.col, job.val, row0, row1, q, n_cols, sink);
-    else aggregate_rows<G, false>(xs, rp, job.col, nullptr, row0, row1, q, n_cols, sink);
+    else aggregate_rows<G, false>(xs, rp, job.col, (global_ptr<const float>)nullptr, row0, row1, q, n_cols, sink);
     WDG_STAMP(3);
 #ifdef WDG_STAMPS
     __syncthreads();
@@ -319,16 +319,16 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const wdg_spmm_job *__
     if (gtask >= n_tasks) return;
     const int job_id = static_cast<int>(gtask / tasks_per_job);
     const long long t = gtask % tasks_per_job;
-    const wdg_spmm_job job = jobs ? jobs[job_id] : inline_job;
+    const JobView job = load_job(jobs, inline_job, job_id);
     const int row = static_cast<int>(t / n_chunks), chunk = static_cast<int>(t % n_chunks);
     if (row >= job.n_rows) return;
     const int F = job.n_feat;
     const int f = chunk * CH + (threadIdx.x % GL) * VEC;
     if (chunk * CH >= F) return;
-    const TIN *__restrict__ X = static_cast<const TIN *>(job.X);
+    const global_ptr<const TIN> X = (global_ptr<const TIN>)job.X;
     const int start = job.rowptr[row], end = job.rowptr[row + 1];
     const bool vec_ok = VEC == 4 && sizeof(TIN) == 4 && (f + VEC <= F) && (job.ldx % 4 == 0) &&
-                        ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+                        (((uintptr_t)X & 15) == 0);
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -349,9 +349,9 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const wdg_spmm_job *__
         float x[U][VEC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const TIN *src = X + static_cast<int64_t>(c[u]) * job.ldx + f;
+            const global_ptr<const TIN> src = X + static_cast<int64_t>(c[u]) * job.ldx + f;
             if (vec_ok) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                const float4 t4 = load_f32x4((global_ptr<const float>)src);
                 x[u][0] = t4.x;
                 if constexpr (VEC == 4) { x[u][1] = t4.y; x[u][2] = t4.z; x[u][3] = t4.w; }
             } else {
@@ -368,13 +368,13 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const wdg_spmm_job *__
         const int c = job.col[p];
         float w = job.val ? job.val[p] : 1.f;
         if (job.col_scale) w *= job.col_scale[c];
-        const TIN *src = X + static_cast<int64_t>(c) * job.ldx + f;
+        const global_ptr<const TIN> src = X + static_cast<int64_t>(c) * job.ldx + f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
             if (f + v < F) acc[v] = fmaf(w, to_f32(src[v]), acc[v]);
     }
     const float rs = job.row_scale ? job.row_scale[row] : 1.f;
-    float *dst = job.Y + static_cast<int64_t>(row) * job.ldy + f;
+    const global_ptr<float> dst = job.Y + static_cast<int64_t>(row) * job.ldy + f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v)
         if (f + v < F) dst[v] = rs * acc[v];
@@ -539,9 +539,9 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
                   int *threads_out) {
     if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, n_feat)) {
         const int rpt = (max_rows + 1023) / 1024;
-        if (slab_out) *slab_out = ((rpt <= 2) && n_feat > 16 && !((flags & WDG_SPMM_DMA_OK) && rpt <= 4)) ? 32 : 16;  // features per item
+        if (slab_out) *slab_out = ((rpt <= 2) && n_feat > 16 && !rowlane_pipelined(max_rows, flags)) ? 32 : 16;  // features per item
         if (threads_out) *threads_out = 1024;
-        return ((flags & WDG_SPMM_DMA_OK) && rpt <= 4) ? 3 : 2;
+        return rowlane_pipelined(max_rows, flags) ? 3 : 2;
     }
     const Plan p = make_plan(max_rows, max_cols, n_feat, n_jobs > 0 ? n_jobs : 1);
     if (slab_out) *slab_out = p.slab;

@@ -27,6 +27,7 @@
 #include <atomic>
 
 #include "wdg_common.h"
+#include "spmm_job_view.h"
 
 namespace wdg {
 int exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int64_t *total64, void *ws, hipStream_t st);
@@ -41,7 +42,6 @@ constexpr int RL_THREADS = 1024;
 constexpr int RL_WAVES = RL_THREADS / 64;
 constexpr int RL_MAX_ROWS = 6 * RL_THREADS;  // 6 rows per thread at 4 float4 accumulators each
 constexpr int SELL_SENTINEL = 0x7fffffff;  // padding entry
-constexpr int RL_LDS_ROW_BYTES = 128;      // the block size is chosen for 32-feature (128-B) staged rows
 
 #ifdef WDG_STAMPS  // diagnostic build only (make STAMPS=1): wave 0's clock at phase boundaries, one 16-slot record per
                    // (workgroup, item iteration); the s_waitcnt(0) makes wave 0 drain its queues, so timings are perturbed
@@ -196,42 +196,19 @@ __global__ __launch_bounds__(256) void sell_fill(const int32_t *__restrict__ row
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-// A job descriptor as the kernels use it: scalars plus GLOBAL-address-space pointers (see wdg_common.h, global_ptr).
-struct JobView {
-    global_ptr<const int32_t> sell_ptr, sell_col, sell_perm;
-    global_ptr<const float> sell_val, row_scale, col_scale;
-    global_ptr<const void> X;
-    global_ptr<float> Y;
-    int64_t ldx, ldy;
-    int32_t n_rows, n_cols, n_feat, reserved, sell_block_cols, sell_n_blocks;
-};
-// job `id` of the table, or the by-value descriptor of a single-graph launch.  Both live at wave-uniform addresses that
-// are only read: viewed through the constant address space the fields arrive by scalar loads (a generic pointer that may
-// be either would be read with flat vector loads)
-__device__ __forceinline__ JobView load_job(const wdg_spmm_job *__restrict__ jobs, const wdg_spmm_job &inline_job, int id) {
-    typedef const wdg_spmm_job __attribute__((address_space(4))) *desc_ptr;
-    const desc_ptr j = jobs ? (desc_ptr)(jobs + id) : (desc_ptr)(&inline_job);
-    JobView v;
-    v.sell_ptr = to_global(j->sell_ptr); v.sell_col = to_global(j->sell_col); v.sell_perm = to_global(j->sell_perm);
-    v.sell_val = to_global(j->sell_val); v.row_scale = to_global(j->row_scale); v.col_scale = to_global(j->col_scale);
-    v.X = to_global(j->X); v.Y = to_global(j->Y);
-    v.ldx = j->ldx; v.ldy = j->ldy;
-    v.n_rows = j->n_rows; v.n_cols = j->n_cols; v.n_feat = j->n_feat; v.reserved = j->reserved;
-    v.sell_block_cols = j->sell_block_cols; v.sell_n_blocks = j->sell_n_blocks;
-    return v;
-}
-
 // work-queue counters, one slot per launch in flight (slots are handed out round-robin by the launcher and re-armed by
 // the last workgroup of the launch that used them)
 constexpr int RL_QUEUE_SLOTS = 256;
 __device__ unsigned int rl_queue_next[RL_QUEUE_SLOTS * kXcds];
 __device__ unsigned int rl_queue_done[RL_QUEUE_SLOTS];
 
-// The k-th slice of a wave: boustrophedon over the length-sorted slices (wave w: w, 31 - w, 32 + w, ...), so that every wave
-// gets long and short slices alike - with w, 16 + w, ... wave 0 would hold the longest slice of every round and every
-// barrier would wait for it (measured: +45 % sweep time on the by-block sorted sweep graphs)
+// The k-th slice of a wave.  With two rounds (graphs of 1025..2048 rows, the sweep graphs): wave w takes slices w and
+// 31 - w of the length-sorted order, a long and a short one - with w and 16 + w wave 0 would hold the longest slice of both
+// rounds and every barrier would wait for it (by-block sorted sweep graphs: +45 % sweep time).  More rounds keep the plain
+// order: on the skewed 6-round squirrel graph the alternating order measured 2x SLOWER (1300 vs 636 us).
+template <int RPT>
 __device__ __forceinline__ int rl_slice(int wave, int k) {
-    return k * RL_WAVES + ((k & 1) ? RL_WAVES - 1 - wave : wave);
+    return k * RL_WAVES + ((RPT == 2 && (k & 1)) ? RL_WAVES - 1 - wave : wave);
 }
 
 // workgroup barrier that waits for this wave's LDS traffic only: global stores and loads stay in flight across it
@@ -366,7 +343,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
         int base[RPT], width[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int slice = rl_slice(wave, k);
+            const int slice = rl_slice<RPT>(wave, k);
             base[k] = width[k] = 0;
             if (slice < n_slices && !(job.reserved & 4)) {  // reserved bit 2: timing ablation (no sweep)
                 const int task = blk * n_slices + slice;
@@ -384,7 +361,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
         if (blk + 1 == n_blocks) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const int slot = rl_slice(wave, k) * 64 + lane;  // SELL slot -> original row (length-sort permutation)
+                const int slot = rl_slice<RPT>(wave, k) * 64 + lane;  // SELL slot -> original row (length-sort permutation)
                 out_row[k] = (slot < n_rows) ? (job.sell_perm ? job.sell_perm[slot] : slot) : n_rows;
                 out_scale[k] = (job.row_scale && out_row[k] < n_rows) ? job.row_scale[out_row[k]] : 1.f;
             }
@@ -488,7 +465,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     constexpr int ROWS_PER_IT = 64 / QUADS;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int slice = rl_slice(wave, k);
+        const int slice = rl_slice<RPT>(wave, k);
         if (slice >= n_slices) continue;
         const int row = out_row[k];
         const float rs = out_scale[k];
@@ -564,7 +541,9 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
                                                                         int n_jobs, int queue_slot, int buf_slots) {
     constexpr int FG = QUADS * 4;
     constexpr int U = rl_pipe_chunk(RPT, HAS_VAL);  // index entries per register chunk
-    constexpr int ROWS_PASS = 256 / QUADS;        // rows a wave transposes at a time through its 4 KiB of LDS
+    constexpr int STAGE_PIECES = (1016 * QUADS + RL_THREADS - 1) / RL_THREADS;  // DMA wave-instructions per wave and block
+    constexpr int TR_SLOTS = 128;                 // float4 per wave: its private 2-KiB transpose tile
+    constexpr int ROWS_PASS = TR_SLOTS / QUADS;   // rows a wave transposes at a time
     constexpr int PASSES = 64 / ROWS_PASS;
     constexpr int READS = ROWS_PASS * QUADS / 64;  // float4 a lane reads back (and stores) per pass
     constexpr int ROWS_PER_READ = 64 / QUADS;
@@ -579,21 +558,15 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
     const int first_claim = wgs_per_xcd * (kXcds / n_queues);
     unsigned *queues = rl_queue_next + queue_slot * kXcds;
 
-    auto claim_sync = [&](int queue) -> int {  // exposed round trip: once, at kernel start
-        if (threadIdx.x == 0) steal_box[0] = static_cast<int>(first_claim + atomicAdd(&queues[queue], 1u));
-        rl_barrier_lds();
-        const int v = __builtin_amdgcn_readfirstlane(steal_box[0]);
-        rl_barrier_lds();
-        return v;
-    };
     // X[begin:end, f0:f0+FG] of `j` -> dst, one 1-KiB wave-instruction per 8 (QUADS = 8) or 16 staged rows
     auto stage = [&](const JobView &j, int f0, int blk, float4 *dst, int lane) {
         const int begin = blk * j.sell_block_cols, end = min(begin + j.sell_block_cols, j.n_cols);
         const int n_stage = (j.reserved & 2) ? 0 : (end - begin) * QUADS;  // reserved bit 1: timing ablation
-        const global_ptr<const float> X = (global_ptr<const float>)j.X;
+        [[maybe_unused]] const global_ptr<const float> X = (global_ptr<const float>)j.X;
         for (int i0 = wave * 64; i0 < n_stage; i0 += RL_THREADS) {
             const int i = i0 + lane;
-            const int r = begin + i / QUADS, qd = i % QUADS;
+            [[maybe_unused]] const int r = begin + i / QUADS;
+            const int qd = i % QUADS;
             if (i < n_stage && f0 + qd * 4 < j.n_feat) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(r) * j.ldx + f0 + qd * 4,
@@ -602,12 +575,29 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
             }
         }
     };
+    // the same, one wave-instruction (piece j of this wave) at a time: issued between the entries of a sweep, so that the
+    // block's 64 KiB enter the CU's memory pipeline as a trickle - issued all at once they fill its queues, and every wave
+    // then blocks at its next memory instruction (instruction issue is in order) until the pipeline has drained
+    auto stage_piece = [&](const JobView &j, int f0, int blk, float4 *dst, int lane, int piece) {
+        const int begin = blk * j.sell_block_cols, end = min(begin + j.sell_block_cols, j.n_cols);
+        const int n_stage = (j.reserved & 2) ? 0 : (end - begin) * QUADS;
+        [[maybe_unused]] const global_ptr<const float> X = (global_ptr<const float>)j.X;
+        const int i0 = wave * 64 + piece * RL_THREADS, i = i0 + lane;
+        [[maybe_unused]] const int r = begin + i / QUADS;
+        const int qd = i % QUADS;
+        if (i < n_stage && f0 + qd * 4 < j.n_feat) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(r) * j.ldx + f0 + qd * 4,
+                                             (__attribute__((address_space(3))) void *)(dst + i0), 16, 0, 0);
+#endif
+        }
+    };
     // extents of this wave's (block, slice) pairs: lane b * RPT + k holds sell_ptr[b * S + slice] and its successor
     auto load_extents = [&](const JobView &j, int lane, int &lo, int &hi) {
         const int n_slices = (j.n_rows + 63) >> 6;
         lo = hi = 0;
         if (lane < j.sell_n_blocks * RPT) {
-            const int slice = rl_slice(wave, lane % RPT);
+            const int slice = rl_slice<RPT>(wave, lane % RPT);
             if (slice < n_slices && !(j.reserved & 4)) {  // reserved bit 2: timing ablation (no sweep)
                 const int task = (lane / RPT) * n_slices + slice;
                 lo = j.sell_ptr[task];
@@ -619,31 +609,35 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
     RL_STAMP_ITER;
     int q = xcd % n_queues;
     int t = (xcd / n_queues) * wgs_per_xcd + blockIdx.x / kXcds;
-    int t_next = claim_sync(q);
+    // Item t+1 is claimed a whole item ahead: thread 0 holds the reply of the claim it issued at the top of the previous
+    // item, publishes it before this item's first barrier (everyone reads it after) and issues the next claim.
+    unsigned claim_reply = 0;
+    if (threadIdx.x == 0) claim_reply = atomicAdd(&queues[q], 1u);
     int p = 0;            // buffer that holds (or will hold) block 0 of item t
     bool primed = false;  // item t's block 0, extents and head chunks were requested during the previous item
     int ext_lo = 0, ext_hi = 0;
     // Index registers.  vmcnt retires in order, so an index load issued AFTER a block's DMA cannot be consumed before that
     // DMA has landed: a sweep that fetched its indices as it went would run at the DMA's latency, not the LDS's.  The
     // first U entries of EVERY slice of block b+1 are therefore requested at the top of block b, BEFORE block b+1's DMA
-    // is issued (head[][], copied to cur[][] at the top of block b+1); slices wider than U fetch the rest in-sweep and
-    // pay that wait once per block.
+    // is issued (head[][], copied to the sweep's registers at the top of block b+1); slices wider than U fetch the rest
+    // in-sweep and pay that wait once per block.
     int head[RPT][U];
     float headw[RPT][U];
+    float4 *const buf0 = lds, *const buf1 = lds + buf_slots;
+    float4 *const tr = lds + 2 * buf_slots + wave * TR_SLOTS;  // this wave's transpose tile: no barrier guards it
 
-    for (int round = 0;;) {
+    for (int round = 0;; ++round) {
         const int q_items = ((n_jobs - q + n_queues - 1) / n_queues) * ng;
         if (t >= q_items) {  // queue drained: take over a queue that still has work, or leave
             const RlSteal st = rl_steal(queues, xcd, n_queues, n_jobs, ng, first_claim, steal_box);
             if (st.queue < 0) break;
             q = st.queue;
             t = st.t;
-            t_next = st.t_next;
+            if (threadIdx.x == 0) claim_reply = static_cast<unsigned>(st.t_next - first_claim);  // already claimed
             primed = false;
+            --round;
             continue;
         }
-        unsigned claimed = 0;  // the item after next; thread 0 keeps the reply in a register until the epilogue
-        if (threadIdx.x == 0) claimed = atomicAdd(&queues[q], 1u);
         RL_STAMP(0);
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // opaque per item: no hoisting of per-thread address arithmetic out of the item loop
@@ -656,34 +650,13 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
         const int n_rows = job.n_rows, F = job.n_feat, n_blocks = job.sell_n_blocks, block_cols = job.sell_block_cols;
         const int n_slices = (n_rows + 63) >> 6;
         const bool ext_vec = n_blocks * RPT <= 64;
-        float4 *const buf0 = lds, *const buf1 = lds + buf_slots;
-
-        // the item after this one (same queue)
-        const bool next_in_queue = t_next < q_items;
-        const int next_job_id = __builtin_amdgcn_readfirstlane((t_next / ng) * n_queues + q);
-        const int next_f0 = __builtin_amdgcn_readfirstlane(t_next % ng) * FG;
-        const JobView nxt = load_job(next_in_queue ? jobs : nullptr, inline_job, next_job_id);
-        const bool next_live = next_in_queue && next_f0 < nxt.n_feat;
-        const bool next_ext_vec = nxt.sell_n_blocks * RPT <= 64;
-        const int next_slices = (nxt.n_rows + 63) >> 6;
-        int next_lo = 0, next_hi = 0;  // its extents: requested now, read at the top of this item's last block
-        if (next_live && next_ext_vec) load_extents(nxt, lane, next_lo, next_hi);
-        bool next_staged = false;
-
-        float4 acc[RPT][QUADS];
-#pragma unroll
-        for (int k = 0; k < RPT; ++k)
-#pragma unroll
-            for (int h = 0; h < QUADS; ++h) acc[k][h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int out_row[RPT];
-        float out_scale[RPT];
 
         auto extent = [&](int blk, int k, int &base, int &width) {  // wave-uniform
             if (ext_vec) {
                 base = __builtin_amdgcn_readlane(ext_lo, blk * RPT + k);
                 width = (__builtin_amdgcn_readlane(ext_hi, blk * RPT + k) - base) >> 6;
             } else {
-                const int slice = rl_slice(wave, k);
+                const int slice = rl_slice<RPT>(wave, k);
                 base = width = 0;
                 if (slice < n_slices && !(job.reserved & 4)) {
                     base = job.sell_ptr[blk * n_slices + slice];
@@ -691,20 +664,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
                 }
             }
         };
-        auto next_extent = [&](int k, int &base, int &width) {  // block 0 of the next item
-            if (next_ext_vec) {
-                base = __builtin_amdgcn_readlane(next_lo, k);
-                width = (__builtin_amdgcn_readlane(next_hi, k) - base) >> 6;
-            } else {
-                const int slice = rl_slice(wave, k);
-                base = width = 0;
-                if (slice < next_slices && !(nxt.reserved & 4)) {
-                    base = nxt.sell_ptr[slice];
-                    width = (nxt.sell_ptr[slice + 1] - base) >> 6;
-                }
-            }
-        };
-        // head[][] <- the first U entries of every slice of block `blk` of this item / of block 0 of the next item
+        // head[][] <- the first U entries of every slice of block `blk`
         auto load_heads = [&](int blk) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
@@ -717,11 +677,58 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
                 }
             }
         };
-        auto load_next_heads = [&]() {
+
+        if (live && !primed) {  // first item of the workgroup / after a queue switch: nothing was requested ahead
+            if (ext_vec) load_extents(job, lane, ext_lo, ext_hi);
+            load_heads(0);
+            stage(job, f0, 0, p ? buf1 : buf0, lane);
+        }
+        int out_row[RPT];
+        float out_scale[RPT];
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {  // destination rows of this wave's slots (the length-sort permutation)
+                const int slot = rl_slice<RPT>(wave, k) * 64 + lane;
+                out_row[k] = (slot < n_rows) ? (job.sell_perm ? job.sell_perm[slot] : slot) : n_rows;
+            }
+        }
+        // ---- the item's first barrier: block 0 and its head chunks have landed (a primed item's were waited for before the
+        //      previous item's stores), everyone is done with the previous item's sweeps; the next item's index is published
+        unsigned claim_next = 0;
+        if (threadIdx.x == 0) {
+            next_item[round & 1] = static_cast<int>(first_claim + claim_reply);
+            claim_next = atomicAdd(&queues[q], 1u);
+        }
+        if (!primed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rl_barrier_lds();
+        const int t_next = __builtin_amdgcn_readfirstlane(next_item[round & 1]);
+        RL_STAMP(1);
+
+        // the item after this one (same queue): descriptor, extents (read at the top of this item's last block)
+        const bool next_in_queue = t_next < q_items;
+        const int next_job_id = __builtin_amdgcn_readfirstlane((t_next / ng) * n_queues + q);
+        const int next_f0 = __builtin_amdgcn_readfirstlane(t_next % ng) * FG;
+        const JobView nxt = load_job(next_in_queue ? jobs : nullptr, inline_job, next_job_id);
+        const bool next_live = next_in_queue && next_f0 < nxt.n_feat;
+        const bool next_ext_vec = nxt.sell_n_blocks * RPT <= 64;
+        const int next_slices = (nxt.n_rows + 63) >> 6;
+        int next_lo = 0, next_hi = 0;
+        if (next_live && next_ext_vec) load_extents(nxt, lane, next_lo, next_hi);
+        bool next_staged = false;
+        auto load_next_heads = [&]() {  // head[][] <- block 0 of the next item
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                int base, width;
-                next_extent(k, base, width);
+                int base = 0, width = 0;
+                if (next_ext_vec) {
+                    base = __builtin_amdgcn_readlane(next_lo, k);
+                    width = (__builtin_amdgcn_readlane(next_hi, k) - base) >> 6;
+                } else {
+                    const int slice = rl_slice<RPT>(wave, k);
+                    if (slice < next_slices && !(nxt.reserved & 4)) {
+                        base = nxt.sell_ptr[slice];
+                        width = (nxt.sell_ptr[slice + 1] - base) >> 6;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     head[k][u] = (u < width) ? nxt.sell_col[base + lane + u * 64] : SELL_SENTINEL;
@@ -730,30 +737,26 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
             }
         };
 
-        if (live && !primed) {  // first item of the workgroup / after a queue switch: nothing was requested ahead
-            if (ext_vec) load_extents(job, lane, ext_lo, ext_hi);
-            load_heads(0);
-            stage(job, f0, 0, p ? buf1 : buf0, lane);
-        }
+        float4 acc[RPT][QUADS];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+#pragma unroll
+            for (int h = 0; h < QUADS; ++h) acc[k][h] = make_float4(0.f, 0.f, 0.f, 0.f);
 
         int last = p;
         if (live) {
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {  // destination rows of this wave's slots (the length-sort permutation)
-                const int slot = rl_slice(wave, k) * 64 + lane;
-                out_row[k] = (slot < n_rows) ? (job.sell_perm ? job.sell_perm[slot] : slot) : n_rows;
-            }
             for (int blk = 0; blk < n_blocks; ++blk) {
                 const int begin = blk * block_cols;
                 asm volatile("" : "+v"(lane));
                 const int cur_i = p ^ (blk & 1);
                 float4 *const cur = cur_i ? buf1 : buf0, *const oth = cur_i ? buf0 : buf1;
                 last = cur_i;
-                // this wave's pieces of block blk and its head chunks have landed (for a primed block 0 that was waited
-                // for before the previous item's stores), then: everyone's pieces have, and everyone is done reading `oth`
-                if (blk > 0 || !primed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                rl_barrier_lds();
-                RL_STAMP(1 + (blk < 4 ? blk : 3) * 2);  // block's data complete for all waves
+                if (blk > 0) {  // this wave's pieces of block blk and its head chunks have landed; then everyone's have,
+                                // and everyone is done reading `oth`
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    rl_barrier_lds();
+                    RL_STAMP(1 + (blk < 4 ? blk : 3) * 2);
+                }
                 int c[RPT][U];
                 float w[RPT][U];
 #pragma unroll
@@ -763,13 +766,12 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
                         c[k][u] = head[k][u];
                         w[k][u] = headw[k][u];
                     }
-                // requests for the block after this one: head chunks FIRST, then the DMA (see head[][])
-                if (blk + 1 < n_blocks) {
-                    load_heads(blk + 1);
-                    stage(job, f0, blk + 1, oth, lane);
-                } else if (next_live) {  // last block: the other buffer is free for the NEXT item's block 0
+                // requests for the block after this one: head chunks FIRST, then the DMA (see head[][]), piece by piece
+                // between the entries of the first slice (stage_piece).  Last block: the NEXT item's block 0.
+                const bool stage_own = blk + 1 < n_blocks, stage_next = !stage_own && next_live;
+                if (stage_own) load_heads(blk + 1);
+                else if (stage_next) {
                     load_next_heads();
-                    stage(nxt, next_f0, 0, oth, lane);
                     next_staged = true;
                 }
                 // ---- sweep
@@ -786,8 +788,19 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
+                        if (k == 0 && u < STAGE_PIECES) {  // blocks hold <= 1016 rows of 64 B: <= 4 pieces per wave
+                            if (stage_own) stage_piece(job, f0, blk + 1, oth, lane, u);
+                            else if (stage_next) stage_piece(nxt, next_f0, 0, oth, lane, u);
+                        }
                         if (c[k][u] != SELL_SENTINEL) rl_accumulate<QUADS, HAS_VAL>(acc[k], cur, c[k][u] - begin, w[k][u], lane);
                         __builtin_amdgcn_sched_barrier(0);  // one entry's LDS reads in flight per wave (16 waves fill the pipe)
+                    }
+                    if (k == 0) {  // chunks shorter than the piece count
+#pragma unroll
+                        for (int u = U; u < STAGE_PIECES; ++u) {
+                            if (stage_own) stage_piece(job, f0, blk + 1, oth, lane, u);
+                            else if (stage_next) stage_piece(nxt, next_f0, 0, oth, lane, u);
+                        }
                     }
                     for (int e0 = U; e0 < width; e0 += U) {
                         const int left = width - (e0 + U);  // wave-uniform
@@ -831,20 +844,16 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
                 out_scale[k] = (job.row_scale && out_row[k] < n_rows) ? job.row_scale[out_row[k]] : 1.f;
         }
         RL_STAMP(9);
-        if (threadIdx.x == 0) next_item[round & 1] = static_cast<int>(first_claim + claimed);
-        rl_barrier_lds();  // every wave has finished the last sweep: its buffer is free for the transposes
-        const int t_after = __builtin_amdgcn_readfirstlane(next_item[round & 1]);
-        RL_STAMP(10);
 
+        // ---- epilogue, wave by wave (no barrier: the transposes go through the wave's own tile, so a wave that is done
+        //      sweeping stores while the others still sweep): scale, transpose, whole-line stores
         asm volatile("" : "+v"(lane));
         bool settled = !next_live;  // the next item's head has been waited for
         if (live) {
-            // ---- epilogue: scale, transpose through LDS (ROWS_PASS rows per wave at a time), whole-line stores
-            float4 *tr = (last ? buf1 : buf0) + wave * 256;
             const bool y_ok = !(job.reserved & 1);  // reserved bit 0: timing ablation (no stores)
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                if (rl_slice(wave, k) >= n_slices) continue;  // wave-uniform
+                if (rl_slice<RPT>(wave, k) >= n_slices) continue;  // wave-uniform
                 const int row = out_row[k];
                 const float rs = out_scale[k];
 #pragma unroll
@@ -858,7 +867,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (k == 0 && ps == 0 && !settled) {
+                    if (!settled) {
                         // the next item's head (block 0, head chunks) must have landed before anything is queued behind
                         // it: a wait placed after the stores would cover them too
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -899,8 +908,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
         p = next_p;
         primed = next_live;
         t = t_next;
-        t_next = t_after;
-        ++round;
+        claim_reply = claim_next;
     }
     if (threadIdx.x == 0) {  // the last workgroup to leave re-arms the queue slot for a later launch
         __threadfence();
@@ -917,7 +925,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
 // 512-row blocks; every extra block adds padding - a slice runs as long as its longest row IN THAT BLOCK - and the sweep is
 // LDS-bound: N = 2000, degree 10: 4 blocks pad 2.5x, 2 blocks ~1.2x with the by-block row sort.)  The single-buffer kernel
 // stages one 1024-row block of 128-B rows at a time.  Blocks are balanced: N = 2000 -> 2 x 1000.
-int sell_block_cap(int /*n_rows*/) { return 1024; }
+int sell_block_cap(int /*n_rows*/) { return 1016; }  // 2 x 1016 x 64 B + 16 x 2 KiB transpose tiles + static LDS <= 160 KiB
 int sell_block_cols_for(int n_rows, int n_cols) {
     const int cap = sell_block_cap(n_rows);
     const int blocks = static_cast<int>(ceil_div(n_cols > 0 ? n_cols : 1, cap));
@@ -940,9 +948,9 @@ int launch_rowlane_pipe(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n
     const int n_groups = static_cast<int>(ceil_div(max_feat, QUADS * 4));
     const int64_t n_items = static_cast<int64_t>(n_jobs) * n_groups;
     if (n_items >= (1ll << 31) - 4096) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: too many work items");
-    // two block buffers; a buffer also serves the 16 waves' 4-KiB transpose tiles (64 KiB)
-    const int buf_slots = std::max(std::min(sell_block_cap(max_rows), max_cols) * QUADS, RL_WAVES * 256);
-    const size_t lds = static_cast<size_t>(buf_slots) * 2 * 16;
+    // two block buffers + a 2-KiB transpose tile per wave
+    const int buf_slots = std::min(sell_block_cap(max_rows), max_cols) * QUADS;
+    const size_t lds = (static_cast<size_t>(buf_slots) * 2 + RL_WAVES * 128) * 16;
     auto kv = spmm_rowlane_pipe_kernel<QUADS, RPT, true>;
     auto kn = spmm_rowlane_pipe_kernel<QUADS, RPT, false>;
     static thread_local bool configured = false;
@@ -984,14 +992,19 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
     return check_launch("spmm_rowlane_kernel");
 }
 
+bool pipelined_enabled(int max_rows) {
+    const char *e = getenv("WDG_SPMM_PIPELINED");
+    return e && atoi(e) && ceil_div(max_rows, RL_THREADS) <= 4;
+}
+
 template <typename TIN>
 int rowlane_dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
                      int max_feat, bool has_val, bool dma_ok, hipStream_t st) {
     const int rpt = static_cast<int>(ceil_div(max_rows, RL_THREADS));
     const bool wide = (rpt <= 2) && max_feat > 16;  // 32-feature items need 8 float4 accumulators per row
-    if (const char *e = getenv("WDG_SPMM_NO_PIPE"))
-        if (atoi(e)) dma_ok = false;
-    if (dma_ok && sizeof(TIN) == 4) {
+    // The pipelined variant is opt-in (WDG_SPMM_PIPELINED=1): on the sweep workload it measures 288 us against the 259 us
+    // of the single-buffer kernel - its per-item costs are paid twice as often (16-feature items).
+    if (dma_ok && sizeof(TIN) == 4 && pipelined_enabled(max_rows)) {
 #define WDG_RL_PIPE_CASE(R) \
     if (rpt == R) return launch_rowlane_pipe<4, R>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
         WDG_RL_PIPE_CASE(1) WDG_RL_PIPE_CASE(2) WDG_RL_PIPE_CASE(3) WDG_RL_PIPE_CASE(4)  // more rows per thread: no room
@@ -1008,6 +1021,8 @@ int rowlane_dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jo
 }  // namespace
 
 namespace wdg {
+
+bool rowlane_pipelined(int max_rows, int flags) { return (flags & WDG_SPMM_DMA_OK) && pipelined_enabled(max_rows); }
 
 bool rowlane_eligible(int max_rows, int max_cols, int max_feat) {
     if (const char *s = getenv("WDG_SPMM_NO_ROWLANE"))

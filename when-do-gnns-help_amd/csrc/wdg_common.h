@@ -44,6 +44,15 @@ template <typename T>
 __device__ __forceinline__ global_ptr<T> to_global(T *p) {
     return (global_ptr<T>)p;
 }
+// A job descriptor of a table (wave-uniform index) or the by-value descriptor of a single-problem launch, read through the
+// constant address space: both are read-only and at uniform addresses, so the fields arrive by scalar loads (a generic
+// pointer that may be either is read with flat VECTOR loads).  The pointers inside still have to go through to_global().
+template <typename J>
+using desc_ptr = const J __attribute__((address_space(4))) *;
+template <typename J>
+__device__ __forceinline__ desc_ptr<J> descriptor(const J *jobs, const J &inline_job, int id) {
+    return jobs ? (desc_ptr<J>)(jobs + id) : (desc_ptr<J>)(&inline_job);
+}
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_f32x4(global_ptr<const float> p) {
     const f32x4_t v = *(global_ptr<const f32x4_t>)p;
