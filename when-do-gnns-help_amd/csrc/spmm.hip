@@ -396,7 +396,11 @@ Plan make_plan(int max_rows, int max_cols, int n_feat, int n_jobs) {
     const int64_t budget_one = kLdsBytes - 512 - rp_bytes;   // one workgroup per CU
     const int64_t rows = static_cast<int64_t>(max_cols) + 1;
     const int forced = env_int("WDG_SPMM_SLAB", 0);
-    if (rows * 16 <= budget_one && env_int("WDG_SPMM_FORCE_GATHER", 0) == 0) {
+    // tiny feature counts (label propagation, logits: F = C) are not worth an LDS slab: the slab family would launch
+    // n_jobs x 1-2 workgroups that each walk a whole graph (100-graph sweep batch, F = 5: 53 us), the gather family
+    // one lane group per row across the chip with X (8 KB .. 40 KB per graph) served by L2 (14 us)
+    const bool tiny_feat = n_feat <= 8 && env_int("WDG_SPMM_SLAB", 0) == 0;
+    if (rows * 16 <= budget_one && !tiny_feat && env_int("WDG_SPMM_FORCE_GATHER", 0) == 0) {
         p.family = 0;
         int slab = 4;
         const int cus = 256;
@@ -423,7 +427,7 @@ Plan make_plan(int max_rows, int max_cols, int n_feat, int n_jobs) {
     else if (n_feat >= 64) { p.slab = 16; p.threads = 4; }
     else if (n_feat >= 32) { p.slab = 32; p.threads = 1; }
     else if (n_feat >= 16) { p.slab = 16; p.threads = 1; }
-    else if (n_feat >= 8) { p.slab = 8; p.threads = 1; }
+    else if (n_feat > 4) { p.slab = 8; p.threads = 1; }
     else { p.slab = 4; p.threads = 1; }
     return p;
 }
