@@ -322,7 +322,8 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     const int block_cols = job.sell_block_cols, n_blocks = job.sell_n_blocks;
     const global_ptr<const TIN> X = (global_ptr<const TIN>)job.X;
     const bool full = (f0 + FG <= F);
-    const bool x_vec = full && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    // 16-byte accesses to X / Y: whole float4 chunks inside the row (a ragged last group works chunk by chunk when F % 4 == 0)
+    const bool x_vec = (full || F % 4 == 0) && sizeof(TIN) == 4 && (job.ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
     const int n_slices = (n_rows + 63) >> 6;
     const bool dma = x_vec && !job.col_scale && !(job.reserved & 8);  // reserved bit 3: diagnostic, forces register staging
 
@@ -334,6 +335,27 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
 
     int out_row[RPT];
     float out_scale[RPT];
+    // X[begin:end, f0:f0+FG] -> LDS by LDS-DMA (global_load_lds_dwordx4: a wave-instruction fills 1 KiB = 8 staged rows, no data
+    // registers, every load of the block in flight at once); chunks beyond a ragged F stay unwritten (their sums are
+    // never stored)
+    auto issue_dma = [&](int blk) {
+        if constexpr (sizeof(TIN) == 4) {
+            const int begin = blk * block_cols, end = min(begin + block_cols, n_cols);
+            const int n_stage = (job.reserved & 2) ? 0 : (end - begin) * QUADS;
+            for (int i0 = wave * 64; i0 < n_stage; i0 += RL_THREADS) {  // wave-uniform LDS destination xs[i0 + lane]
+                const int i = i0 + lane;
+                [[maybe_unused]] const int r = begin + i / QUADS;
+                const int qd = i % QUADS;
+                if (i < n_stage && f0 + qd * 4 < F) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
+                    __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(r) * job.ldx + f0 + qd * 4,
+                                                     (__attribute__((address_space(3))) void *)(xs + i0), 16, 0, 0);
+#endif
+                }
+            }
+        }
+    };
+    if (dma) issue_dma(0);  // first thing of the item: only the descriptor's latency precedes it
     for (int blk = 0; blk < n_blocks; ++blk) {
         const int begin = blk * block_cols, end = min(begin + block_cols, n_cols);
         const int n_stage = (job.reserved & 2) ? 0 : (end - begin) * QUADS;  // float4 slots to fill (reserved bit 1: timing ablation)
@@ -368,22 +390,10 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
         }
         RL_STAMP(1 + blk * 4);  // extents, first chunk (and epilogue operands) landed
         if (blk > 0) rl_barrier_lds();              // previous block's readers are done
-        // ---- stage X[begin:end, f0:f0+FG] -> LDS in whole 128-B row segments.  fp32, aligned, unscaled rows go by
-        //      LDS-DMA (global_load_lds_dwordx4: a wave-instruction fills 1 KiB = 8 staged rows, no data registers, every
-        //      load of the block in flight at once); the rest through registers, NL loads in flight per thread
+        // ---- stage X[begin:end, f0:f0+FG] -> LDS in whole 128-B row segments: fp32, aligned, unscaled rows by LDS-DMA
+        //      (block 0's was issued at the top of the item), the rest through registers, NL loads in flight per thread
         if (dma) {
-            if constexpr (sizeof(TIN) == 4) {
-                for (int i0 = wave * 64; i0 < n_stage; i0 += RL_THREADS) {  // wave-uniform LDS destination xs[i0 + lane]
-                    const int i = i0 + lane;
-                    if (i < n_stage) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
-                        const int r = begin + i / QUADS, qd = i % QUADS;
-                        __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(r) * job.ldx + f0 + qd * 4,
-                                                         (__attribute__((address_space(3))) void *)(xs + i0), 16, 0, 0);
-#endif
-                    }
-                }
-            }
+            if (blk > 0) issue_dma(blk);
         } else
         for (int i0 = 0; i0 < n_stage; i0 += RL_THREADS * NL) {
             float4 v[NL];
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
                     const int r = begin + i / QUADS, qd = i % QUADS;
                     const global_ptr<const TIN> src = X + static_cast<int64_t>(r) * job.ldx + f0 + qd * 4;
                     if (x_vec) {
-                        v[j] = load_f32x4((global_ptr<const float>)src);
+                        if (f0 + qd * 4 < F) v[j] = load_f32x4((global_ptr<const float>)src);
                     } else {
                         const int f = f0 + qd * 4;
                         if (f + 0 < F) v[j].x = rl_f32(src[0]);
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     rl_barrier_lds();  // every wave has finished sweeping: the staged block may be overwritten by the transpose tiles
     RL_STAMP(13);
     float4 *tr = xs + wave * 64 * QUADS;
-    const bool y_vec = full && (job.ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
+    const bool y_vec = (full || F % 4 == 0) && (job.ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
     constexpr int ROWS_PER_IT = 64 / QUADS;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
             if (grow < n_rows && !((job.reserved & 1) && a.x != 12345.678f)) {  // reserved bit 0: timing ablation
                 const global_ptr<float> dst = job.Y + static_cast<int64_t>(grow) * job.ldy + f0 + qd * 4;
                 if (y_vec) {
-                    store_f32x4(dst, a);
+                    if (f0 + qd * 4 < F) store_f32x4(dst, a);
                 } else {
                     const int f = f0 + qd * 4;
                     if (f + 0 < F) dst[0] = a.x;
