@@ -112,7 +112,8 @@ def main():
         fam, slab, threads = batch.spmm.plan()
         kernel_name = {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
                        2: f"spmm_rowlane_kernel<{slab // 4},{(args.nodes + 1023) // 1024},float,false>",
-                       3: f"spmm_rowlane_pipe_kernel<{slab // 4},{(args.nodes + 1023) // 1024},false>"}[fam]
+                       3: f"spmm_rowlane_pipe_kernel<{slab // 4},{(args.nodes + 1023) // 1024},false>",
+                       4: f"spmm_rowlane_shared_kernel<{(args.nodes + 1023) // 1024},false>"}[fam]
         out = {
             "metric": "aggregation edges/sec (whole job; + %HBM roofline of the SpMM kernel)",
             "value": total_edges * args.steps / elapsed,

@@ -142,10 +142,15 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
 #define WDG_SPMM_DMA_OK 4   /* every job: X and Y 16-byte aligned, ldx, ldy and n_feat multiples of 4, col_scale NULL:
                                X rows may be staged by LDS-DMA; with WDG_SPMM_PIPELINED=1 in the environment such
                                batches run the pipelined row-lane kernel (family 3), an opt-in schedule */
+#define WDG_SPMM_SHARED_X(r) (((r) & 0xff) << 8) /* every aligned group of r (2..255) consecutive jobs of the table has the
+                               same X, ldx, n_cols and n_feat (the h-levels of one seed): with WDG_SPMM_ALL_SELL |
+                               WDG_SPMM_DMA_OK, <= 2032 columns and <= 2048 rows the shared-X row-lane kernel (family 4)
+                               stages each 16-feature slab of X once per group instead of once per job */
 int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
                          int32_t max_feat, int flags, wdg_stream_t stream);
 /* Which kernel family a batch of n_jobs such shapes dispatches to (0 = LDS column-slab, 1 = row gather,
- * 2 = row-lane when `flags` has WDG_SPMM_ALL_SELL, 3 = pipelined row-lane when it also has WDG_SPMM_DMA_OK);
+ * 2 = row-lane when `flags` has WDG_SPMM_ALL_SELL, 3 = pipelined row-lane when it also has WDG_SPMM_DMA_OK and
+ * WDG_SPMM_PIPELINED=1 is set, 4 = shared-X row-lane when it also has WDG_SPMM_SHARED_X);
  * for tests/bench. */
 int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int flags, int *slab_out,
                   int *threads_out);

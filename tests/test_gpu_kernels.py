@@ -458,7 +458,9 @@ def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power
         assert ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL | ops.SPMM_DMA_OK)[0] == 3
         y1 = ops.spmm(g, x, row_scale=d, use_values=use_values).clone()
         ys = [torch.empty_like(y0) for _ in range(3)]
+        monkeypatch.setenv("WDG_SPMM_RUN", "0")  # (the three jobs share X: keep them off the shared-X kernel here)
         batch = ops.SpmmBatch([(g, x, y, d, None, use_values) for y in ys])
+        monkeypatch.delenv("WDG_SPMM_RUN")
         assert batch.plan()[0] == 3
         batch.launch()
         torch.cuda.synchronize()

@@ -26,7 +26,8 @@
 namespace wdg {  // row-lane family (spmm_rowlane.hip)
 bool rowlane_eligible(int max_rows, int max_cols, int max_feat);
 bool rowlane_pipelined(int max_rows, int flags);
-int rowlane_dispatch_f32(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, bool, hipStream_t);
+int rowlane_dispatch_f32(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, bool, int, hipStream_t);
+bool rowlane_shared_x(int n_jobs, int max_rows, int max_cols, int max_feat, int flags);
 int rowlane_dispatch_bf16(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
 }  // namespace wdg
 
@@ -472,7 +473,8 @@ int dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int 
     if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, max_feat)) {
         const bool has_val = (flags & WDG_SPMM_ANY_VAL) != 0;
         if (sizeof(TIN) == 4)
-            return rowlane_dispatch_f32(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, (flags & WDG_SPMM_DMA_OK) != 0, st);
+            return rowlane_dispatch_f32(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, (flags & WDG_SPMM_DMA_OK) != 0,
+                                        (flags >> 8) & 0xff, st);
         return rowlane_dispatch_bf16(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
     }
     const Plan p = make_plan(max_rows, max_cols, max_feat, n_jobs);
@@ -545,6 +547,10 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
         const int rpt = (max_rows + 1023) / 1024;
         if (slab_out) *slab_out = ((rpt <= 2) && n_feat > 16 && !rowlane_pipelined(max_rows, flags)) ? 32 : 16;  // features per item
         if (threads_out) *threads_out = 1024;
+        if (rowlane_shared_x(n_jobs, max_rows, max_cols, n_feat, flags)) {
+            if (slab_out) *slab_out = 16;
+            return 4;
+        }
         return rowlane_pipelined(max_rows, flags) ? 3 : 2;
     }
     const Plan p = make_plan(max_rows, max_cols, n_feat, n_jobs > 0 ? n_jobs : 1);

@@ -930,6 +930,256 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the shared-X kernel
+// The sweep aggregates the SAME feature matrix over many graphs (the h-levels of one seed).  With WDG_SPMM_SHARED_X(R) the
+// caller promises that every aligned group of R consecutive jobs has the same X, ldx, n_cols and n_feat; an item is then
+// (run of R graphs, 16-feature group): the workgroup stages X[:, 16 features] ONCE (all <= 2032 rows, 64 B each, LDS-DMA)
+// and every wave walks the run's graphs on its own - no barrier between graphs, because the only shared state, X, is
+// read-only, and the transposes go through the wave's private 2-KiB tile.  X is read once per run instead of once per
+// graph, the per-item latency chain is paid once per R graphs, and a wave's stores drain behind the next graph's sweep
+// (the next graph's extents and first index chunk are requested before the stores: vmcnt retires in order).
+// Same arithmetic and summation order as the other row-lane kernels (blocks ascend, entries ascend): bit-identical.
+constexpr int RL_SHARED_MAX_COLS = 2032;  // 2032 x 64 B + 16 x 2 KiB + static <= 160 KiB
+
+template <int RPT, bool HAS_VAL>
+__global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const wdg_spmm_job *__restrict__ jobs, int n_groups,
+                                                                          int n_runs, int run_len, int queue_slot,
+                                                                          int x_slots) {
+    constexpr int QUADS = 4, FG = 16, U = 8;
+    constexpr int TR_SLOTS = 128, ROWS_PASS = TR_SLOTS / QUADS, PASSES = 64 / ROWS_PASS;
+    constexpr int READS = ROWS_PASS * QUADS / 64, ROWS_PER_READ = 64 / QUADS;
+    extern __shared__ float4 lds[];
+    __shared__ int next_item[2];
+    __shared__ int steal_box[3];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ng = n_groups;
+    const int wgs_per_xcd = gridDim.x / kXcds, xcd = blockIdx.x % kXcds;
+    const int n_queues = n_runs >= 8 ? 8 : n_runs >= 4 ? 4 : n_runs >= 2 ? 2 : 1;
+    const int first_claim = wgs_per_xcd * (kXcds / n_queues);
+    unsigned *queues = rl_queue_next + queue_slot * kXcds;
+    float4 *const xs = lds;
+    float4 *const tr = lds + x_slots + wave * TR_SLOTS;
+
+    int q = xcd % n_queues;
+    int t = (xcd / n_queues) * wgs_per_xcd + blockIdx.x / kXcds;  // item: run (t / ng) * n_queues + q, feature group t % ng
+    for (int round = 0;; ++round) {
+        const int q_items = ((n_runs - q + n_queues - 1) / n_queues) * ng;
+        if (t >= q_items) {
+            const RlSteal st = rl_steal(queues, xcd, n_queues, n_runs, ng, first_claim, steal_box);
+            if (st.queue < 0) break;
+            q = st.queue;
+            t = st.t;  // (the second item rl_steal claims is dropped: every item is a whole run here)
+            --round;
+            continue;
+        }
+        unsigned claimed = 0;
+        if (threadIdx.x == 0) claimed = atomicAdd(&queues[q], 1u);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        int lane = tid & 63;
+        const int run = __builtin_amdgcn_readfirstlane((t / ng) * n_queues + q);
+        const int f0 = __builtin_amdgcn_readfirstlane(t % ng) * FG;
+        const int job0 = run * run_len;
+        const JobView first = load_job(jobs, jobs[0], job0);
+        if (f0 < first.n_feat) {
+            // ---- stage X[:, f0:f0+16] for the whole run
+            {
+                const int n_stage = (first.reserved & 2) ? 0 : first.n_cols * QUADS;
+                const global_ptr<const float> X = (global_ptr<const float>)first.X;
+                for (int i0 = wave * 64; i0 < n_stage; i0 += RL_THREADS) {
+                    const int i = i0 + lane;
+                    [[maybe_unused]] const int r = i / QUADS;
+                    const int qd = i % QUADS;
+                    if (i < n_stage && f0 + qd * 4 < first.n_feat) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                        __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(r) * first.ldx + f0 + qd * 4,
+                                                         (__attribute__((address_space(3))) void *)(xs + i0), 16, 0, 0);
+#endif
+                    }
+                }
+            }
+            // head of the run's first graph: extents (lane b * RPT + k <-> block b, k-th slice of this wave), first chunk
+            auto load_extents = [&](const JobView &j, int &lo, int &hi) {
+                const int n_slices = (j.n_rows + 63) >> 6;
+                lo = hi = 0;
+                if (lane < j.sell_n_blocks * RPT) {
+                    const int slice = rl_slice<RPT>(wave, lane % RPT);
+                    if (slice < n_slices && !(j.reserved & 4)) {
+                        const int task = (lane / RPT) * n_slices + slice;
+                        lo = j.sell_ptr[task];
+                        hi = j.sell_ptr[task + 1];
+                    }
+                }
+            };
+            int ext_lo, ext_hi;
+            load_extents(first, ext_lo, ext_hi);
+            int c[U];
+            float w[U];
+            {
+                const int b0 = __builtin_amdgcn_readlane(ext_lo, 0);
+                const int w0 = (__builtin_amdgcn_readlane(ext_hi, 0) - b0) >> 6;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    c[u] = (u < w0) ? first.sell_col[b0 + lane + u * 64] : SELL_SENTINEL;
+                    w[u] = (HAS_VAL && u < w0) ? first.sell_val[b0 + lane + u * 64] : 0.f;
+                }
+            }
+            // destination rows (the length-sort permutation) and row scales of a graph are requested one graph ahead too
+            int out_row[RPT];
+            float out_scale[RPT];
+            auto load_rows = [&](const JobView &j, int (&rows)[RPT]) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const int slot = rl_slice<RPT>(wave, k) * 64 + lane;
+                    rows[k] = (slot < j.n_rows) ? (j.sell_perm ? j.sell_perm[slot] : slot) : j.n_rows;
+                }
+            };
+            auto load_scales = [&](const JobView &j, const int (&rows)[RPT], float (&scales)[RPT]) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) scales[k] = (j.row_scale && rows[k] < j.n_rows) ? j.row_scale[rows[k]] : 1.f;
+            };
+            load_rows(first, out_row);
+            load_scales(first, out_row, out_scale);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rl_barrier_lds();  // X is in place for every wave; from here to the end of the run the waves run free
+
+            for (int g = 0; g < run_len; ++g) {
+                asm volatile("" : "+v"(lane));
+                const JobView job = load_job(jobs, jobs[0], job0 + g);
+                const int n_rows = job.n_rows, F = job.n_feat, n_blocks = job.sell_n_blocks;
+                const int n_slices = (n_rows + 63) >> 6;
+                // the next graph's extents and destination rows: in flight during this graph's first slice
+                const bool has_next = g + 1 < run_len;
+                const JobView nxt = load_job(jobs, jobs[0], has_next ? job0 + g + 1 : job0 + g);
+                int next_lo = 0, next_hi = 0;
+                int next_row[RPT];
+                float next_scale[RPT];
+                if (has_next) {
+                    load_extents(nxt, next_lo, next_hi);
+                    load_rows(nxt, next_row);
+                }
+
+                float4 acc[RPT][QUADS];
+#pragma unroll
+                for (int k = 0; k < RPT; ++k)
+#pragma unroll
+                    for (int h = 0; h < QUADS; ++h) acc[k][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+                // ---- slice by slice: sweep (blocks inner; c/w hold the slice's first chunk, every step requests the next step's
+                //      indices - next chunk, next block, next slice, and after the last slice the NEXT graph's first chunk),
+                //      then scale, transpose through the private tile and store.  Sweeping and storing alternate at slice
+                //      grain, so the 16 free-running waves of a workgroup do not all sweep (LDS) and then all store (memory).
+                const bool y_ok = !(job.reserved & 1);
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    for (int blk = 0; blk < n_blocks; ++blk) {
+                        const int base = __builtin_amdgcn_readlane(ext_lo, blk * RPT + k);
+                        const int width = (__builtin_amdgcn_readlane(ext_hi, blk * RPT + k) - base) >> 6;
+                        // the step after this (blk, k): next block of the slice, else block 0 of the next slice, else the
+                        // next graph's first slice
+                        const bool more_blk = blk + 1 < n_blocks;
+                        const bool own = more_blk || k + 1 < RPT;
+                        const int nidx = more_blk ? (blk + 1) * RPT + k : (k + 1 < RPT ? k + 1 : 0);
+                        const int nlo = own ? ext_lo : next_lo, nhi = own ? ext_hi : next_hi;
+                        const bool nvalid = own || has_next;
+                        const int nbase = nvalid ? __builtin_amdgcn_readlane(nlo, nidx) : 0;
+                        const int nwidth = nvalid ? (__builtin_amdgcn_readlane(nhi, nidx) - nbase) >> 6 : 0;
+                        const global_ptr<const int32_t> ncol = own ? job.sell_col : nxt.sell_col;
+                        const global_ptr<const float> nval = own ? job.sell_val : nxt.sell_val;
+                        if (width == 0) {  // nothing runs that could prefetch the next step
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                c[u] = (u < nwidth) ? ncol[nbase + lane + u * 64] : SELL_SENTINEL;
+                                w[u] = (HAS_VAL && u < nwidth) ? nval[nbase + lane + u * 64] : 0.f;
+                            }
+                            continue;
+                        }
+                        for (int e0 = 0; e0 < width; e0 += U) {
+                            const bool more = e0 + U < width;
+                            const global_ptr<const int32_t> pcol = more ? job.sell_col : ncol;
+                            const global_ptr<const float> pval = more ? job.sell_val : nval;
+                            const int pf = (more ? base + (e0 + U) * 64 : nbase) + lane;
+                            const int left = more ? width - (e0 + U) : nwidth;
+                            int cn[U];
+                            float wn[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                cn[u] = (u < left) ? pcol[pf + u * 64] : SELL_SENTINEL;
+                                wn[u] = (HAS_VAL && u < left) ? pval[pf + u * 64] : 0.f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; ++u)
+                                if (c[u] != SELL_SENTINEL) rl_accumulate<QUADS, HAS_VAL>(acc[k], xs, c[u], w[u], lane);
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                c[u] = cn[u];
+                                w[u] = wn[u];
+                            }
+                        }
+                    }
+                    if (k == 0 && has_next) load_scales(nxt, next_row, next_scale);  // (its rows arrived during the slice)
+                    // ---- this slice's rows
+                    if (rl_slice<RPT>(wave, k) >= n_slices) continue;
+                    if (k == RPT - 1 && has_next) {
+                        // the next graph's first chunk was requested in the last step above: wait for it BEFORE the stores
+                        // (vmcnt retires in order - a wait placed after them would cover their acknowledgements too)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            asm volatile("" : "+v"(c[u]));
+                            if (HAS_VAL) asm volatile("" : "+v"(w[u]));
+                        }
+                    }
+                    const int row = out_row[k];
+                    const float rs = out_scale[k];
+#pragma unroll
+                    for (int ps = 0; ps < PASSES; ++ps) {
+                        if (lane / ROWS_PASS == ps) {
+#pragma unroll
+                            for (int h = 0; h < QUADS; ++h) {
+                                float4 a = acc[k][h];
+                                a.x *= rs; a.y *= rs; a.z *= rs; a.w *= rs;
+                                tr[(lane % ROWS_PASS) * QUADS + ((h + lane) & (QUADS - 1))] = a;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int it = 0; it < READS; ++it) {
+                            const float4 a = tr[it * 64 + lane];
+                            const int grow = __shfl(row, ps * ROWS_PASS + it * ROWS_PER_READ + lane / QUADS);
+                            const int qd = lane % QUADS;
+                            if (grow < n_rows && f0 + qd * 4 < F && y_ok)
+                                store_f32x4(job.Y + static_cast<int64_t>(grow) * job.ldy + f0 + qd * 4, a);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                if (has_next) {
+                    ext_lo = next_lo;
+                    ext_hi = next_hi;
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        out_row[k] = next_row[k];
+                        out_scale[k] = next_scale[k];
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0) next_item[round & 1] = static_cast<int>(first_claim + claimed);
+        rl_barrier_lds();  // every wave is done with this run's X; next_item[] is visible
+        t = __builtin_amdgcn_readfirstlane(next_item[round & 1]);
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&rl_queue_done[queue_slot], 1u) == gridDim.x - 1) {
+            for (int x = 0; x < kXcds; ++x) rl_queue_next[queue_slot * kXcds + x] = 0;
+            rl_queue_done[queue_slot] = 0;
+            __threadfence();
+        }
+    }
+}
+
 // Column-block size of a graph's SELL copy: two blocks must fit the LDS side by side (the pipelined kernel sweeps one while
 // the next lands): it runs 16-feature items, 64-B staged rows, 1024 rows = 64 KiB per block.  (32-feature items would need
 // 512-row blocks; every extra block adds padding - a slice runs as long as its longest row IN THAT BLOCK - and the sweep is
@@ -977,6 +1227,31 @@ int launch_rowlane_pipe(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n
     return check_launch("spmm_rowlane_pipe_kernel");
 }
 
+template <int RPT>
+int launch_rowlane_shared(const wdg_spmm_job *jobs, int n_jobs, int run_len, int max_cols, int max_feat, bool has_val,
+                          hipStream_t st) {
+    const int n_groups = static_cast<int>(ceil_div(max_feat, 16));
+    const int n_runs = n_jobs / run_len;
+    const int64_t n_items = static_cast<int64_t>(n_runs) * n_groups;
+    if (n_items >= (1ll << 31) - 4096) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: too many work items");
+    const int x_slots = max_cols * 4;  // all source rows, 64 B each
+    const size_t lds = (static_cast<size_t>(x_slots) + RL_WAVES * 128) * 16;
+    auto kv = spmm_rowlane_shared_kernel<RPT, true>;
+    auto kn = spmm_rowlane_shared_kernel<RPT, false>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        for (const void *k : {reinterpret_cast<const void *>(kv), reinterpret_cast<const void *>(kn)})
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes) - 1024) != hipSuccess)
+                return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+        configured = true;
+    }
+    const dim3 grid(static_cast<unsigned>(resident_grid(n_items)));
+    const int slot = static_cast<int>(next_queue_slot());
+    if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot, x_slots);
+    else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot, x_slots);
+    return check_launch("spmm_rowlane_shared_kernel");
+}
+
 template <int QUADS, int RPT, typename TIN>
 int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols, int max_feat,
                    bool has_val, hipStream_t st) {
@@ -1007,10 +1282,23 @@ bool pipelined_enabled(int max_rows) {
     return e && atoi(e) && ceil_div(max_rows, RL_THREADS) <= 4;
 }
 
+// Jobs that share X in aligned runs (WDG_SPMM_SHARED_X) and fit the shared-X kernel: LDS-DMA-able, all source rows of a
+// 16-feature slab resident (<= 2032 columns), at most two slices per wave
+bool shared_x_eligible(const wdg_spmm_job *jobs, int n_jobs, int max_rows, int max_cols, int max_feat, bool dma_ok, int run_len) {
+    if (const char *e = getenv("WDG_SPMM_NO_SHARED_X"))
+        if (atoi(e)) return false;
+    return jobs && dma_ok && run_len >= 2 && n_jobs % run_len == 0 && max_cols <= RL_SHARED_MAX_COLS &&
+           max_rows <= 2 * RL_THREADS && max_feat >= 16;
+}
+
 template <typename TIN>
 int rowlane_dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
-                     int max_feat, bool has_val, bool dma_ok, hipStream_t st) {
+                     int max_feat, bool has_val, bool dma_ok, int run_len, hipStream_t st) {
     const int rpt = static_cast<int>(ceil_div(max_rows, RL_THREADS));
+    if (sizeof(TIN) == 4 && shared_x_eligible(jobs, n_jobs, max_rows, max_cols, max_feat, dma_ok, run_len)) {
+        if (rpt == 1) return launch_rowlane_shared<1>(jobs, n_jobs, run_len, max_cols, max_feat, has_val, st);
+        return launch_rowlane_shared<2>(jobs, n_jobs, run_len, max_cols, max_feat, has_val, st);
+    }
     const bool wide = (rpt <= 2) && max_feat > 16;  // 32-feature items need 8 float4 accumulators per row
     // The pipelined variant is opt-in (WDG_SPMM_PIPELINED=1): on the sweep workload it measures 288 us against the 259 us
     // of the single-buffer kernel - its per-item costs are paid twice as often (16-feature items).
@@ -1042,11 +1330,15 @@ bool rowlane_eligible(int max_rows, int max_cols, int max_feat) {
 
 int rowlane_dispatch_bf16(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
                           int max_feat, bool has_val, hipStream_t st) {
-    return rowlane_dispatch<bf16r_t>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, false, st);
+    return rowlane_dispatch<bf16r_t>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, false, 0, st);
 }
 int rowlane_dispatch_f32(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols,
-                         int max_feat, bool has_val, bool dma_ok, hipStream_t st) {
-    return rowlane_dispatch<float>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, dma_ok, st);
+                         int max_feat, bool has_val, bool dma_ok, int run_len, hipStream_t st) {
+    return rowlane_dispatch<float>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, dma_ok, run_len, st);
+}
+bool rowlane_shared_x(int n_jobs, int max_rows, int max_cols, int max_feat, int flags) {
+    static const wdg_spmm_job dummy{};
+    return shared_x_eligible(&dummy, n_jobs, max_rows, max_cols, max_feat, (flags & WDG_SPMM_DMA_OK) != 0, (flags >> 8) & 0xff);
 }
 
 }  // namespace wdg

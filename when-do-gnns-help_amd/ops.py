@@ -226,6 +226,47 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     return job
 
 
+def _sharing_groups(entries):
+    groups = {}
+    for i, (g, x, *_rest) in enumerate(entries):
+        groups.setdefault((x.data_ptr(), x.stride(0), g.n_cols, x.shape[1]), []).append(i)
+    return list(groups.values())
+
+
+def _shared_x_run(entries):
+    """Run length for WDG_SPMM_SHARED_X: divides every sharing group, 2..8, as long as possible while the launch keeps
+    >= 2 items per CU (items = runs x 16-feature groups; measured on the 100-graph sweep batch: runs of 5 = 640 items
+    220 us, runs of 2 = 1600 items 243 us, no sharing 250 us); 0 = no sharing."""
+    forced = os.environ.get("WDG_SPMM_RUN")
+    groups = _sharing_groups(entries)
+    if not entries or min(len(g) for g in groups) < 2:
+        return 0
+    feat_groups = max((e[1].shape[1] + 15) // 16 for e in entries)
+    best = 0
+    for r in range(2, 9):
+        if any(len(g) % r for g in groups):
+            continue
+        if forced is not None and int(forced) == r:
+            return r
+        if best == 0 or (len(entries) // r) * feat_groups >= 2 * 256:
+            best = r
+    return 0 if forced is not None and int(forced) < 2 else best
+
+
+def _shared_x_order(entries, run):
+    runs = []
+    for grp in _sharing_groups(entries):
+        grp = sorted(grp, key=lambda i: -entries[i][0].nnz)
+        n_runs = len(grp) // run
+        cut = [[] for _ in range(n_runs)]
+        for pos, i in enumerate(grp):  # boustrophedon deal: balanced entry counts per run
+            rnd, k = divmod(pos, n_runs)
+            cut[k if rnd % 2 == 0 else n_runs - 1 - k].append(i)
+        runs.extend(cut)
+    runs.sort(key=lambda r: -sum(entries[i][0].nnz for i in r))
+    return [i for r in runs for i in r]
+
+
 def _dma_ok(job):
     """WDG_SPMM_DMA_OK contract of include/wdg.h for one job descriptor."""
     return (not job.col_scale and (job.X or 0) % 16 == 0 and (job.Y or 0) % 16 == 0 and job.ldx % 4 == 0
@@ -266,6 +307,12 @@ class SpmmBatch:
         order = sorted(range(len(entries)), key=lambda i: -entries[i][0].nnz)
         if os.environ.get("WDG_SPMM_ORDER") == "0":
             order = list(range(len(entries)))
+        # graphs aggregating the SAME feature matrix (the h-levels of a seed) are laid out in aligned runs of `run` jobs, so
+        # that the shared-X kernel stages each slab of X once per run (WDG_SPMM_SHARED_X): every sharing group is cut
+        # into runs of equal length with balanced entry counts, the runs go largest first
+        self.run = _shared_x_run(entries)
+        if self.run >= 2:
+            order = _shared_x_order(entries, self.run)
         for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
             if x.dtype != torch.float32 or x.stride(1) != 1:
                 raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
@@ -282,6 +329,8 @@ class SpmmBatch:
         self.table = host.to(dev)
         self.edges = sum(e[0].nnz for e in entries)
         self.flags = (SPMM_ALL_SELL if all_sell else 0) | (SPMM_ANY_VAL if any_val else 0) | (SPMM_DMA_OK if dma_ok else 0)
+        if self.run >= 2 and all_sell and dma_ok:
+            self.flags |= (self.run & 0xff) << 8  # WDG_SPMM_SHARED_X(run)
 
     def launch(self):
         check(lib.wdg_spmm_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, self.max_cols, self.max_feat,
