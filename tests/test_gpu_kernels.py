@@ -472,6 +472,38 @@ def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power
     np.testing.assert_allclose(_np(y1), want, rtol=1e-5, atol=1e-6 * max(np.abs(want).max(), 1e-30))
 
 
+@pytest.mark.parametrize("n,f,groups,use_values", [(2000, 500, (10,), False), (700, 36, (4, 6), True), (2032, 64, (3, 3, 3), False),
+                                                     (1500, 100, (2, 8), True), (64, 16, (2,), False)])
+def test_spmm_shared_x_kernel_bitwise(ops, monkeypatch, n, f, groups, use_values):
+    """Graphs that aggregate the same X run in aligned runs on the shared-X kernel (family 4): every Y must be
+    bit-identical to the single-graph call, whatever the run length, for ragged feature groups and explicit values."""
+    rng = np.random.default_rng(n * 3 + f)
+    entries, want = [], []
+    for gi, size in enumerate(groups):
+        x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
+        for j in range(size):
+            e = int(n * (2 + 3 * j))
+            src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+            g = ops.CsrGraph.from_coo(src, dst, n, rng.random(e, dtype=np.float32), ops.COO_ADD_SELF_LOOPS)
+            d = ops.degree_norm(g, ops.NORM_RW)["dinv"]
+            want.append(ops.spmm(g, x, row_scale=d, use_values=use_values).clone())
+            entries.append((g, x, torch.zeros_like(want[-1]), d, None, use_values))
+    batch = ops.SpmmBatch(entries)
+    assert batch.run >= 2 and batch.plan()[0] == 4, (batch.run, batch.plan())
+    batch.launch()
+    torch.cuda.synchronize()
+    for (_, _, y, _, _, _), w in zip(entries, want):
+        assert torch.equal(y, w)
+    monkeypatch.setenv("WDG_SPMM_NO_SHARED_X", "1")  # same table on the per-graph kernels
+    for e in entries:
+        e[2].zero_()
+    assert batch.plan()[0] in (2, 0)
+    batch.launch()
+    torch.cuda.synchronize()
+    for (_, _, y, _, _, _), w in zip(entries, want):
+        assert torch.equal(y, w)
+
+
 # --------------------------------------------------------------------------------------------- edge / label stats
 STAT_KEYS =("totals", "row_nnz", "row_nnz_noself", "row_match_noself", "compat", "classdeg")
 

@@ -68,3 +68,30 @@ def test_batched_gemm_and_las_mixed_shapes(oracle):
     got = lb.counts.cpu().numpy()
     for i, (s, hd) in enumerate(want):
         assert abs(int(got[i, 0]) - s) <= 1 and abs(int(got[i, 1]) - hd) <= 1
+
+
+@pytest.mark.parametrize("variant,env,family", [("default", {"WDG_SPMM_RUN": "0"}, 2), ("shared-X", {}, 4),
+                                                ("pipelined", {"WDG_SPMM_RUN": "0", "WDG_SPMM_PIPELINED": "1"}, 3)])
+def test_full_sweep_batch_every_item_exactly_once(monkeypatch, variant, env, family):
+    """The bench-size batch (100 graphs, 1 600 / 3 200 / 640 queue items over 256 persistent workgroups, with stealing at
+    the end): every (graph, feature group) item must be produced by every launch - outputs are pre-filled with NaN - and
+    repeated launches must be bitwise equal to the per-graph calls (regression: a steal that claimed two items but
+    processed one)."""
+    from wdg_amd import ops, sweep, synth
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sb = sweep.SweepBatch(sweep.make_jobs(synth.H_LEVELS_10, range(10), k=2), n_feat=500, gcn_hidden=0)
+    assert sb.spmm.plan()[0] == family
+    want = {}
+    for i in (0, 9, 37, 55, 89, 99):
+        g, x, _y, d, _cs, _uv = sb.spmm.keep[i]
+        want[i] = ops.spmm(g, x, row_scale=d, use_values=False).clone()
+    for launch in range(6):
+        for y in sb.y:
+            y.fill_(float("nan"))
+        sb.spmm.launch()
+        torch.cuda.synchronize()
+        for i, (_g, _x, y, _d, _cs, _uv) in enumerate(sb.spmm.keep):
+            assert not bool(torch.isnan(y).any()), (variant, launch, i)
+            if i in want:
+                assert torch.equal(y, want[i]), (variant, launch, i)

@@ -218,12 +218,13 @@ __device__ __forceinline__ void rl_barrier_lds() {
 }
 
 // A workgroup whose queue is drained looks at the other queues' counters first (plain loads, one round trip) and claims
-// two consecutive items from the first one that still has work; `found` < 0: every queue is drained.
+// `count` (1 or 2) consecutive items from the first one that still has work; queue < 0: every queue is drained.  Every
+// claimed item must be processed by the caller: a claim is the only thing that hands an item out.
 struct RlSteal {
     int queue, t, t_next;
 };
 __device__ __forceinline__ RlSteal rl_steal(unsigned *queues, int xcd, int n_queues, int n_jobs, int ng, int first_claim,
-                                            int *mailbox /* LDS, 3 ints */) {
+                                            int *mailbox /* LDS, 3 ints */, unsigned count) {
     if (threadIdx.x == 0) {
         unsigned seen[kXcds];
 #pragma unroll
@@ -237,7 +238,7 @@ __device__ __forceinline__ RlSteal rl_steal(unsigned *queues, int xcd, int n_que
         }
         mailbox[0] = found;
         if (found >= 0) {
-            const unsigned a = atomicAdd(&queues[found], 2u);
+            const unsigned a = atomicAdd(&queues[found], count);
             mailbox[1] = static_cast<int>(first_claim + a);
             mailbox[2] = static_cast<int>(first_claim + a + 1);
         }
@@ -299,10 +300,10 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
     for (int round = 0;;) {
     const int q_items = ((n_jobs - q + n_queues - 1) / n_queues) * ng;
     if (t >= q_items) {              // queue q is drained: take over a queue that still has work, or leave
-        const RlSteal st = rl_steal(const_cast<unsigned *>(queues), xcd, n_queues, n_jobs, ng, first_claim, steal_box);
+        const RlSteal st = rl_steal(const_cast<unsigned *>(queues), xcd, n_queues, n_jobs, ng, first_claim, steal_box, 1u);
         if (st.queue < 0) break;
         q = st.queue;
-        t = st.t;  // (st.t_next stays unused here: this kernel claims one item ahead, asynchronously)
+        t = st.t;
         continue;
     }
     unsigned claimed = 0;  // thread 0 keeps the reply in a register until the item is done: nothing waits for it
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
     for (int round = 0;; ++round) {
         const int q_items = ((n_jobs - q + n_queues - 1) / n_queues) * ng;
         if (t >= q_items) {  // queue drained: take over a queue that still has work, or leave
-            const RlSteal st = rl_steal(queues, xcd, n_queues, n_jobs, ng, first_claim, steal_box);
+            const RlSteal st = rl_steal(queues, xcd, n_queues, n_jobs, ng, first_claim, steal_box, 2u);
             if (st.queue < 0) break;
             q = st.queue;
             t = st.t;
@@ -966,10 +967,10 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const w
     for (int round = 0;; ++round) {
         const int q_items = ((n_runs - q + n_queues - 1) / n_queues) * ng;
         if (t >= q_items) {
-            const RlSteal st = rl_steal(queues, xcd, n_queues, n_runs, ng, first_claim, steal_box);
+            const RlSteal st = rl_steal(queues, xcd, n_queues, n_runs, ng, first_claim, steal_box, 1u);
             if (st.queue < 0) break;
             q = st.queue;
-            t = st.t;  // (the second item rl_steal claims is dropped: every item is a whole run here)
+            t = st.t;
             --round;
             continue;
         }
