@@ -19,11 +19,14 @@ using u64 = unsigned long long;
 
 constexpr int THREADS = 256;
 constexpr int MAX_LDS_CLASSES = 64;  // C x C int32 histogram in LDS up to 16 KiB
+constexpr int PASSES = 8;            // row tiles per workgroup
 
 template <int GL>
 __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job *__restrict__ jobs,
                                                              const wdg_stats_job inline_job, int tiles_per_job) {
-    constexpr int ROWS_PER_BLOCK = THREADS / GL;
+    constexpr int ROWS_PER_PASS = THREADS / GL;
+    constexpr int ROWS_PER_BLOCK = ROWS_PER_PASS * PASSES;  // several passes per block: one flush of the LDS counters
+                                                           // (36 global 64-bit atomics at C = 5) per 128 rows, not per 16
     __shared__ int hist[MAX_LDS_CLASSES * MAX_LDS_CLASSES];
     __shared__ long long cdeg[MAX_LDS_CLASSES];
     __shared__ int tot[6];
@@ -44,7 +47,10 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
     if (threadIdx.x < 6) tot[threadIdx.x] = 0;
     __syncthreads();
 
-    const int row = tile * ROWS_PER_BLOCK + threadIdx.x / GL, q = threadIdx.x % GL;
+    const int q = threadIdx.x % GL;
+    for (int pass = 0; pass < PASSES; ++pass) {
+    const int row = tile * ROWS_PER_BLOCK + pass * ROWS_PER_PASS + threadIdx.x / GL;
+    if (row - static_cast<int>(threadIdx.x / GL) >= N) break;  // workgroup-uniform: no row of this pass exists
     int nn = 0, ns = 0, ms = 0, m_all = 0, lab = 0, lab_m = 0;
     int yu = -1;
     if (row < N) {
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
             else atomicAdd((u64 *)(&classdeg[yu]), static_cast<u64>(static_cast<long long>(nn) - 1));
         }
     }
+    }  // passes
     __syncthreads();
     if (threadIdx.x < 6 && tot[threadIdx.x] != 0)
         atomicAdd((u64 *)(&totals[threadIdx.x]), static_cast<u64>(tot[threadIdx.x]));
@@ -107,7 +114,7 @@ int launch(const wdg_stats_job *jobs, const wdg_stats_job &inl, int n_jobs, int 
     if (n_jobs == 0 || max_rows == 0) return WDG_OK;
 #define WDG_STATS_CASE(G)                                                                                     \
     if (gl == G) {                                                                                            \
-        const int tiles = static_cast<int>(ceil_div(max_rows, THREADS / G));                                  \
+        const int tiles = static_cast<int>(ceil_div(max_rows, (THREADS / G) * PASSES));                       \
         const int64_t blocks = static_cast<int64_t>(tiles) * n_jobs;                                          \
         if (blocks > 0x7fffffffLL) return fail(WDG_ERR_UNSUPPORTED, "edge_label_stats: grid too large");      \
         hipLaunchKernelGGL(edge_stats_kernel<G>, dim3(static_cast<unsigned>(blocks)), dim3(THREADS), 0, st, jobs, inl, \

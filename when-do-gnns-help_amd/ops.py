@@ -381,9 +381,11 @@ class StatsBatch:
         dev = require_gpu()
         self.n_jobs, self.c = len(graphs), int(n_classes)
         c = self.c
-        self.totals = torch.zeros((self.n_jobs, 6), dtype=torch.int64, device=dev)
-        self.compat = torch.zeros((self.n_jobs, c, c), dtype=torch.int64, device=dev)
-        self.classdeg = torch.zeros((self.n_jobs, c), dtype=torch.int64, device=dev)
+        # one pool, three views: a launch zeroes the counters with a single memset
+        self.counters = torch.zeros(self.n_jobs * (6 + c * c + c), dtype=torch.int64, device=dev)
+        self.totals = self.counters[:self.n_jobs * 6].view(self.n_jobs, 6)
+        self.compat = self.counters[self.n_jobs * 6:self.n_jobs * (6 + c * c)].view(self.n_jobs, c, c)
+        self.classdeg = self.counters[self.n_jobs * (6 + c * c):].view(self.n_jobs, c)
         self.max_rows = max([g.n_rows for g in graphs], default=0)
         self.rows = torch.zeros((self.n_jobs, 3, max(self.max_rows, 1)), dtype=torch.int32, device=dev)
         self.labels = [_dev(l, torch.int32, dev) for l in labels_list]
@@ -400,9 +402,7 @@ class StatsBatch:
         self.table = host.to(dev)
 
     def launch(self):
-        self.totals.zero_()
-        self.compat.zero_()
-        self.classdeg.zero_()
+        self.counters.zero_()
         check(lib.wdg_edge_label_stats_batched(_ptr(self.table), self.n_jobs, self.max_rows, self.c, stream_handle()),
               "wdg_edge_label_stats_batched")
 
