@@ -238,11 +238,121 @@ __global__ __launch_bounds__(256) void las_weights_small(const wdg_las_job *__re
     }
 }
 
+// ---- narrow-feature problems of moderate size in ONE launch: a 1024-thread workgroup per problem runs the three steps
+// back to back (partials per 128-row tile -> LDS, tile-ordered reduction, per-row decisions) with two barriers in between.
+// Same tiles, same orders, same arithmetic as the three-kernel path: bit-identical results; the counts need no atomics.
+constexpr int FUSED_THREADS = 1024;
+constexpr int FUSED_LDS_DOUBLES = 6144;  // partial[n_tiles][C][F] + M[C][F]: 48 KiB
+
+__global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_job *__restrict__ jobs, const wdg_las_job inline_job) {
+    __shared__ double partial[FUSED_LDS_DOUBLES];
+    __shared__ int cnt_partial[(FUSED_LDS_DOUBLES / SMALL_F) + 64];  // [n_tiles][C]
+    __shared__ long long cls_cnt[SMALL_F];
+    __shared__ int counts[2];
+    const LasView job = las_view(jobs, inline_job, blockIdx.x);
+    const int n = job.n, F = job.F, C = job.C;
+    if (n <= 0 || C <= 0) return;
+    const int n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *M = partial + static_cast<size_t>(n_tiles) * C * F;
+    if (threadIdx.x < 2) counts[threadIdx.x] = 0;
+    // step 1 (las_middle_partial_small): partial[t][c][f], cnt_partial[t][c]; wave w takes tiles w, w + 16, ...
+    for (int tile = wave; tile < n_tiles; tile += FUSED_THREADS / 64) {
+        float h[TILE_ROWS / 64][SMALL_F];
+        int lab[TILE_ROWS / 64];
+#pragma unroll
+        for (int s = 0; s < TILE_ROWS / 64; ++s) {
+            const int j = tile * TILE_ROWS + s * 64 + lane;
+            lab[s] = -1;
+            if (j < n) {
+                const int r = job.rows ? job.rows[j] : j;
+                lab[s] = job.labels[r];
+#pragma unroll
+                for (int f = 0; f < SMALL_F; ++f) h[s][f] = (f < F) ? job.H[static_cast<int64_t>(r) * job.ldh + f] : 0.f;
+            }
+        }
+        double *out = partial + static_cast<size_t>(tile) * C * F;
+        for (int c = 0; c < C; ++c) {
+            int cnt = 0;
+#pragma unroll
+            for (int s = 0; s < TILE_ROWS / 64; ++s) cnt += (lab[s] == c);
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0) cnt_partial[tile * C + c] = cnt;
+#pragma unroll
+            for (int f = 0; f < SMALL_F; ++f) {
+                if (f >= F) break;
+                double v = 0.0;
+#pragma unroll
+                for (int s = 0; s < TILE_ROWS / 64; ++s) v += (lab[s] == c) ? static_cast<double>(h[s][f]) : 0.0;  // row order
+                v = wave_sum(v);
+                if (lane == 0) out[static_cast<int64_t>(c) * F + f] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // step 2 (las_middle_reduce): tile order
+    for (int i = threadIdx.x; i < C * F; i += FUSED_THREADS) {
+        double acc = 0.0;
+        for (int t = 0; t < n_tiles; ++t) acc += partial[static_cast<int64_t>(t) * C * F + i];
+        M[i] = acc;
+    }
+    if (threadIdx.x < C) {
+        long long sum = 0;
+        for (int t = 0; t < n_tiles; ++t) sum += cnt_partial[t * C + threadIdx.x];
+        cls_cnt[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    // step 3 (las_weights_small): one row per thread and round
+    for (int i0 = 0; i0 < n; i0 += FUSED_THREADS) {
+        const int i = i0 + threadIdx.x;
+        bool soft = false, hard = false;
+        if (i < n) {
+            const int r = job.rows ? job.rows[i] : i;
+            const global_ptr<const float> hp = job.H + static_cast<int64_t>(r) * job.ldh;
+            float h[SMALL_F];
+#pragma unroll
+            for (int f = 0; f < SMALL_F; ++f) h[f] = (f < F) ? hp[f] : 0.f;
+            const int y = job.labels[r];
+            double own = 0.0, tot = 0.0, best = 0.0;
+            int best_c = -1;
+            for (int c = 0; c < C; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int f = 0; f < SMALL_F; ++f)
+                    if (f < F) acc += static_cast<double>(h[f]) * M[static_cast<int64_t>(c) * F + f];
+                if (job.W_out) job.W_out[static_cast<int64_t>(i) * C + c] = acc;
+                tot += acc;
+                if (c == y) own = acc;
+                if (best_c < 0 || acc > best) {
+                    best = acc;
+                    best_c = c;
+                }
+            }
+            const double ny = (y >= 0 && y < C) ? static_cast<double>(cls_cnt[y]) : 0.0;
+            const double ratio = (own / ny) / ((tot - own) / (static_cast<double>(n) - ny));
+            soft = !(ratio != ratio) && ratio >= 1.0;
+            hard = best_c == y;
+        }
+        const unsigned long long ms = __ballot(soft), mh = __ballot(hard);
+        if (lane == 0) {
+            if (ms) atomicAdd(&counts[0], __popcll(ms));
+            if (mh) atomicAdd(&counts[1], __popcll(mh));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) job.count_out[threadIdx.x] = counts[threadIdx.x];
+}
+
 int launch_las(const wdg_las_job *jobs, const wdg_las_job &inl, int n_jobs, int max_n, int max_F, int max_C, hipStream_t st) {
     const int n_tiles = static_cast<int>(ceil_div(max_n, TILE_ROWS));
     const int fchunks = static_cast<int>(ceil_div(max_F > 0 ? max_F : 1, 64));
     const int cf = max_C * (max_F > 0 ? max_F : 1);
     const bool small = max_F <= SMALL_F;
+    if (small && max_C <= SMALL_F && max_F > 0 &&
+        (static_cast<int64_t>(n_tiles) + 1) * max_C * max_F <= FUSED_LDS_DOUBLES && n_tiles * max_C <= FUSED_LDS_DOUBLES / SMALL_F) {
+        hipLaunchKernelGGL(las_small_fused, dim3(n_jobs), dim3(FUSED_THREADS), 0, st, jobs, inl);
+        return check_launch("las_small_fused");
+    }
     if (small) hipLaunchKernelGGL(las_middle_partial_small, dim3(n_tiles, 1, n_jobs), dim3(64), 0, st, jobs, inl);
     else hipLaunchKernelGGL(las_middle_partial, dim3(n_tiles, fchunks, n_jobs), dim3(64), 0, st, jobs, inl);
     hipLaunchKernelGGL(las_middle_reduce, dim3(ceil_div(cf > max_C ? cf : max_C, 256), 1, n_jobs), dim3(256), 0, st, jobs, inl);
