@@ -1,29 +1,37 @@
-// Row-lane aggregation kernel + column-blocked SELL-64 index layout (the fast path of the homophily sweep,
-// graphs of <= 4096 rows).
+// Row-lane aggregation kernels + the sorted, column-blocked SELL-64 index layout they read (the fast path of the
+// homophily sweep; graphs of <= 6144 rows).
 //
 // replaces: torch.spmm / torch.mm(adj, X) - same call sites as csrc/spmm.hip.
 //
-// Why a second LDS kernel: a CU's memory pipeline keeps a limited number of cache-line requests in flight, so
+// Why LDS kernels of their own: a CU's memory pipeline keeps a limited number of cache-line requests in flight, so
 // what counts is BYTES PER REQUEST and LOADS IN FLIGHT PER WAVE.  The column-slab kernel of spmm.hip moves X and Y
 // in 32..64-byte row pieces (one request each) and walks CSR rows through data-dependent loops the compiler
-// cannot pipeline (72 % of its wave cycles sit in s_waitcnt).  Here every byte moves in whole 128-byte lines and
-// every loop has a static shape:
+// cannot pipeline (72 % of its wave cycles sit in s_waitcnt).  Here every byte moves in whole 64- or 128-byte row
+// pieces and every loop has a static shape:
 //
-//   * a workgroup (1024 threads) owns one (graph, 32-feature group) item and ALL destination rows: thread t owns
-//     rows t, t+1024, ... and keeps their 32 output floats in registers (8 float4 per row);
-//   * X[:, 32 features] does not fit the 160 KiB LDS for N = 2000 (256 KB), so the SOURCE rows are swept in P
-//     balanced column blocks: pass p stages X[p*CB:(p+1)*CB, 32 features] (128 contiguous bytes per row, 8 loads
-//     in flight per thread) and accumulators persist across passes, so X is read exactly once per item;
-//   * the adjacency is stored per column block in SELL-64 (slices of 64 rows, entry-major inside a slice): the
-//     lane <-> row mapping turns every index load into a coalesced 256-B wave access, the entry loop is a plain
-//     counted loop whose next eight index loads are issued before the current eight entries are consumed;
-//   * each lane reads its source row's eight 16-B chunks in a lane-rotated order ((h + lane) % 8): the two lanes
-//     of an LDS service group that share a chunk position collide only when their rows have equal parity
-//     (<= 2-way instead of the 8-way a fixed order gives on 128-B rows);
-//   * finished rows are transposed through the (now dead) LDS so that 8 consecutive lanes write one row's
-//     128 bytes: Y leaves the CU in whole lines as well.
-// Summation order per row = column order of the CSR row (blocks ascend, entries ascend inside a block) ->
-// bitwise reproducible, the order a sequential CPU sweep over the coalesced COO uses.
+//   * a 1024-thread workgroup owns one (graph, feature group) item and ALL destination rows: thread t owns SELL slots
+//     t, t+1024, ... and keeps their output floats in registers (4 or 8 float4 per row);
+//   * the source rows X[:, group] are staged in LDS (LDS-DMA when X is fp32, aligned and unscaled) - in balanced
+//     column blocks when they do not fit (N = 2000 at 128 B/row: 2 x 1000 rows), with accumulators persisting across
+//     blocks, so X is read once per item;
+//   * the adjacency is stored per column block in SELL-64 (slices of 64 slots, entry-major inside a slice), rows
+//     sorted so that a slice holds rows of equal length (sell_sort_rows): the lane <-> slot mapping turns every index
+//     load into a coalesced 256-B wave access, the entry loop is a plain counted loop whose next eight index loads are
+//     issued before the current eight entries are consumed;
+//   * each lane reads its source row's 16-B chunks in a lane-rotated order ((h + lane) % QUADS): lanes of an LDS service
+//     group that share a chunk position collide only when their rows fall into the same bank window;
+//   * finished rows are transposed through LDS so that consecutive lanes write one row's bytes: Y leaves the CU in
+//     whole row pieces as well;
+//   * workgroups are persistent and draw items from per-XCD atomic queues (a graph's feature groups stay on one XCD).
+// Three schedules share these parts (DESIGN.md 4.1 has the measurements that led from one to the next):
+//   spmm_rowlane_kernel         32-feature items, one block buffer; any X (bf16, scaled, ragged): the general kernel
+//   spmm_rowlane_shared_kernel  16-feature items over a RUN of graphs that aggregate the same X: X staged once per run,
+//                               waves free-running across the run's graphs (what the sweep batch uses)
+//   spmm_rowlane_pipe_kernel    16-feature items, two block buffers, next block / next item requested behind the
+//                               sweep (opt-in: measured slower than the general kernel)
+// Summation order per row = column order of the CSR row (blocks ascend, entries ascend inside a block) in all of
+// them -> bitwise reproducible, bit-identical across schedules, the order a sequential CPU sweep over the
+// coalesced COO uses.
 #include <atomic>
 
 #include "wdg_common.h"

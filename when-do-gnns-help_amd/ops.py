@@ -286,7 +286,7 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
     y = out if out is not None else torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=dev)
     row_scale, col_scale = _dev(row_scale, torch.float32, dev), _dev(col_scale, torch.float32, dev)
     if x.shape[1] >= 8:
-        g.ensure_sell()  # one-time SELL-64 copy -> row-lane kernel for graphs of <= 4096 rows
+        g.ensure_sell()  # one-time SELL-64 copy -> row-lane kernels for graphs of <= 6144 rows
     job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values)
     fn = lib.wdg_spmm_csr_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_csr_f32
     check(fn(ctypes.byref(job), stream_handle()), "wdg_spmm_csr")
