@@ -98,6 +98,13 @@ int wdg_normalise_values(const int32_t *rowptr, const int32_t *col, const float 
  */
 int wdg_row_l1_normalise_f32(const float *X, int64_t ldx, float *Y, int64_t ldy, int32_t N, int32_t F, int use_abs,
                              wdg_stream_t stream);
+/*
+ * Bit-packed 0/1 feature rows (the graph container of graph_io.py: bit j of word w = feature 32 w + j) -> dense fp32
+ * [N, F]; normalise != 0 fuses the row-L1 scaling above (each set bit becomes 1 / #set bits of its row, empty rows stay 0).
+ * replaces: th.FloatTensor(features) of the bag-of-words datasets utils/util_funcs.py:339 (+ preprocess_features :39-46).
+ */
+int wdg_unpack_bits_f32(const uint32_t *words, int64_t ldw, int32_t N, int32_t F, int normalise, float *out, int64_t ldo,
+                        wdg_stream_t stream);
 
 /* ------------------------------------------------------------------ aggregation (SpMM) */
 /*

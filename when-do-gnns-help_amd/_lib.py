@@ -54,6 +54,7 @@ SIGNATURES = {
     "wdg_normalise_values": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
     "wdg_row_l1_normalise_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
+    "wdg_unpack_bits_f32": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p, c_int64, c_void_p]),
     "wdg_spmm_csr_f32": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
     "wdg_spmm_csr_bf16": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
     "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),

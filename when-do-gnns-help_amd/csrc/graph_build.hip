@@ -432,6 +432,32 @@ __global__ __launch_bounds__(256) void row_l1_kernel(const float *__restrict__ X
 
 inline unsigned wave_rows_grid(int32_t N) { return static_cast<unsigned>(ceil_div(static_cast<int64_t>(N) * 64, 256)); }
 
+// Bit-packed binary features -> dense fp32 rows (graph_io.py containers): one workgroup per row; bit j of word w is
+// feature 32 w + j.  With `normalise` the row is scaled by 1 / (number of set bits) - preprocess_features' row-L1
+// normalisation of a 0/1 matrix, empty rows stay 0 (its inf -> 0 guard).
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const uint32_t *__restrict__ words, int64_t ldw, int32_t F,
+                                                          int normalise, float *__restrict__ out, int64_t ldo) {
+    __shared__ int wave_cnt[4];
+    const uint32_t *row = words + static_cast<int64_t>(blockIdx.x) * ldw;
+    float *dst = out + static_cast<int64_t>(blockIdx.x) * ldo;
+    const int n_words = (F + 31) >> 5;
+    float scale = 1.f;
+    if (normalise) {
+        int cnt = 0;
+        for (int w = threadIdx.x; w < n_words; w += 256) {
+            uint32_t v = row[w];
+            if (w == n_words - 1 && (F & 31)) v &= (1u << (F & 31)) - 1u;  // bits past F are padding
+            cnt += __popc(v);
+        }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        scale = total > 0 ? 1.f / static_cast<float>(total) : 0.f;
+    }
+    for (int f = threadIdx.x; f < F; f += 256) dst[f] = ((row[f >> 5] >> (f & 31)) & 1u) ? scale : 0.f;
+}
+
 }  // namespace
 
 namespace wdg {
@@ -554,6 +580,16 @@ int wdg_row_l1_normalise_f32(const float *X, int64_t ldx, float *Y, int64_t ldy,
     hipLaunchKernelGGL(row_l1_kernel, dim3(wave_rows_grid(N)), dim3(256), 0, as_stream(stream), X, ldx, Y, ldy, N, F,
                        use_abs);
     return check_launch("row_l1_normalise");
+}
+
+int wdg_unpack_bits_f32(const uint32_t *words, int64_t ldw, int32_t N, int32_t F, int normalise, float *out, int64_t ldo,
+                        wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && F >= 0, "unpack_bits: negative size");
+    if (N == 0 || F == 0) return WDG_OK;
+    WDG_REQUIRE(words && out && ldw >= (F + 31) / 32 && ldo >= F, "unpack_bits: bad matrix");
+    hipLaunchKernelGGL(unpack_bits_kernel, dim3(static_cast<unsigned>(N)), dim3(256), 0, as_stream(stream), words, ldw, F,
+                       normalise, out, ldo);
+    return check_launch("unpack_bits");
 }
 
 }  // extern "C"

@@ -44,6 +44,13 @@ LARGE_NODES = 20000  # the reference switches to its scipy path for the LINKX da
 def load_npz_graph(path):
     """-> (adj sparse COO fp32 [N,N] on CPU, features dense fp32, labels int64): what `full_load_data_large` returns.
     File keys: adj_row, adj_col[, adj_val], labels, and either dense `features` or CSR `feat_indptr/indices/data`."""
+    if path.endswith(".wdgg"):  # the binary container of graph_io.py
+        from . import graph_io
+        g = graph_io.load_graph(path)
+        rows, cols = graph_io.csr_to_coo(g["rowptr"], g["col"])
+        idx = torch.from_numpy(np.vstack([rows, cols]).astype(np.int64))
+        adj = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (g["n_nodes"], g["n_nodes"]))
+        return adj, torch.from_numpy(np.array(g["features"], np.float32)), torch.from_numpy(g["labels"].astype(np.int64))
     z = np.load(path)
     n = int(z["labels"].shape[0])
     idx = torch.from_numpy(np.vstack([z["adj_row"], z["adj_col"]]).astype(np.int64))
@@ -99,14 +106,15 @@ def main(argv=None):
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter)
     p.add_argument('--no-cuda', action='store_true', default=False, help='accepted for compatibility; ignored')
-    p.add_argument('--dataset_name', type=str, required=True, help='name of <data_dir>/real_<name>.npz or a path to an .npz graph')
+    p.add_argument('--dataset_name', type=str, required=True, help='name of <data_dir>/real_<name>.npz, or a path to an .npz / .wdgg (graph_io container) graph')
     p.add_argument('--data_dir', type=str, default=os.path.join(here, "tests", "golden"))
     p.add_argument('--symmetric', type=float, default=0, help='1 for symmetric renormalized adj, 0 for random walk renormalized adj')
     p.add_argument('--sample_max', type=float, default=500, help='maxinum number of samples used in gntk')
     p.add_argument('--base_classifier', type=str, default='kernel_reg1', choices=BASE_CLASSIFIERS)
     p.add_argument('--homophily_metric', required=True, choices=list(METRIC_LIST.keys()))
     args = p.parse_args(argv)
-    path = args.dataset_name if args.dataset_name.endswith(".npz") else os.path.join(args.data_dir, f"real_{args.dataset_name}.npz")
+    path = (args.dataset_name if args.dataset_name.endswith((".npz", ".wdgg"))
+            else os.path.join(args.data_dir, f"real_{args.dataset_name}.npz"))
     lvl = run(path, args.homophily_metric, args.symmetric, args.sample_max, args.base_classifier)
     if isinstance(lvl, tuple):
         lvl = lvl[0]

@@ -204,6 +204,16 @@ def row_l1_normalise(x, use_abs=False):
     return y
 
 
+def unpack_bits(words, n_feat, row_normalise=False):
+    """[N, ceil(F / 32)] int32 words of bit-packed 0/1 features (graph_io.pack_bits) -> dense fp32 [N, F] on the GPU."""
+    dev = require_gpu()
+    words = _dev(words, torch.int32, dev)
+    out = torch.empty((words.shape[0], int(n_feat)), dtype=torch.float32, device=dev)
+    check(lib.wdg_unpack_bits_f32(_ptr(words), words.stride(0), words.shape[0], int(n_feat), int(row_normalise), _ptr(out),
+                                  out.stride(0), stream_handle()), "wdg_unpack_bits_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- aggregation
 def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     job.rowptr, job.col = g.rowptr.data_ptr(), g.col.data_ptr()
