@@ -99,3 +99,29 @@ def test_cli_counterpart_matches_golden(name):
     assert set(cli.METRIC_LIST) == {"node_homo", "edge_homo", "class_homo", "node_hom_generalized", "agg_homo_soft",
                                     "agg_homo_hard", "adj_homo", "label_info", "kernel_reg0_based_homo",
                                     "kernel_reg1_based_homo", "gnb_based_homo"}
+
+
+@pytest.mark.parametrize("kind", ["sgc", "gcn"])
+def test_graph_captured_training_equals_eager(kind):
+    """epochs replayed from captured hipGraphs give bitwise the weights and the model selection of the
+    same step functions run eagerly (dropout off: the two runs must consume no RNG differently)."""
+    from wdg_amd import models, synth
+    n, f, c = 800, 64, 5
+    src, dst, labels = synth.regular_graph(n, c, 2, 0.4, seed=3)
+    x = torch.from_numpy(synth.features(n, f, seed=3, labels=labels)).cuda()
+    from wdg_amd import ops
+    adj = models.NormAdj(ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS), add_self_loops=False)
+    y = torch.from_numpy(labels)
+    torch.manual_seed(5)
+    masks = models.random_disassortative_splits(y, y.max() + 1)
+    res, weights = {}, {}
+    for capture in (False, True):
+        torch.manual_seed(11)
+        m = models.SGC1(f, c) if kind == "sgc" else models.GCN2(f, c, nhid=32, dropout=0.0)
+        res[capture] = models.train_eval_graphed(m, adj, x, y, masks=masks, epochs=30, capture=capture)
+        weights[capture] = [p.detach().clone() for p in m.parameters()]
+    for a, b in zip(weights[False], weights[True]):
+        assert torch.equal(a, b)
+    for k in ("val_acc", "test_acc", "epoch"):
+        assert res[False][k] == res[True][k]
+    assert res[True]["val_acc"] > 1.5 / c  # it learns: the features carry class signal

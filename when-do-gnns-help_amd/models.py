@@ -119,3 +119,88 @@ def train_eval(model, adj, x, labels, masks=None, epochs=200, lr=0.01, weight_de
             best = dict(val_acc=v, test_acc=t, epoch=ep)
     best["epochs"] = epochs
     return best
+
+
+def train_eval_graphed(model, adj, x, labels, masks=None, epochs=200, lr=0.01, weight_decay=5e-4, capture=True):
+    """`train_eval` with each epoch replayed from two captured hipGraphs: one for
+    zero_grad + forward + loss + backward + Adam step, one for the evaluation forward + accuracies + model selection.
+    Nothing leaves the GPU between epochs (the running best lives in device tensors; one read-back at the end), every
+    shape is static (index vectors instead of boolean masks), and the HIP kernels behind `ops.spmm` / `ops.gemm` are
+    captured like any other launch on torch's stream.  `capture=False` runs the identical step functions eagerly (the
+    parity yardstick: same kernels, same order, same optimizer arithmetic -> bitwise equal weights).
+    Returns dict(val_acc, test_acc, epoch, epochs, seconds) - `seconds` is the wall time of the epoch loop."""
+    import time
+    dev = adj.graph.device
+    x, labels = x.to(dev, torch.float32).contiguous(), labels.to(dev)
+    model = model.to(dev)
+    if masks is None:
+        masks = random_disassortative_splits(labels, labels.max() + 1)
+    tr, va, te = (m.to(dev).nonzero().flatten() for m in masks)
+    y_tr, y_va, y_te = labels[tr], labels[va], labels[te]
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True)
+    best_val = torch.full((), -1.0, device=dev)
+    best_test = torch.zeros((), device=dev)
+    best_epoch = torch.zeros((), dtype=torch.int64, device=dev)
+    epoch = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def train_step():
+        model.train()
+        opt.zero_grad(set_to_none=False)
+        out = torch.log_softmax(model(adj, x), 1)
+        loss = torch.nn.functional.nll_loss(out.index_select(0, tr), y_tr)
+        loss.backward()
+        opt.step()
+
+    def eval_step():
+        model.eval()
+        with torch.no_grad():
+            pred = model(adj, x).argmax(1)
+            v = (pred.index_select(0, va) == y_va).float().mean()
+            t = (pred.index_select(0, te) == y_te).float().mean()
+            better = v > best_val
+            best_test.copy_(torch.where(better, t, best_test))
+            best_epoch.copy_(torch.where(better, epoch, best_epoch))
+            best_val.copy_(torch.where(better, v, best_val))
+            epoch.add_(1)
+
+    for p in model.parameters():  # gradients must exist (and keep their addresses) before anything is captured
+        p.grad = torch.zeros_like(p)
+    g_train = g_eval = None
+    if capture:
+        saved = [p.detach().clone() for p in model.parameters()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up off the capture stream: lazy state (Adam moments, SELL copies, kernel attributes)
+            for _ in range(2):
+                train_step()
+                eval_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():  # rewind to the initial state, in place (the graphs will address these very tensors)
+            for p, s in zip(model.parameters(), saved):
+                p.copy_(s)
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            best_val.fill_(-1.0); best_test.zero_(); best_epoch.zero_(); epoch.zero_()
+        g_train, g_eval = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_train):
+            train_step()
+        with torch.cuda.graph(g_eval):
+            eval_step()
+        with torch.no_grad():  # capturing does not execute: state is still the initial one, but make that explicit
+            for p, s in zip(model.parameters(), saved):
+                p.copy_(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        if capture:
+            g_train.replay()
+            g_eval.replay()
+        else:
+            train_step()
+            eval_step()
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    return dict(val_acc=float(best_val), test_acc=float(best_test), epoch=int(best_epoch), epochs=epochs, seconds=seconds)
