@@ -165,7 +165,10 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
 /*
  * CSR -> column-blocked SELL-64: the columns are cut into ceil(n_cols / B) blocks of B = wdg_sell_block_cols(n_rows, n_cols)
  * (what one LDS pass of the row-lane kernel can stage); inside a block the rows are grouped in slices of 64, stored
- * entry-major, padded with 0x7fffffff / value 0.  Column indices stay global, order inside a row is preserved.
+ * entry-major, padded with 0x7fffffff / value 0.  Column indices stay global.  Inside a (row, block) segment the entries
+ * are stored in a bank-aware order (the four lanes of an LDS service group that read the same chunk position get
+ * columns of different classes mod 4 wherever the rows allow it), which fixes the order of the row's sum; with
+ * WDG_SELL_ORDER=0 in the environment of the build call the segment keeps column order (the sequential CSR order).
  * Rows are first sorted (sell_perm[slot] = row, ties by row id) so that a slice holds rows of similar length and
  * pads by percents instead of multiples: by total length, longest first, for skewed graphs (longest row > 4x the
  * mean) or more than 4 column blocks; otherwise lexicographically by the per-block lengths (block 0 first).

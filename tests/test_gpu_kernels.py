@@ -346,7 +346,12 @@ def test_spmm_full_size_properties(ops):
 
 
 # --------------------------------------------------------------------------------------------- SELL-64 + row-lane kernel
-def test_sell_layout_matches_csr(ops, oracle):
+@pytest.mark.parametrize("column_order", [False, True])
+def test_sell_layout_matches_csr(ops, oracle, monkeypatch, column_order):
+    """Every (row, block) segment holds exactly the row's entries of that block - in column order with WDG_SELL_ORDER=0,
+    in the bank-aware order otherwise - padded with the sentinel."""
+    if column_order:
+        monkeypatch.setenv("WDG_SELL_ORDER", "0")
     rng = np.random.default_rng(31)
     for n, e in ((1, 1), (64, 500), (65, 700), (2000, 20000), (4096, 9000), (130, 0), (5201, 40000), (6144, 7000)):
         src, dst = _rand_graph(rng, n, e)
@@ -382,8 +387,13 @@ def test_sell_layout_matches_csr(ops, oracle):
                     sel = (cr >= b * bc) & (cr < (b + 1) * bc)
                     l = int(sel.sum())
                     longest = max(longest, l)
-                    np.testing.assert_array_equal(blk_c[:l, lane], cr[sel])
-                    np.testing.assert_array_equal(blk_v[:l, lane], vr[sel])
+                    if column_order:
+                        np.testing.assert_array_equal(blk_c[:l, lane], cr[sel])
+                        np.testing.assert_array_equal(blk_v[:l, lane], vr[sel])
+                    else:  # same (column, value) pairs, any order; columns are unique inside a row
+                        order = np.argsort(blk_c[:l, lane])
+                        np.testing.assert_array_equal(blk_c[:l, lane][order], cr[sel])
+                        np.testing.assert_array_equal(blk_v[:l, lane][order], vr[sel])
                     assert (blk_c[l:, lane] == 0x7fffffff).all() and (blk_v[l:, lane] == 0).all()
                 assert width == longest
                 assert (blk_c[:, rows.size:] == 0x7fffffff).all()
@@ -424,7 +434,9 @@ def test_spmm_rowlane_family_shapes(ops, oracle, n, f, e):
 
 
 def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch):
-    """Both LDS kernels sum a row in CSR column order: results must be bit-identical."""
+    """With the SELL copy in column order (WDG_SELL_ORDER=0) both LDS kernels sum a row in CSR column order: results
+    must be bit-identical.  (The default bank-aware order changes the order of a row's sum: covered by the 1e-5 tests.)"""
+    monkeypatch.setenv("WDG_SELL_ORDER", "0")
     rng = np.random.default_rng(77)
     n, f, e = 2000, 500, 40000
     src, dst = _rand_graph(rng, n, e)

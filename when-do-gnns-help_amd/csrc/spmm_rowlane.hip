@@ -29,9 +29,9 @@
 //                               waves free-running across the run's graphs (what the sweep batch uses)
 //   spmm_rowlane_pipe_kernel    16-feature items, two block buffers, next block / next item requested behind the
 //                               sweep (opt-in: measured slower than the general kernel)
-// Summation order per row = column order of the CSR row (blocks ascend, entries ascend inside a block) in all of
-// them -> bitwise reproducible, bit-identical across schedules, the order a sequential CPU sweep over the
-// coalesced COO uses.
+// Summation order per row = the order of the SELL copy: blocks ascend; inside a (row, block) segment the bank-aware
+// order chosen once by sell_fill (column order with WDG_SELL_ORDER=0, then the order a sequential CPU sweep over the
+// coalesced COO uses) -> bitwise reproducible and bit-identical across the three schedules.
 #include <atomic>
 
 #include "wdg_common.h"
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(256) void sell_fill(const int32_t *__restrict__ row
                                                  const float *__restrict__ val, const int32_t *__restrict__ perm,
                                                  int32_t N, int32_t n_slices, int32_t n_blocks, int32_t block_cols,
                                                  const int32_t *__restrict__ sell_ptr, int32_t *__restrict__ sell_col,
-                                                 float *__restrict__ sell_val) {
+                                                 float *__restrict__ sell_val, int reorder) {
     const int task = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (task >= n_slices * n_blocks) return;
+    if (task >= n_slices * n_blocks) return;  // (whole waves: a task is a wave)
     const int blk = task / n_slices, slice = task % n_slices;
     const int slot = slice * 64 + lane;
     const int row = slot < N ? perm[slot] : N;
@@ -196,10 +196,59 @@ __global__ __launch_bounds__(256) void sell_fill(const int32_t *__restrict__ row
         const int b = (blk + 1 == n_blocks) ? e : lower_bound_col(col, a, e, (blk + 1) * block_cols);
         len = b - a;
     }
+    if (!reorder || width > 64 || width < 2) {  // plain copy: the segment in column order
+        for (int e = 0; e < width; ++e) {
+            const bool ok = e < len;
+            sell_col[base + e * 64 + lane] = ok ? col[a + e] : SELL_SENTINEL;
+            if (sell_val) sell_val[base + e * 64 + lane] = ok ? (val ? val[a + e] : 1.f) : 0.f;
+        }
+        return;
+    }
+    // Bank-aware entry order (default; WDG_SELL_ORDER=0 keeps column order).  The sweep reads, for entry e of every lane, the 64-B LDS row of its
+    // column; a ds_read_b128 is served 16 lanes at a time ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32), and the four
+    // lanes of such a group that read the same chunk position (equal lane & 3) collide when their rows fall into the same
+    // bank window, i.e. when their columns agree mod 4.  Each row's entries inside a block may be visited in any order, so
+    // the four lanes of a quadruple choose, step by step and in rank order, a remaining entry whose column class is not
+    // taken yet in this step (the class they hold most of first): random order costs 2.1 LDS cycles per quadruple and
+    // step, this 1.2 - 1.7.  The order of a row's summation changes with it (still fixed per graph: reproducible).
+    const int x = lane & 31, q = lane & 3;
+    const bool g0 = x < 4 || (x >= 12 && x < 16) || (x >= 20 && x < 28);
+    // the quadruple's lanes, ascending: {q, 12+q, 20+q, 24+q} or {4+q, 8+q, 16+q, 28+q} (+ 32 for the upper half)
+    const int m0 = (g0 ? q : 4 + q), m1 = (g0 ? 12 + q : 8 + q), m2 = (g0 ? 20 + q : 16 + q), m3 = (g0 ? 24 + q : 28 + q);
+    const int rank = (x == m0) ? 0 : (x == m1) ? 1 : (x == m2) ? 2 : 3;
+    const int half = lane & 32;
+    unsigned long long taken = 0;  // entries of this lane's segment already placed (width <= 64)
     for (int e = 0; e < width; ++e) {
+        unsigned used = 0;  // column classes taken in this step by lower ranks of the quadruple
+        int pick = -1;
+        for (int r = 0; r < 4; ++r) {
+            int cls = -1;
+            if (rank == r && e < len) {
+                int cnt[4] = {0, 0, 0, 0}, first[4] = {-1, -1, -1, -1};
+                for (int j = 0; j < len; ++j) {
+                    if ((taken >> j) & 1ull) continue;
+                    const int c4 = col[a + j] & 3;
+                    if (first[c4] < 0) first[c4] = j;
+                    ++cnt[c4];
+                }
+                int best = -1, best_any = -1;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    if (cnt[c4] == 0) continue;
+                    if (best_any < 0 || cnt[c4] > cnt[best_any]) best_any = c4;
+                    if (!((used >> c4) & 1u) && (best < 0 || cnt[c4] > cnt[best])) best = c4;
+                }
+                cls = best >= 0 ? best : best_any;
+                pick = first[cls];
+                taken |= 1ull << pick;
+            }
+            const int src_lane = half + (r == 0 ? m0 : r == 1 ? m1 : r == 2 ? m2 : m3);
+            const int got = __shfl(cls, src_lane);
+            if (got >= 0) used |= 1u << got;
+        }
         const bool ok = e < len;
-        sell_col[base + e * 64 + lane] = ok ? col[a + e] : SELL_SENTINEL;
-        if (sell_val) sell_val[base + e * 64 + lane] = ok ? (val ? val[a + e] : 1.f) : 0.f;
+        sell_col[base + e * 64 + lane] = ok ? col[a + pick] : SELL_SENTINEL;
+        if (sell_val) sell_val[base + e * 64 + lane] = ok ? (val ? val[a + pick] : 1.f) : 0.f;
     }
 }
 
@@ -1194,11 +1243,17 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const w
 // 512-row blocks; every extra block adds padding - a slice runs as long as its longest row IN THAT BLOCK - and the sweep is
 // LDS-bound: N = 2000, degree 10: 4 blocks pad 2.5x, 2 blocks ~1.2x with the by-block row sort.)  The single-buffer kernel
 // stages one 1024-row block of 128-B rows at a time.  Blocks are balanced: N = 2000 -> 2 x 1000.
+bool sell_reorder_enabled() {  // bank-aware entry order inside (row, block) segments: on unless WDG_SELL_ORDER=0
+    const char *e = getenv("WDG_SELL_ORDER");
+    return !(e && atoi(e) == 0);
+}
+
 int sell_block_cap(int /*n_rows*/) { return 1016; }  // 2 x 1016 x 64 B + 16 x 2 KiB transpose tiles + static LDS <= 160 KiB
 int sell_block_cols_for(int n_rows, int n_cols) {
     const int cap = sell_block_cap(n_rows);
     const int blocks = static_cast<int>(ceil_div(n_cols > 0 ? n_cols : 1, cap));
-    return static_cast<int>(ceil_div(n_cols > 0 ? n_cols : 1, blocks));
+    const int even = static_cast<int>(ceil_div(n_cols > 0 ? n_cols : 1, blocks));
+    return std::min(cap, (even + 3) & ~3);  // a multiple of 4: a column's bank class (col mod 4) is the same in every block
 }
 
 unsigned next_queue_slot() {
@@ -1397,7 +1452,7 @@ int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float 
     if (tasks == 0) return WDG_OK;
     WDG_REQUIRE(rowptr, "csr_to_sell_fill: null rowptr");
     hipLaunchKernelGGL(sell_fill, dim3(wdg::ceil_div(tasks * 64, 256)), dim3(256), 0, wdg::as_stream(stream), rowptr, col,
-                       val, sell_perm, N, n_slices, n_blocks, block_cols, sell_ptr, sell_col, sell_val);
+                       val, sell_perm, N, n_slices, n_blocks, block_cols, sell_ptr, sell_col, sell_val, sell_reorder_enabled());
     return wdg::check_launch("csr_to_sell_fill");
 }
 
