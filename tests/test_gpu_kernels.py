@@ -664,3 +664,60 @@ def test_gram_matches_oracle(ops, oracle):
     smp = g0["gntk_sample"]
     gram = _np(ops.gemm(torch.from_numpy(x[smp]), torch.from_numpy(x[smp]), transb=True))
     np.testing.assert_allclose(gram, oracle.gram(x, smp), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_spmm_fuzz_shapes_and_batches(ops, oracle, seed):
+    """Random shapes through whatever family the plan picks: rectangular patterns, empty rows, ragged F, explicit values,
+    row/column scales, bf16 input, single calls and mixed batches (some jobs sharing X) - all against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    entries, want = [], []
+    shared_x = None
+    for case in range(10):
+        n_rows = int(rng.choice([1, 5, 63, 64, 65, 300, 1000, 2000, 2048, 2100, 5000]))
+        n_cols = n_rows if rng.random() < 0.6 else int(rng.choice([1, 7, 64, 500, 1016, 1017, 2032, 2033, 3000]))
+        f = int(rng.choice([1, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 64, 100, 130]))
+        e = int(rng.integers(0, 6 * n_rows + 1))
+        src, dst = rng.integers(0, n_rows, e), rng.integers(0, n_cols, e)
+        key = np.unique(src.astype(np.int64) * n_cols + dst)
+        rows, cols = (key // n_cols).astype(np.int32), (key % n_cols).astype(np.int32)
+        rowptr = np.zeros(n_rows + 1, np.int32)
+        np.add.at(rowptr, rows + 1, 1)
+        rowptr = np.cumsum(rowptr).astype(np.int32)
+        val = rng.random(len(cols), dtype=np.float32) if rng.random() < 0.5 else None
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(cols).cuda(),
+                         None if val is None else torch.from_numpy(val).cuda(), n_rows, n_cols)
+        if shared_x is not None and shared_x.shape[0] == n_cols and rng.random() < 0.7:
+            x = shared_x
+            f = x.shape[1]
+        else:
+            x = torch.from_numpy(rng.standard_normal((n_cols, f)).astype(np.float32)).cuda()
+            if n_cols <= 2032 and n_rows <= 2048 and f % 4 == 0 and f >= 16:
+                shared_x = x
+        rs = torch.from_numpy(rng.random(n_rows, dtype=np.float32)).cuda() if rng.random() < 0.6 else None
+        cs = torch.from_numpy(rng.random(n_cols, dtype=np.float32)).cuda() if rng.random() < 0.3 else None
+        v = np.ones(len(cols), np.float32) if val is None else val
+        if rs is not None:
+            v = v * _np(rs)[rows]
+        if cs is not None:
+            v = v * _np(cs)[cols]
+        ref = oracle.spmm_csr(rowptr, cols, v.astype(np.float32), _np(x))
+        tol = dict(rtol=2e-5, atol=2e-6 * max(float(np.abs(ref).max()), 1e-30))
+        y = ops.spmm(g, x, row_scale=rs, col_scale=cs)
+        np.testing.assert_allclose(_np(y), ref, **tol, err_msg=f"single call, case {case}: {n_rows}x{n_cols} F={f} e={len(cols)}")
+        if rng.random() < 0.3:  # bf16 features, fp32 accumulation
+            xb = x.to(torch.bfloat16)
+            refb = oracle.spmm_csr(rowptr, cols, v.astype(np.float32), _np(xb.float()))
+            np.testing.assert_allclose(_np(ops.spmm(g, xb, row_scale=rs, col_scale=cs)), refb, rtol=2e-5,
+                                       atol=2e-6 * max(float(np.abs(refb).max()), 1e-30))
+        entries.append((g, x, torch.full((n_rows, f), float("nan"), device="cuda"), rs, cs, True))
+        want.append((ref, tol))
+    by_feat = {}
+    for ent, w in zip(entries, want):  # one batch per feature width (a table has one max_feat; widths may differ, too)
+        by_feat.setdefault(ent[1].shape[1] >= 8, []).append((ent, w))
+    for group in by_feat.values():
+        batch = ops.SpmmBatch([ent for ent, _ in group])
+        batch.launch()
+        torch.cuda.synchronize()
+        for (ent, (ref, tol)) in group:
+            np.testing.assert_allclose(_np(ent[2]), ref, **tol, err_msg=f"batched, plan {batch.plan()}")

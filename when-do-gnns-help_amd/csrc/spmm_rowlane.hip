@@ -309,6 +309,14 @@ __device__ __forceinline__ RlSteal rl_steal(unsigned *queues, int xcd, int n_que
     return r;
 }
 
+// weight of an entry: the job's explicit value, 1 for a job without values inside a batch where other jobs have them
+// (the kernel variant is chosen per batch), 0 where there is no entry
+template <bool HAS_VAL>
+__device__ __forceinline__ float rl_weight(global_ptr<const float> vals, int idx, bool present) {
+    if (!HAS_VAL || !present) return 0.f;
+    return vals ? vals[idx] : 1.f;
+}
+
 template <int QUADS, bool HAS_VAL>
 __device__ __forceinline__ void rl_accumulate(float4 (&acc)[QUADS], const float4 *xs, int c, float w, int lane) {
     const float4 *src = xs + c * QUADS;
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             c[u] = (u < width[0]) ? job.sell_col[base[0] + lane + u * 64] : SELL_SENTINEL;
-            w[u] = (HAS_VAL && u < width[0]) ? job.sell_val[base[0] + lane + u * 64] : 0.f;
+            w[u] = rl_weight<HAS_VAL>(job.sell_val, base[0] + lane + u * 64, u < width[0]);
         }
         if (blk + 1 == n_blocks) {
 #pragma unroll
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     c[u] = (u < nwidth) ? job.sell_col[nbase + lane + u * 64] : SELL_SENTINEL;
-                    w[u] = (HAS_VAL && u < nwidth) ? job.sell_val[nbase + lane + u * 64] : 0.f;
+                    w[u] = rl_weight<HAS_VAL>(job.sell_val, nbase + lane + u * 64, u < nwidth);
                 }
             }
             for (int e0 = 0; e0 < width[k]; e0 += U) {
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_kernel(const wdg_spmm
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     cn[u] = (u < left) ? job.sell_col[pf + u * 64] : SELL_SENTINEL;
-                    wn[u] = (HAS_VAL && u < left) ? job.sell_val[pf + u * 64] : 0.f;
+                    wn[u] = rl_weight<HAS_VAL>(job.sell_val, pf + u * 64, u < left);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -741,7 +749,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     head[k][u] = (u < width) ? job.sell_col[base + lane + u * 64] : SELL_SENTINEL;
-                    headw[k][u] = (HAS_VAL && u < width) ? job.sell_val[base + lane + u * 64] : 0.f;
+                    headw[k][u] = rl_weight<HAS_VAL>(job.sell_val, base + lane + u * 64, u < width);
                 }
             }
         };
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     head[k][u] = (u < width) ? nxt.sell_col[base + lane + u * 64] : SELL_SENTINEL;
-                    headw[k][u] = (HAS_VAL && u < width) ? nxt.sell_val[base + lane + u * 64] : 0.f;
+                    headw[k][u] = rl_weight<HAS_VAL>(nxt.sell_val, base + lane + u * 64, u < width);
                 }
             }
         };
@@ -852,7 +860,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         cx[u] = (U + u < width) ? job.sell_col[base + lane + (U + u) * 64] : SELL_SENTINEL;
-                        wx[u] = (HAS_VAL && U + u < width) ? job.sell_val[base + lane + (U + u) * 64] : 0.f;
+                        wx[u] = rl_weight<HAS_VAL>(job.sell_val, base + lane + (U + u) * 64, U + u < width);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -877,7 +885,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             cy[u] = (u < left) ? job.sell_col[base + lane + (e0 + U + u) * 64] : SELL_SENTINEL;
-                            wy[u] = (HAS_VAL && u < left) ? job.sell_val[base + lane + (e0 + U + u) * 64] : 0.f;
+                            wy[u] = rl_weight<HAS_VAL>(job.sell_val, base + lane + (e0 + U + u) * 64, u < left);
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
@@ -1080,7 +1088,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const w
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     c[u] = (u < w0) ? first.sell_col[b0 + lane + u * 64] : SELL_SENTINEL;
-                    w[u] = (HAS_VAL && u < w0) ? first.sell_val[b0 + lane + u * 64] : 0.f;
+                    w[u] = rl_weight<HAS_VAL>(first.sell_val, b0 + lane + u * 64, u < w0);
                 }
             }
             // destination rows (the length-sort permutation) and row scales of a graph are requested one graph ahead too
@@ -1149,7 +1157,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const w
 #pragma unroll
                             for (int u = 0; u < U; ++u) {
                                 c[u] = (u < nwidth) ? ncol[nbase + lane + u * 64] : SELL_SENTINEL;
-                                w[u] = (HAS_VAL && u < nwidth) ? nval[nbase + lane + u * 64] : 0.f;
+                                w[u] = rl_weight<HAS_VAL>(nval, nbase + lane + u * 64, u < nwidth);
                             }
                             continue;
                         }
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const w
 #pragma unroll
                             for (int u = 0; u < U; ++u) {
                                 cn[u] = (u < left) ? pcol[pf + u * 64] : SELL_SENTINEL;
-                                wn[u] = (HAS_VAL && u < left) ? pval[pf + u * 64] : 0.f;
+                                wn[u] = rl_weight<HAS_VAL>(pval, pf + u * 64, u < left);
                             }
 #pragma unroll
                             for (int u = 0; u < U; ++u)
