@@ -721,3 +721,75 @@ def test_spmm_fuzz_shapes_and_batches(ops, oracle, seed):
         torch.cuda.synchronize()
         for (ent, (ref, tol)) in group:
             np.testing.assert_allclose(_np(ent[2]), ref, **tol, err_msg=f"batched, plan {batch.plan()}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_build_stats_las_gemm(ops, oracle, seed):
+    """Random inputs through the other entry points: COO->CSR with every flag combination (duplicates, self-loops,
+    explicit values: bit exact), edge/label statistics with unlabelled nodes and class counts on both sides of the LDS
+    histogram limit (bit exact), LAS weights in fp64 for narrow and wide features with row subsets, GEMM shapes around
+    the tile edges with strides, bias, relu and transb (bitwise equal to the k-ordered fma chain)."""
+    rng = np.random.default_rng(500 + seed)
+    # ---- graph build
+    n = int(rng.choice([1, 2, 63, 64, 65, 500, 3000]))
+    e = int(rng.integers(0, 8 * n + 1))
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    if e:
+        dup = rng.integers(0, e, e // 4)
+        src, dst = np.concatenate([src, src[dup]]), np.concatenate([dst, dst[dup]])
+    val = rng.random(len(src), dtype=np.float32) if rng.random() < 0.5 else None
+    flag_bits = [ops.COO_SYMMETRISE, ops.COO_BINARISE, ops.COO_ADD_SELF_LOOPS, ops.COO_DROP_SELF_LOOPS, ops.COO_KEEP_DUPLICATES]
+    flags = 0
+    for b in flag_bits:
+        if rng.random() < 0.35:
+            flags |= b
+    if flags & ops.COO_ADD_SELF_LOOPS and flags & ops.COO_DROP_SELF_LOOPS:
+        flags &= ~ops.COO_DROP_SELF_LOOPS
+    g = ops.CsrGraph.from_coo(src, dst, n, val, flags)
+    rowptr, col, v = oracle.coo_to_csr(src, dst, n, val, flags)
+    np.testing.assert_array_equal(_np(g.rowptr), rowptr, err_msg=f"flags {flags}")
+    np.testing.assert_array_equal(_np(g.col), col)
+    np.testing.assert_array_equal(_np(g.val), v)
+    # ---- statistics (merged pattern: the statistics are defined on coalesced adjacency)
+    g2 = ops.CsrGraph.from_coo(src, dst, n, None, flags & ~ops.COO_KEEP_DUPLICATES)
+    rp2, c2, _ = oracle.coo_to_csr(src, dst, n, None, flags & ~ops.COO_KEEP_DUPLICATES)
+    c = int(rng.choice([1, 2, 5, 7, 64, 65, 100]))
+    labels = rng.integers(0, c, n)
+    labels[rng.random(n) < 0.1] = -1  # unlabelled
+    st = ops.edge_label_stats(g2, torch.from_numpy(labels), n_classes=c)
+    ref = oracle.edge_label_stats(rp2, c2, labels, c)
+    for k in STAT_KEYS:
+        np.testing.assert_array_equal(_np(st[k]), ref[k], err_msg=f"{k} (C={c})")
+    # ---- LAS weights
+    nl, f, cl = int(rng.choice([1, 100, 129, 1000, 2500])), int(rng.choice([1, 5, 16, 17, 80])), int(rng.choice([2, 5, 16, 20]))
+    h = rng.integers(0, 4, (nl, f)).astype(np.float32)  # integer-valued: every sum is exact, counts must match exactly
+    lab = rng.integers(0, cl, nl)
+    cnt, n_used, w = ops.las(torch.from_numpy(h), torch.from_numpy(lab), cl, want_weights=True)
+    wref = oracle.las_weights(h, lab, cl, f64=True)
+    np.testing.assert_array_equal(_np(w), wref)
+    rows = np.sort(rng.choice(nl, max(1, nl // 3), replace=False))
+    cnt_s, n_s, w_s = ops.las(torch.from_numpy(h), torch.from_numpy(lab), cl, rows=torch.from_numpy(rows), want_weights=True)
+    np.testing.assert_array_equal(_np(w_s), oracle.las_weights(h[rows], lab[rows], cl, f64=True))
+    assert n_s == len(rows)
+    # ---- GEMM
+    m, kk, nn = int(rng.choice([1, 31, 32, 33, 127, 128, 129, 700])), int(rng.choice([1, 2, 15, 16, 17, 100, 500])), int(rng.choice([1, 5, 31, 32, 33, 64, 65, 100]))
+    a = rng.standard_normal((m, kk + 3)).astype(np.float32)[:, :kk]  # non-contiguous leading dimension
+    b = rng.standard_normal((kk, nn)).astype(np.float32)
+    bias = rng.standard_normal(nn).astype(np.float32) if rng.random() < 0.5 else None
+    relu = bool(rng.random() < 0.5)
+    at = torch.from_numpy(np.ascontiguousarray(rng.standard_normal((m, kk + 3)).astype(np.float32))).cuda()
+    at[:, :kk] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = ops.gemm(at[:, :kk], torch.from_numpy(b).cuda(), bias=None if bias is None else torch.from_numpy(bias), relu=relu)
+    chain = np.zeros((m, nn), np.float32)  # the k-ordered fma chain (one rounding per step), bias added last, then relu
+    for k in range(kk):
+        chain = (a[:, k:k + 1].astype(np.float64) * b[k:k + 1, :].astype(np.float64) + chain.astype(np.float64)).astype(np.float32)
+    plain = chain.copy()
+    if bias is not None:
+        chain = chain + bias[None, :]
+    if relu:
+        chain = np.maximum(chain, 0)
+    np.testing.assert_array_equal(_np(got), chain)
+    ref = oracle.gemm(np.ascontiguousarray(a), b, bias, relu)
+    np.testing.assert_allclose(_np(got), ref, rtol=1e-5, atol=1e-5 * max(float(np.abs(ref).max()), 1e-30))
+    got_t = ops.gemm(at[:, :kk], torch.from_numpy(np.ascontiguousarray(b.T)).cuda(), transb=True)
+    np.testing.assert_array_equal(_np(got_t), plain)

@@ -32,6 +32,12 @@ def _dev(t, dtype, dev):
     return t.to(device=dev, dtype=dtype).contiguous()
 
 
+def _ld(t):
+    """Leading dimension of a row-major matrix for the C ABI.  torch / numpy report an arbitrary stride for a dimension
+    of size 1 (a [1, K] view of a [K, 1] array has stride(0) == 1): with one row any value >= the row length is valid."""
+    return t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
+
+
 class CsrGraph:
     """Device-resident CSR adjacency: int32 rowptr[n_rows+1], int32 col[nnz], optional fp32 val[nnz].
 
@@ -119,12 +125,12 @@ class CsrGraph:
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         ws_bytes = lib.wdg_scan_workspace_bytes(n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        check(lib.wdg_dense_to_csr_count(_ptr(a), a.stride(0), n, m, _ptr(rowptr), _ptr(ws), ws_bytes,
+        check(lib.wdg_dense_to_csr_count(_ptr(a), _ld(a), n, m, _ptr(rowptr), _ptr(ws), ws_bytes,
                                          stream_handle()), "wdg_dense_to_csr_count")
         nnz = int(rowptr[-1].item())
         col = torch.empty(nnz, dtype=torch.int32, device=dev)
         val = torch.empty(nnz, dtype=torch.float32, device=dev)
-        check(lib.wdg_dense_to_csr_fill(_ptr(a), a.stride(0), n, m, _ptr(rowptr), _ptr(col), _ptr(val),
+        check(lib.wdg_dense_to_csr_fill(_ptr(a), _ld(a), n, m, _ptr(rowptr), _ptr(col), _ptr(val),
                                         stream_handle()), "wdg_dense_to_csr_fill")
         return CsrGraph(rowptr, col, val, n, m)
 
@@ -199,7 +205,7 @@ def row_l1_normalise(x, use_abs=False):
     dev = require_gpu()
     x = _dev(x, torch.float32, dev)
     y = torch.empty_like(x)
-    check(lib.wdg_row_l1_normalise_f32(_ptr(x), x.stride(0), _ptr(y), y.stride(0), x.shape[0], x.shape[1],
+    check(lib.wdg_row_l1_normalise_f32(_ptr(x), _ld(x), _ptr(y), _ld(y), x.shape[0], x.shape[1],
                                        int(use_abs), stream_handle()), "wdg_row_l1_normalise_f32")
     return y
 
@@ -209,8 +215,8 @@ def unpack_bits(words, n_feat, row_normalise=False):
     dev = require_gpu()
     words = _dev(words, torch.int32, dev)
     out = torch.empty((words.shape[0], int(n_feat)), dtype=torch.float32, device=dev)
-    check(lib.wdg_unpack_bits_f32(_ptr(words), words.stride(0), words.shape[0], int(n_feat), int(row_normalise), _ptr(out),
-                                  out.stride(0), stream_handle()), "wdg_unpack_bits_f32")
+    check(lib.wdg_unpack_bits_f32(_ptr(words), _ld(words), words.shape[0], int(n_feat), int(row_normalise), _ptr(out),
+                                  _ld(out), stream_handle()), "wdg_unpack_bits_f32")
     return out
 
 
@@ -221,7 +227,7 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     job.row_scale = 0 if row_scale is None else row_scale.data_ptr()
     job.col_scale = 0 if col_scale is None else col_scale.data_ptr()
     job.X, job.Y = x.data_ptr(), y.data_ptr()
-    job.ldx, job.ldy = x.stride(0), y.stride(0)
+    job.ldx, job.ldy = _ld(x), _ld(y)
     job.n_rows, job.n_cols, job.n_feat = g.n_rows, g.n_cols, x.shape[1]
     job.reserved = int(os.environ.get("WDG_SPMM_ABLATE", "0"))  # diagnostics only (timing ablations)
     wants_val = bool(job.val)
@@ -239,7 +245,7 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
 def _sharing_groups(entries):
     groups = {}
     for i, (g, x, *_rest) in enumerate(entries):
-        groups.setdefault((x.data_ptr(), x.stride(0), g.n_cols, x.shape[1]), []).append(i)
+        groups.setdefault((x.data_ptr(), _ld(x), g.n_cols, x.shape[1]), []).append(i)
     return list(groups.values())
 
 
@@ -435,7 +441,7 @@ class LasBatch:
         for i, (job, (h, lab)) in enumerate(zip(arr, entries)):
             job.H, job.labels, job.rows, job.W_out = h.data_ptr(), lab.data_ptr(), 0, 0
             job.count_out, job.workspace = self.counts[i].data_ptr(), self.ws.data_ptr() + int(offs[i])
-            job.ldh, job.n, job.F, job.C = h.stride(0), h.shape[0], h.shape[1], self.c
+            job.ldh, job.n, job.F, job.C = _ld(h), h.shape[0], h.shape[1], self.c
             self.max_n, self.max_f = max(self.max_n, h.shape[0]), max(self.max_f, h.shape[1])
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
         self.table = host.to(dev)
@@ -462,7 +468,7 @@ class GemmBatch:
                 raise ValueError("GemmBatch: shape / layout mismatch")
             job.A, job.B, job.C = a.data_ptr(), b.data_ptr(), c.data_ptr()
             job.bias = 0 if bias is None else bias.data_ptr()
-            job.lda, job.ldb, job.ldc = a.stride(0), b.stride(0), c.stride(0)
+            job.lda, job.ldb, job.ldc = _ld(a), _ld(b), _ld(c)
             job.M, job.N, job.K, job.act = m, n, k, (ACT_RELU if relu else ACT_NONE)
             self.max_m, self.max_n = max(self.max_m, m), max(self.max_n, n)
             self.flops += 2 * m * n * k
@@ -483,7 +489,7 @@ def edge_cosine(g, x, entries=None, skip_self=True):
     entries = _dev(entries, torch.int32, dev)
     n = int(entries.shape[0]) if entries is not None else g.nnz
     out = torch.empty(n, dtype=torch.float32, device=dev)
-    check(lib.wdg_edge_cosine_f32(_ptr(g.rowptr), _ptr(g.col), _ptr(entries), n, _ptr(x), x.stride(0), g.n_rows,
+    check(lib.wdg_edge_cosine_f32(_ptr(g.rowptr), _ptr(g.col), _ptr(entries), n, _ptr(x), _ld(x), g.n_rows,
                                   x.shape[1], int(skip_self), _ptr(out), stream_handle()), "wdg_edge_cosine_f32")
     return out
 
@@ -501,7 +507,7 @@ def las(h, labels, n_classes, rows=None, want_weights=False):
     cnt = torch.empty(2, dtype=torch.int64, device=dev)
     ws_bytes = lib.wdg_las_workspace_bytes(n, f, c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.wdg_las_f32(_ptr(h), h.stride(0), _ptr(labels), _ptr(rows), n, f, c, _ptr(w), _ptr(cnt), _ptr(ws), ws_bytes,
+    check(lib.wdg_las_f32(_ptr(h), _ld(h), _ptr(labels), _ptr(rows), n, f, c, _ptr(w), _ptr(cnt), _ptr(ws), ws_bytes,
                           stream_handle()), "wdg_las_f32")
     return cnt, n, w
 
@@ -516,7 +522,7 @@ def gemm(a, b, bias=None, relu=False, transb=False, out=None):
     if (b.shape[1] if transb else b.shape[0]) != k:
         raise ValueError("gemm: inner dimensions differ")
     c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
-    check(lib.wdg_gemm_f32(_ptr(a), a.stride(0), _ptr(b), b.stride(0), int(transb), _ptr(bias),
-                           ACT_RELU if relu else ACT_NONE, _ptr(c), c.stride(0), m, n, k, stream_handle()),
+    check(lib.wdg_gemm_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), int(transb), _ptr(bias),
+                           ACT_RELU if relu else ACT_NONE, _ptr(c), _ld(c), m, n, k, stream_handle()),
           "wdg_gemm_f32")
     return c
