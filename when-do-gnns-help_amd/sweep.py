@@ -9,9 +9,11 @@ over ranks (one process per GPU).  Jobs are independent, so the data path has no
 only the job table (broadcast from rank 0) and the per-job result rows (all_gather) through torch.distributed
 (RCCL over xGMI on a GPU node, gloo in the CPU tests).
 """
+import os
 from dataclasses import dataclass
 
 import numpy as np
+
 import torch
 
 from . import synth
@@ -138,6 +140,7 @@ class SweepBatch:
 
         # GCN-2 forward (build-defined model, models.py): logits = A_hat relu((A_hat X) W0) W1, every job its own weights
         self.gcn = None
+        self.side = torch.cuda.Stream() if os.environ.get("WDG_SWEEP_STREAMS", "2") != "1" else None  # see step_rest
         if gcn_hidden:
             gen = torch.Generator(device="cpu").manual_seed(1234)
             w0 = [(torch.randn((n_feat, gcn_hidden), generator=gen) * (2.0 / (n_feat + gcn_hidden)) ** 0.5).to(dev) for _ in self.jobs]
@@ -173,14 +176,32 @@ class SweepBatch:
         self.step_rest()
 
     def step_rest(self):
-        """everything of a step after the feature aggregation (bench.py times that launch separately)"""
+        """everything of a step after the feature aggregation (bench.py times that launch separately).
+
+        Two independent chains: the metric chain (statistics, label aggregation, LAS: ~75 us of small launches) and the
+        GCN-2 forward (two GEMMs + the logits aggregation).  They run on two HIP streams: the GEMM's second round of
+        workgroups leaves most CUs idle, which the metric chain's kernels fill."""
+        main = torch.cuda.current_stream()
+        if self.gcn and self.side is not None:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._metric_chain()
+            self._gcn_chain()
+            main.wait_stream(self.side)
+        else:
+            self._metric_chain()
+            if self.gcn:
+                self._gcn_chain()
+
+    def _metric_chain(self):
         self.stats.launch()       # edge / node / class / adjusted homophily, label informativeness counters
         self.spmm_las.launch()    # H = A_hat onehot(labels)          (F = C)
         self.las.launch()         # soft / hard LAS counts
-        if self.gcn:
-            self.gcn["gemm1"].launch()  # relu(Y W0)                  fp32 MFMA
-            self.gcn["gemm2"].launch()  # (.) W1
-            self.gcn["spmm"].launch()   # logits = A_hat (.)           (F = C)
+
+    def _gcn_chain(self):
+        self.gcn["gemm1"].launch()  # relu(Y W0)                  fp32 MFMA
+        self.gcn["gemm2"].launch()  # (.) W1
+        self.gcn["spmm"].launch()   # logits = A_hat (.)           (F = C)
 
     def results(self):
         """[jobs, len(METRIC_NAMES)] fp32: dense-flavour metric scalars (utils/homophily_plot.py) from the counters."""
