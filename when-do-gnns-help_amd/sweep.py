@@ -193,6 +193,18 @@ class SweepBatch:
             if self.gcn:
                 self._gcn_chain()
 
+    def capture_rest(self):
+        """step_rest() as one hipGraph (both streams, fork / join included): replaying it replaces eight launches and two
+        stream dependencies by one graph launch.  Returns the replay callable; outputs land in the same tensors."""
+        for _ in range(2):  # lazy state (kernel attributes, code objects) must exist before the capture
+            self.step_rest()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step_rest()
+        self._graph = graph  # keep alive
+        return graph.replay
+
     def _metric_chain(self):
         self.stats.launch()       # edge / node / class / adjusted homophily, label informativeness counters
         self.spmm_las.launch()    # H = A_hat onehot(labels)          (F = C)
