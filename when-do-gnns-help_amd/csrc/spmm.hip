@@ -119,17 +119,10 @@ struct RowSink {
     int64_t ldy;
     int f, F;
     bool vec;
-    float4 *stage;  // experiment: finished rows parked in LDS, stored after the stream (no store in the load stream)
-    int gq;         // G-relative position of this lane: stage index = row * G + q
-    int G_;
     __device__ __forceinline__ void put(int row, float4 acc) const {
         if (row_scale) {
             const float s = row_scale[row];
             acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
-        }
-        if (stage) {
-            stage[row * G_ + gq] = acc;
-            return;
         }
         const global_ptr<float> dst = Y + static_cast<int64_t>(row) * ldy + f;
         if (vec) {
@@ -286,11 +279,6 @@ __global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *
     sink.f = f0 + q * 4;
     sink.F = F;
     sink.vec = full && (job.ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
-    const bool defer = (job.reserved & 8) != 0;  // experiment switch: needs LDS room for n_rows * SLAB * 4 more bytes
-    float4 *ystage = reinterpret_cast<float4 *>(rs + ((n_rows + 3) & ~3));
-    sink.stage = defer ? ystage : nullptr;
-    sink.gq = q;
-    sink.G_ = G;
     if (job.val) aggregate_rows<G, true>(xs, rp, job.col, job.val, row0, row1, q, n_cols, sink);
     else aggregate_rows<G, false>(xs, rp, job.col, (global_ptr<const float>)nullptr, row0, row1, q, n_cols, sink);
     WDG_STAMP(3);
@@ -298,15 +286,6 @@ __global__ __launch_bounds__(THREADS) void spmm_slab_kernel(const wdg_spmm_job *
     __syncthreads();
     WDG_STAMP(4);
 #endif
-    if (defer) {
-        __syncthreads();
-        sink.stage = nullptr;
-        sink.row_scale = nullptr;
-        for (int i = tid; i < n_rows * G; i += THREADS) {
-            sink.f = f0 + (i % G) * 4;
-            sink.put(i / G, ystage[i]);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
