@@ -95,3 +95,47 @@ def test_full_sweep_batch_every_item_exactly_once(monkeypatch, variant, env, fam
             assert not bool(torch.isnan(y).any()), (variant, launch, i)
             if i in want:
                 assert torch.equal(y, want[i]), (variant, launch, i)
+
+
+@pytest.mark.parametrize("kind", ["sgc", "gcn"])
+def test_batched_training_matches_per_graph_training(kind):
+    """SURVEY 8(f) N4, batched: every graph's model trained inside one batch of launches (manual gradients through the
+    transposed graphs, one Adam over the stacked parameters, epoch replayed from a hipGraph) ends where the per-graph
+    autograd training of models.py ends when started from the same weights and splits."""
+    from wdg_amd import models, sweep, synth
+    jobs = sweep.make_jobs([0.2, 0.5, 0.8], range(2), k=2, n_nodes=600)
+    sb = sweep.SweepBatch(jobs, n_feat=64, gcn_hidden=0)
+    for s in sb.x:  # features with class signal, so that there is something to learn
+        lab = synth.regular_graph(600, 5, 2, 0.5, s)[2]
+        sb.x[s].copy_(torch.from_numpy(synth.features(600, 64, s, labels=lab)))
+    epochs = 12
+    res = {}
+    for capture in (False, True):
+        tb = sweep.TrainBatch(sb, kind=kind, hidden=16, seed=3)
+        init = [p.detach().clone() for p in tb.params]
+        res[capture] = (tb.run(epochs=epochs, capture=capture), [p.detach().clone() for p in tb.params], tb)
+    for a, b in zip(res[False][1], res[True][1]):  # graph replay == eager launches, bitwise
+        assert torch.equal(a, b)
+    assert torch.equal(res[False][0]["val_acc"], res[True][0]["val_acc"])
+    out, weights, tb = res[True]
+    for j in (0, 3, 5):  # per-graph autograd training from the same start
+        adj = models.NormAdj(sb.graphs[j], add_self_loops=False)
+        masks = []
+        for idx in (tb.tr[j], tb.va[j], tb.te[j]):
+            m = torch.zeros(600, dtype=torch.bool, device="cuda")
+            m[idx] = True
+            masks.append(m)
+        if kind == "sgc":
+            model = models.SGC1(64, 5)
+            with torch.no_grad():
+                model.weight.copy_(init[0][j])
+        else:
+            model = models.GCN2(64, 5, nhid=16, dropout=0.0)
+            with torch.no_grad():
+                model.w0.copy_(init[0][j]); model.w1.copy_(init[1][j])
+        ref = models.train_eval_graphed(model.cuda(), adj, sb.x[jobs[j].seed], tb.labels[j], masks=masks, epochs=epochs, capture=False)
+        got = [w[j] for w in weights]
+        for g, p in zip(got, model.parameters()):
+            torch.testing.assert_close(g, p.detach(), rtol=2e-3, atol=2e-4)
+        assert abs(float(out["val_acc"][j]) - ref["val_acc"]) <= 2.5 / tb.va.shape[1]
+    assert float(out["val_acc"].mean()) > 0.3

@@ -243,3 +243,173 @@ class SweepBatch:
         li = 2 - (pc * torch.log(pc)).sum((1, 2)) / (p_bar * torch.log(p_bar)).sum(1)
         soft_las = self.las.counts[:, 0].to(torch.float32) / self.las.n
         return torch.stack([edge, node, cls, adj, li, soft_las], 1)
+
+
+class TrainBatch:
+    """Train + evaluate one model per graph for ALL graphs of a shard at once (the sweep's graphs/s
+    with the model loop).  Every stage of an epoch is one batched launch over the job tables (aggregations forward and
+    through the transposed graphs backward, GEMMs forward and for both gradients); PyTorch supplies the stacked
+    parameters, log-softmax / NLL gradient on the stacked logits, the ReLU masks and one Adam over all models.  Shapes
+    are static, nothing syncs with the host: an epoch (train step + evaluation + model selection) is captured once and
+    replayed as a hipGraph.
+
+        kind "sgc":  logits_j = (A_hat_j X) W_j                    (the aggregation Y_j is computed once)
+        kind "gcn":  logits_j = A_hat_j relu(A_hat_j (X W0_j)) W1_j   (hidden 64)
+    Per-graph reference with identical arithmetic: models.train_eval_graphed."""
+
+    def __init__(self, sb, kind="gcn", hidden=64, lr=0.01, weight_decay=5e-4, train_frac=0.6, seed=0):
+        from .utils.util_funcs import random_disassortative_splits
+        ops = sb.ops
+        self.sb, self.kind = sb, kind
+        jobs = sb.jobs
+        J = len(jobs)
+        n, c, f = jobs[0].n_nodes, sb.n_classes, sb.n_feat
+        if any(j.n_nodes != n for j in jobs):
+            raise ValueError("TrainBatch: graphs of one batch must have the same node count")
+        dev = sb.graphs[0].device
+        self.J, self.n, self.c, self.f, self.h = J, n, c, f, hidden
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        labels = torch.stack([l.long() for l in sb.labels])  # [J, n]
+        torch.manual_seed(seed)
+        tr, va, te = [], [], []
+        for j in range(J):  # the reference's split routine per graph (same sizes for every graph: balanced classes)
+            a, b, d = random_disassortative_splits(labels[j].cpu(), labels[j].max().cpu() + 1, train_frac)
+            tr.append(a.nonzero().flatten()); va.append(b.nonzero().flatten()); te.append(d.nonzero().flatten())
+        self.tr, self.va, self.te = (torch.stack(t).to(dev) for t in (tr, va, te))  # [J, n_split] row indices
+        self.y_tr, self.y_va, self.y_te = (labels.gather(1, t) for t in (self.tr, self.va, self.te))
+        self.labels = labels
+
+        def xavier(*shape):
+            bound = (6.0 / (shape[-2] + shape[-1])) ** 0.5
+            return ((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(dev)
+
+        self.logits = torch.empty((J, n, c), device=dev)
+        self.dlogits = torch.zeros((J, n, c), device=dev)
+        graphs_t = [g.transpose() for g in sb.graphs]
+        rs = sb.dinv  # A_hat = diag(dinv) (A + I) (random-walk normalisation of the sweep); A_hat^T = (A + I)^T diag(dinv)
+
+        def fwd_spmm(xs, ys):
+            return ops.SpmmBatch([(g, x, y, d, None, False) for g, x, y, d in zip(sb.graphs, xs, ys, rs)])
+
+        def bwd_spmm(xs, ys):
+            return ops.SpmmBatch([(gt, x, y, None, d, False) for gt, x, y, d in zip(graphs_t, xs, ys, rs)])
+
+        if kind == "sgc":
+            sb.spmm.launch()  # Y_j = A_hat_j X, once
+            torch.cuda.synchronize()
+            self.yt = torch.stack([y.t().contiguous() for y in sb.y])  # [J, F, n] for dW = Y^T dlogits
+            self.w = torch.nn.Parameter(xavier(J, f, c))
+            self.w.grad = torch.zeros_like(self.w)
+            self.params = [self.w]
+            self.fwd = [ops.GemmBatch([(sb.y[j], self.w.data[j], self.logits[j], None) for j in range(J)])]
+            self.bwd = [ops.GemmBatch([(self.yt[j], self.dlogits[j], self.w.grad[j], None) for j in range(J)])]
+        elif kind == "gcn":
+            xt = {s: x.t().contiguous() for s, x in sb.x.items()}  # X^T per seed, for dW0 = X^T dP
+            self.w0 = torch.nn.Parameter(xavier(J, f, hidden))
+            self.w1 = torch.nn.Parameter(xavier(J, hidden, c))
+            self.w0.grad, self.w1.grad = torch.zeros_like(self.w0), torch.zeros_like(self.w1)
+            self.params = [self.w0, self.w1]
+            z = lambda *s: torch.empty((J,) + s, device=dev)  # noqa: E731
+            self.p, self.hid, self.hid_t, self.z = z(n, hidden), z(n, hidden), z(hidden, n), z(n, c)
+            self.dz, self.dhid, self.dp, self.w1t = z(n, c), z(n, hidden), z(n, hidden), z(c, hidden)
+            xs = [sb.x[j.seed] for j in jobs]
+            self.fwd = [ops.GemmBatch([(xs[j], self.w0.data[j], self.p[j], None) for j in range(J)]),   # P = X W0
+                        fwd_spmm(self.p, self.hid),                                                      # A_hat P (relu below)
+                        ops.GemmBatch([(self.hid[j], self.w1.data[j], self.z[j], None) for j in range(J)]),  # Z = H W1
+                        fwd_spmm(self.z, self.logits)]                                                   # logits = A_hat Z
+            self.bwd = [bwd_spmm(self.dlogits, self.dz),                                                 # dZ = A_hat^T dlogits
+                        ops.GemmBatch([(self.hid_t[j], self.dz[j], self.w1.grad[j], None) for j in range(J)]),  # dW1 = H^T dZ
+                        ops.GemmBatch([(self.dz[j], self.w1t[j], self.dhid[j], None) for j in range(J)]),       # dH = dZ W1^T
+                        bwd_spmm(self.dhid, self.dp),                                                    # dP = A_hat^T (dH * mask)
+                        ops.GemmBatch([(xt[jobs[j].seed], self.dp[j], self.w0.grad[j], None) for j in range(J)])]  # dW0 = X^T dP
+        else:
+            raise ValueError(f"unknown model kind {kind!r}")
+        self.opt = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay, capturable=True)
+        self.best_val = torch.full((J,), -1.0, device=dev)
+        self.best_test = torch.zeros(J, device=dev)
+        self.graph = None
+
+    # -- one epoch ---------------------------------------------------------------------------------------------
+    def _forward(self):
+        if self.kind == "sgc":
+            self.fwd[0].launch()
+        else:
+            self.fwd[0].launch()
+            self.fwd[1].launch()
+            self.hid.clamp_(min=0)  # relu
+            self.fwd[2].launch()
+            self.fwd[3].launch()
+
+    def train_step(self):
+        self._forward()
+        with torch.no_grad():
+            # d(mean NLL over the training rows) / dlogits = (softmax - onehot) / n_train on those rows, 0 elsewhere
+            sm = torch.softmax(self.logits.gather(1, self.tr.unsqueeze(-1).expand(-1, -1, self.c)), 2)
+            sm.scatter_add_(2, self.y_tr.unsqueeze(-1), torch.full_like(sm[..., :1], -1.0))
+            self.dlogits.zero_()
+            self.dlogits.scatter_(1, self.tr.unsqueeze(-1).expand(-1, -1, self.c), sm / self.tr.shape[1])
+            if self.kind == "sgc":
+                self.bwd[0].launch()
+            else:
+                self.bwd[0].launch()
+                self.hid_t.copy_(self.hid.transpose(1, 2))
+                self.bwd[1].launch()
+                self.w1t.copy_(self.w1.data.transpose(1, 2))
+                self.bwd[2].launch()
+                self.dhid.mul_(self.hid > 0)
+                self.bwd[3].launch()
+                self.bwd[4].launch()
+        self.opt.step()
+
+    def eval_step(self):
+        with torch.no_grad():
+            self._forward()
+            pred = self.logits.argmax(2)
+            v = (pred.gather(1, self.va) == self.y_va).float().mean(1)
+            t = (pred.gather(1, self.te) == self.y_te).float().mean(1)
+            better = v > self.best_val
+            self.best_test.copy_(torch.where(better, t, self.best_test))
+            self.best_val.copy_(torch.where(better, v, self.best_val))
+
+    def epoch(self):
+        self.train_step()
+        self.eval_step()
+
+    def capture(self):
+        """Capture one epoch as a hipGraph (after a warm-up whose effects are rewound); returns the replay callable."""
+        saved = [p.detach().clone() for p in self.params]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.epoch()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, s in zip(self.params, saved):
+                p.copy_(s)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            self.best_val.fill_(-1.0)
+            self.best_test.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.epoch()
+        with torch.no_grad():
+            for p, s in zip(self.params, saved):
+                p.copy_(s)
+        return self.graph.replay
+
+    def run(self, epochs=200, capture=True):
+        """-> dict(val_acc [J], test_acc [J], seconds, graphs_per_s): train + evaluate every model for `epochs` epochs."""
+        import time
+        step = self.capture() if capture else self.epoch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dict(val_acc=self.best_val.cpu(), test_acc=self.best_test.cpu(), seconds=dt, graphs_per_s=self.J / dt, epochs=epochs)
