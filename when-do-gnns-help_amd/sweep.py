@@ -341,7 +341,7 @@ class TrainBatch:
             self.fwd[3].launch()
 
     def train_step(self):
-        self._forward()
+        # (the forward pass of these weights has been run already: by the previous epoch's evaluation, or by run())
         with torch.no_grad():
             # d(mean NLL over the training rows) / dlogits = (softmax - onehot) / n_train on those rows, 0 elsewhere
             sm = torch.softmax(self.logits.gather(1, self.tr.unsqueeze(-1).expand(-1, -1, self.c)), 2)
@@ -372,6 +372,8 @@ class TrainBatch:
             self.best_val.copy_(torch.where(better, v, self.best_val))
 
     def epoch(self):
+        """gradient of the current logits -> Adam step -> forward with the new weights -> evaluation.  The evaluation's
+        forward pass is the next epoch's training forward pass (no dropout: the two would be identical)."""
         self.train_step()
         self.eval_step()
 
@@ -381,6 +383,8 @@ class TrainBatch:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            with torch.no_grad():
+                self._forward()
             for _ in range(2):
                 self.epoch()
         torch.cuda.current_stream().wait_stream(side)
@@ -406,6 +410,8 @@ class TrainBatch:
         """-> dict(val_acc [J], test_acc [J], seconds, graphs_per_s): train + evaluate every model for `epochs` epochs."""
         import time
         step = self.capture() if capture else self.epoch
+        with torch.no_grad():
+            self._forward()  # logits of the initial weights
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(epochs):
