@@ -274,6 +274,14 @@ typedef struct wdg_gemm_job {
 } wdg_gemm_job;
 int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
                          wdg_stream_t stream);
+/* Same, with what the host knows about the table: max_K = the largest K, flags = WDG_GEMM_*.  With WDG_GEMM_A_VEC4 the
+ * caller promises that in EVERY job A is 16-byte aligned, lda % 4 == 0 and K % 4 == 0 (any contiguous fp32 row-major
+ * activation matrix with K % 4 == 0); tall-skinny tables (max_N <= 64, max_K <= 512, max_M >= 256) then run on the
+ * B-resident kernel (B of a job copied to LDS once, A streamed straight into the MFMA operand layout, no K-step
+ * barriers).  Results are bit-identical either way (same fp32 fma chain in k order). */
+#define WDG_GEMM_A_VEC4 1u
+int wdg_gemm_batched_flags_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
+                               int32_t max_K, uint32_t flags, wdg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -25,3 +25,10 @@ for jobs in (1, 4, 16, 32, 64, 100, 200):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     print(f"jobs={jobs:4d} workgroups={jobs * 16:5d}: {us:8.1f} us  {2.0 * m * k * n * jobs / us / 1e6:7.1f} TFLOP/s  A stream {4.0 * m * k * jobs / us / 1e6:6.2f} TB/s", flush=True)
+    if os.environ.get("WDG_GEMM_CHECK"):
+        os.environ["WDG_GEMM_TILE"] = "1"
+        c2 = [torch.empty(m, n, device="cuda") for _ in range(jobs)]
+        ops.GemmBatch(list(zip(a, b, c2, [None] * jobs)), relu=True).launch()
+        torch.cuda.synchronize()
+        del os.environ["WDG_GEMM_TILE"]
+        print("   bitwise equal to the tile kernel:", all(torch.equal(x, y) for x, y in zip(c, c2)), flush=True)

@@ -636,6 +636,76 @@ def test_gemm_is_a_k_ordered_fp32_fma_chain(ops):
     np.testing.assert_array_equal(out, ref)
 
 
+def _fma_chain(a, b, bias=None, relu=False):
+    """the k-ordered fp32 fma chain (one rounding per step), bias added last, then relu"""
+    out = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    for kk in range(a.shape[1]):
+        out = (a[:, kk:kk + 1].astype(np.float64) * b[kk:kk + 1, :].astype(np.float64) + out.astype(np.float64)).astype(np.float32)
+    if bias is not None:
+        out = out + bias[None, :]
+    return np.maximum(out, 0) if relu else out
+
+
+@pytest.mark.parametrize("m,n,k,lda_pad", [(2000, 64, 500, 0), (257, 64, 512, 0), (300, 5, 64, 0), (1000, 33, 20, 4),
+                                            (31, 32, 36, 0), (640, 17, 4, 8), (2048, 64, 100, 0), (999, 48, 228, 12)])
+def test_gemm_b_resident_kernel_single(ops, oracle, monkeypatch, m, n, k, lda_pad):
+    """The B-resident kernel (B in LDS, A streamed into the MFMA layout through v_permlane32_swap), forced for every
+    shape it accepts: K % 32 leftovers, ragged last row tile, N below / across the two column tiles, padded lda, bias
+    + relu.  Bitwise equal to the k-ordered fma chain and to the tile kernel; the oracle within 1e-5."""
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    store = rng.standard_normal((m, k + lda_pad)).astype(np.float32)
+    a = store[:, :k]
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    at = torch.from_numpy(store).cuda()[:, :k]
+    bt, biast = torch.from_numpy(b).cuda(), torch.from_numpy(bias).cuda()
+    monkeypatch.setenv("WDG_GEMM_RESIDENT", "1")
+    plain, fused = _np(ops.gemm(at, bt)), _np(ops.gemm(at, bt, bias=biast, relu=True))
+    monkeypatch.delenv("WDG_GEMM_RESIDENT")
+    monkeypatch.setenv("WDG_GEMM_TILE", "1")
+    np.testing.assert_array_equal(plain, _np(ops.gemm(at, bt)))
+    np.testing.assert_array_equal(fused, _np(ops.gemm(at, bt, bias=biast, relu=True)))
+    np.testing.assert_array_equal(plain, _fma_chain(a, b))
+    np.testing.assert_array_equal(fused, _fma_chain(a, b, bias, relu=True))
+    ref = oracle.gemm(np.ascontiguousarray(a), b, bias, relu=True)
+    np.testing.assert_allclose(fused, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
+def test_gemm_b_resident_kernel_batched(ops, monkeypatch):
+    """A job table with different M, N, K per job on the B-resident kernel (its LDS is sized by the largest K, its row
+    chunks by the largest M), with and without bias, against the tile kernel bit for bit; a table whose A is not
+    vectorisable (K % 4 != 0) must fall back to the tile kernel by itself."""
+    rng = np.random.default_rng(77)
+    shapes = [(2000, 64, 500), (700, 64, 500), (33, 5, 64), (1200, 40, 260), (512, 64, 32), (1, 1, 4), (900, 64, 508)]
+    entries, outs = [], []
+    for i, (m, n, k) in enumerate(shapes):
+        a = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32)).cuda()
+        b = torch.from_numpy(rng.standard_normal((k, n)).astype(np.float32)).cuda()
+        bias = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda() if i % 2 else None
+        entries.append((a, b, torch.full((m, n), float("nan"), device="cuda"), bias))
+    batch = ops.GemmBatch(entries, relu=True)
+    assert batch.flags == ops.GEMM_A_VEC4 and batch.max_k == 508
+    monkeypatch.setenv("WDG_GEMM_RESIDENT", "1")
+    batch.launch()
+    torch.cuda.synchronize()
+    outs = [e[2].clone() for e in entries]
+    monkeypatch.delenv("WDG_GEMM_RESIDENT")
+    monkeypatch.setenv("WDG_GEMM_TILE", "1")
+    for e in entries:
+        e[2].fill_(float("nan"))
+    batch.launch()
+    torch.cuda.synchronize()
+    for (a, b, c, bias), got in zip(entries, outs):
+        assert torch.equal(c, got)
+        np.testing.assert_array_equal(_np(got), _fma_chain(_np(a), _np(b), None if bias is None else _np(bias), relu=True))
+    monkeypatch.delenv("WDG_GEMM_TILE")
+    odd = ops.GemmBatch([(torch.ones(300, 6, device="cuda"), torch.ones(6, 3, device="cuda"), torch.empty(300, 3, device="cuda"), None)])
+    assert odd.flags == 0
+    monkeypatch.setenv("WDG_GEMM_RESIDENT", "1")
+    odd.launch()
+    assert torch.equal(odd.keep[0][2], torch.full((300, 3), 6.0, device="cuda"))
+
+
 def test_edge_cosine_sddmm(ops, oracle):
     rng = np.random.default_rng(41)
     for n, f, e in ((500, 37, 6000), (2708, 1433, 13000), (30, 3, 200)):

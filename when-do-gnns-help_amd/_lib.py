@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwdg_hip.so")
 
 c_void_p, c_int, c_int32, c_int64, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
                                                ctypes.c_size_t)
+c_uint32 = ctypes.c_uint32
 
 
 class WdgError(RuntimeError):
@@ -76,6 +77,7 @@ SIGNATURES = {
     "wdg_gemm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64,
                              c_int32, c_int32, c_int32, c_void_p]),
     "wdg_gemm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_gemm_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
     "wdg_las_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
 }
 

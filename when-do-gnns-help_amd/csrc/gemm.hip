@@ -22,6 +22,42 @@ constexpr int LDA_S = BK + 1;  // As[m][k], odd stride -> lanes m=0..31 hit dist
 
 // One launch serves a single problem (descriptor by value) or a table of independent problems (blockIdx.z = job):
 // the sweep transforms every graph's features with that graph's own weights in one go.
+// Epilogue of one 32-row x (NT x 32)-column tile held in MFMA accumulators.  C/D map of a 32x32 tile: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The bias values are loaded BEFORE the K loop (tile_bias) and pinned here:
+// a load first used inside the store sequence makes the compiler put s_waitcnt vmcnt(0) in front of every store, which
+// also waits for the previous store (one counter) - 32 serialised stores per wave.  Rows are walked by pointer.
+template <int NT>
+__device__ __forceinline__ void tile_bias(global_ptr<const float> bias, int col0, int li, int N, float (&bv)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int gn = col0 + t * 32 + li;
+        bv[t] = (bias && gn < N) ? bias[gn] : 0.f;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void tile_store(const f32x16 (&acc)[NT], float (&bv)[NT], global_ptr<float> C, int64_t ldc, int row0,
+                                           int col0, int li, int lk, int M, int N, int act) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(bv[t]));  // the one wait for the bias load lands here
+    const bool relu = act == WDG_ACT_RELU;
+    const bool full = row0 + 32 <= M;  // uniform
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int gn = col0 + t * 32 + li;
+        if (gn >= N) continue;
+        global_ptr<float> p = C + static_cast<int64_t>(row0 + 4 * lk) * ldc + gn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[t][r] + bv[t];
+            if (relu) v = fmaxf(v, 0.f);
+            if (full || row0 + (r & 3) + 8 * (r >> 2) + 4 * lk < M) *p = v;
+            p += ((r & 3) == 3) ? 5 * ldc : ldc;
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four store addresses live at a time
+        }
+    }
+}
+
 template <int NT, bool TRANSB>
 __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *__restrict__ jobs,
                                                            const wdg_gemm_job inline_job) {
@@ -90,6 +126,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int li = lane & 31, lk = lane >> 5;
+    float bv[NT];
+    tile_bias<NT>(bias, n0, li, N, bv);
     load_tiles(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();  // previous step's operand reads are done
@@ -109,22 +147,175 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
         }
     }
 
-    // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    tile_store<NT>(acc, bv, C, ldc, m0 + wave * 32, n0, li, lk, M, N, act);
+}
+
+// ------------------------------------------------------------------------------------------------ B-resident kernel
+// Tall-skinny products whose whole B fits the LDS (K x 64 floats <= 128 KiB: the sweep's Y W0 with K = 500, N = 64) need no
+// K-step machinery at all: a 1024-thread workgroup copies B into LDS ONCE, after which its 16 waves are independent -
+// each takes 32-row tiles of A and runs the full K loop without a single barrier: the A operand comes straight from
+// memory (lane i and lane i + 32 read 16 consecutive floats each of row i per group, one group ahead, and trade halves
+// with v_permlane32_swap into the k = 2h / 2h + 1 split v_mfma_f32_32x32x2_f32 wants, see bres_compute), the
+// B operand is a conflict-free ds_read_b32 (32 consecutive floats of row k + j).  The shipped tile kernel spends 136 of
+// its 185 us on this launch in its load -> LDS -> barrier -> operand-read chain per K-step; here that chain is gone.
+// Same arithmetic: one fp32 fma chain in k order per output element -> bit-identical to the tile kernel.
+constexpr int BRES_THREADS = 1024, BRES_COLS = 64;
+
+struct BresGroup {  // 16 consecutive floats of one A row per lane = 32 consecutive k between the lane pair (i, i + 32)
+    f32x4_t r[4];
+};
+
+// MFMA operands of 32 consecutive k from a group: lane i holds k = base + 0..15, lane i + 32 holds k = base + 16..31, the
+// 32x32x2 MFMA wants k = 2h in lane i and k = 2h + 1 in lane i + 32: two v_permlane32_swap per float4 (x <-> y and
+// z <-> w across the halves of the wave) produce exactly that - x', z' serve k = 4j .. 4j + 3 and y', w' serve
+// k = 16 + 4j .. 16 + 4j + 3 - with no select and no duplicated load.  Steps are issued in ascending k.
+template <int NT>
+__device__ __forceinline__ void bres_compute(const BresGroup &grp, int kbase, int lk, int li, const float *Bres,
+                                             f32x16 (&acc)[NT]) {
+    float lo[8], hi[8];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int gn = n0 + t * 32 + li;
-        if (gn >= N) continue;
-        const float bv = bias ? bias[gn] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+        const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(grp.r[j].x), __float_as_uint(grp.r[j].y), false, false);
+        const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(grp.r[j].z), __float_as_uint(grp.r[j].w), false, false);
+        lo[2 * j] = __uint_as_float(xy[0]), hi[2 * j] = __uint_as_float(xy[1]);
+        lo[2 * j + 1] = __uint_as_float(zw[0]), hi[2 * j + 1] = __uint_as_float(zw[1]);
+    }
+    // B operands are read one chunk of CH steps ahead of the MFMAs that use them (ds_read latency off the MFMA chain)
+    constexpr int CH = 2, CHUNKS = 16 / CH;
+    float bq[2][CH][NT];
+    auto read_chunk = [&](int c, float (&dst)[CH][NT]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gm = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (gm < M) {
-                float v = acc[t][r] + bv;
-                if (act == WDG_ACT_RELU) v = fmaxf(v, 0.f);
-                C[static_cast<int64_t>(gm) * ldc + gn] = v;
-            }
+        for (int s = 0; s < CH; ++s) {
+            const int row = kbase + 2 * (CH * c + s) + lk;  // k is even: row k + lk is odd iff lk; rows K .. are zero
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dst[s][t] = Bres[row * BRES_COLS + ((t * 32 + li) ^ (lk << 5))];
+        }
+    };
+    read_chunk(0, bq[0]);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        if (c + 1 < CHUNKS) read_chunk(c + 1, bq[(c + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int h = CH * c + s;  // this step covers k = kbase + 2 h and k + 1
+            const float a = h < 8 ? lo[h] : hi[h - 8];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[c & 1][s][t], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(BRES_THREADS) void gemm_bres_kernel(const wdg_gemm_job *__restrict__ jobs,
+                                                                   const wdg_gemm_job inline_job, int n_parts) {
+    extern __shared__ float Bres[];  // [K rounded up to 32][64], columns >= N and rows >= K zero
+    const int job_id = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
+    const desc_ptr<wdg_gemm_job> job = descriptor(jobs, inline_job, job_id);
+    const global_ptr<const float> A = to_global(job->A), B = to_global(job->B), bias = to_global(job->bias);
+    const global_ptr<float> C = to_global(job->C);
+    const int64_t lda = job->lda, ldb = job->ldb, ldc = job->ldc;
+    const int M = job->M, N = job->N, K = job->K, act = job->act;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    if (M <= 0 || N <= 0) return;
+    // B -> LDS, eight loads in flight per thread.  Odd rows are stored with their column halves swapped (column ^ 32):
+    // the operand read of lane half j = 1 (row k + 1) then falls into the other 32 banks than half j = 0 (row k).
+    const int k_rows = (K + 31) / 32 * 32;  // the LDS holds whole groups of 32 rows; rows >= K are zero
+    for (int base = threadIdx.x; base < k_rows * BRES_COLS; base += 8 * BRES_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * BRES_THREADS, k = idx / BRES_COLS, n = idx % BRES_COLS;
+            v[u] = (k < K && n < N) ? B[static_cast<int64_t>(k) * ldb + n] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * BRES_THREADS, k = idx / BRES_COLS;
+            if (idx < k_rows * BRES_COLS) Bres[idx ^ ((k & 1) << 5)] = v[u];
         }
     }
+    __syncthreads();  // the only barrier
+
+    const int tiles = (M + 31) / 32, per_part = (tiles + n_parts - 1) / n_parts;
+    const int t_end = min((part + 1) * per_part, tiles);
+    const int full = K / 32;
+    for (int tile = part * per_part + wave; tile < t_end; tile += BRES_THREADS / 64) {
+        const int gm = tile * 32 + li;
+        const global_ptr<const float> a_lane = A + static_cast<int64_t>(gm < M ? gm : M - 1) * lda + 16 * lk;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        float bv[NT];
+        tile_bias<NT>(bias, 0, li, N, bv);
+        BresGroup g0, g1;
+        auto load_group = [&](int g, BresGroup &dst) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst.r[j] = *(const global_ptr<const f32x4_t>)(a_lane + g * 32 + j * 4);
+        };
+        int g = 0;
+        if (full > 0) load_group(0, g0);
+        for (; g + 2 <= full; g += 2) {  // two groups per trip, each loaded one group of MFMAs ahead, no register moves
+            load_group(g + 1, g1);
+            __builtin_amdgcn_sched_barrier(0);  // keep load / compute phases in this order: the waits count on it
+            bres_compute<NT>(g0, g * 32, lk, li, Bres, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load_group(min(g + 2, full - 1), g0);  // unconditional (re-reads the last group at the end): no branch
+            __builtin_amdgcn_sched_barrier(0);
+            bres_compute<NT>(g1, (g + 1) * 32, lk, li, Bres, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g < full) bres_compute<NT>(g0, g * 32, lk, li, Bres, acc), ++g;
+        if (full * 32 < K) {  // K % 32 leftover (K % 4 == 0): float4s past K read as zero and meet zero rows of B; adding
+                              // +0 products to an accumulator that started at +0 never changes a bit
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k0 = full * 32 + 16 * lk + j * 4;
+                g1.r[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (k0 < K) g1.r[j] = *(const global_ptr<const f32x4_t>)(a_lane + full * 32 + j * 4);
+            }
+            bres_compute<NT>(g1, full * 32, lk, li, Bres, acc);
+        }
+        tile_store<NT>(acc, bv, C, ldc, tile * 32, 0, li, lk, M, N, act);
+    }
+}
+
+// Shapes the B-resident kernel takes (everything the host can see; the per-job operands of a table must be promised
+// aligned by the caller: 16-byte aligned A, lda % 4 == 0 - every row-major fp32 torch tensor with K % 4 == 0 is), and
+// where it pays: it has a floor of one full K loop per wave (about 70 us at K = 500), so the tile kernel keeps the
+// launches that do not fill the chip about three times over (measured crossover at M = 2000, K = 500, N = 64: 32 jobs
+// 58 us tile / 77 us resident, 64 jobs 114 / 90, 100 jobs 200 / 159-175).
+bool bres_shape_ok(int n_jobs, int max_M, int max_N, int K) {
+    if (!(max_N <= BRES_COLS && K > 0 && K % 4 == 0 && ceil_div(K, 32) * 32 * BRES_COLS * 4 <= 128 * 1024)) return false;
+    if (getenv("WDG_GEMM_TILE")) return false;
+    if (getenv("WDG_GEMM_RESIDENT")) return true;  // tests: take the kernel whenever the shape allows
+    return static_cast<int64_t>(n_jobs) * ceil_div(max_M, BM) >= 3 * std::max(wdg_device_cus(), 8);
+}
+
+int launch_bres(const wdg_gemm_job *jobs, const wdg_gemm_job &inl, int n_jobs, int max_M, int max_N, int K, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        for (const void *k : {reinterpret_cast<const void *>(gemm_bres_kernel<1>), reinterpret_cast<const void *>(gemm_bres_kernel<2>)})
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+        configured = true;
+    }
+    const int tiles = static_cast<int>(ceil_div(max_M, 32));
+    const int cus = std::max(wdg_device_cus(), 8);
+    // row chunks per job: the fewest that minimise (workgroup rounds on the chip) x (16-tile rounds inside a workgroup)
+    int parts = 1;
+    int64_t best = INT64_MAX;
+    for (int p = 1; p <= 16 && (p == 1 || tiles / p >= 8); ++p) {
+        const int64_t cost = ceil_div(static_cast<int64_t>(n_jobs) * p, cus) * ceil_div(ceil_div(tiles, p), BRES_THREADS / 64);
+        if (cost < best) best = cost, parts = p;
+    }
+    const size_t lds = static_cast<size_t>(ceil_div(K, 32) * 32) * BRES_COLS * 4;
+    const dim3 grid(static_cast<unsigned>(n_jobs) * parts);
+    if (max_N > 32) hipLaunchKernelGGL(gemm_bres_kernel<2>, grid, dim3(BRES_THREADS), lds, st, jobs, inl, parts);
+    else hipLaunchKernelGGL(gemm_bres_kernel<1>, grid, dim3(BRES_THREADS), lds, st, jobs, inl, parts);
+    return check_launch("gemm_bres_kernel");
 }
 
 }  // namespace
@@ -139,6 +330,13 @@ int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int t
     WDG_REQUIRE(lda >= K && ldc >= N && ldb >= (transb ? K : N), "gemm: leading dimension too small");
     WDG_REQUIRE(act == WDG_ACT_NONE || act == WDG_ACT_RELU, "gemm: bad activation");
     hipStream_t st = wdg::as_stream(stream);
+    if (!transb && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0 && bres_shape_ok(1, M, N, K)) {
+        wdg_gemm_job jb{};
+        jb.A = A; jb.B = B; jb.bias = bias; jb.C = C;
+        jb.lda = lda; jb.ldb = ldb; jb.ldc = ldc;
+        jb.M = M; jb.N = N; jb.K = K; jb.act = act;
+        return launch_bres(nullptr, jb, 1, M, N, K, st);
+    }
     const bool wide = N > 32;
     const dim3 grid(static_cast<unsigned>(wdg::ceil_div(M, BM)), static_cast<unsigned>(wdg::ceil_div(N, wide ? 64 : 32)));
     wdg_gemm_job j{};
@@ -156,18 +354,25 @@ int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int t
     return wdg::check_launch("gemm_f32_kernel");
 }
 
-int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
-                         wdg_stream_t stream) {
-    WDG_REQUIRE(n_jobs >= 0 && max_M >= 0 && max_N >= 0, "gemm_batched: negative size");
+int wdg_gemm_batched_flags_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N, int32_t max_K,
+                               uint32_t flags, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_M >= 0 && max_N >= 0 && max_K >= 0, "gemm_batched: negative size");
     if (n_jobs == 0 || max_M == 0 || max_N == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev != nullptr, "gemm_batched: null job table");
     WDG_REQUIRE(n_jobs <= 65535, "gemm_batched: more than 65535 jobs per launch");
+    if ((flags & WDG_GEMM_A_VEC4) && bres_shape_ok(n_jobs, max_M, max_N, max_K))
+        return launch_bres(jobs_dev, wdg_gemm_job{}, n_jobs, max_M, max_N, max_K, wdg::as_stream(stream));
     const bool wide = max_N > 32;
     const dim3 grid(static_cast<unsigned>(wdg::ceil_div(max_M, BM)), static_cast<unsigned>(wdg::ceil_div(max_N, wide ? 64 : 32)),
                     static_cast<unsigned>(n_jobs));
     if (wide) hipLaunchKernelGGL((gemm_f32_kernel<2, false>), grid, dim3(THREADS), 0, wdg::as_stream(stream), jobs_dev, wdg_gemm_job{});
     else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), grid, dim3(THREADS), 0, wdg::as_stream(stream), jobs_dev, wdg_gemm_job{});
     return wdg::check_launch("gemm_f32_kernel (batched)");
+}
+
+int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
+                         wdg_stream_t stream) {
+    return wdg_gemm_batched_flags_f32(jobs_dev, n_jobs, max_M, max_N, 0, 0, stream);
 }
 
 }  // extern "C"

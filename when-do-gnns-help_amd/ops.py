@@ -357,6 +357,7 @@ class SpmmBatch:
 
 
 SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK = 1, 2, 4
+GEMM_A_VEC4 = 1
 
 
 def spmm_plan(n_rows, n_cols, n_feat, n_jobs=1, flags=0):
@@ -459,8 +460,9 @@ class GemmBatch:
         dev = require_gpu()
         self.keep = entries
         arr = (_lib.GemmJob * len(entries))()
-        self.max_m = self.max_n = 0
+        self.max_m = self.max_n = self.max_k = 0
         self.flops = 0
+        self.flags = GEMM_A_VEC4  # cleared by the first job whose A is not 16-byte aligned with lda % 4 == K % 4 == 0
         for job, (a, b, c, bias) in zip(arr, entries):
             m, k = a.shape
             n = b.shape[1]
@@ -470,15 +472,17 @@ class GemmBatch:
             job.bias = 0 if bias is None else bias.data_ptr()
             job.lda, job.ldb, job.ldc = _ld(a), _ld(b), _ld(c)
             job.M, job.N, job.K, job.act = m, n, k, (ACT_RELU if relu else ACT_NONE)
-            self.max_m, self.max_n = max(self.max_m, m), max(self.max_n, n)
+            self.max_m, self.max_n, self.max_k = max(self.max_m, m), max(self.max_n, n), max(self.max_k, k)
+            if a.data_ptr() % 16 or job.lda % 4 or k % 4:
+                self.flags = 0
             self.flops += 2 * m * n * k
         self.n_jobs = len(entries)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
         self.table = host.to(dev)
 
     def launch(self):
-        check(lib.wdg_gemm_batched_f32(_ptr(self.table), self.n_jobs, self.max_m, self.max_n, stream_handle()),
-              "wdg_gemm_batched_f32")
+        check(lib.wdg_gemm_batched_flags_f32(_ptr(self.table), self.n_jobs, self.max_m, self.max_n, self.max_k, self.flags,
+                                             stream_handle()), "wdg_gemm_batched_flags_f32")
 
 
 # ------------------------------------------------------------------------------------------- per-edge cosine
