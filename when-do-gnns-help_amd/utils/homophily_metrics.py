@@ -233,7 +233,7 @@ def classifier_based_performance_metric(features, adj, labels, sample_max, base_
     """Classifier-based performance metric -> (p_value, seconds).  reference: utils/homophily_metrics.py:260-349.
 
     GPU: the aggregation A X (hoisted out of the epoch loop - it is loop invariant), the sampled
-    Gram products and the arc-cosine map.  Host, exactly as in the reference: split sampling from torch's CPU
+    Gram products and the arc-cosine map (hoisted too when nnodes <= sample_max: the sample is then every node).  Host, exactly as in the reference: split sampling from torch's CPU
     generator, `np.linalg.pinv` (the reference moves the kernels to the CPU for it, :286-290), sklearn GNB/SVM,
     scipy's Welch t-test."""
     from sklearn import svm
@@ -251,6 +251,7 @@ def classifier_based_performance_metric(features, adj, labels, sample_max, base_
     h_agg = ops.spmm(g, features)
     n_cls = int(labels.max().item()) + 1
     labels_cpu = labels.cpu()
+    fixed_kernels = None  # nnodes <= sample_max: every epoch uses all nodes -> the kernels are loop invariant as well
     for j in range(epochs):
         if nnodes <= sample_max:
             sample = np.arange(nnodes)
@@ -265,8 +266,13 @@ def classifier_based_performance_metric(features, adj, labels, sample_max, base_
         idx_train, idx_val = idx_train.cpu(), (idx_val + idx_test).cpu()
         if base_classifier in {'kernel_reg0', 'kernel_reg1'}:
             nlayers = 0 if base_classifier == 'kernel_reg0' else 1
-            K_graph, K = _gntk_from_aggregate(h_agg, features, sample, nlayers)
-            K_graph, K = K_graph.cpu(), K.cpu()
+            if nnodes <= sample_max and fixed_kernels is not None:
+                K_graph, K = fixed_kernels
+            else:
+                K_graph, K = _gntk_from_aggregate(h_agg, features, sample, nlayers)
+                K_graph, K = K_graph.cpu(), K.cpu()
+                if nnodes <= sample_max:
+                    fixed_kernels = (K_graph, K)
             preds = []
             for kern in (K_graph, K):
                 k_tt = kern[idx_train, :][:, idx_train]
