@@ -23,12 +23,17 @@ constexpr int PASSES = 8;            // row tiles per workgroup
 
 template <int GL>
 __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job *__restrict__ jobs,
-                                                             const wdg_stats_job inline_job, int tiles_per_job) {
+                                                             const wdg_stats_job inline_job, int tiles_per_job, int lds_classes) {
     constexpr int ROWS_PER_PASS = THREADS / GL;
     constexpr int ROWS_PER_BLOCK = ROWS_PER_PASS * PASSES;  // several passes per block: one flush of the LDS counters
                                                            // (36 global 64-bit atomics at C = 5) per 128 rows, not per 16
-    __shared__ int hist[MAX_LDS_CLASSES * MAX_LDS_CLASSES];
-    __shared__ long long cdeg[MAX_LDS_CLASSES];
+    // dynamic LDS sized by the launch's largest class count (lds_classes): [lds_classes] 64-bit class degrees, then the
+    // lds_classes^2 int32 histogram - 0.2 KiB at C = 5 instead of a fixed 16.5 KiB, so that the workgroups of this
+    // latency-bound kernel fit beside whatever else is resident (the sweep runs it next to the B-resident GEMM, which
+    // leaves 32 KiB of LDS per CU)
+    extern __shared__ long long stats_lds[];
+    long long *cdeg = stats_lds;
+    int *hist = reinterpret_cast<int *>(stats_lds + lds_classes);
     __shared__ int tot[6];
 
     const int job_id = blockIdx.x / tiles_per_job, tile = blockIdx.x % tiles_per_job;
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
                               row_match_noself = to_global(d->row_match_noself);
     const int N = d->n_rows, C = d->n_classes;
     if (tile * ROWS_PER_BLOCK >= N) return;
-    const bool lds_hist = C <= MAX_LDS_CLASSES;
+    const bool lds_hist = C <= lds_classes;
     if (lds_hist) {
         for (int i = threadIdx.x; i < C * C; i += THREADS) hist[i] = 0;
         for (int i = threadIdx.x; i < C; i += THREADS) cdeg[i] = 0;
@@ -110,15 +115,18 @@ __global__ __launch_bounds__(THREADS) void edge_stats_kernel(const wdg_stats_job
     }
 }
 
-int launch(const wdg_stats_job *jobs, const wdg_stats_job &inl, int n_jobs, int max_rows, int gl, hipStream_t st) {
+int launch(const wdg_stats_job *jobs, const wdg_stats_job &inl, int n_jobs, int max_rows, int max_classes, int gl,
+           hipStream_t st) {
     if (n_jobs == 0 || max_rows == 0) return WDG_OK;
+    const int lds_classes = std::min(std::max(max_classes, 1), MAX_LDS_CLASSES);  // jobs with more classes: global atomics
+    const size_t lds = static_cast<size_t>(lds_classes) * 8 + static_cast<size_t>(lds_classes) * lds_classes * 4;
 #define WDG_STATS_CASE(G)                                                                                     \
     if (gl == G) {                                                                                            \
         const int tiles = static_cast<int>(ceil_div(max_rows, (THREADS / G) * PASSES));                       \
         const int64_t blocks = static_cast<int64_t>(tiles) * n_jobs;                                          \
         if (blocks > 0x7fffffffLL) return fail(WDG_ERR_UNSUPPORTED, "edge_label_stats: grid too large");      \
-        hipLaunchKernelGGL(edge_stats_kernel<G>, dim3(static_cast<unsigned>(blocks)), dim3(THREADS), 0, st, jobs, inl, \
-                           tiles);                                                                            \
+        hipLaunchKernelGGL(edge_stats_kernel<G>, dim3(static_cast<unsigned>(blocks)), dim3(THREADS), lds, st, jobs, inl, \
+                           tiles, lds_classes);                                                               \
         return check_launch("edge_stats_kernel");                                                             \
     }
     WDG_STATS_CASE(4) WDG_STATS_CASE(16) WDG_STATS_CASE(64)
@@ -150,14 +158,14 @@ int wdg_edge_label_stats(const int32_t *rowptr, const int32_t *col, const int32_
     j.n_rows = N; j.n_classes = C;
     // group width from the mean row length is a host-side guess the caller can refine through the batched API;
     // 16 lanes/row suits the 3..100-entry rows of every reference dataset.
-    return launch(nullptr, j, 1, N, 16, st);
+    return launch(nullptr, j, 1, N, C, 16, st);
 }
 
 int wdg_edge_label_stats_batched(const wdg_stats_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_classes,
                                  wdg_stream_t stream) {
     WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_classes >= 0, "edge_label_stats_batched: negative size");
     WDG_REQUIRE(n_jobs == 0 || jobs_dev, "edge_label_stats_batched: null job table");
-    return launch(jobs_dev, wdg_stats_job{}, n_jobs, max_rows, 16, as_stream(stream));
+    return launch(jobs_dev, wdg_stats_job{}, n_jobs, max_rows, max_classes, 16, as_stream(stream));
 }
 
 }  // extern "C"

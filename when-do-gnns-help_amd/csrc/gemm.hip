@@ -311,6 +311,7 @@ int launch_bres(const wdg_gemm_job *jobs, const wdg_gemm_job &inl, int n_jobs, i
         const int64_t cost = ceil_div(static_cast<int64_t>(n_jobs) * p, cus) * ceil_div(ceil_div(tiles, p), BRES_THREADS / 64);
         if (cost < best) best = cost, parts = p;
     }
+    if (const char *e = getenv("WDG_GEMM_PARTS")) parts = std::max(1, atoi(e));  // experiments
     const size_t lds = static_cast<size_t>(ceil_div(K, 32) * 32) * BRES_COLS * 4;
     const dim3 grid(static_cast<unsigned>(n_jobs) * parts);
     if (max_N > 32) hipLaunchKernelGGL(gemm_bres_kernel<2>, grid, dim3(BRES_THREADS), lds, st, jobs, inl, parts);

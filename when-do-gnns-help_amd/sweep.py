@@ -140,7 +140,10 @@ class SweepBatch:
 
         # GCN-2 forward (build-defined model, models.py): logits = A_hat relu((A_hat X) W0) W1, every job its own weights
         self.gcn = None
-        self.side = torch.cuda.Stream() if os.environ.get("WDG_SWEEP_STREAMS", "2") != "1" else None  # see step_rest
+        n_streams = int(os.environ.get("WDG_SWEEP_STREAMS", "3"))  # see step_rest
+        self.side = torch.cuda.Stream() if n_streams >= 2 else None
+        self.side2 = torch.cuda.Stream() if n_streams >= 3 else None
+        self._fork = torch.cuda.Event()
         if gcn_hidden:
             gen = torch.Generator(device="cpu").manual_seed(1234)
             w0 = [(torch.randn((n_feat, gcn_hidden), generator=gen) * (2.0 / (n_feat + gcn_hidden)) ** 0.5).to(dev) for _ in self.jobs]
@@ -183,11 +186,22 @@ class SweepBatch:
         workgroups leaves most CUs idle, which the metric chain's kernels fill."""
         main = torch.cuda.current_stream()
         if self.gcn and self.side is not None:
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                self._metric_chain()
+            self._fork.record(main)  # one marker on the main queue for both side streams
+            self.side.wait_event(self._fork)
+            if self.side2 is not None:
+                self.side2.wait_event(self._fork)
+                with torch.cuda.stream(self.side):
+                    self.stats.launch()
+                with torch.cuda.stream(self.side2):
+                    self.spmm_las.launch()
+                    self.las.launch()
+            else:
+                with torch.cuda.stream(self.side):
+                    self._metric_chain()
             self._gcn_chain()
             main.wait_stream(self.side)
+            if self.side2 is not None:
+                main.wait_stream(self.side2)
         else:
             self._metric_chain()
             if self.gcn:
