@@ -181,9 +181,10 @@ class SweepBatch:
     def step_rest(self):
         """everything of a step after the feature aggregation (bench.py times that launch separately).
 
-        Two independent chains: the metric chain (statistics, label aggregation, LAS: ~75 us of small launches) and the
-        GCN-2 forward (two GEMMs + the logits aggregation).  They run on two HIP streams: the GEMM's second round of
-        workgroups leaves most CUs idle, which the metric chain's kernels fill."""
+        Three independent chains on three HIP streams: the statistics pass, label aggregation -> LAS, and the GCN-2
+        forward (two GEMMs + the logits aggregation).  The B-resident GEMM occupies 200 of the 256 CUs for ~155 us; the
+        small latency-bound kernels of the other two chains use the remaining CUs meanwhile and finish next to the
+        GCN chain's tail (scripts/step_timeline.py on a kernel trace).  WDG_SWEEP_STREAMS=1|2 for fewer streams."""
         main = torch.cuda.current_stream()
         if self.gcn and self.side is not None:
             self._fork.record(main)  # one marker on the main queue for both side streams
@@ -208,7 +209,7 @@ class SweepBatch:
                 self._gcn_chain()
 
     def capture_rest(self):
-        """step_rest() as one hipGraph (both streams, fork / join included): replaying it replaces eight launches and two
+        """step_rest() as one hipGraph (all streams, fork / join included): replaying it replaces eight launches and the
         stream dependencies by one graph launch.  Returns the replay callable; outputs land in the same tensors."""
         for _ in range(2):  # lazy state (kernel attributes, code objects) must exist before the capture
             self.step_rest()
