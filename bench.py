@@ -85,6 +85,7 @@ def main():
         batch.spmm.launch()
         ev[s][1].record()
         step_rest()
+    enqueue_s = time.perf_counter() - t0  # host time to enqueue every step (the device runs behind it)
     rows = batch.results()
     gathered = sweep.gather_results(rows, dev)  # the sweep's one exchange step: per-job metric rows (KBs)
     sync_all()
@@ -136,6 +137,7 @@ def main():
                        "parallelism": f"independent sweep shards x{world} (no data-path collective; job-table broadcast + result all_gather)"},
             "graphs_per_s": n_graphs * args.steps / elapsed,
             "edge_features_per_s": total_edges * args.feat * args.steps / elapsed,
+            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name,

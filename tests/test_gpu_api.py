@@ -160,6 +160,35 @@ def test_classifier_metric_seeded(mods, name, clf):
     assert abs(p - float(g0[f"m_cpm_{clf}_seed11_e6_s200"])) <= 0.15
 
 
+@pytest.mark.parametrize("clf", ["kernel_reg1", "kernel_reg0"])
+def test_classifier_metric_device_solver(mods, clf):
+    """solver="device" (SURVEY.md 8(f) N1): batched symmetric-eigendecomposition pseudo-inverse on the GPU.  Same splits
+    as the host solver (same torch CPU RNG stream); with the well-conditioned arc-cosine kernel the per-epoch
+    accuracies match the host LAPACK path to a few validation nodes, the rank-deficient linear kernel only has to
+    produce a valid p-value (both solvers invert rounding noise there)."""
+    _, hm, _ = mods
+    g0 = load("real_texas")
+    adj_raw, features, labels = _raw(g0)
+    seen = {}
+    for solver in ("host", "device"):
+        torch.manual_seed(11)
+        accs = []
+        orig = hm.accuracy
+        hm.accuracy = lambda lab, out, _o=orig, _a=accs: (_a.append(float(_o(lab, out))), _o(lab, out))[1]
+        try:
+            p, secs = hm.classifier_based_performance_metric(features, adj_raw, labels, 200.0, base_classifier=clf, epochs=6,
+                                                             solver=solver)
+        finally:
+            hm.accuracy = orig
+        assert 0.0 <= p <= 1.0 and secs > 0 and len(accs) == 12
+        seen[solver] = (p, np.array(accs))
+    if clf == "kernel_reg1":
+        assert np.abs(seen["host"][1] - seen["device"][1]).max() <= 0.06  # <= 4 of the 73 validation nodes of texas
+        assert abs(seen["host"][0] - seen["device"][0]) <= 0.15
+    with pytest.raises(ValueError):
+        hm.classifier_based_performance_metric(features, adj_raw, labels, 200.0, solver="fpga")
+
+
 # ------------------------------------------------------------------------------- synthetic_plot.py loop body
 @pytest.mark.parametrize("name", SYN)
 def test_synthetic_sweep_job(mods, name):
