@@ -116,6 +116,7 @@ def main():
             except Exception:
                 traffic = None
         fam, slab, threads = batch.spmm.plan()
+        n_launches = 4 + (batch.spmm_las is not None) + (1 if batch.gcn["mlp"] is not None else 2)
         kernel_name = {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
                        2: f"spmm_rowlane_kernel<{slab // 4},{(args.nodes + 1023) // 1024},float,false>",
                        3: f"spmm_rowlane_pipe_kernel<{slab // 4},{(args.nodes + 1023) // 1024},false>",
@@ -132,7 +133,9 @@ def main():
                                    f"{len(h_levels)} h-levels x {args.seeds} seeds = {len(mine)} graphs/GPU/step, "
                                    f"N={args.nodes} nodes, k={args.k}, F={args.feat} fp32, C=5; step = batched "
                                    f"D^-1(A+I)X aggregation + edge/label statistics + label aggregation & LAS + "
-                                   f"GCN-2 forward (hidden 64, per-graph weights), 7 launches",
+                                   f"GCN-2 forward (hidden 64, per-graph weights), {n_launches} launches"
+                                   + (f"; the C one-hot label columns of the LAS metric ride in the feature aggregation "
+                                      f"(F_agg={batch.agg_feat})" if batch.spmm_las is None else ""),
                        "graphs_per_step_per_gpu": len(mine), "edges_per_step_per_gpu": batch.edges,
                        "parallelism": f"independent sweep shards x{world} (no data-path collective; job-table broadcast + result all_gather)"},
             "graphs_per_s": n_graphs * args.steps / elapsed,

@@ -283,6 +283,27 @@ int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t m
 int wdg_gemm_batched_flags_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
                                int32_t max_K, uint32_t flags, wdg_stream_t stream);
 
+/* Fused two-layer feature transform Z = act(A W0 + b0) W1 + b1 for every graph of a batch in one launch and one pass
+ * over A (hidden width H <= 64, C <= 8 outputs, K <= 512): the build-defined GCN-2 feature path relu(Y W0) W1 (SURVEY
+ * 7.3 / K10; the reference has no model code - gnns_on_syn.py:9-154 is a results table - so the operator is ours).  The
+ * hidden activations stay in registers (B-resident kernel with swapped MFMA operands, second product as per-lane fma)
+ * and are not stored (a caller that needs them calls wdg_gemm_batched_f32 twice).  Contract as WDG_GEMM_A_VEC4: every A 16-byte aligned, lda % 4 == 0, K % 4 == 0.  The first product
+ * is bit-identical to wdg_gemm_f32; the second sums a row's hidden columns in the order (r & 3) + 8 (r >> 2) + 4 j
+ * (+ 32 t), j = 0 half first - fp32, not the k-ordered chain of a separate wdg_gemm_f32 call (parity within 1e-5).
+ * Returns WDG_ERR_UNSUPPORTED for larger shapes: call wdg_gemm_batched_f32 twice. */
+typedef struct wdg_mlp2_job {
+    const float *A;    /* [M,K] */
+    const float *W0;   /* [K,H] */
+    const float *b0;   /* [H] or NULL */
+    const float *W1;   /* [H,C] */
+    const float *b1;   /* [C] or NULL */
+    float *Z;          /* [M,C] */
+    int64_t lda, ldw0, ldw1, ldz;
+    int32_t M, K, H, C, act, reserved; /* act on the hidden layer: WDG_ACT_* */
+} wdg_mlp2_job;
+int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
+                         int32_t max_C, wdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

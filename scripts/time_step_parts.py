@@ -9,9 +9,10 @@ import torch
 from wdg_amd import sweep, synth
 
 batch = sweep.SweepBatch(sweep.make_jobs(synth.H_LEVELS_10, range(10), k=2), n_feat=500)
-parts = [("spmm (F=500)", batch.spmm), ("edge stats", batch.stats), ("spmm label aggregation (F=C)", batch.spmm_las),
-         ("las", batch.las), ("gemm1 relu(Y W0)", batch.gcn["gemm1"]), ("gemm2", batch.gcn["gemm2"]),
-         ("spmm logits (F=C)", batch.gcn["spmm"])]
+parts = [(f"spmm (F={batch.agg_feat})", batch.spmm), ("edge stats", batch.stats), ("spmm label aggregation (F=C)", batch.spmm_las),
+         ("las", batch.las), ("fused relu(Y W0) W1", batch.gcn["mlp"]), ("gemm1 relu(Y W0)", batch.gcn["gemm1"]),
+         ("gemm2", batch.gcn["gemm2"]), ("spmm logits (F=C)", batch.gcn["spmm"])]
+parts = [(n, p) for n, p in parts if p is not None]
 for _ in range(3):
     batch.step()
 torch.cuda.synchronize()

@@ -706,6 +706,47 @@ def test_gemm_b_resident_kernel_batched(ops, monkeypatch):
     assert torch.equal(odd.keep[0][2], torch.full((300, 3), 6.0, device="cuda"))
 
 
+@pytest.mark.parametrize("relu", [True, False])
+def test_mlp2_fused_transform(ops, oracle, relu):
+    """wdg_mlp2_batched_f32: Z = act(A W0 + b0) W1 + b1 in one pass over A, every job its own shapes (hidden width below /
+    across the two column tiles, C = 1..8, K % 32 leftovers, ragged row tiles, padded lda, with / without biases)
+    against the oracle's two GEMMs (fp64-accumulated yardstick: 1e-5 of the largest output) and against the unfused
+    GPU path (two wdg_gemm calls: same first product bit for bit, second product in another summation order)."""
+    rng = np.random.default_rng(5 + relu)
+    shapes = [(2000, 500, 64, 5), (700, 500, 64, 5), (33, 64, 32, 1), (1200, 260, 40, 8), (512, 32, 17, 3), (1, 4, 1, 1), (999, 508, 64, 7)]
+    entries, refs, unfused = [], [], []
+    for i, (m, k, h, c) in enumerate(shapes):
+        store = torch.from_numpy(rng.standard_normal((m, k + 4 * (i % 2))).astype(np.float32)).cuda()
+        a = store[:, :k]
+        w0 = torch.from_numpy((rng.standard_normal((k, h)) / np.sqrt(k)).astype(np.float32)).cuda()
+        w1 = torch.from_numpy((rng.standard_normal((h, c)) / np.sqrt(h)).astype(np.float32)).cuda()
+        b0 = torch.from_numpy(rng.standard_normal(h).astype(np.float32)).cuda() if i % 3 else None
+        b1 = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).cuda() if i % 2 else None
+        entries.append((a, w0, b0, w1, b1, torch.full((m, c), float("nan"), device="cuda")))
+        an, f = _np(a).astype(np.float64), lambda t: None if t is None else _np(t).astype(np.float64)
+        hid = an @ f(w0) + (0 if b0 is None else f(b0))
+        hid = np.maximum(hid, 0) if relu else hid
+        refs.append(hid @ f(w1) + (0 if b1 is None else f(b1)))
+        unfused.append(ops.gemm(ops.gemm(a, w0, bias=b0, relu=relu), w1, bias=b1))
+    assert ops.Mlp2Batch.eligible(entries)
+    batch = ops.Mlp2Batch(entries, relu=relu)
+    batch.launch()
+    batch.launch()  # relaunch: same answers
+    torch.cuda.synchronize()
+    for (a, w0, b0, w1, b1, z), ref, two in zip(entries, refs, unfused):
+        scale = max(np.abs(ref).max(), 1e-30)
+        np.testing.assert_allclose(_np(z), ref, rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(_np(z), _np(two), rtol=1e-5, atol=2e-6 * scale)
+        ref32 = oracle.gemm(oracle.gemm(np.ascontiguousarray(_np(a)), _np(w0), None if b0 is None else _np(b0), relu=relu),
+                            _np(w1), None if b1 is None else _np(b1))
+        np.testing.assert_allclose(_np(z), ref32, rtol=1e-5, atol=1e-5 * scale)
+    # shapes the fused kernel does not take are reported, not mangled
+    big = (torch.ones(8, 8, device="cuda"), torch.ones(8, 65, device="cuda"), None, torch.ones(65, 3, device="cuda"), None, torch.empty(8, 3, device="cuda"))
+    assert not ops.Mlp2Batch.eligible([big])
+    with pytest.raises(ValueError):
+        ops.Mlp2Batch([big])
+
+
 def test_edge_cosine_sddmm(ops, oracle):
     rng = np.random.default_rng(41)
     for n, f, e in ((500, 37, 6000), (2708, 1433, 13000), (30, 3, 200)):

@@ -7,9 +7,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused_mlp,ride_labels", [("1", "1"), ("0", "0"), ("1", "0")])
 @pytest.mark.parametrize("symmetric", [0, 1])
-def test_sweep_step_against_oracle(oracle, symmetric):
+def test_sweep_step_against_oracle(oracle, symmetric, fused_mlp, ride_labels, monkeypatch):
     from wdg_amd import sweep, synth
+    monkeypatch.setenv("WDG_SWEEP_FUSED_MLP", fused_mlp)
+    monkeypatch.setenv("WDG_SWEEP_RIDE_LABELS", ride_labels)
     jobs = sweep.make_jobs([0.1, 0.5, 0.9], [0, 1], k=2, n_nodes=1000) + sweep.make_jobs([0.2, 0.4], [2], k=10, n_nodes=1000)
     batch = sweep.SweepBatch(jobs, n_feat=96, symmetric=symmetric, gcn_hidden=32)
     batch.step()
@@ -17,6 +20,7 @@ def test_sweep_step_against_oracle(oracle, symmetric):
     torch.cuda.synchronize()
     rows = batch.results().cpu().numpy()
     assert rows.shape == (len(jobs), len(sweep.METRIC_NAMES))
+    assert (batch.spmm_las is None) == (ride_labels == "1") and batch.agg_feat == (104 if ride_labels == "1" else 96)
     for i, j in enumerate(jobs):
         src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
         x = synth.features(j.n_nodes, 96, j.seed)
@@ -24,6 +28,9 @@ def test_sweep_step_against_oracle(oracle, symmetric):
         vhat = oracle.normalised_csr(rowptr, col, val, symmetric, oracle.PREC_F32)
         y = oracle.spmm_csr(rowptr, col, vhat, x)
         np.testing.assert_allclose(batch.y[i].cpu().numpy(), y, rtol=1e-5, atol=1e-6 * np.abs(y).max())
+        onehot32 = np.eye(j.n_classes, dtype=np.float32)[lab]
+        h_ref = oracle.spmm_csr(rowptr, col, vhat, onehot32)  # the label aggregation (riding along or its own launch)
+        np.testing.assert_allclose(batch.h_las[i].cpu().numpy(), h_ref, rtol=1e-5, atol=1e-6)
         st = oracle.edge_label_stats(rowptr, col, lab, j.n_classes)
         want = [oracle.edge_homophily_dense(st), oracle.node_homophily_dense(st), oracle.class_homophily_dense(st, lab),
                 oracle.adjusted_homophily_dense(st, lab), oracle.label_informativeness(st, lab)]
@@ -33,7 +40,9 @@ def test_sweep_step_against_oracle(oracle, symmetric):
         assert abs(rows[i, 5] - soft) <= 2.01 / j.n_nodes
         g = batch.gcn
         hid = oracle.gemm(y, g["w0"][i].cpu().numpy(), relu=True)
-        np.testing.assert_allclose(g["hid"][i].cpu().numpy(), hid, rtol=1e-5, atol=1e-5 * np.abs(hid).max())
+        assert (g["hid"] is None) == (fused_mlp == "1")  # the fused transform keeps the hidden layer in registers
+        if g["hid"] is not None:
+            np.testing.assert_allclose(g["hid"][i].cpu().numpy(), hid, rtol=1e-5, atol=1e-5 * np.abs(hid).max())
         logits = oracle.spmm_csr(rowptr, col, vhat, oracle.gemm(hid, g["w1"][i].cpu().numpy()))
         np.testing.assert_allclose(g["logits"][i].cpu().numpy(), logits, rtol=1e-5, atol=1e-5 * np.abs(logits).max())
 

@@ -78,6 +78,7 @@ SIGNATURES = {
                              c_int32, c_int32, c_int32, c_void_p]),
     "wdg_gemm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_gemm_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
+    "wdg_mlp2_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_las_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
 }
 
@@ -93,6 +94,13 @@ class GemmJob(ctypes.Structure):
     """mirror of `wdg_gemm_job` (include/wdg.h)"""
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("lda", c_int64), ("ldb", c_int64),
                 ("ldc", c_int64), ("M", c_int32), ("N", c_int32), ("K", c_int32), ("act", c_int32)]
+
+class Mlp2Job(ctypes.Structure):
+    """mirror of `wdg_mlp2_job` (include/wdg.h)"""
+    _fields_ = [("A", c_void_p), ("W0", c_void_p), ("b0", c_void_p), ("W1", c_void_p), ("b1", c_void_p), ("Z", c_void_p),
+                ("lda", c_int64), ("ldw0", c_int64), ("ldw1", c_int64), ("ldz", c_int64),
+                ("M", c_int32), ("K", c_int32), ("H", c_int32), ("C", c_int32), ("act", c_int32), ("reserved", c_int32)]
+
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -169,7 +169,9 @@ struct BresGroup {  // 16 consecutive floats of one A row per lane = 32 consecut
 // 32x32x2 MFMA wants k = 2h in lane i and k = 2h + 1 in lane i + 32: two v_permlane32_swap per float4 (x <-> y and
 // z <-> w across the halves of the wave) produce exactly that - x', z' serve k = 4j .. 4j + 3 and y', w' serve
 // k = 16 + 4j .. 16 + 4j + 3 - with no select and no duplicated load.  Steps are issued in ascending k.
-template <int NT>
+// SWAP: the two MFMA operands trade places - the accumulators then hold the TRANSPOSED tile (register index <-> column
+// of B, lane <-> row of A), same products in the same k order, i.e. the same bits (used by the fused two-layer kernel).
+template <int NT, bool SWAP>
 __device__ __forceinline__ void bres_compute(const BresGroup &grp, int kbase, int lk, int li, const float *Bres,
                                              f32x16 (&acc)[NT]) {
     float lo[8], hi[8];
@@ -201,9 +203,66 @@ __device__ __forceinline__ void bres_compute(const BresGroup &grp, int kbase, in
             const int h = CH * c + s;  // this step covers k = kbase + 2 h and k + 1
             const float a = h < 8 ? lo[h] : hi[h - 8];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[c & 1][s][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                acc[t] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bq[c & 1][s][t], a, acc[t], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[c & 1][s][t], acc[t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// B -> LDS ([K rounded up to 32][64], columns >= N and rows >= K zero), eight loads in flight per thread.  Odd rows are
+// stored with their column halves swapped (column ^ 32): the operand read of lane half j = 1 (row k + 1) then falls into
+// the other 32 banks than half j = 0 (row k).  The caller synchronises.
+__device__ __forceinline__ void bres_stage_b(global_ptr<const float> B, int64_t ldb, int K, int N, float *Bres) {
+    const int k_rows = (K + 31) / 32 * 32;  // the LDS holds whole groups of 32 rows
+    for (int base = threadIdx.x; base < k_rows * BRES_COLS; base += 8 * BRES_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * BRES_THREADS, k = idx / BRES_COLS, n = idx % BRES_COLS;
+            v[u] = (k < K && n < N) ? B[static_cast<int64_t>(k) * ldb + n] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * BRES_THREADS, k = idx / BRES_COLS;
+            if (idx < k_rows * BRES_COLS) Bres[idx ^ ((k & 1) << 5)] = v[u];
+        }
+    }
+}
+
+// The whole K loop of one 32-row tile: a_lane = the lane's row of A + 16 (lane / 32); K % 4 == 0.
+template <int NT, bool SWAP>
+__device__ __forceinline__ void bres_tile(global_ptr<const float> a_lane, int K, int lk, int li, const float *Bres,
+                                          f32x16 (&acc)[NT]) {
+    const int full = K / 32;
+    BresGroup g0, g1;
+    auto load_group = [&](int g, BresGroup &dst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst.r[j] = *(const global_ptr<const f32x4_t>)(a_lane + g * 32 + j * 4);
+    };
+    int g = 0;
+    if (full > 0) load_group(0, g0);
+    for (; g + 2 <= full; g += 2) {  // two groups per trip, each loaded one group of MFMAs ahead, no register moves
+        load_group(g + 1, g1);
+        __builtin_amdgcn_sched_barrier(0);  // keep load / compute phases in this order: the waits count on it
+        bres_compute<NT, SWAP>(g0, g * 32, lk, li, Bres, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(min(g + 2, full - 1), g0);  // unconditional (re-reads the last group at the end): no branch
+        __builtin_amdgcn_sched_barrier(0);
+        bres_compute<NT, SWAP>(g1, (g + 1) * 32, lk, li, Bres, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (g < full) bres_compute<NT, SWAP>(g0, g * 32, lk, li, Bres, acc), ++g;
+    if (full * 32 < K) {  // K % 32 leftover (K % 4 == 0): float4s past K read as zero and meet zero rows of B; adding
+                          // +0 products to an accumulator that started at +0 never changes a bit
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k0 = full * 32 + 16 * lk + j * 4;
+            g1.r[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (k0 < K) g1.r[j] = *(const global_ptr<const f32x4_t>)(a_lane + full * 32 + j * 4);
+        }
+        bres_compute<NT, SWAP>(g1, full * 32, lk, li, Bres, acc);
     }
 }
 
@@ -219,27 +278,11 @@ __global__ __launch_bounds__(BRES_THREADS) void gemm_bres_kernel(const wdg_gemm_
     const int M = job->M, N = job->N, K = job->K, act = job->act;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
     if (M <= 0 || N <= 0) return;
-    // B -> LDS, eight loads in flight per thread.  Odd rows are stored with their column halves swapped (column ^ 32):
-    // the operand read of lane half j = 1 (row k + 1) then falls into the other 32 banks than half j = 0 (row k).
-    const int k_rows = (K + 31) / 32 * 32;  // the LDS holds whole groups of 32 rows; rows >= K are zero
-    for (int base = threadIdx.x; base < k_rows * BRES_COLS; base += 8 * BRES_THREADS) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * BRES_THREADS, k = idx / BRES_COLS, n = idx % BRES_COLS;
-            v[u] = (k < K && n < N) ? B[static_cast<int64_t>(k) * ldb + n] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * BRES_THREADS, k = idx / BRES_COLS;
-            if (idx < k_rows * BRES_COLS) Bres[idx ^ ((k & 1) << 5)] = v[u];
-        }
-    }
+    bres_stage_b(B, ldb, K, N, Bres);
     __syncthreads();  // the only barrier
 
     const int tiles = (M + 31) / 32, per_part = (tiles + n_parts - 1) / n_parts;
     const int t_end = min((part + 1) * per_part, tiles);
-    const int full = K / 32;
     for (int tile = part * per_part + wave; tile < t_end; tile += BRES_THREADS / 64) {
         const int gm = tile * 32 + li;
         const global_ptr<const float> a_lane = A + static_cast<int64_t>(gm < M ? gm : M - 1) * lda + 16 * lk;
@@ -250,35 +293,91 @@ __global__ __launch_bounds__(BRES_THREADS) void gemm_bres_kernel(const wdg_gemm_
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         float bv[NT];
         tile_bias<NT>(bias, 0, li, N, bv);
-        BresGroup g0, g1;
-        auto load_group = [&](int g, BresGroup &dst) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst.r[j] = *(const global_ptr<const f32x4_t>)(a_lane + g * 32 + j * 4);
-        };
-        int g = 0;
-        if (full > 0) load_group(0, g0);
-        for (; g + 2 <= full; g += 2) {  // two groups per trip, each loaded one group of MFMAs ahead, no register moves
-            load_group(g + 1, g1);
-            __builtin_amdgcn_sched_barrier(0);  // keep load / compute phases in this order: the waits count on it
-            bres_compute<NT>(g0, g * 32, lk, li, Bres, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load_group(min(g + 2, full - 1), g0);  // unconditional (re-reads the last group at the end): no branch
-            __builtin_amdgcn_sched_barrier(0);
-            bres_compute<NT>(g1, (g + 1) * 32, lk, li, Bres, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (g < full) bres_compute<NT>(g0, g * 32, lk, li, Bres, acc), ++g;
-        if (full * 32 < K) {  // K % 32 leftover (K % 4 == 0): float4s past K read as zero and meet zero rows of B; adding
-                              // +0 products to an accumulator that started at +0 never changes a bit
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k0 = full * 32 + 16 * lk + j * 4;
-                g1.r[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (k0 < K) g1.r[j] = *(const global_ptr<const f32x4_t>)(a_lane + full * 32 + j * 4);
-            }
-            bres_compute<NT>(g1, full * 32, lk, li, Bres, acc);
-        }
+        bres_tile<NT, false>(a_lane, K, lk, li, Bres, acc);
         tile_store<NT>(acc, bv, C, ldc, tile * 32, 0, li, lk, M, N, act);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused two-layer kernel
+// Z = act(A W0 + b0) W1 + b1 for H <= 64 hidden units and C <= 8 outputs (the GCN-2 feature path relu(Y W0) W1 of the sweep)
+// in ONE pass over A: the B-resident K loop with the MFMA operands swapped leaves the hidden tile TRANSPOSED in the
+// accumulators - lane i (and i + 32) holds row i of the tile, register r of column tile t holds hidden column
+// 32 t + (r & 3) + 8 (r >> 2) + 4 (lane / 32) - so the second product is per-lane arithmetic: 32 columns x C fma per lane
+// against W1 rows read from LDS (broadcast reads, padded to 8 floats), one cross-half add, one 4C-byte store per row.
+// The hidden activations never reach memory (a caller that wants them uses two wdg_gemm calls) and the second GEMM
+// launch disappears.
+// Summation order of the second product: the lane's 32 columns in register order, then the other half-wave's sum; the
+// first product is bit-identical to wdg_gemm_f32.
+constexpr int MLP2_MAX_C = 8;
+
+template <int NT>
+__global__ __launch_bounds__(BRES_THREADS) void mlp2_bres_kernel(const wdg_mlp2_job *__restrict__ jobs, int n_parts) {
+    extern __shared__ float Bres[];  // W0 as in gemm_bres_kernel, then W1 [64][8] and b0 [64]
+    const int job_id = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
+    const desc_ptr<wdg_mlp2_job> job = (desc_ptr<wdg_mlp2_job>)(jobs + job_id);
+    const global_ptr<const float> A = to_global(job->A), W0 = to_global(job->W0), b0 = to_global(job->b0);
+    const global_ptr<const float> W1 = to_global(job->W1), b1 = to_global(job->b1);
+    const global_ptr<float> Z = to_global(job->Z);
+    const int64_t lda = job->lda, ldw0 = job->ldw0, ldw1 = job->ldw1, ldz = job->ldz;
+    const int M = job->M, K = job->K, H = job->H, C = job->C, act = job->act;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    if (M <= 0 || H <= 0 || C <= 0) return;
+    float *const w1s = Bres + (K + 31) / 32 * 32 * BRES_COLS;
+    float *const b0s = w1s + BRES_COLS * MLP2_MAX_C;
+    bres_stage_b(W0, ldw0, K, H, Bres);
+    for (int idx = threadIdx.x; idx < BRES_COLS * MLP2_MAX_C; idx += BRES_THREADS) {
+        const int col = idx / MLP2_MAX_C, c = idx % MLP2_MAX_C;
+        w1s[idx] = (col < H && c < C) ? W1[static_cast<int64_t>(col) * ldw1 + c] : 0.f;
+    }
+    if (threadIdx.x < BRES_COLS) b0s[threadIdx.x] = (b0 && threadIdx.x < H) ? b0[threadIdx.x] : 0.f;
+    __syncthreads();  // the only barrier
+
+    const int tiles = (M + 31) / 32, per_part = (tiles + n_parts - 1) / n_parts;
+    const int t_end = min((part + 1) * per_part, tiles);
+    const bool relu = act == WDG_ACT_RELU;
+    for (int tile = part * per_part + wave; tile < t_end; tile += BRES_THREADS / 64) {
+        const int gm = tile * 32 + li;
+        const global_ptr<const float> a_lane = A + static_cast<int64_t>(gm < M ? gm : M - 1) * lda + 16 * lk;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        bres_tile<NT, true>(a_lane, K, lk, li, Bres, acc);
+
+        float z[MLP2_MAX_C];
+#pragma unroll
+        for (int c = 0; c < MLP2_MAX_C; ++c) z[c] = 0.f;
+        int lds_off = lk * 4;  // opaque per tile: the W1 / b0 reads and column predicates below are tile-invariant and
+        asm volatile("" : "+v"(lds_off));  // would otherwise be hoisted out of the tile loop and spilled
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int col0 = t * 32 + r4 * 8 + lds_off;  // this lane's four hidden columns of the register quadruple
+                const float4 bb = *reinterpret_cast<const float4 *>(b0s + col0);
+                float h[4] = {acc[t][4 * r4] + bb.x, acc[t][4 * r4 + 1] + bb.y, acc[t][4 * r4 + 2] + bb.z, acc[t][4 * r4 + 3] + bb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (relu) h[e] = fmaxf(h[e], 0.f);
+                    const float4 wa = *reinterpret_cast<const float4 *>(w1s + (col0 + e) * MLP2_MAX_C);
+                    const float4 wb = *reinterpret_cast<const float4 *>(w1s + (col0 + e) * MLP2_MAX_C + 4);
+                    z[0] = fmaf(h[e], wa.x, z[0]); z[1] = fmaf(h[e], wa.y, z[1]);
+                    z[2] = fmaf(h[e], wa.z, z[2]); z[3] = fmaf(h[e], wa.w, z[3]);
+                    z[4] = fmaf(h[e], wb.x, z[4]); z[5] = fmaf(h[e], wb.y, z[5]);
+                    z[6] = fmaf(h[e], wb.z, z[6]); z[7] = fmaf(h[e], wb.w, z[7]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one register quadruple's LDS reads at a time
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MLP2_MAX_C; ++c) z[c] += __shfl_xor(z[c], 32);
+        if (lk == 0 && gm < M) {
+            const global_ptr<float> zp = Z + static_cast<int64_t>(gm) * ldz;
+#pragma unroll
+            for (int c = 0; c < MLP2_MAX_C; ++c)
+                if (c < C) zp[c] = z[c] + (b1 ? b1[c] : 0.f);
+        }
     }
 }
 
@@ -294,6 +393,20 @@ bool bres_shape_ok(int n_jobs, int max_M, int max_N, int K) {
     return static_cast<int64_t>(n_jobs) * ceil_div(max_M, BM) >= 3 * std::max(wdg_device_cus(), 8);
 }
 
+// row chunks per job: the fewest that minimise (workgroup rounds on the chip) x (16-tile rounds inside a workgroup)
+int bres_parts(int n_jobs, int max_M) {
+    const int tiles = static_cast<int>(ceil_div(max_M, 32));
+    const int cus = std::max(wdg_device_cus(), 8);
+    int parts = 1;
+    int64_t best = INT64_MAX;
+    for (int p = 1; p <= 16 && (p == 1 || tiles / p >= 8); ++p) {
+        const int64_t cost = ceil_div(static_cast<int64_t>(n_jobs) * p, cus) * ceil_div(ceil_div(tiles, p), BRES_THREADS / 64);
+        if (cost < best) best = cost, parts = p;
+    }
+    if (const char *e = getenv("WDG_GEMM_PARTS")) parts = std::max(1, atoi(e));  // experiments
+    return parts;
+}
+
 int launch_bres(const wdg_gemm_job *jobs, const wdg_gemm_job &inl, int n_jobs, int max_M, int max_N, int K, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
@@ -302,16 +415,7 @@ int launch_bres(const wdg_gemm_job *jobs, const wdg_gemm_job &inl, int n_jobs, i
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
         configured = true;
     }
-    const int tiles = static_cast<int>(ceil_div(max_M, 32));
-    const int cus = std::max(wdg_device_cus(), 8);
-    // row chunks per job: the fewest that minimise (workgroup rounds on the chip) x (16-tile rounds inside a workgroup)
-    int parts = 1;
-    int64_t best = INT64_MAX;
-    for (int p = 1; p <= 16 && (p == 1 || tiles / p >= 8); ++p) {
-        const int64_t cost = ceil_div(static_cast<int64_t>(n_jobs) * p, cus) * ceil_div(ceil_div(tiles, p), BRES_THREADS / 64);
-        if (cost < best) best = cost, parts = p;
-    }
-    if (const char *e = getenv("WDG_GEMM_PARTS")) parts = std::max(1, atoi(e));  // experiments
+    const int parts = bres_parts(n_jobs, max_M);
     const size_t lds = static_cast<size_t>(ceil_div(K, 32) * 32) * BRES_COLS * 4;
     const dim3 grid(static_cast<unsigned>(n_jobs) * parts);
     if (max_N > 32) hipLaunchKernelGGL(gemm_bres_kernel<2>, grid, dim3(BRES_THREADS), lds, st, jobs, inl, parts);
@@ -374,6 +478,32 @@ int wdg_gemm_batched_flags_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int
 int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
                          wdg_stream_t stream) {
     return wdg_gemm_batched_flags_f32(jobs_dev, n_jobs, max_M, max_N, 0, 0, stream);
+}
+
+int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
+                         int32_t max_C, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_M >= 0 && max_K >= 0 && max_H >= 0 && max_C >= 0, "mlp2_batched: negative size");
+    if (n_jobs == 0 || max_M == 0 || max_H == 0 || max_C == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "mlp2_batched: null job table");
+    if (max_H > BRES_COLS || max_C > MLP2_MAX_C || max_K <= 0 || max_K % 4 != 0 ||
+        wdg::ceil_div(max_K, 32) * 32 * BRES_COLS * 4 > 128 * 1024)
+        return wdg::fail(WDG_ERR_UNSUPPORTED, "mlp2_batched: needs H <= 64, C <= 8, 0 < K <= 512, K % 4 == 0 (use two wdg_gemm calls)");
+    WDG_REQUIRE(static_cast<int64_t>(n_jobs) * 16 <= 0x7fffffffLL, "mlp2_batched: too many jobs");
+    const size_t lds_max = 128 * 1024 + (BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        for (const void *k : {reinterpret_cast<const void *>(mlp2_bres_kernel<1>), reinterpret_cast<const void *>(mlp2_bres_kernel<2>)})
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_max)) != hipSuccess)
+                return wdg::fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+        configured = true;
+    }
+    const int parts = bres_parts(n_jobs, max_M);
+    const size_t lds = (static_cast<size_t>(wdg::ceil_div(max_K, 32) * 32) * BRES_COLS + BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);
+    const dim3 grid(static_cast<unsigned>(n_jobs) * parts);
+    hipStream_t st = wdg::as_stream(stream);
+    if (max_H > 32) hipLaunchKernelGGL(mlp2_bres_kernel<2>, grid, dim3(BRES_THREADS), lds, st, jobs_dev, parts);
+    else hipLaunchKernelGGL(mlp2_bres_kernel<1>, grid, dim3(BRES_THREADS), lds, st, jobs_dev, parts);
+    return wdg::check_launch("mlp2_bres_kernel");
 }
 
 }  // extern "C"

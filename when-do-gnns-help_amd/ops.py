@@ -485,6 +485,50 @@ class GemmBatch:
                                              stream_handle()), "wdg_gemm_batched_flags_f32")
 
 
+class Mlp2Batch:
+    """Job table for wdg_mlp2_batched_f32: Z_i = act(A_i W0_i + b0_i) W1_i + b1_i, one launch, one pass over A_i, the hidden
+    layer never stored.  `eligible(entries)` says whether the fused kernel takes the shapes (else: two GemmBatch)."""
+
+    MAX_H, MAX_C, MAX_K = 64, 8, 512
+
+    @classmethod
+    def eligible(cls, entries):
+        for a, w0, b0, w1, b1, z in entries:
+            k, h, c = a.shape[1], w0.shape[1], w1.shape[1]
+            if h > cls.MAX_H or c > cls.MAX_C or k > cls.MAX_K or k % 4 or k == 0 or a.data_ptr() % 16 or _ld(a) % 4:
+                return False
+        return len(entries) > 0
+
+    def __init__(self, entries, relu=True):
+        """entries: list of (A [M,K], W0 [K,H], b0 [H]|None, W1 [H,C], b1 [C]|None, Z [M,C]) fp32 device tensors."""
+        dev = require_gpu()
+        if not self.eligible(entries):
+            raise ValueError("Mlp2Batch: needs H <= 64, C <= 8, K <= 512, K % 4 == 0, 16-byte aligned rows of A")
+        self.keep = entries
+        arr = (_lib.Mlp2Job * len(entries))()
+        self.max_m = self.max_k = self.max_h = self.max_c = 0
+        self.flops = 0
+        for job, (a, w0, b0, w1, b1, z) in zip(arr, entries):
+            (m, k), h, c = a.shape, w0.shape[1], w1.shape[1]
+            if w0.shape[0] != k or w1.shape[0] != h or tuple(z.shape) != (m, c) or \
+                    any(t.stride(1) != 1 or t.dtype != torch.float32 for t in (a, w0, w1, z)):
+                raise ValueError("Mlp2Batch: shape / layout mismatch")
+            job.A, job.W0, job.W1, job.Z = a.data_ptr(), w0.data_ptr(), w1.data_ptr(), z.data_ptr()
+            job.b0 = 0 if b0 is None else b0.data_ptr()
+            job.b1 = 0 if b1 is None else b1.data_ptr()
+            job.lda, job.ldw0, job.ldw1, job.ldz = _ld(a), _ld(w0), _ld(w1), _ld(z)
+            job.M, job.K, job.H, job.C, job.act = m, k, h, c, (ACT_RELU if relu else ACT_NONE)
+            self.max_m, self.max_k = max(self.max_m, m), max(self.max_k, k)
+            self.max_h, self.max_c = max(self.max_h, h), max(self.max_c, c)
+            self.flops += 2 * m * h * (k + c)
+        self.n_jobs = len(entries)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+    def launch(self):
+        check(lib.wdg_mlp2_batched_f32(_ptr(self.table), self.n_jobs, self.max_m, self.max_k, self.max_h, self.max_c,
+                                       stream_handle()), "wdg_mlp2_batched_f32")
+
+
 # ------------------------------------------------------------------------------------------- per-edge cosine
 def edge_cosine(g, x, entries=None, skip_self=True):
     """fp32 cosine similarity of the endpoints of every stored entry (or of the listed entry ids); wdg_edge_cosine_f32."""

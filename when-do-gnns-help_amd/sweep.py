@@ -101,23 +101,40 @@ class SweepBatch:
         self.jobs = list(jobs)
         dev = ops.require_gpu()
         self.n_feat = n_feat
+        n_classes = max([j.n_classes for j in self.jobs], default=0)
+        # Label columns ride along: the aggregation walks X in 16-feature groups and the last group of F = 500 is three
+        # quarters empty, so [X | onehot(labels) | 0] (F_agg = 508) costs the same 32 groups and the separate F = C
+        # aggregation launch of the LAS metric disappears.  Needs one label vector per feature matrix (true for the
+        # generator: labels = node // class size); WDG_SWEEP_RIDE_LABELS=0 keeps the separate launch.
+        ride = os.environ.get("WDG_SWEEP_RIDE_LABELS", "1") != "0" and n_classes > 0
+        self.agg_feat = (n_feat + n_classes + 3) // 4 * 4 if ride else n_feat
         feats, self.graphs, self.dinv, self.labels, self.y = {}, [], [], [], []
+        self.y_agg, seed_labels = [], {}
         for j in self.jobs:
-            if j.seed not in feats:
-                feats[j.seed] = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed)).to(dev)
             src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+            if j.seed not in feats:
+                x = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed)).to(dev)
+                if ride:
+                    xa = torch.zeros((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev)
+                    xa[:, :n_feat] = x
+                    xa[torch.arange(j.n_nodes, device=dev), n_feat + torch.from_numpy(lab).to(dev)] = 1.0
+                    x = xa
+                feats[j.seed], seed_labels[j.seed] = x, lab
+            elif ride and not np.array_equal(seed_labels[j.seed], lab):
+                raise ValueError("SweepBatch: jobs of one seed differ in labels; set WDG_SWEEP_RIDE_LABELS=0")
             g = ops.CsrGraph.from_coo(src, dst, j.n_nodes, None, ops.COO_ADD_SELF_LOOPS)  # A + I (synthetic_plot.py:92)
             d = ops.degree_norm(g, ops.NORM_SYM if symmetric else ops.NORM_RW, ops.PREC_F32, use_values=True)["dinv"]
             self.graphs.append(g)
             self.dinv.append(d)
             self.labels.append(torch.from_numpy(lab).to(dev).to(torch.int32))
-            self.y.append(torch.empty((j.n_nodes, n_feat), dtype=torch.float32, device=dev))
-        self.x = feats
+            self.y_agg.append(torch.empty((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev))
+            self.y.append(self.y_agg[-1][:, :n_feat])  # the feature part (a view: leading dimension agg_feat)
+        self.x_agg = feats                                        # what the aggregation reads: [X | onehot | 0]
+        self.x = {s: x[:, :n_feat] for s, x in feats.items()}     # the features proper (views)
         # A + I has unit values except a doubled pre-existing loop; the generator emits no loops -> pattern only
-        entries = [(g, self.x[j.seed], y, d, d if symmetric else None, False)
-                   for j, g, y, d in zip(self.jobs, self.graphs, self.y, self.dinv)]
+        entries = [(g, self.x_agg[j.seed], y, d, d if symmetric else None, False)
+                   for j, g, y, d in zip(self.jobs, self.graphs, self.y_agg, self.dinv)]
         self.spmm = ops.SpmmBatch(entries)
-        n_classes = max([j.n_classes for j in self.jobs], default=0)
         self.n_classes = n_classes
         self.stats = ops.StatsBatch(self.graphs, self.labels, n_classes)
         self.edges = sum(g.nnz for g in self.graphs)
@@ -126,16 +143,17 @@ class SweepBatch:
             return d if symmetric else None
 
         # aggregation homophily (soft LAS, synthetic_plot.py:106): H = A_hat Z with one-hot Z, then W = H (H^T Y)
-        onehot = {}
         self.h_las = []
-        las_entries = []
-        for j, lab in zip(self.jobs, self.labels):
-            key = (j.n_nodes, j.n_classes)
-            if key not in onehot:
-                onehot[key] = torch.eye(n_classes, device=dev)[lab.long()].contiguous()
-            self.h_las.append(torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev))
-            las_entries.append((self.graphs[len(las_entries)], onehot[key], self.h_las[-1]))
-        self.spmm_las = ops.SpmmBatch([(g, z, h, d, scale(d), False) for (g, z, h), d in zip(las_entries, self.dinv)])
+        if ride:
+            self.h_las = [ya[:, n_feat:n_feat + n_classes] for ya in self.y_agg]  # written by the feature aggregation
+            self.spmm_las = None
+        else:
+            las_entries = []
+            for j, lab in zip(self.jobs, self.labels):
+                onehot = torch.eye(n_classes, device=dev)[lab.long()].contiguous()
+                self.h_las.append(torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev))
+                las_entries.append((self.graphs[len(las_entries)], onehot, self.h_las[-1]))
+            self.spmm_las = ops.SpmmBatch([(g, z, h, d, scale(d), False) for (g, z, h), d in zip(las_entries, self.dinv)])
         self.las = ops.LasBatch(list(zip(self.h_las, self.labels)), n_classes)
 
         # GCN-2 forward (build-defined model, models.py): logits = A_hat relu((A_hat X) W0) W1, every job its own weights
@@ -151,7 +169,11 @@ class SweepBatch:
             hid = [torch.empty((j.n_nodes, gcn_hidden), dtype=torch.float32, device=dev) for j in self.jobs]
             z2 = [torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev) for j in self.jobs]
             out = [torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev) for j in self.jobs]
-            self.gcn = dict(w0=w0, w1=w1, hid=hid, z2=z2, logits=out,
+            mlp = [(y, a, None, b, None, z) for y, a, b, z in zip(self.y, w0, w1, z2)]
+            fused = os.environ.get("WDG_SWEEP_FUSED_MLP", "1") != "0" and ops.Mlp2Batch.eligible(mlp)
+            self.gcn = dict(w0=w0, w1=w1, hid=None if fused else hid, z2=z2, logits=out,
+                            # fused: relu(Y W0) W1 in one pass over Y, the hidden layer stays in registers
+                            mlp=ops.Mlp2Batch(mlp, relu=True) if fused else None,
                             gemm1=ops.GemmBatch([(y, a, h, None) for y, a, h in zip(self.y, w0, hid)], relu=True),
                             gemm2=ops.GemmBatch([(h, b, z, None) for h, b, z in zip(hid, w1, z2)]),
                             spmm=ops.SpmmBatch([(g, z, o, d, scale(d), False)
@@ -161,15 +183,15 @@ class SweepBatch:
     def spmm_algorithmic_bytes(self):
         tot = 0
         for g in self.graphs:
-            n, e, f = g.n_rows, g.nnz, self.n_feat
+            n, e, f = g.n_rows, g.nnz, self.agg_feat
             tot += 4 * (n + 1) + 4 * e + 4 * n + 4 * n * f + 4 * n * f
         return tot
 
     def spmm_unique_bytes(self):
         """same, counting each distinct feature matrix once (graphs of one seed share X)"""
-        tot = sum(4 * x.numel() for x in self.x.values())
+        tot = sum(4 * x.numel() for x in self.x_agg.values())
         for g in self.graphs:
-            tot += 4 * (g.n_rows + 1) + 4 * g.nnz + 4 * g.n_rows + 4 * g.n_rows * self.n_feat
+            tot += 4 * (g.n_rows + 1) + 4 * g.nnz + 4 * g.n_rows + 4 * g.n_rows * self.agg_feat
         return tot
 
     def step(self):
@@ -194,7 +216,8 @@ class SweepBatch:
                 with torch.cuda.stream(self.side):
                     self.stats.launch()
                 with torch.cuda.stream(self.side2):
-                    self.spmm_las.launch()
+                    if self.spmm_las is not None:
+                        self.spmm_las.launch()
                     self.las.launch()
             else:
                 with torch.cuda.stream(self.side):
@@ -222,12 +245,16 @@ class SweepBatch:
 
     def _metric_chain(self):
         self.stats.launch()       # edge / node / class / adjusted homophily, label informativeness counters
-        self.spmm_las.launch()    # H = A_hat onehot(labels)          (F = C)
+        if self.spmm_las is not None:
+            self.spmm_las.launch()  # H = A_hat onehot(labels)        (F = C; else: columns of the feature aggregation)
         self.las.launch()         # soft / hard LAS counts
 
     def _gcn_chain(self):
-        self.gcn["gemm1"].launch()  # relu(Y W0)                  fp32 MFMA
-        self.gcn["gemm2"].launch()  # (.) W1
+        if self.gcn["mlp"] is not None:
+            self.gcn["mlp"].launch()    # relu(Y W0) W1               fp32 MFMA + per-lane second product, one launch
+        else:
+            self.gcn["gemm1"].launch()  # relu(Y W0)                  fp32 MFMA
+            self.gcn["gemm2"].launch()  # (.) W1
         self.gcn["spmm"].launch()   # logits = A_hat (.)           (F = C)
 
     def results(self):
