@@ -8,13 +8,14 @@
 Workload per rank (weak scaling: fixed per-GPU work): the `data_synthesis/800`-equivalent sweep shard
   10 homophily levels x `--seeds` seeds (default 10) = 100 graphs, N = 2000 nodes, k = 2, F = 500 fp32 features
   (the directory name "800" is k*400, every graph has 2000 nodes - SURVEY G3).
-A step = one pass of the hot path over that batch with all inputs resident in HBM, 7 batched launches:
-  (1) A_hat X aggregation, A_hat = D^-1 (A + I) fused into the SpMM (csrc/spmm_rowlane.hip; graphs of a seed share X)
-  (2) edge/label statistics pass (csrc/edge_stats.hip)
-  (3) label aggregation A_hat onehot(y) (csrc/spmm.hip) and (4) LAS counts (csrc/las.hip)
-  (5-7) GCN-2 forward with per-graph weights: relu(Y W0), (.) W1 on the fp32 matrix pipe (csrc/gemm.hip), A_hat (.)
+A step = one pass of the hot path over that batch with all inputs resident in HBM, 5 batched launches:
+  (1) A_hat [X | onehot(y)] aggregation, A_hat = D^-1 (A + I) fused into the SpMM (csrc/spmm_rowlane.hip; graphs of a
+      seed share X; the label aggregation of the LAS metric rides in the last, otherwise mostly empty feature group)
+  (2) edge/label statistics pass (csrc/edge_stats.hip)            (3) LAS counts (csrc/las.hip)
+  (4) GCN-2 feature path with per-graph weights relu(Y W0) W1, fused, fp32 matrix pipe (csrc/gemm.hip)   (5) A_hat (.)
+  (WDG_SWEEP_RIDE_LABELS=0 / WDG_SWEEP_FUSED_MLP=0 restore the separate label aggregation / the two GEMM launches: 7)
 `value` = stored entries of A+I aggregated per second over the whole job (all ranks); the dominant kernel's
-roofline is measured live with HIP events on the launch stream; a bounded CPU sample of the same workload,
+roofline is measured live with HIP events on the launch stream (sampled: 50 launches over the timed region); a bounded CPU sample of the same workload,
 run the way the reference does it, is reported as `cpu_baseline` (rank 0, N=1 only).
 """
 import argparse
