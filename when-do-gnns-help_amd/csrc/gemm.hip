@@ -5,10 +5,15 @@
 // table), so this is the build-defined transform of SURVEY.md 7.3 / K10: SGC-1 logits (A_hat X) W and the two
 // GCN-2 layers, plus the sampled Gram H_s H_s^T of utils/homophily_metrics.py:234-235,246 via transb.
 //
-// Shapes here are tall and skinny (M = nodes x graphs, N = 64 hidden or C classes), i.e. bound by streaming A
-// once from HBM: 128-row x 32/64-column workgroup tiles, K in steps of 16 through padded LDS tiles
-// (conflict-free ds_read_b32 operand fetches), next K-step's global loads issued before the MFMAs of the
-// current one.
+// Shapes here are tall and skinny (M = nodes x graphs, N = 64 hidden or C classes), i.e. one pass over A.  Three kernels:
+//   gemm_f32_kernel   128-row x 32/64-column workgroup tiles, K in steps of 16 through padded LDS tiles (conflict-free
+//                     ds_read_b32 operand fetches), next K-step's global loads issued before the MFMAs of the current
+//                     one: every shape (transb Gram products, any K and N), and launches too small to fill the chip
+//   gemm_bres_kernel  B (<= 512 x 64) copied to LDS once per workgroup, A streamed from memory straight into the MFMA
+//                     operand layout (v_permlane32_swap), no barrier in the K loop: big tall-skinny tables
+//   mlp2_bres_kernel  the same loop with the MFMA operands swapped (transposed accumulator tile) + a per-lane second
+//                     product: act(A W0 + b0) W1 + b1 in one pass, the hidden layer never stored
+// All three run the same k-ordered fp32 fma chain per output element of the (first) product: identical bits.
 #include "wdg_common.h"
 
 namespace {
