@@ -740,7 +740,11 @@ def test_mlp2_fused_transform(ops, oracle, relu):
         ref32 = oracle.gemm(oracle.gemm(np.ascontiguousarray(_np(a)), _np(w0), None if b0 is None else _np(b0), relu=relu),
                             _np(w1), None if b1 is None else _np(b1))
         np.testing.assert_allclose(_np(z), ref32, rtol=1e-5, atol=1e-5 * scale)
-    # shapes the fused kernel does not take are reported, not mangled
+    # shapes the fused kernel does not take are reported, not mangled (C ABI: WDG_ERR_UNSUPPORTED, nothing launched)
+    from wdg_amd import _lib
+    for max_k, max_h, max_c in ((500, 65, 5), (500, 64, 9), (516, 64, 5), (498, 64, 5)):
+        assert _lib.lib.wdg_mlp2_batched_f32(batch.table.data_ptr(), batch.n_jobs, 2000, max_k, max_h, max_c, None) == -4
+    assert "mlp2_batched" in _lib.lib.wdg_last_error().decode()
     big = (torch.ones(8, 8, device="cuda"), torch.ones(8, 65, device="cuda"), None, torch.ones(65, 3, device="cuda"), None, torch.empty(8, 3, device="cuda"))
     assert not ops.Mlp2Batch.eligible([big])
     with pytest.raises(ValueError):
