@@ -506,6 +506,14 @@ def test_spmm_shared_x_kernel_bitwise(ops, monkeypatch, n, f, groups, use_values
     torch.cuda.synchronize()
     for (_, _, y, _, _, _), w in zip(entries, want):
         assert torch.equal(y, w)
+    monkeypatch.setenv("WDG_SPMM_SHARED8", "1")  # opt-in variant: 8-feature items, two workgroups per CU
+    for e in entries:
+        e[2].zero_()
+    batch.launch()
+    torch.cuda.synchronize()
+    for (_, _, y, _, _, _), w in zip(entries, want):
+        assert torch.equal(y, w)
+    monkeypatch.delenv("WDG_SPMM_SHARED8")
     monkeypatch.setenv("WDG_SPMM_NO_SHARED_X", "1")  # same table on the per-graph kernels
     for e in entries:
         e[2].zero_()

@@ -1007,12 +1007,11 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_pipe_kernel(const wdg
 // Same arithmetic and summation order as the other row-lane kernels (blocks ascend, entries ascend): bit-identical.
 constexpr int RL_SHARED_MAX_COLS = 2032;  // 2032 x 64 B + 16 x 2 KiB + static <= 160 KiB
 
-template <int RPT, bool HAS_VAL>
-__global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const wdg_spmm_job *__restrict__ jobs, int n_groups,
-                                                                          int n_runs, int run_len, int queue_slot,
-                                                                          int x_slots) {
-    constexpr int QUADS = 4, FG = 16, U = 8;
-    constexpr int TR_SLOTS = 128, ROWS_PASS = TR_SLOTS / QUADS, PASSES = 64 / ROWS_PASS;
+template <int RPT, bool HAS_VAL, int QUADS>
+__device__ __forceinline__ void rl_shared_body(const wdg_spmm_job *__restrict__ jobs, int n_groups, int n_runs, int run_len,
+                                               int queue_slot, int x_slots) {
+    constexpr int FG = QUADS * 4, U = QUADS == 2 ? 4 : 8;
+    constexpr int TR_SLOTS = 32 * QUADS, ROWS_PASS = TR_SLOTS / QUADS, PASSES = 64 / ROWS_PASS;
     constexpr int READS = ROWS_PASS * QUADS / 64, ROWS_PER_READ = 64 / QUADS;
     extern __shared__ float4 lds[];
     __shared__ int next_item[2];
@@ -1246,6 +1245,22 @@ __global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const w
     }
 }
 
+template <int RPT, bool HAS_VAL>
+__global__ __launch_bounds__(RL_THREADS) void spmm_rowlane_shared_kernel(const wdg_spmm_job *__restrict__ jobs, int n_groups,
+                                                                          int n_runs, int run_len, int queue_slot,
+                                                                          int x_slots) {
+    rl_shared_body<RPT, HAS_VAL, 4>(jobs, n_groups, n_runs, run_len, queue_slot, x_slots);
+}
+
+// 8-feature items: 32-B rows (a 2000-row slab is 64 KB) and at most 64 VGPRs, so that TWO workgroups = 32 waves share a CU.
+// Opt-in (WDG_SPMM_SHARED8=1), bit-identical, measured SLOWER on the sweep batch (262 against 219 us): twice the items,
+// i.e. twice the staging / extent / index chains, and the phases of the two co-resident workgroups still add up.
+template <int RPT, bool HAS_VAL>
+__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rowlane_shared8_kernel(
+    const wdg_spmm_job *__restrict__ jobs, int n_groups, int n_runs, int run_len, int queue_slot, int x_slots) {
+    rl_shared_body<RPT, HAS_VAL, 2>(jobs, n_groups, n_runs, run_len, queue_slot, x_slots);
+}
+
 // Column-block size of a graph's SELL copy: two blocks must fit the LDS side by side (the pipelined kernel sweeps one while
 // the next lands): it runs 16-feature items, 64-B staged rows, 1024 rows = 64 KiB per block.  (32-feature items would need
 // 512-row blocks; every extra block adds padding - a slice runs as long as its longest row IN THAT BLOCK - and the sweep is
@@ -1302,12 +1317,31 @@ int launch_rowlane_pipe(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n
 template <int RPT>
 int launch_rowlane_shared(const wdg_spmm_job *jobs, int n_jobs, int run_len, int max_cols, int max_feat, bool has_val,
                           hipStream_t st) {
-    const int n_groups = static_cast<int>(ceil_div(max_feat, 16));
+    const bool narrow_env = getenv("WDG_SPMM_SHARED8") != nullptr;  // opt-in: 8-feature items, two workgroups per CU (slower)
+    const bool narrow = narrow_env && static_cast<size_t>(max_cols) * 32 + RL_WAVES * 64 * 16 + 64 <= kLdsBytes / 2;
+    const int quads = narrow ? 2 : 4;
+    const int n_groups = static_cast<int>(ceil_div(max_feat, quads * 4));
     const int n_runs = n_jobs / run_len;
     const int64_t n_items = static_cast<int64_t>(n_runs) * n_groups;
     if (n_items >= (1ll << 31) - 4096) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: too many work items");
-    const int x_slots = max_cols * 4;  // all source rows, 64 B each
-    const size_t lds = (static_cast<size_t>(x_slots) + RL_WAVES * 128) * 16;
+    const int x_slots = max_cols * quads;  // all source rows, 64 (32) B each
+    const size_t lds = (static_cast<size_t>(x_slots) + RL_WAVES * 32 * quads) * 16;
+    if (narrow) {
+        auto k8v = spmm_rowlane_shared8_kernel<RPT, true>;
+        auto k8n = spmm_rowlane_shared8_kernel<RPT, false>;
+        static thread_local bool configured8 = false;
+        if (!configured8) {
+            for (const void *k : {reinterpret_cast<const void *>(k8v), reinterpret_cast<const void *>(k8n)})
+                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes / 2)) != hipSuccess)
+                    return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+            configured8 = true;
+        }
+        const dim3 grid8(static_cast<unsigned>(std::min<int64_t>(n_items, 2 * resident_grid(n_items))));
+        const int slot8 = static_cast<int>(next_queue_slot());
+        if (has_val) hipLaunchKernelGGL(k8v, grid8, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot8, x_slots);
+        else hipLaunchKernelGGL(k8n, grid8, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot8, x_slots);
+        return check_launch("spmm_rowlane_shared8_kernel");
+    }
     auto kv = spmm_rowlane_shared_kernel<RPT, true>;
     auto kn = spmm_rowlane_shared_kernel<RPT, false>;
     static thread_local bool configured = false;
