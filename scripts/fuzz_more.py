@@ -13,7 +13,7 @@ import time
 bad = 0
 t0 = time.time()
 for seed in range(100, int(sys.argv[1]) if len(sys.argv) > 1 else 260):
-    for fn in (T.test_spmm_fuzz_shapes_and_batches, T.test_fuzz_build_stats_las_gemm):
+    for fn in (T.test_spmm_fuzz_shapes_and_batches, T.test_fuzz_build_stats_las_gemm, T.test_fuzz_resident_gemm_and_mlp2):
         try:
             fn(ops, orc, seed)
         except Exception as e:  # noqa: BLE001

@@ -759,6 +759,47 @@ def test_mlp2_fused_transform(ops, oracle, relu):
         ops.Mlp2Batch([big])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_resident_gemm_and_mlp2(ops, oracle, seed, monkeypatch=None):
+    """Seeded fuzz of the two B-resident kernels over random shapes, leading dimensions, biases and activations: the GEMM
+    against the tile kernel (bitwise), the fused transform against two GEMM calls (1e-5 of the largest output)."""
+    rng = np.random.default_rng(9000 + seed)
+    gemm_entries, mlp_entries = [], []
+    for _ in range(int(rng.integers(1, 6))):
+        m, k, n = int(rng.integers(1, 3000)), 4 * int(rng.integers(1, 129)), int(rng.integers(1, 65))
+        pad = 4 * int(rng.integers(0, 3))
+        a = torch.from_numpy(rng.standard_normal((m, k + pad)).astype(np.float32)).cuda()[:, :k]
+        b = torch.from_numpy(rng.standard_normal((k, n)).astype(np.float32)).cuda()
+        bias = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda() if rng.random() < 0.5 else None
+        gemm_entries.append((a, b, torch.empty((m, n), device="cuda"), bias))
+        c = int(rng.integers(1, 9))
+        w1 = torch.from_numpy((rng.standard_normal((n, c)) / np.sqrt(n)).astype(np.float32)).cuda()
+        b1 = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).cuda() if rng.random() < 0.5 else None
+        mlp_entries.append((a, b / float(np.sqrt(k)), bias, w1, b1, torch.empty((m, c), device="cuda")))
+    relu = bool(rng.integers(0, 2))
+    outs = {}
+    for env in ("WDG_GEMM_RESIDENT", "WDG_GEMM_TILE"):
+        os.environ[env] = "1"
+        try:
+            batch = ops.GemmBatch(gemm_entries, relu=relu)
+            for e in gemm_entries:
+                e[2].fill_(float("nan"))
+            batch.launch()
+            torch.cuda.synchronize()
+            outs[env] = [e[2].clone() for e in gemm_entries]
+        finally:
+            del os.environ[env]
+    for x, y in zip(outs["WDG_GEMM_RESIDENT"], outs["WDG_GEMM_TILE"]):
+        assert torch.equal(x, y) and not bool(torch.isnan(x).any())
+    fused = ops.Mlp2Batch(mlp_entries, relu=relu)
+    fused.launch()
+    torch.cuda.synchronize()
+    for a, w0, b0, w1, b1, z in mlp_entries:
+        two = ops.gemm(ops.gemm(a, w0, bias=b0, relu=relu), w1, bias=b1)
+        scale = max(float(two.abs().max()), 1e-30)
+        np.testing.assert_allclose(_np(z), _np(two), rtol=1e-5, atol=2e-6 * scale)
+
+
 def test_edge_cosine_sddmm(ops, oracle):
     rng = np.random.default_rng(41)
     for n, f, e in ((500, 37, 6000), (2708, 1433, 13000), (30, 3, 200)):
