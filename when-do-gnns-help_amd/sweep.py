@@ -108,6 +108,7 @@ class SweepBatch:
         # generator: labels = node // class size); WDG_SWEEP_RIDE_LABELS=0 keeps the separate launch.
         ride = os.environ.get("WDG_SWEEP_RIDE_LABELS", "1") != "0" and n_classes > 0
         self.agg_feat = (n_feat + n_classes + 3) // 4 * 4 if ride else n_feat
+        self.alg_feat = n_feat + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
         feats, self.graphs, self.dinv, self.labels, self.y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
         for j in self.jobs:
@@ -183,15 +184,15 @@ class SweepBatch:
     def spmm_algorithmic_bytes(self):
         tot = 0
         for g in self.graphs:
-            n, e, f = g.n_rows, g.nnz, self.agg_feat
+            n, e, f = g.n_rows, g.nnz, self.alg_feat
             tot += 4 * (n + 1) + 4 * e + 4 * n + 4 * n * f + 4 * n * f
         return tot
 
     def spmm_unique_bytes(self):
         """same, counting each distinct feature matrix once (graphs of one seed share X)"""
-        tot = sum(4 * x.numel() for x in self.x_agg.values())
+        tot = sum(4 * x.shape[0] * self.alg_feat for x in self.x_agg.values())
         for g in self.graphs:
-            tot += 4 * (g.n_rows + 1) + 4 * g.nnz + 4 * g.n_rows + 4 * g.n_rows * self.agg_feat
+            tot += 4 * (g.n_rows + 1) + 4 * g.nnz + 4 * g.n_rows + 4 * g.n_rows * self.alg_feat
         return tot
 
     def step(self):
