@@ -20,7 +20,7 @@ def test_sweep_step_against_oracle(oracle, symmetric, fused_mlp, ride_labels, mo
     torch.cuda.synchronize()
     rows = batch.results().cpu().numpy()
     assert rows.shape == (len(jobs), len(sweep.METRIC_NAMES))
-    assert (batch.spmm_las is None) == (ride_labels == "1") and batch.agg_feat == (104 if ride_labels == "1" else 96)
+    assert (batch.spmm_las is None) == (ride_labels == "1") and batch.agg_feat == (112 if ride_labels == "1" else 96)
     for i, j in enumerate(jobs):
         src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
         x = synth.features(j.n_nodes, 96, j.seed)

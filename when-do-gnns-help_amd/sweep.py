@@ -103,11 +103,14 @@ class SweepBatch:
         self.n_feat = n_feat
         n_classes = max([j.n_classes for j in self.jobs], default=0)
         # Label columns ride along: the aggregation walks X in 16-feature groups and the last group of F = 500 is three
-        # quarters empty, so [X | onehot(labels) | 0] (F_agg = 508) costs the same 32 groups and the separate F = C
+        # quarters empty, so [X | onehot(labels) | 0] (F_agg = 512) costs the same 32 groups and the separate F = C
         # aggregation launch of the LAS metric disappears.  Needs one label vector per feature matrix (true for the
         # generator: labels = node // class size); WDG_SWEEP_RIDE_LABELS=0 keeps the separate launch.
         ride = os.environ.get("WDG_SWEEP_RIDE_LABELS", "1") != "0" and n_classes > 0
-        self.agg_feat = (n_feat + n_classes + 3) // 4 * 4 if ride else n_feat
+        # rows of [X | onehot | 0] and of Y are padded to whole 16-feature groups: every 64-byte row segment an item stores
+        # is then 64-byte aligned (one L2 write request instead of two: 220 against 225 us per launch; ..._ALIGN=4 to compare)
+        align = int(os.environ.get("WDG_SWEEP_AGG_ALIGN", "16"))
+        self.agg_feat = (n_feat + n_classes + align - 1) // align * align if ride else n_feat
         self.alg_feat = n_feat + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
         feats, self.graphs, self.dinv, self.labels, self.y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
