@@ -75,7 +75,7 @@ def main():
     for _ in range(args.warmup):
         batch.step()
     sweep.gather_results(batch.results(), dev)  # untimed: first use of the tail ops loads their code objects
-    # WDG_BENCH_GRAPH=1 replays everything after the aggregation launch from one captured hipGraph (8 launches on three
+    # WDG_BENCH_GRAPH=1 replays everything after the aggregation launch from one captured hipGraph (the launches of both
     # streams -> 1); measured slower than the plain launches (0.517 vs 0.486 ms per step), so off by default
     step_rest = batch.capture_rest() if os.environ.get("WDG_BENCH_GRAPH", "0") == "1" else batch.step_rest
     # HIP events around the aggregation launch of every `stride`-th step (about 50 samples over the timed region): an

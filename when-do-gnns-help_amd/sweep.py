@@ -162,7 +162,7 @@ class SweepBatch:
 
         # GCN-2 forward (build-defined model, models.py): logits = A_hat relu((A_hat X) W0) W1, every job its own weights
         self.gcn = None
-        n_streams = int(os.environ.get("WDG_SWEEP_STREAMS", "3"))  # see step_rest
+        n_streams = int(os.environ.get("WDG_SWEEP_STREAMS", "2"))  # see step_rest
         self.side = torch.cuda.Stream() if n_streams >= 2 else None
         self.side2 = torch.cuda.Stream() if n_streams >= 3 else None
         self._fork = torch.cuda.Event()
@@ -207,10 +207,12 @@ class SweepBatch:
     def step_rest(self):
         """everything of a step after the feature aggregation (bench.py times that launch separately).
 
-        Three independent chains on three HIP streams: the statistics pass, label aggregation -> LAS, and the GCN-2
-        forward (two GEMMs + the logits aggregation).  The B-resident GEMM occupies 200 of the 256 CUs for ~155 us; the
-        small latency-bound kernels of the other two chains use the remaining CUs meanwhile and finish next to the
-        GCN chain's tail (scripts/step_timeline.py on a kernel trace).  WDG_SWEEP_STREAMS=1|2 for fewer streams."""
+        Two independent chains on two HIP streams: the metric chain (LAS, then the statistics pass) and the GCN-2 forward
+        (fused feature transform + the logits aggregation).  The B-resident GEMM occupies 200 of the 256 CUs for ~150 us;
+        the metric kernels use the remaining CUs meanwhile: LAS first (large workgroups, done within ~50 us), then the
+        statistics kernel, whose remainder overlaps the logits aggregation (scripts/step_timeline.py on a kernel trace).
+        Measured per step: one stream 0.47 ms, two streams statistics-first 0.439, three streams 0.425, two streams
+        LAS-first 0.408.  WDG_SWEEP_STREAMS=1|3 for the other arrangements."""
         main = torch.cuda.current_stream()
         if self.gcn and self.side is not None:
             self._fork.record(main)  # one marker on the main queue for both side streams
@@ -248,10 +250,12 @@ class SweepBatch:
         return graph.replay
 
     def _metric_chain(self):
-        self.stats.launch()       # edge / node / class / adjusted homophily, label informativeness counters
+        # LAS first: its 100 workgroups of 1024 threads + 51 KiB of LDS need whole free CUs, which the 1 600 small
+        # workgroups of the statistics kernel would otherwise occupy for as long as that kernel crawls beside the GEMM
         if self.spmm_las is not None:
             self.spmm_las.launch()  # H = A_hat onehot(labels)        (F = C; else: columns of the feature aggregation)
-        self.las.launch()         # soft / hard LAS counts
+        self.las.launch()           # soft / hard LAS counts
+        self.stats.launch()         # edge / node / class / adjusted homophily, label informativeness counters
 
     def _gcn_chain(self):
         if self.gcn["mlp"] is not None:
