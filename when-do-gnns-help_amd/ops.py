@@ -418,8 +418,14 @@ class StatsBatch:
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
         self.table = host.to(dev)
 
-    def launch(self):
+    def zero(self):
+        """the counters must be zero when the kernel starts (launch() does it; callers that want the memset off a
+        dependency chain call zero() earlier and launch(zero=False))"""
         self.counters.zero_()
+
+    def launch(self, zero=True):
+        if zero:
+            self.counters.zero_()
         check(lib.wdg_edge_label_stats_batched(_ptr(self.table), self.n_jobs, self.max_rows, self.c, stream_handle()),
               "wdg_edge_label_stats_batched")
 

@@ -252,10 +252,11 @@ class SweepBatch:
     def _metric_chain(self):
         # LAS first: its 100 workgroups of 1024 threads + 51 KiB of LDS need whole free CUs, which the 1 600 small
         # workgroups of the statistics kernel would otherwise occupy for as long as that kernel crawls beside the GEMM
+        self.stats.zero()           # (the counters' memset, ahead of LAS instead of between the two kernels)
         if self.spmm_las is not None:
             self.spmm_las.launch()  # H = A_hat onehot(labels)        (F = C; else: columns of the feature aggregation)
         self.las.launch()           # soft / hard LAS counts
-        self.stats.launch()         # edge / node / class / adjusted homophily, label informativeness counters
+        self.stats.launch(zero=False)  # edge / node / class / adjusted homophily, label informativeness counters
 
     def _gcn_chain(self):
         if self.gcn["mlp"] is not None:
