@@ -47,6 +47,26 @@ def test_sweep_step_against_oracle(oracle, symmetric, fused_mlp, ride_labels, mo
         np.testing.assert_allclose(g["logits"][i].cpu().numpy(), logits, rtol=1e-5, atol=1e-5 * np.abs(logits).max())
 
 
+def test_step_rest_graph_replay_equals_plain_launches():
+    """SweepBatch.capture_rest(): the post-aggregation launches of a step (both streams, fork / join included) replayed
+    from one hipGraph give bit for bit the outputs of the plain launches."""
+    from wdg_amd import sweep
+    jobs = sweep.make_jobs([0.2, 0.6], [0, 1], k=2, n_nodes=1000)
+    batch = sweep.SweepBatch(jobs, n_feat=64, gcn_hidden=32)
+    batch.step()
+    torch.cuda.synchronize()
+    want = ([l.clone() for l in batch.gcn["logits"]], batch.results().clone(), batch.las.counts.clone())
+    replay = batch.capture_rest()
+    for l in batch.gcn["logits"]:
+        l.fill_(float("nan"))
+    batch.spmm.launch()
+    replay()
+    torch.cuda.synchronize()
+    for a, b in zip(batch.gcn["logits"], want[0]):
+        assert torch.equal(a, b)
+    assert torch.equal(batch.results(), want[1]) and torch.equal(batch.las.counts, want[2])
+
+
 def test_batched_gemm_and_las_mixed_shapes(oracle):
     from wdg_amd import ops
     rng = np.random.default_rng(3)
