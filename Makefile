@@ -13,7 +13,7 @@ $(LIB): $(OBJS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/wdg_common.h include/wdg.h
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/wdg.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: aggregation edges/s on the synthetic homophily sweep (BASELINE.json configs[1]).
+"""Headline benchmark: aggregation edges/s on the synthetic homophily sweep the north star quotes its target on
+(BASELINE.json configs[2], SURVEY.md 8(d) config C3: the `data_synthesis/4000`-equivalent set).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N worker processes (one per
+GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU, forwards rank 0's JSON line and
+exits non-zero when a worker fails.
 
-Workload per rank (weak scaling: fixed per-GPU work): the `data_synthesis/800`-equivalent sweep shard
-  10 homophily levels x `--seeds` seeds (default 10) = 100 graphs, N = 2000 nodes, k = 2, F = 500 fp32 features
-  (the directory name "800" is k*400, every graph has 2000 nodes - SURVEY G3).
+Workload per rank (weak scaling: fixed per-GPU work): the `data_synthesis/4000`-equivalent sweep shard
+  10 homophily levels x `--seeds` seeds (default 5: the C3 job set) = 50 graphs, N = 2000 nodes, k = 10 (12 .. 67 stored
+  entries per row of A + I), F = 500 fp32 features (the directory name "4000" is k*400, every graph has 2000 nodes -
+  SURVEY G3).  `--k 2 --seeds 10` is the `800` set (C2), the round-1 headline; it is emitted as `secondary` when
+  `--secondary` is given.
 A step = one pass of the hot path over that batch with all inputs resident in HBM, 5 batched launches:
   (1) A_hat [X | onehot(y)] aggregation, A_hat = D^-1 (A + I) fused into the SpMM (csrc/spmm_rowlane.hip; graphs of a
       seed share X; the label aggregation of the LAS metric rides in the last, otherwise mostly empty feature group)
@@ -31,37 +37,42 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seeds", type=int, default=10, help="seeds per rank (x 10 homophily levels = graphs per step)")
-    ap.add_argument("--nodes", type=int, default=2000)
-    ap.add_argument("--feat", type=int, default=500)
-    ap.add_argument("--k", type=int, default=2, help="same-class out-neighbours per node (2 = `800` set, 10 = `4000` set)")
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
-    args = ap.parse_args()
+def launch_workers(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N workers (one per GPU) from a parent that never touches the
+    GPU, forward rank 0's stdout (the JSON line), return non-zero when any worker fails.  WDG_BENCH_WORKER (tests) names a
+    stand-in worker script."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = os.environ.get("WDG_BENCH_WORKER", os.path.abspath(__file__))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: workers failed (rank, rc): {bad}", file=sys.stderr)
+        return 1
+    return 0
 
+
+def measure(args, k, seeds, steps, warmup, world, rank, dev):
+    """Build this rank's shard of the (k, seeds) sweep, time `steps` steps -> dict of raw measurements (every rank)."""
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
-
     from wdg_amd import sweep, synth
-    h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
+    h_levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
     # rank 0 defines the whole job list and broadcasts it; every rank takes its shard (whole seeds)
-    jobs = sweep.make_jobs(h_levels, range(args.seeds * world), k=args.k, n_nodes=args.nodes) if rank == 0 else []
+    jobs = sweep.make_jobs(h_levels, range(seeds * world), k=k, n_nodes=args.nodes) if rank == 0 else []
     jobs = sweep.broadcast_jobs(jobs, dev)
     mine = sweep.shard_jobs(jobs, world, rank)
     batch = sweep.SweepBatch(mine, n_feat=args.feat)
@@ -72,7 +83,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         batch.step()
     sweep.gather_results(batch.results(), dev)  # untimed: first use of the tail ops loads their code objects
     # WDG_BENCH_GRAPH=1 replays everything after the aggregation launch from one captured hipGraph (the launches of both
@@ -81,11 +92,11 @@ def main():
     # HIP events around the aggregation launch of every `stride`-th step (about 50 samples over the timed region): an
     # event pair costs ~20 us of queue markers per step (scripts/time_gaps.py: 0.443 -> 0.423 ms without them), so the
     # roofline figure is sampled instead of taxing every step; all steps run the same launches either way
-    stride = max(1, args.steps // 50)
-    ev = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in range(0, args.steps, stride)}
+    stride = max(1, steps // 50)
+    ev = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in range(0, steps, stride)}
     sync_all()
     t0 = time.perf_counter()
-    for s in range(args.steps):
+    for s in range(steps):
         if s in ev:
             ev[s][0].record()       # torch's current stream == the stream the kernels are launched on
             batch.spmm.launch()
@@ -107,63 +118,122 @@ def main():
         total_edges = int(e.item())
     else:
         total_edges = batch.edges
-    n_graphs = sum(g.shape[0] for g in gathered)
+    spmm_ms = sorted(a.elapsed_time(b) for a, b in ev.values())
+    return dict(batch=batch, mine=mine, h_levels=h_levels, elapsed=elapsed, enqueue_s=enqueue_s, total_edges=total_edges,
+                n_graphs=sum(g.shape[0] for g in gathered), spmm_ms=spmm_ms, k=k, seeds=seeds, steps=steps)
 
+
+def traffic_for(n_graphs, n_feat, k):
+    """PMC-derived HBM bytes per aggregation launch of the same workload (profiles/traffic.json: one record per k)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tpath))
+    except Exception:
+        return None
+    for rec in (tj if isinstance(tj, list) else [tj]):
+        if rec.get("graphs_per_launch") == n_graphs and rec.get("n_feat") == n_feat and rec.get("k") == k:
+            return rec.get("hbm_bytes_per_launch")
+    return None
+
+
+def roofline_of(args, m):
+    batch = m["batch"]
+    spmm_ms = m["spmm_ms"]
+    spmm_avg_ms = sum(spmm_ms) / len(spmm_ms)
+    alg = batch.spmm_algorithmic_bytes()
+    achieved = alg / (spmm_avg_ms * 1e-3) / 1e9
+    traffic = traffic_for(len(m["mine"]), args.feat, m["k"])
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # the same launch priced by the bytes the chip really moved (PMC): X is fetched once per group of graphs that
+            # share it, the algorithmic figure of SURVEY 8(d) counts it once per graph
+            "frac_traffic": (traffic / (spmm_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "kernel": batch.spmm.kernel_name(),
+            "avg_launch_us": spmm_avg_ms * 1e3, "median_launch_us": spmm_ms[len(spmm_ms) // 2] * 1e3,
+            "algorithmic_bytes_per_launch": alg, "unique_bytes_per_launch": batch.spmm_unique_bytes(),
+            "launches_timed": len(spmm_ms)}
+
+
+def workload_text(args, m, world):
+    batch = m["batch"]
+    n_launches = 4 + (batch.spmm_las is not None) + (1 if batch.gcn["mlp"] is not None else 2)
+    return (f"synthetic homophily sweep (data_synthesis/{m['k'] * 400}-equivalent): "
+            f"{len(m['h_levels'])} h-levels x {m['seeds']} seeds = {len(m['mine'])} graphs/GPU/step, "
+            f"N={args.nodes} nodes, k={m['k']}, F={args.feat} fp32, C=5; step = batched "
+            f"D^-1(A+I)X aggregation + edge/label statistics + label aggregation & LAS + "
+            f"GCN-2 forward (hidden 64, per-graph weights), {n_launches} launches"
+            + (f"; the C one-hot label columns of the LAS metric ride in the feature aggregation "
+               f"(F_agg={batch.agg_feat})" if batch.spmm_las is None else ""))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seeds", type=int, default=5, help="seeds per rank (x 10 homophily levels = graphs per step)")
+    ap.add_argument("--nodes", type=int, default=2000)
+    ap.add_argument("--feat", type=int, default=500)
+    ap.add_argument("--k", type=int, default=10, help="same-class out-neighbours per node (10 = `4000` set, 2 = `800` set)")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--secondary", type=int, default=1, help="1: also time the `800` set (k=2, 10 seeds) and report it as `secondary` (N=1 only)")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_workers(args, sys.argv[1:]))  # the parent never initialises the GPU
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    m = measure(args, args.k, args.seeds, args.steps, args.warmup, world, rank, dev)
     if rank == 0:
-        spmm_ms = sorted(a.elapsed_time(b) for a, b in ev.values())
-        spmm_avg_ms = sum(spmm_ms) / len(spmm_ms)
-        alg = batch.spmm_algorithmic_bytes()
-        achieved = alg / (spmm_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch of the same command
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("graphs_per_launch") == len(mine) and tj.get("n_feat") == args.feat and tj.get("k") == args.k:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        fam, slab, threads = batch.spmm.plan()
-        n_launches = 4 + (batch.spmm_las is not None) + (1 if batch.gcn["mlp"] is not None else 2)
-        kernel_name = {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
-                       2: f"spmm_rowlane_kernel<{slab // 4},{(args.nodes + 1023) // 1024},float,false>",
-                       3: f"spmm_rowlane_pipe_kernel<{slab // 4},{(args.nodes + 1023) // 1024},false>",
-                       4: f"spmm_rowlane_shared_kernel<{(args.nodes + 1023) // 1024},false>"}[fam]
+        batch = m["batch"]
         out = {
             "metric": "aggregation edges/sec (whole job; + %HBM roofline of the SpMM kernel)",
-            "value": total_edges * args.steps / elapsed,
+            "value": m["total_edges"] * args.steps / m["elapsed"],
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": m["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic homophily sweep (data_synthesis/{args.k * 400}-equivalent): "
-                                   f"{len(h_levels)} h-levels x {args.seeds} seeds = {len(mine)} graphs/GPU/step, "
-                                   f"N={args.nodes} nodes, k={args.k}, F={args.feat} fp32, C=5; step = batched "
-                                   f"D^-1(A+I)X aggregation + edge/label statistics + label aggregation & LAS + "
-                                   f"GCN-2 forward (hidden 64, per-graph weights), {n_launches} launches"
-                                   + (f"; the C one-hot label columns of the LAS metric ride in the feature aggregation "
-                                      f"(F_agg={batch.agg_feat})" if batch.spmm_las is None else ""),
-                       "graphs_per_step_per_gpu": len(mine), "edges_per_step_per_gpu": batch.edges,
+            "config": {"workload": workload_text(args, m, world),
+                       "graphs_per_step_per_gpu": len(m["mine"]), "edges_per_step_per_gpu": batch.edges,
                        "parallelism": f"independent sweep shards x{world} (no data-path collective; job-table broadcast + result all_gather)"},
-            "graphs_per_s": n_graphs * args.steps / elapsed,
-            "edge_features_per_s": total_edges * args.feat * args.steps / elapsed,
-            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name,
-                         "avg_launch_us": spmm_avg_ms * 1e3, "median_launch_us": spmm_ms[len(spmm_ms) // 2] * 1e3,
-                         "algorithmic_bytes_per_launch": alg, "unique_bytes_per_launch": batch.spmm_unique_bytes(),
-                         "launches_timed": len(spmm_ms)},
+            "graphs_per_s": m["n_graphs"] * args.steps / m["elapsed"],
+            "edge_features_per_s": m["total_edges"] * args.feat * args.steps / m["elapsed"],
+            "host_enqueue_ms_per_step": m["enqueue_s"] / args.steps * 1e3,
+            "roofline": roofline_of(args, m),
         }
+    del m
+    if world == 1 and args.secondary and not (args.k == 2 and args.seeds == 10):
+        torch.cuda.empty_cache()
+        steps2 = max(20, args.steps // 2)
+        m2 = measure(args, 2, 10, steps2, min(args.warmup, 10), world, rank, dev)
+        out["secondary"] = {"workload": workload_text(args, m2, world), "steps": steps2,
+                            "value": m2["total_edges"] * steps2 / m2["elapsed"], "unit": "edges/s",
+                            "ms_per_step": m2["elapsed"] / steps2 * 1e3,
+                            "graphs_per_s": m2["n_graphs"] * steps2 / m2["elapsed"],
+                            "roofline": roofline_of(args, m2)}
+        del m2
+    if rank == 0:
         if world == 1 and args.cpu_budget > 0:
             from oracle import cpu_ref
+            from wdg_amd import sweep, synth
+            h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
             sample = sweep.make_jobs(h_levels, [0], k=args.k, n_nodes=args.nodes)
-            cb = cpu_ref.time_sample(sample, args.feat, budget_s=args.cpu_budget)
-            out["cpu_baseline"] = {"value": cb["edges_per_s"], "unit": "edges/s", "cores": cb["cores"], "kind": "port",
-                                   "sample": f"{len(sample)} graphs (seed 0, {len(h_levels)} h-levels) x {cb['passes']} passes "
-                                             f"= {cb['graphs']} graph evaluations in {cb['seconds']:.1f} s; dense torch.spmm "
-                                             f"+ oracle edge metrics, the reference's call pattern (synthetic_plot.py:92-109)"}
+            out["cpu_baseline"] = cpu_ref.baseline_record(sample, args.feat, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

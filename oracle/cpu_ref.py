@@ -59,3 +59,31 @@ def time_sample(jobs, n_feat, budget_s=12.0, threads=None):
             break
     return dict(edges_per_s=edges / el, seconds=el, passes=passes, graphs=len(inputs) * passes,
                 cores=torch.get_num_threads())
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def baseline_record(jobs, n_feat, budget_s=12.0):
+    """The `cpu_baseline` object of bench.py's JSON line: the all-threads figure is `value`; a 1-thread figure of the same
+    sample rides along (BASELINE.md section 3 asks for both).  About 3/4 of the budget goes to the all-threads run."""
+    all_threads = torch.get_num_threads()
+    cb = time_sample(jobs, n_feat, budget_s=budget_s * 0.75)
+    one = time_sample(jobs, n_feat, budget_s=budget_s * 0.25, threads=1)
+    torch.set_num_threads(all_threads)
+    hs = sorted({j.h for j in jobs})
+    return {"value": cb["edges_per_s"], "unit": "edges/s", "cores": cb["cores"], "kind": "port",
+            "cpu_model": cpu_model(), "value_1_thread": one["edges_per_s"],
+            "sample": f"{len(jobs)} graphs (seed {jobs[0].seed}, {len(hs)} h-levels, k={jobs[0].k}) x {cb['passes']} passes = "
+                      f"{cb['graphs']} graph evaluations in {cb['seconds']:.1f} s on {cb['cores']} torch threads (+ {one['graphs']} "
+                      f"evaluations in {one['seconds']:.1f} s on 1 thread): dense torch.spmm aggregation as the reference runs it "
+                      f"(synthetic_plot.py:92, utils/homophily_plot.py:246) + the edge/label metrics computed by the C oracle "
+                      f"(oracle/wdg_oracle.c), NOT by the reference's Python loops (utils/homophily_plot.py:81-186), so this "
+                      f"understates the reference's cost"}

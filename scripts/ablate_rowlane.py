@@ -8,14 +8,14 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from wdg_amd import sweep, synth
+from wdg_amd import ops, sweep, synth
 
 jobs = sweep.make_jobs(synth.H_LEVELS_10, range(10), k=2)
 names = {0: "full", 1: "no Y store", 2: "no X staging", 4: "no sweep", 3: "sweep only", 5: "staging only",
          6: "stores only", 7: "nothing", 8: "full, register staging"}
 codes = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 3, 5, 6, 7, 8]
 for ab in codes:
-    os.environ["WDG_SPMM_ABLATE"] = str(ab)
+    ops.ABLATE_BITS = ab
     batch = sweep.SweepBatch(jobs, n_feat=500)
     for _ in range(3):
         batch.spmm.launch()

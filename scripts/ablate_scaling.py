@@ -6,11 +6,11 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from wdg_amd import sweep, synth
+from wdg_amd import ops, sweep, synth
 
 codes = [int(a) for a in sys.argv[1:]] or [7, 0]
 for ab in codes:
-    os.environ["WDG_SPMM_ABLATE"] = str(ab)
+    ops.ABLATE_BITS = ab
     for seeds in (1, 2, 5, 10, 20):
         batch = sweep.SweepBatch(sweep.make_jobs(synth.H_LEVELS_10, range(seeds), k=2), n_feat=500)
         for _ in range(3):

@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from wdg_amd import sweep, synth
+from wdg_amd import ops, sweep, synth
 
 cfgs = [(8, 512), (16, 1024)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 jobs = sweep.make_jobs(synth.H_LEVELS_10, range(10), k=2)
@@ -15,7 +15,7 @@ names = {0: "full", 1: "no Y store", 2: "no X load", 4: "no edge loop", 3: "no X
 for slab, thr in cfgs:
     os.environ["WDG_SPMM_SLAB"], os.environ["WDG_SPMM_THREADS"] = str(slab), str(thr)
     for ab in (0, 1, 2, 4, 3, 5, 6, 7):
-        os.environ["WDG_SPMM_ABLATE"] = str(ab)
+        ops.ABLATE_BITS = ab
         batch = sweep.SweepBatch(jobs, n_feat=500)
         for _ in range(3):
             batch.spmm.launch()

@@ -160,6 +160,23 @@ def test_row_l1_normalise(ops, oracle):
     assert (z == 0).all()  # inf -> 0 guard
 
 
+def test_normalize_scipy_rectangular(ops):
+    """normalize / preprocess_features on a scipy N x F matrix with F > N and F < N (utils/util_funcs.py:29-46 of the
+    reference: fp64 coefficients; the device stores fp32 values, hence 1.2e-7 relative)"""
+    import scipy.sparse as sp
+    from wdg_amd.utils import util_funcs as uf
+    rng = np.random.default_rng(5)
+    for n, f in ((183, 1703), (300, 120), (1, 7), (5, 1)):
+        dense = (rng.random((n, f)) < 0.05) * rng.random((n, f))
+        dense[n // 2] = 0.0  # an empty row: 1 / 0 -> inf -> 0
+        mx = sp.lil_matrix(dense)
+        want = sp.diags(np.nan_to_num(1.0 / dense.sum(1), posinf=0.0)).dot(sp.csr_matrix(dense)).toarray()
+        for fn in (uf.normalize, uf.preprocess_features):
+            got = fn(mx)
+            assert sp.issparse(got) and got.shape == (n, f) and got.dtype == mx.dtype
+            np.testing.assert_allclose(got.toarray(), want, rtol=1.2e-7, atol=0)
+
+
 # --------------------------------------------------------------------------------------------- SpMM
 def _check_spmm(ops, oracle, rowptr, col, val, x, row_scale=None, col_scale=None, tol=1e-5, dtype=torch.float32):
     n = rowptr.shape[0] - 1

@@ -17,6 +17,7 @@ COO_SYMMETRISE, COO_BINARISE, COO_ADD_SELF_LOOPS, COO_DROP_SELF_LOOPS, COO_KEEP_
 NORM_RW, NORM_SYM = 0, 1
 PREC_F32, PREC_F64 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
+ABLATE_BITS = 0  # diagnostics: scripts/ablate_*.py set this to wdg_spmm_job.reserved timing-ablation bits (results are wrong then)
 
 
 def _ptr(t):
@@ -56,8 +57,9 @@ class CsrGraph:
         """Build the SELL-64 copy (wdg_csr_to_sell_*) that the row-lane SpMM consumes.  One-time per graph.
         Skipped (returns False) for graphs too large for that kernel or whose slices would pad too much."""
         if self.sell is not None:
-            return True
+            return self.sell is not False
         if self.n_rows == 0 or self.n_rows > self.SELL_MAX_ROWS or self.nnz == 0:
+            self.sell = False  # decided once: later calls (and hipGraph captures) never redo the count / host sync
             return False
         dev = self.device
         n_slices = (self.n_rows + 63) // 64
@@ -71,7 +73,8 @@ class CsrGraph:
                                         _ptr(sell_ptr), _ptr(ws), ws_bytes, stream_handle()), "wdg_csr_to_sell_count")
         total = int(sell_ptr[-1].item())
         if total > max_padding * self.nnz + 64 * 64 * n_blocks:
-            return False  # very skewed rows: the CSR kernels are the better fit
+            self.sell = False  # very skewed rows: the CSR kernels are the better fit (remembered)
+            return False
         sell_col = torch.empty(total, dtype=torch.int32, device=dev)
         sell_val = torch.empty(total, dtype=torch.float32, device=dev) if self.val is not None else None
         check(lib.wdg_csr_to_sell_fill(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), self.n_rows, self.n_cols,
@@ -138,6 +141,17 @@ class CsrGraph:
     def from_scipy(mx, flags=0):
         coo = mx.tocoo()
         return CsrGraph.from_coo(coo.row, coo.col, coo.shape[0], coo.data, flags)
+
+    @staticmethod
+    def from_scipy_csr(mx):
+        """scipy sparse of ANY shape (N x F feature matrices included) -> device CSR by uploading `tocsr()`'s arrays
+        (duplicates summed, rows sorted by scipy: the same canonical form the COO builder produces)."""
+        dev = require_gpu()
+        csr = mx.tocsr().copy()
+        csr.sum_duplicates()
+        csr.sort_indices()
+        return CsrGraph(_dev(csr.indptr, torch.int32, dev), _dev(csr.indices, torch.int32, dev),
+                        _dev(csr.data, torch.float32, dev), csr.shape[0], csr.shape[1])
 
     @staticmethod
     def from_any(a, flags=0):
@@ -229,9 +243,9 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     job.X, job.Y = x.data_ptr(), y.data_ptr()
     job.ldx, job.ldy = _ld(x), _ld(y)
     job.n_rows, job.n_cols, job.n_feat = g.n_rows, g.n_cols, x.shape[1]
-    job.reserved = int(os.environ.get("WDG_SPMM_ABLATE", "0"))  # diagnostics only (timing ablations)
+    job.reserved = ABLATE_BITS  # 0 on every product path; only scripts/ablate_*.py assign the module variable
     wants_val = bool(job.val)
-    if g.sell is not None and (not wants_val or g.sell[2] is not None):
+    if g.sell and (not wants_val or g.sell[2] is not None):
         job.sell_ptr, job.sell_col = g.sell[0].data_ptr(), g.sell[1].data_ptr()
         job.sell_val = g.sell[2].data_ptr() if (wants_val and g.sell[2] is not None) else 0
         job.sell_block_cols, job.sell_n_blocks = g.sell[3], g.sell[4]
@@ -354,6 +368,16 @@ class SpmmBatch:
 
     def plan(self):
         return spmm_plan(self.max_rows, self.max_cols, self.max_feat, self.n_jobs, self.flags)
+
+    def kernel_name(self):
+        """name of the kernel this table launches, as rocprofv3 prints it (bench.py / scripts/bench_configs.py)"""
+        fam, slab, threads = self.plan()
+        rpt = (self.max_rows + 1023) // 1024
+        val = "true" if self.flags & SPMM_ANY_VAL else "false"
+        return {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
+                2: f"spmm_rowlane_kernel<{slab // 4},{rpt},float,{val}>",
+                3: f"spmm_rowlane_pipe_kernel<{slab // 4},{rpt},{val}>",
+                4: f"spmm_rowlane_shared_kernel<{rpt},{val}>"}.get(fam, f"family {fam}")
 
 
 SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK = 1, 2, 4

@@ -29,7 +29,9 @@ def _csr_to_scipy(g, dtype=np.float64):
 def normalize(mx):
     """Row-normalise: diag(1/rowsum) mx, inf -> 0.  reference: utils/util_funcs.py:29-36."""
     if _is_scipy(mx):
-        g = ops.normalise_values(CsrGraph.from_scipy(mx), ops.NORM_RW, ops.PREC_F32)
+        # any shape (feature matrices are N x F): the CSR arrays are uploaded as they are - the COO builder is for square
+        # adjacencies; coefficients in fp64 like scipy's, stored values are the fp32 roundings (device values are fp32)
+        g = ops.normalise_values(CsrGraph.from_scipy_csr(mx), ops.NORM_RW, ops.PREC_F64)
         return _csr_to_scipy(g, mx.dtype)
     if isinstance(mx, torch.Tensor):
         return ops.row_l1_normalise(mx)
