@@ -19,6 +19,12 @@ def ops():
     return o
 
 
+@pytest.fixture
+def old_families(monkeypatch):
+    """keep a test on the round-1 kernel families (slab / gather / row-lane): the quad-row kernel would take the call"""
+    monkeypatch.setenv("WDG_SPMM_NO_QUAD", "1")
+
+
 def _np(t):
     return t.detach().cpu().numpy()
 
@@ -203,7 +209,7 @@ def _check_spmm(ops, oracle, rowptr, col, val, x, row_scale=None, col_scale=None
 @pytest.mark.parametrize("n,f,e", [(2000, 500, 20000), (2000, 500, 82000), (2708, 1433, 13264), (500, 5, 3000),
                                    (300, 64, 5000), (1200, 33, 9000), (4000, 128, 60000), (5201, 131, 50000),
                                    (1, 1, 1), (64, 3, 0), (5000, 20, 40000)])
-def test_spmm_slab_family_shapes(ops, oracle, n, f, e, monkeypatch):
+def test_spmm_slab_family_shapes(ops, oracle, n, f, e, monkeypatch, old_families):
     monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")  # keep the column-slab kernel covered
     rng = np.random.default_rng(n + f)
     src, dst = _rand_graph(rng, n, e)
@@ -218,7 +224,7 @@ def test_spmm_slab_family_shapes(ops, oracle, n, f, e, monkeypatch):
 
 @pytest.mark.parametrize("slab", [4, 8, 16, 32])
 @pytest.mark.parametrize("threads", [512, 1024])
-def test_spmm_every_slab_variant(ops, oracle, slab, threads, monkeypatch):
+def test_spmm_every_slab_variant(ops, oracle, slab, threads, monkeypatch, old_families):
     monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")
     monkeypatch.setenv("WDG_SPMM_SLAB", str(slab))
     monkeypatch.setenv("WDG_SPMM_THREADS", str(threads))
@@ -235,7 +241,7 @@ def test_spmm_every_slab_variant(ops, oracle, slab, threads, monkeypatch):
 @pytest.mark.parametrize("n,f,e", [(60000, 7, 400000), (60000, 64, 300000), (50000, 300, 200000), (45000, 17, 100000),
                                    (70000, 2, 500000), (41000, 130, 90000), (2000, 5, 20000), (300, 8, 3000),
                                    (100, 1, 500), (2000, 4, 9000)])
-def test_spmm_gather_family(ops, oracle, n, f, e):
+def test_spmm_gather_family(ops, oracle, n, f, e, old_families):
     rng = np.random.default_rng(f)
     src, dst = _rand_graph(rng, n, e)
     rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
@@ -246,7 +252,7 @@ def test_spmm_gather_family(ops, oracle, n, f, e):
     _check_spmm(ops, oracle, rowptr, col, None, x, row_scale=d, col_scale=d)
 
 
-def test_spmm_forced_gather_on_small_graph(ops, oracle, monkeypatch):
+def test_spmm_forced_gather_on_small_graph(ops, oracle, monkeypatch, old_families):
     monkeypatch.setenv("WDG_SPMM_FORCE_GATHER", "1")
     rng = np.random.default_rng(8)
     for n, f, e in ((2000, 500, 30000), (700, 1433, 5000), (300, 9, 4000)):
@@ -419,7 +425,7 @@ def test_sell_layout_matches_csr(ops, oracle, monkeypatch, column_order):
 @pytest.mark.parametrize("n,f,e", [(2000, 500, 20000), (2000, 500, 82000), (2708, 1433, 13264), (1000, 32, 6000),
                                    (4096, 64, 30000), (3000, 17, 20000), (100, 8, 300), (2048, 100, 2048), (1025, 33, 9000),
                                    (4000, 500, 100000), (64, 129, 64)])
-def test_spmm_rowlane_family_shapes(ops, oracle, n, f, e):
+def test_spmm_rowlane_family_shapes(ops, oracle, n, f, e, old_families):
     rng = np.random.default_rng(n * 7 + f)
     src, dst = _rand_graph(rng, n, e)
     rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
@@ -450,7 +456,7 @@ def test_spmm_rowlane_family_shapes(ops, oracle, n, f, e):
     run(True, d, d, torch.bfloat16)
 
 
-def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch):
+def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch, old_families):
     """With the SELL copy in column order (WDG_SELL_ORDER=0) both LDS kernels sum a row in CSR column order: results
     must be bit-identical.  (The default bank-aware order changes the order of a row's sum: covered by the 1e-5 tests.)"""
     monkeypatch.setenv("WDG_SELL_ORDER", "0")
@@ -469,7 +475,7 @@ def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch):
 
 @pytest.mark.parametrize("n,f,e,power_law", [(2000, 500, 20000, False), (1000, 64, 9000, False), (3000, 100, 30000, False),
                                               (4096, 36, 50000, True), (700, 16, 0, False), (2277, 2324, 60000, True)])
-def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power_law):
+def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power_law, old_families):
     """The opt-in pipelined schedule (WDG_SPMM_PIPELINED=1, family 3) sums in the same order as the default row-lane
     kernel: bit-identical results, single-graph and batched, with and without explicit values."""
     from wdg_amd import synth
@@ -503,7 +509,7 @@ def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power
 
 @pytest.mark.parametrize("n,f,groups,use_values", [(2000, 500, (10,), False), (700, 36, (4, 6), True), (2032, 64, (3, 3, 3), False),
                                                      (1500, 100, (2, 8), True), (64, 16, (2,), False)])
-def test_spmm_shared_x_kernel_bitwise(ops, monkeypatch, n, f, groups, use_values):
+def test_spmm_shared_x_kernel_bitwise(ops, monkeypatch, n, f, groups, use_values, old_families):
     """Graphs that aggregate the same X run in aligned runs on the shared-X kernel (family 4): every Y must be
     bit-identical to the single-graph call, whatever the run length, for ragged feature groups and explicit values."""
     rng = np.random.default_rng(n * 3 + f)
@@ -539,6 +545,235 @@ def test_spmm_shared_x_kernel_bitwise(ops, monkeypatch, n, f, groups, use_values
     torch.cuda.synchronize()
     for (_, _, y, _, _, _), w in zip(entries, want):
         assert torch.equal(y, w)
+
+
+# --------------------------------------------------------------------------------------------- SELL-16 + quad-row kernel
+def _skewed_graph(rng, n, e):
+    """power-law rows: a few hubs, many short rows, some empty"""
+    w = 1.0 / np.arange(1, n + 1) ** 0.9
+    src = rng.choice(n, e, p=w / w.sum())
+    return src.astype(np.int64), rng.integers(0, n, e).astype(np.int64)
+
+
+@pytest.mark.parametrize("column_order", [False, True])
+def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
+    """wdg_csr_to_sell16_*: rows by length (ties by id), slices of 16, column blocks of <= 2528, chunks of 16 entries per
+    row; every (row, block) segment holds exactly the row's entries of that block as pre-scaled local offsets - in column
+    order with WDG_SELL_ORDER=0, in the bank-aware order otherwise - and pads with the zero row's offset / value 0."""
+    if column_order:
+        monkeypatch.setenv("WDG_SELL_ORDER", "0")
+    rng = np.random.default_rng(32)
+    for n, m, e, skew in ((1, 1, 1, False), (16, 16, 100, False), (17, 40, 300, False), (2000, 2000, 60000, False),
+                          (130, 130, 0, False), (5201, 5201, 50000, True), (3000, 2529, 9000, False), (700, 9000, 20000, True)):
+        src, dst = _skewed_graph(rng, n, e) if skew else _rand_graph(rng, n, e)
+        dst = dst % m
+        key = np.unique(src * m + dst)
+        rows, col = (key // m).astype(np.int64), (key % m).astype(np.int32)
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+        val = rng.random(col.shape[0], dtype=np.float32)
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, m)
+        if not g.ensure_quad(max_padding=1e9):
+            assert col.shape[0] == 0
+            continue
+        q = g.quad
+        bc, nb, ns = q["block_cols"], q["n_blocks"], q["n_slices"]
+        assert bc % 4 == 0 and bc <= 2528 and nb == (m + bc - 1) // bc and ns == (n + 15) // 16
+        lens = np.diff(rowptr)
+        perm_all = _np(q["perm"])
+        perm = perm_all[:n]
+        np.testing.assert_array_equal(perm, np.argsort(-lens, kind="stable"))
+        assert perm_all.shape[0] == ns * 16 and (perm_all[n:] == perm[-1]).all()  # padding slots repeat the last row
+        ext = _np(q["ext"]).reshape(-1, 2)
+        qc, qv = _np(q["col"]), _np(q["val"])
+        chunk = 0
+        for b in range(nb):
+            for sl in range(ns):
+                c0, width = ext[b * ns + sl]
+                assert c0 == chunk
+                rws = perm[sl * 16:min(n, sl * 16 + 16)]
+                n_chunks = (width + 15) // 16
+                blk_c = qc[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)
+                blk_v = qv[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)
+                longest = 0
+                for r16, r in enumerate(rws):
+                    cr, vr = col[rowptr[r]:rowptr[r + 1]], val[rowptr[r]:rowptr[r + 1]]
+                    sel = (cr >= b * bc) & (cr < (b + 1) * bc)
+                    l = int(sel.sum())
+                    longest = max(longest, l)
+                    want_off = (cr[sel] - b * bc) * 64
+                    if column_order:
+                        np.testing.assert_array_equal(blk_c[r16, :l], want_off)
+                        np.testing.assert_array_equal(blk_v[r16, :l], vr[sel])
+                    else:  # the same (offset, value) pairs in some order; columns are unique inside a row
+                        o = np.argsort(blk_c[r16, :l])
+                        np.testing.assert_array_equal(blk_c[r16, :l][o], want_off)
+                        np.testing.assert_array_equal(blk_v[r16, :l][o], vr[sel])
+                    assert (blk_c[r16, l:] == bc * 64).all() and (blk_v[r16, l:] == 0).all()
+                assert width == longest
+                for r16 in range(rws.size, 16):  # padding slots: the last row's entries in the last row's order
+                    np.testing.assert_array_equal(blk_c[r16], blk_c[rws.size - 1])
+                    np.testing.assert_array_equal(blk_v[r16], blk_v[rws.size - 1])
+                chunk += n_chunks
+        assert tuple(ext[-1]) == (chunk, 0) and q["chunks"] == chunk
+
+
+def test_sell16_bank_aware_order_reduces_conflicts(ops, oracle):
+    """the bank-aware order: the four rows an LDS service group reads per step ({0,3,5,6}, {1,2,4,7} + 8) should mostly hold
+    columns of four different classes mod 4 (random order: 2.1 LDS cycles per group and step on average)"""
+    from wdg_amd import synth
+    src, dst, _ = synth.regular_graph(2000, 5, 10, 0.3, 0)
+    g = ops.CsrGraph.from_coo(src, dst, 2000, None, ops.COO_ADD_SELF_LOOPS)
+    assert g.ensure_quad()
+    q = g.quad
+    ext, qc = _np(q["ext"]).reshape(-1, 2), _np(q["col"])
+    cycles, steps = 0, 0
+    for sl in range(q["n_slices"]):
+        c0, width = ext[sl]
+        n_chunks = (width + 15) // 16
+        blk = qc[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)[:, :width]
+        cls = (blk // 64) & 3
+        for grp in ((0, 3, 5, 6), (1, 2, 4, 7), (8, 11, 13, 14), (9, 10, 12, 15)):
+            for e in range(width):
+                cycles += np.bincount(cls[list(grp), e], minlength=4).max()
+                steps += 1
+    assert cycles / steps < 1.35, cycles / steps
+
+
+QUAD_SHAPES = [(2000, 2000, 512, 60000), (2000, 2000, 500, 20000), (2708, 2708, 1433, 13264), (100, 100, 8, 300),
+               (1, 1, 16, 1), (17, 33, 40, 200), (3000, 2528, 64, 20000), (3000, 2529, 36, 20000), (5201, 5201, 130, 100000),
+               (700, 9000, 24, 30000), (4000, 4000, 100, 100000), (2048, 2048, 10, 2048), (1500, 1500, 9, 9000)]
+
+
+@pytest.mark.parametrize("n,m,f,e", QUAD_SHAPES)
+def test_spmm_quad_family_shapes(ops, oracle, n, m, f, e):
+    """the quad-row kernel through the single-graph entry: one and several column blocks, ragged feature groups, feature
+    counts that are not multiples of 4 (scalar staging / stores), explicit values, row / column scales, bf16 input"""
+    rng = np.random.default_rng(n * 11 + f)
+    src, dst = _rand_graph(rng, n, e)
+    dst = dst % m
+    key = np.unique(src * m + dst)
+    rows, col = (key // m).astype(np.int64), (key % m).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    val = rng.random(col.shape[0], dtype=np.float32)
+    x = rng.standard_normal((m, f)).astype(np.float32)
+    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, m)
+    assert g.ensure_quad(max_padding=1e9)
+
+    def run(use_values, rs, cs, dtype=torch.float32):
+        xt = torch.from_numpy(x).cuda().to(dtype)
+        y = _np(ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
+                         col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values))
+        assert g.sell is None, "the call must have gone to the quad-row kernel (no SELL-64 copy was built)"
+        v = val.copy() if use_values else np.ones_like(val)
+        if cs is not None:
+            v = v * cs[col]
+        xr = _np(xt.float())
+        ref, ref64 = oracle.spmm_csr(rowptr, col, v, xr), oracle.spmm_csr(rowptr, col, v, xr, f64acc=True)
+        if rs is not None:
+            ref, ref64 = ref * rs[:, None], ref64 * rs[:, None]
+        scale = np.abs(ref64).max() + 1e-30
+        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(y, ref64, rtol=1e-5, atol=1e-6 * scale)
+
+    d, dc = rng.random(n, dtype=np.float32), rng.random(m, dtype=np.float32)
+    run(True, None, None)
+    run(False, d, None)
+    run(False, d, dc)
+    run(True, d, dc, torch.bfloat16)
+
+
+def test_spmm_quad_column_order_equals_sequential_sum_bitwise(ops, monkeypatch):
+    """With WDG_SELL_ORDER=0 the quad-row kernel adds a row's entries in CSR column order, one fp32 add each: the result is
+    bit-identical to the sequential sum (what a CPU sweep over the coalesced COO produces), here taken from the slab
+    kernel, which sums the same way."""
+    monkeypatch.setenv("WDG_SELL_ORDER", "0")
+    rng = np.random.default_rng(78)
+    n, f, e = 2000, 500, 40000
+    src, dst = _rand_graph(rng, n, e)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+    x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
+    d = ops.degree_norm(g, ops.NORM_RW)["dinv"]
+    y_quad = ops.spmm(g, x, row_scale=d).clone()
+    assert g.quad and g.sell is None
+    g2 = ops.CsrGraph(g.rowptr, g.col, g.val, n, n)
+    monkeypatch.setenv("WDG_SPMM_NO_QUAD", "1")
+    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")
+    y_slab = ops.spmm(g2, x, row_scale=d)
+    assert not g2.quad
+    assert torch.equal(y_quad, y_slab)
+
+
+@pytest.mark.parametrize("n,f,groups,use_values", [(2000, 512, (10, 10), False), (700, 36, (4, 6), True), (2528, 64, (3, 3, 3), False),
+                                                     (1500, 100, (2, 8, 1), True), (64, 16, (2,), False), (4000, 48, (3, 2), False),
+                                                     (40, 2089, (3,), True)])
+def test_spmm_quad_batched_equals_single_bitwise(ops, n, f, groups, use_values):
+    """The batched entry (tape of units cut into equal-cost segments, phases of graphs that share X) must give every graph
+    the bits of its single-graph call: a row's sum depends on the SELL-16 copy only, not on how the units were dealt."""
+    rng = np.random.default_rng(n * 3 + f)
+    entries, want = [], []
+    for gi, size in enumerate(groups):
+        x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
+        for j in range(size):
+            e = int(n * (2 + 3 * j))
+            src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+            g = ops.CsrGraph.from_coo(src, dst, n, rng.random(e, dtype=np.float32), ops.COO_ADD_SELF_LOOPS)
+            d = ops.degree_norm(g, ops.NORM_RW)["dinv"]
+            want.append(ops.spmm(g, x, row_scale=d, use_values=use_values).clone())
+            entries.append((g, x, torch.full_like(want[-1], float("nan")), d, None, use_values))
+    batch = ops.SpmmBatch(entries)
+    assert batch.quad and batch.plan()[0] == 5
+    batch.launch()
+    torch.cuda.synchronize()
+    for (_, _, y, _, _, _), w in zip(entries, want):
+        assert torch.equal(y, w)
+    batch.launch()  # relaunch: no state carried between launches
+    torch.cuda.synchronize()
+    for (_, _, y, _, _, _), w in zip(entries, want):
+        assert torch.equal(y, w)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_spmm_quad_fuzz_batches(ops, oracle, seed):
+    """random mixed batches on the quad-row kernel: different sizes and feature widths in one table, some graphs sharing X,
+    rectangular patterns, empty graphs' worth of rows, explicit values, both scales - against the oracle"""
+    rng = np.random.default_rng(2000 + seed)
+    entries, want = [], []
+    shared = None
+    for case in range(8):
+        n_rows = int(rng.choice([1, 15, 16, 17, 300, 1000, 2000, 2600, 5000]))
+        n_cols = n_rows if rng.random() < 0.6 else int(rng.choice([1, 7, 64, 500, 2528, 2529, 3000, 6000]))
+        f = int(rng.choice([8, 9, 12, 16, 17, 32, 36, 64, 100]))
+        if shared is not None and rng.random() < 0.5:
+            x = shared
+            n_cols, f = x.shape
+        else:
+            x = torch.from_numpy(rng.standard_normal((n_cols, f)).astype(np.float32)).cuda()
+            shared = x
+        e = int(rng.integers(0, 8 * n_rows + 1))
+        src, dst = rng.integers(0, n_rows, e), rng.integers(0, n_cols, e)
+        key = np.unique(src.astype(np.int64) * n_cols + dst)
+        rows, cols = (key // n_cols).astype(np.int64), (key % n_cols).astype(np.int32)
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n_rows))]).astype(np.int32)
+        if len(cols) == 0:
+            continue
+        val = rng.random(len(cols), dtype=np.float32) if rng.random() < 0.5 else None
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(cols).cuda(),
+                         None if val is None else torch.from_numpy(val).cuda(), n_rows, n_cols)
+        rs = torch.from_numpy(rng.random(n_rows, dtype=np.float32)).cuda() if rng.random() < 0.6 else None
+        v = np.ones(len(cols), np.float32) if val is None else val
+        if rs is not None:
+            v = v * _np(rs)[rows]
+        ref = oracle.spmm_csr(rowptr, cols, v.astype(np.float32), _np(x))
+        entries.append((g, x, torch.full((n_rows, f), float("nan"), device="cuda"), rs, None, True))
+        want.append((ref, dict(rtol=2e-5, atol=2e-6 * max(float(np.abs(ref).max()), 1e-30))))
+    if not entries:
+        return
+    batch = ops.SpmmBatch(entries)
+    assert batch.quad
+    batch.launch()
+    torch.cuda.synchronize()
+    for ent, (ref, tol) in zip(entries, want):
+        np.testing.assert_allclose(_np(ent[2]), ref, **tol)
 
 
 # --------------------------------------------------------------------------------------------- edge / label stats

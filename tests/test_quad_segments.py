@@ -1,0 +1,88 @@
+"""Host logic of the quad-row batch: the tape of 16-row units is cut into equal-cost segments and phases (ops._quad_segments)
+such that every unit of every job is covered exactly once, phases never mix feature matrices, and segment costs are level."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+class _X:
+    def __init__(self, ptr, n, f):
+        self.ptr, self.shape = ptr, (n, f)
+
+    def data_ptr(self):
+        return self.ptr
+
+    def stride(self, d):
+        return self.shape[1] if d == 0 else 1
+
+
+class _G:
+    def __init__(self, n_rows, n_cols, widths):
+        self.n_rows, self.n_cols = n_rows, n_cols
+        self.quad = dict(widths=widths, n_slices=widths.shape[1], n_blocks=widths.shape[0])
+
+
+def _coverage(entries, order, items, seg_ptr):
+    seen = {i: np.zeros(entries[i][0].quad["n_slices"], int) for i in order}
+    for fj, nj, ub, ue in items:
+        assert nj >= 1 and 0 <= ub < ue
+        offs = np.cumsum([0] + [entries[order[fj + k]][0].quad["n_slices"] for k in range(nj)])
+        assert ue <= offs[-1] and ub < offs[1], "a phase starts in its first job and ends inside its last"
+        assert ue > offs[-2], "no trailing job without units"
+        xs = {entries[order[fj + k]][1].data_ptr() for k in range(nj)}
+        assert len(xs) == 1, "a phase aggregates one feature matrix"
+        for u in range(ub, ue):
+            k = int(np.searchsorted(offs, u, side="right") - 1)
+            seen[order[fj + k]][u - offs[k]] += 1
+    for i in order:
+        assert (seen[i] == 1).all(), f"job {i}: every unit exactly once"
+    assert seg_ptr[0] == 0 and seg_ptr[-1] == len(items) and all(a <= b for a, b in zip(seg_ptr, seg_ptr[1:]))
+
+
+@pytest.mark.parametrize("n_feat", [512, 64, 16, 2089])
+def test_segments_cover_every_unit_once(n_feat):
+    from wdg_amd import ops
+    rng = np.random.default_rng(3)
+    entries = []
+    for seed in range(5):
+        x = _X(1000 + seed, 2000, n_feat)
+        for h in range(10):
+            w = np.full((1, 125), int(rng.integers(3, 70)))
+            entries.append((_G(2000, 2000, w), x, None, None, None, False))
+    order = list(range(len(entries)))
+    items, seg_ptr, n_seg = ops._quad_segments(entries, order, n_feat)
+    assert n_seg % 8 == 0 and len(seg_ptr) == n_seg + 1
+    _coverage(entries, order, items, seg_ptr)
+    # level costs: no segment more than 3 % (+ one unit) above the mean
+    costs = []
+    for s in range(n_seg):
+        c = 0.0
+        for fj, nj, ub, ue in items[seg_ptr[s]:seg_ptr[s + 1]]:
+            offs = np.cumsum([0] + [entries[order[fj + k]][0].quad["n_slices"] for k in range(nj)])
+            for u in range(ub, ue):
+                k = int(np.searchsorted(offs, u, side="right") - 1)
+                c += entries[order[fj + k]][0].quad["widths"][:, u - offs[k]].sum() + 6
+        costs.append(c)
+    assert max(costs) <= 1.03 * np.mean(costs) + 80
+
+
+def test_segments_ragged_and_multiblock():
+    from wdg_amd import ops
+    rng = np.random.default_rng(4)
+    entries = []
+    for j in range(7):  # different sizes, own X each, some tiny
+        n = int(rng.integers(1, 900))
+        sl = (n + 15) // 16
+        entries.append((_G(n, n, rng.integers(0, 40, (1, sl))), _X(j, n, 96), None, None, None, False))
+    order = list(range(len(entries)))
+    items, seg_ptr, n_seg = ops._quad_segments(entries, order, 96)
+    _coverage(entries, order, items, seg_ptr)
+    # several column blocks: phases of at most 128 units
+    entries = [(_G(5201, 5201, rng.integers(0, 90, (3, 326))), _X(9, 5201, 2089), None, None, None, False)]
+    items, seg_ptr, n_seg = ops._quad_segments(entries, [0], 2089)
+    _coverage(entries, [0], items, seg_ptr)
+    assert all(ue - ub <= 128 for _, _, ub, ue in items)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SpmmJob, StatsJob, c_void_p, check, lib, require_gpu, stream_handle
+from ._lib import SpmmItem, SpmmJob, StatsJob, c_void_p, check, lib, require_gpu, stream_handle
 
 # flags / modes of include/wdg.h
 COO_SYMMETRISE, COO_BINARISE, COO_ADD_SELF_LOOPS, COO_DROP_SELF_LOOPS, COO_KEEP_DUPLICATES = 1, 2, 4, 8, 16
@@ -52,6 +52,7 @@ class CsrGraph:
         self.rowptr, self.col, self.val = rowptr, col, val
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.sell = None  # (sell_ptr, sell_col, sell_val|None): SELL-64 copy of the pattern, built on demand
+        self.quad = None  # SELL-16 copy (dict) for the quad-row kernel, built on demand; False = decided against
 
     def ensure_sell(self, max_padding=3.0):
         """Build the SELL-64 copy (wdg_csr_to_sell_*) that the row-lane SpMM consumes.  One-time per graph.
@@ -81,6 +82,46 @@ class CsrGraph:
                                        _ptr(sell_perm), _ptr(sell_ptr), _ptr(sell_col), _ptr(sell_val), stream_handle()),
               "wdg_csr_to_sell_fill")
         self.sell = (sell_ptr, sell_col, sell_val, block_cols, n_blocks, sell_perm)
+        return True
+
+    QUAD_MAX_BLOCKS = 4  # column blocks of <= 2528 columns the quad-row kernel sweeps (csrc/spmm_quad.hip)
+
+    def ensure_quad(self, max_padding=4.0):
+        """Build the SELL-16 copy (wdg_csr_to_sell16_*) that the quad-row SpMM consumes.  One-time per graph; False for
+        graphs of more than 4 column blocks (10 112 columns) or whose slices would pad too much (the decision is kept)."""
+        if self.quad is not None:
+            return self.quad is not False
+        if quad_disabled() or self.n_rows == 0 or self.nnz == 0:
+            self.quad = False
+            return False
+        block_cols = lib.wdg_sell16_block_cols(self.n_cols)
+        n_blocks = (max(self.n_cols, 1) + block_cols - 1) // block_cols
+        if n_blocks > self.QUAD_MAX_BLOCKS:
+            self.quad = False
+            return False
+        dev = self.device
+        n_slices = (self.n_rows + 15) // 16
+        tasks = n_slices * n_blocks
+        ext = torch.empty(2 * (tasks + 1), dtype=torch.int32, device=dev)
+        perm = torch.empty(n_slices * 16, dtype=torch.int32, device=dev)  # padding slots repeat the last row
+        ws_bytes = lib.wdg_sell16_workspace_bytes(self.n_rows, self.n_cols)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.wdg_csr_to_sell16_count(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, _ptr(perm), _ptr(ext),
+                                          _ptr(ws), ws_bytes, stream_handle()), "wdg_csr_to_sell16_count")
+        ext_host = ext.cpu().numpy().reshape(-1, 2)  # the one host sync of the build: sizes the index arrays
+        chunks = int(ext_host[-1, 0])
+        if chunks * 256 > max_padding * self.nnz + 256 * tasks:
+            self.quad = False  # very skewed rows: the CSR kernels are the better fit (remembered)
+            return False
+        # (+ 2 chunks of slack: the kernel requests a unit's first two chunks unconditionally)
+        q_col = torch.zeros((chunks + 2) * 256, dtype=torch.int32, device=dev)
+        q_val = torch.zeros((chunks + 2) * 256, dtype=torch.float32, device=dev) if self.val is not None else None
+        check(lib.wdg_csr_to_sell16_fill(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), self.n_rows, self.n_cols,
+                                         _ptr(perm), _ptr(ext), _ptr(q_col), _ptr(q_val), stream_handle()),
+              "wdg_csr_to_sell16_fill")
+        widths = ext_host[:-1, 1].reshape(n_blocks, n_slices)  # per (block, slice): the cost model of SpmmBatch reads it
+        self.quad = dict(ext=ext, col=q_col, val=q_val, perm=perm, block_cols=block_cols, n_blocks=n_blocks,
+                         n_slices=n_slices, widths=widths, chunks=chunks)
         return True
 
     @property
@@ -189,7 +230,7 @@ class CsrGraph:
         val = self.val if self.val is not None else torch.ones(self.nnz, device=self.device)
         return torch.sparse_coo_tensor(idx, val, (self.n_rows, self.n_cols)).coalesce()
 
-    def with_values(self, val):
+    def with_values(self, val):  # (neither SELL copy is shared: both hold values)
         return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)  # SELL copy (holds values) not shared
 
 
@@ -253,7 +294,20 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     else:
         job.sell_ptr = job.sell_col = job.sell_val = job.sell_perm = 0
         job.sell_block_cols = job.sell_n_blocks = 0
+    q = g.quad
+    if q and (not wants_val or q["val"] is not None):
+        job.q_ext, job.q_col, job.q_perm = q["ext"].data_ptr(), q["col"].data_ptr(), q["perm"].data_ptr()
+        job.q_val = q["val"].data_ptr() if (wants_val and q["val"] is not None) else 0
+        job.q_block_cols, job.q_n_blocks = q["block_cols"], q["n_blocks"]
+    else:
+        job.q_ext = job.q_col = job.q_val = job.q_perm = 0
+        job.q_block_cols = job.q_n_blocks = 0
     return job
+
+
+def quad_disabled():
+    """WDG_SPMM_NO_QUAD=1: keep every aggregation on the round-1 kernel families (A/B comparisons, tests)"""
+    return os.environ.get("WDG_SPMM_NO_QUAD", "0") not in ("", "0")
 
 
 def _sharing_groups(entries):
@@ -315,16 +369,76 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
         raise ValueError(f"spmm: X has {x.shape[0]} rows, adjacency has {g.n_cols} columns")
     y = out if out is not None else torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=dev)
     row_scale, col_scale = _dev(row_scale, torch.float32, dev), _dev(col_scale, torch.float32, dev)
-    if x.shape[1] >= 8:
-        g.ensure_sell()  # one-time SELL-64 copy -> row-lane kernels for graphs of <= 6144 rows
+    if x.shape[1] >= 8 and not g.ensure_quad():  # one-time SELL-16 copy -> quad-row kernel (<= 10 112 columns)
+        g.ensure_sell()  # else the SELL-64 copy -> row-lane kernels for graphs of <= 6144 rows
     job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values)
     fn = lib.wdg_spmm_csr_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_csr_f32
     check(fn(ctypes.byref(job), stream_handle()), "wdg_spmm_csr")
     return y
 
 
+def _quad_segments(entries, order, n_feat, cus=256):
+    """Cut the tape of 16-row units of the jobs (in table order `order`) into 8 x S segments of equal modelled cost and
+    split every segment into phases (runs of jobs that aggregate the same X); -> (items [(first_job, n_jobs, unit_begin,
+    unit_end)], seg_ptr, n_segments).  Cost of a unit = its entries per row (all column blocks) + WDG_QUAD_ALPHA (the
+    store and the per-unit overhead, in entries; default 6)."""
+    alpha = float(os.environ.get("WDG_QUAD_ALPHA", "6"))
+    n_groups = (n_feat + 15) // 16
+    per_xcd = max(cus // 8, 1)
+    costs, job_off, group_id = [], [0], []
+    keys = {}
+    multi = False
+    for i in order:
+        g, x, _y, _rs, cs = entries[i][:5]
+        q = g.quad
+        costs.append(q["widths"].sum(0).astype(np.float64) + alpha)
+        job_off.append(job_off[-1] + q["n_slices"])
+        key = (x.data_ptr(), _ld(x), g.n_cols, x.shape[1], 0 if cs is None else cs.data_ptr())
+        group_id.append(keys.setdefault(key, len(keys)))
+        multi = multi or q["n_blocks"] > 1
+    n_units = job_off[-1]
+    cum = np.concatenate([[0.0], np.cumsum(np.concatenate(costs))]) if costs else np.zeros(1)
+    # segments per XCD: one (segment, feature group) pair per workgroup when there are fewer groups than workgroups per XCD,
+    # else the S in 1..4 that leaves the least idle tail; never more segments than 16-unit bundles
+    if n_groups >= per_xcd:
+        subs = min(range(1, 5), key=lambda s_: (-(-s_ * n_groups // per_xcd) / (s_ * n_groups / per_xcd), s_))
+    else:
+        subs = -(-per_xcd // n_groups)
+    forced = os.environ.get("WDG_QUAD_SUBS")
+    if forced:
+        subs = int(forced)
+    subs = max(1, min(subs, max(1, n_units // (8 * 16))))
+    if multi:  # a wave keeps at most 8 units across the column blocks: phases of <= 128 units
+        subs = max(subs, -(-n_units // (8 * 128)))
+    n_seg = 8 * subs
+    cuts = np.searchsorted(cum, cum[-1] * np.arange(1, n_seg) / n_seg, side="left")
+    cuts = np.concatenate([[0], np.clip(cuts, 0, n_units), [n_units]])
+    cuts = np.maximum.accumulate(cuts)
+    job_off_a = np.asarray(job_off)
+    items, seg_ptr = [], [0]
+    for s_ in range(n_seg):
+        a, b = int(cuts[s_]), int(cuts[s_ + 1])
+        while a < b:
+            j0 = int(np.searchsorted(job_off_a, a, side="right") - 1)
+            j1 = j0
+            while j1 + 1 < len(order) and job_off[j1 + 1] < b and group_id[j1 + 1] == group_id[j0]:
+                j1 += 1
+            end = min(b, job_off[j1 + 1])
+            if multi:
+                end = min(end, a + 128)
+                j1 = int(np.searchsorted(job_off_a, end - 1, side="right") - 1)
+            items.append((j0, j1 - j0 + 1, a - job_off[j0], end - job_off[j0]))
+            a = end
+        seg_ptr.append(len(items))
+    return items, seg_ptr, n_seg
+
+
 class SpmmBatch:
-    """Job table for wdg_spmm_batched_f32: many graphs, one launch.  Built once, launched many times."""
+    """Job table for the batched aggregation: many graphs, one launch.  Built once, launched many times.
+
+    Tables whose graphs all carry a SELL-16 copy (<= 10 112 columns, F >= 8) run on the quad-row kernel
+    (wdg_spmm_quad_batched_f32: the tape of 16-row units cut into equal-cost segments, graphs that aggregate the same X
+    adjacent so that a workgroup stages X once per run); the rest on wdg_spmm_batched_f32 (WDG_SPMM_NO_QUAD=1: all)."""
 
     def __init__(self, entries):
         """entries: list of (CsrGraph, X, Y, row_scale|None, col_scale|None, use_values)."""
@@ -333,20 +447,32 @@ class SpmmBatch:
         arr = (SpmmJob * len(entries))()
         self.max_rows = self.max_cols = self.max_feat = 0
         all_sell, any_val, dma_ok = len(entries) > 0, False, len(entries) > 0
+        for g, x, *_ in entries:
+            if x.dtype != torch.float32 or x.stride(1) != 1:
+                raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
+        feats = {e[1].shape[1] for e in entries}
+        self.quad = (len(entries) > 0 and not quad_disabled() and min(feats) >= 8
+                     and all(e[0].ensure_quad() for e in entries)
+                     and all((not (e[5] and e[0].val is not None)) or e[0].quad["val"] is not None for e in entries))
         # the kernels start jobs in table order: most stored entries first, so the long jobs do not end up in the tail
         order = sorted(range(len(entries)), key=lambda i: -entries[i][0].nnz)
         if os.environ.get("WDG_SPMM_ORDER") == "0":
             order = list(range(len(entries)))
-        # graphs aggregating the SAME feature matrix (the h-levels of a seed) are laid out in aligned runs of `run` jobs, so
-        # that the shared-X kernel stages each slab of X once per run (WDG_SPMM_SHARED_X): every sharing group is cut
-        # into runs of equal length with balanced entry counts, the runs go largest first
-        self.run = _shared_x_run(entries)
-        if self.run >= 2:
-            order = _shared_x_order(entries, self.run)
+        self.run = 0
+        if self.quad:
+            # graphs that aggregate the same X adjacent (largest first inside a group, groups by total entries)
+            groups = _sharing_groups(entries)
+            groups.sort(key=lambda grp: -sum(entries[i][0].nnz for i in grp))
+            order = [i for grp in groups for i in sorted(grp, key=lambda i: -entries[i][0].nnz)]
+        else:
+            # graphs aggregating the SAME feature matrix (the h-levels of a seed) are laid out in aligned runs of `run` jobs,
+            # so that the shared-X kernel stages each slab of X once per run (WDG_SPMM_SHARED_X): every sharing group is cut
+            # into runs of equal length with balanced entry counts, the runs go largest first
+            self.run = _shared_x_run(entries)
+            if self.run >= 2:
+                order = _shared_x_order(entries, self.run)
         for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
-            if x.dtype != torch.float32 or x.stride(1) != 1:
-                raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
-            if x.shape[1] >= 8:
+            if x.shape[1] >= 8 and not self.quad:
                 g.ensure_sell()
             _fill_job(job, g, x, y, rs, cs, uv)
             all_sell = all_sell and bool(job.sell_ptr)
@@ -361,12 +487,27 @@ class SpmmBatch:
         self.flags = (SPMM_ALL_SELL if all_sell else 0) | (SPMM_ANY_VAL if any_val else 0) | (SPMM_DMA_OK if dma_ok else 0)
         if self.run >= 2 and all_sell and dma_ok:
             self.flags |= (self.run & 0xff) << 8  # WDG_SPMM_SHARED_X(run)
+        if self.quad:
+            items, seg_ptr, self.n_segments = _quad_segments(entries, order, self.max_feat, max(lib.wdg_device_cus(), 8))
+            iarr = (SpmmItem * max(len(items), 1))()
+            for it, (fj, nj, ub, ue) in zip(iarr, items):
+                it.first_job, it.n_jobs, it.unit_begin, it.unit_end = fj, nj, ub, ue
+            self.items = torch.frombuffer(bytearray(bytes(iarr)), dtype=torch.uint8).to(dev)
+            self.seg_ptr = torch.tensor(seg_ptr, dtype=torch.int32, device=dev)
+            self.n_items = len(items)
 
     def launch(self):
+        if self.quad:
+            check(lib.wdg_spmm_quad_batched_f32(_ptr(self.table), self.n_jobs, _ptr(self.items), _ptr(self.seg_ptr),
+                                                self.n_segments, self.max_cols, self.max_feat, self.flags, stream_handle()),
+                  "wdg_spmm_quad_batched_f32")
+            return
         check(lib.wdg_spmm_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, self.max_cols, self.max_feat,
                                        self.flags, stream_handle()), "wdg_spmm_batched_f32")
 
     def plan(self):
+        if self.quad:
+            return 5, 16, 1024
         return spmm_plan(self.max_rows, self.max_cols, self.max_feat, self.n_jobs, self.flags)
 
     def kernel_name(self):
@@ -377,7 +518,8 @@ class SpmmBatch:
         return {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
                 2: f"spmm_rowlane_kernel<{slab // 4},{rpt},float,{val}>",
                 3: f"spmm_rowlane_pipe_kernel<{slab // 4},{rpt},{val}>",
-                4: f"spmm_rowlane_shared_kernel<{rpt},{val}>"}.get(fam, f"family {fam}")
+                4: f"spmm_rowlane_shared_kernel<{rpt},{val}>",
+                5: f"spmm_quad_kernel<float,{val},{'true' if self.max_cols > 2528 else 'false'}>"}.get(fam, f"family {fam}")
 
 
 SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK = 1, 2, 4
