@@ -135,14 +135,16 @@ typedef struct wdg_spmm_job {
     const int32_t *sell_perm; /* [n_rows] SELL slot -> row (rows sorted by length, longest first); NULL = identity */
     /* optional SELL-16 copy of the same pattern (wdg_csr_to_sell16_*): enables the quad-row kernel (a quad of lanes per
        row, 16-row slices; graphs of up to 4 column blocks of 2528 columns); NULL = none */
-    const int32_t *q_ext;  /* [q_n_blocks * ceil(n_rows/16) + 1] pairs {first chunk, width} per (block, slice), block-major;
-                              the trailing pair = {chunk count, 0} */
+    const int32_t *q_ext;  /* [q_n_blocks * S + 1] pairs {first chunk, width} per (block, slice), block-major, S = 4 ceil(n_rows/64)
+                              slices (the slices that pad the last super-unit repeat the last real slice); the trailing
+                              pair = {chunk count, 0} */
     const int32_t *q_col;  /* chunk c = 256 ints: entry e (0..15) of slice row r at q_col[256 c + 16 r + e], value = 64 x
                               (column - block * q_block_cols) = byte offset of the source row in the staged slab block;
                               padding = 64 x q_block_cols (an all-zero row the kernel appends)                           */
     const float *q_val;    /* same layout, needed when `val` is given (padding 0)                                        */
-    const int32_t *q_perm; /* [ceil(n_rows/16) * 16] slot -> row (rows by length, longest first; the slots that pad the last
-                              slice repeat the last row, entries included: they store that row's sums a second time)    */
+    const int32_t *q_perm; /* [64 ceil(n_rows/64)] slot -> row (rows by length, longest first; the slots that pad the last slice
+                              repeat the last row, the slices that pad the last super-unit repeat the last slice: they
+                              store those rows' sums a second time)                                                      */
     int32_t q_block_cols;  /* columns per block = wdg_sell16_block_cols(n_cols)                                          */
     int32_t q_n_blocks;    /* ceil(n_cols / q_block_cols), 1 .. 4                                                        */
 } wdg_spmm_job;
@@ -161,6 +163,8 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
 #define WDG_SPMM_DMA_OK 4   /* every job: X and Y 16-byte aligned, ldx, ldy and n_feat multiples of 4, col_scale NULL:
                                X rows may be staged by LDS-DMA; with WDG_SPMM_PIPELINED=1 in the environment such
                                batches run the pipelined row-lane kernel (family 3), an opt-in schedule */
+#define WDG_SPMM_SMALL_OFFSETS 8 /* every job: n_rows x ldy < 2^30 elements and fewer than 2^22 index chunks (byte offsets into Y and
+                                   into q_col / q_val fit 32 bits): with WDG_SPMM_DMA_OK the quad-row kernel's pipelined loop */
 #define WDG_SPMM_SHARED_X(r) (((r) & 0xff) << 8) /* every aligned group of r (2..255) consecutive jobs of the table has the
                                same X, ldx, n_cols and n_feat (the h-levels of one seed): with WDG_SPMM_ALL_SELL |
                                WDG_SPMM_DMA_OK, <= 2032 columns and <= 2048 rows the shared-X row-lane kernel (family 4)
@@ -201,7 +205,7 @@ int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float 
  * 16-feature slab of X occupies in LDS), entries in chunks of 16 per row.  Inside a (row, block) segment the entries are
  * stored in a bank-aware order (the four rows an LDS service group reads together get columns of different classes mod 4
  * wherever the rows allow it), which fixes the order of the row's sum; WDG_SELL_ORDER=0 in the environment of the fill
- * call keeps column order (the sequential CSR order).  Two calls: count fills q_perm (ceil(N/16) * 16 entries) and q_ext
+ * call keeps column order (the sequential CSR order).  Two calls: count fills q_perm (64 ceil(N/64) entries) and q_ext
  * (read the trailing pair's chunk count back to size q_col / q_val: 256 entries per chunk, PLUS two chunks of slack that
  * the kernel may read but never uses), then fill.  One-time per graph.
  */
@@ -213,19 +217,21 @@ int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const floa
                            const int32_t *q_perm, const int32_t *q_ext, int32_t *q_col, float *q_val, wdg_stream_t stream);
 
 /*
- * The batched aggregation on the quad-row kernel (every job carries its SELL-16 copy).  The caller lays the jobs' 16-row
- * units out as one tape (jobs in table order, job j contributes ceil(n_rows_j / 16) units) and cuts it into n_segments
+ * The batched aggregation on the quad-row kernel (every job carries its SELL-16 copy).  The caller lays the jobs'
+ * super-units (64 rows = four 16-row slices: what a wave is dealt) out as one tape (jobs in table order, job j contributes
+ * ceil(n_rows_j / 64) of them) and cuts it into n_segments
  * (a multiple of 8) segments of about equal cost; segment s consists of the phases items[seg_ptr[s] .. seg_ptr[s + 1]):
  * a phase is a run of consecutive jobs that aggregate the SAME X (same X, ldx, n_cols, n_feat, col_scale) and the unit
  * range [unit_begin, unit_end) of their concatenated units it covers.  XCD x of the chip processes segments
  * x S .. x S + S - 1 (S = n_segments / 8), one workgroup per (segment, 16-feature group); a workgroup stages X[:, group]
- * once per phase.  Graphs of more than 2528 columns (several column blocks): at most 128 units per phase.
+ * once per phase.  Graphs of more than 2528 columns (several column blocks): at most 32 super-units per item.
  * replaces: the same torch.spmm / torch.mm(adj, X) call sites as wdg_spmm_batched_f32, for the loop of
  * synthetic_plot.py:64-109 (every graph of a sweep shard in one launch).
  */
 typedef struct wdg_spmm_item {
-    int32_t first_job, n_jobs;    /* jobs [first_job, first_job + n_jobs) of the table */
-    int32_t unit_begin, unit_end; /* units of their concatenation covered by this phase */
+    int32_t first_job, n_jobs;    /* jobs [first_job, first_job + n_jobs) of the table: they aggregate the same X */
+    int32_t unit_begin, unit_end; /* super-units (64 rows) of the jobs' concatenated super-units covered by this item */
+    int32_t flags, reserved;      /* 0 */
 } wdg_spmm_item;
 int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
                               const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat, int flags,

@@ -577,18 +577,24 @@ def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
             continue
         q = g.quad
         bc, nb, ns = q["block_cols"], q["n_blocks"], q["n_slices"]
-        assert bc % 4 == 0 and bc <= 2528 and nb == (m + bc - 1) // bc and ns == (n + 15) // 16
+        real = (n + 15) // 16  # ns = the slices padded to whole super-units of four
+        assert bc % 4 == 0 and bc <= 2528 and nb == (m + bc - 1) // bc and ns == (n + 63) // 64 * 4
         lens = np.diff(rowptr)
         perm_all = _np(q["perm"])
         perm = perm_all[:n]
         np.testing.assert_array_equal(perm, np.argsort(-lens, kind="stable"))
-        assert perm_all.shape[0] == ns * 16 and (perm_all[n:] == perm[-1]).all()  # padding slots repeat the last row
+        assert perm_all.shape[0] == ns * 16 and (perm_all[n:real * 16] == perm[-1]).all()  # padding slots repeat the last row
+        for gs in range(real, ns):  # ghost slices repeat the last real slice
+            np.testing.assert_array_equal(perm_all[gs * 16:gs * 16 + 16], perm_all[(real - 1) * 16:real * 16])
         ext = _np(q["ext"]).reshape(-1, 2)
         qc, qv = _np(q["col"]), _np(q["val"])
         chunk = 0
         for b in range(nb):
             for sl in range(ns):
                 c0, width = ext[b * ns + sl]
+                if sl >= real:  # a ghost slice: the last real slice's extent
+                    assert tuple(ext[b * ns + sl]) == tuple(ext[b * ns + real - 1])
+                    continue
                 assert c0 == chunk
                 rws = perm[sl * 16:min(n, sl * 16 + 16)]
                 n_chunks = (width + 15) // 16
@@ -627,7 +633,7 @@ def test_sell16_bank_aware_order_reduces_conflicts(ops, oracle):
     q = g.quad
     ext, qc = _np(q["ext"]).reshape(-1, 2), _np(q["col"])
     cycles, steps = 0, 0
-    for sl in range(q["n_slices"]):
+    for sl in range(125):
         c0, width = ext[sl]
         n_chunks = (width + 15) // 16
         blk = qc[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)[:, :width]

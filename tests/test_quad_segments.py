@@ -22,24 +22,35 @@ class _X:
 
 class _G:
     def __init__(self, n_rows, n_cols, widths):
+        """widths: [n_blocks, padded slices] (a multiple of 4 slices = whole super-units)"""
+        assert widths.shape[1] % 4 == 0
         self.n_rows, self.n_cols = n_rows, n_cols
-        self.quad = dict(widths=widths, n_slices=widths.shape[1], n_blocks=widths.shape[0])
+        self.quad = dict(widths=widths, n_slices=widths.shape[1], n_su=widths.shape[1] // 4, n_blocks=widths.shape[0])
+
+
+def _units_of(entries, order, item):
+    """(job position, super-unit) of every unit of an item, in the kernel's order (the jobs' super-units concatenated)"""
+    fj, nj, ub, ue = item
+    assert nj >= 1 and 0 <= ub < ue
+    ns = [entries[order[fj + k]][0].quad["n_su"] for k in range(nj)]
+    xs = {entries[order[fj + k]][1].data_ptr() for k in range(nj)}
+    assert len(xs) == 1, "an item aggregates one feature matrix"
+    offs = np.cumsum([0] + ns)
+    assert ue <= offs[-1]
+    out = []
+    for u in range(ub, ue):
+        k = int(np.searchsorted(offs, u, side="right") - 1)
+        out.append((fj + k, u - offs[k]))
+    return out
 
 
 def _coverage(entries, order, items, seg_ptr):
-    seen = {i: np.zeros(entries[i][0].quad["n_slices"], int) for i in order}
-    for fj, nj, ub, ue in items:
-        assert nj >= 1 and 0 <= ub < ue
-        offs = np.cumsum([0] + [entries[order[fj + k]][0].quad["n_slices"] for k in range(nj)])
-        assert ue <= offs[-1] and ub < offs[1], "a phase starts in its first job and ends inside its last"
-        assert ue > offs[-2], "no trailing job without units"
-        xs = {entries[order[fj + k]][1].data_ptr() for k in range(nj)}
-        assert len(xs) == 1, "a phase aggregates one feature matrix"
-        for u in range(ub, ue):
-            k = int(np.searchsorted(offs, u, side="right") - 1)
-            seen[order[fj + k]][u - offs[k]] += 1
-    for i in order:
-        assert (seen[i] == 1).all(), f"job {i}: every unit exactly once"
+    seen = {pos: np.zeros(entries[i][0].quad["n_su"], int) for pos, i in enumerate(order)}
+    for item in items:
+        for pos, su in _units_of(entries, order, item):
+            seen[pos][su] += 1
+    for pos in seen:
+        assert (seen[pos] == 1).all(), f"job {pos}: every super-unit exactly once"
     assert seg_ptr[0] == 0 and seg_ptr[-1] == len(items) and all(a <= b for a, b in zip(seg_ptr, seg_ptr[1:]))
 
 
@@ -51,7 +62,7 @@ def test_segments_cover_every_unit_once(n_feat):
     for seed in range(5):
         x = _X(1000 + seed, 2000, n_feat)
         for h in range(10):
-            w = np.full((1, 125), int(rng.integers(3, 70)))
+            w = np.full((1, 128), int(rng.integers(3, 70)))
             entries.append((_G(2000, 2000, w), x, None, None, None, False))
     order = list(range(len(entries)))
     items, seg_ptr, n_seg = ops._quad_segments(entries, order, n_feat)
@@ -61,13 +72,12 @@ def test_segments_cover_every_unit_once(n_feat):
     costs = []
     for s in range(n_seg):
         c = 0.0
-        for fj, nj, ub, ue in items[seg_ptr[s]:seg_ptr[s + 1]]:
-            offs = np.cumsum([0] + [entries[order[fj + k]][0].quad["n_slices"] for k in range(nj)])
-            for u in range(ub, ue):
-                k = int(np.searchsorted(offs, u, side="right") - 1)
-                c += entries[order[fj + k]][0].quad["widths"][:, u - offs[k]].sum() + 6
+        for item in items[seg_ptr[s]:seg_ptr[s + 1]]:
+            for pos, su in _units_of(entries, order, item):
+                w = entries[order[pos]][0].quad["widths"][:, 4 * su:4 * su + 4].sum(0)
+                c += (np.maximum(w, 8) + 4).sum()
         costs.append(c)
-    assert max(costs) <= 1.03 * np.mean(costs) + 80
+    assert max(costs) <= 1.03 * np.mean(costs) + 4 * 80
 
 
 def test_segments_ragged_and_multiblock():
@@ -76,13 +86,13 @@ def test_segments_ragged_and_multiblock():
     entries = []
     for j in range(7):  # different sizes, own X each, some tiny
         n = int(rng.integers(1, 900))
-        sl = (n + 15) // 16
+        sl = (n + 63) // 64 * 4
         entries.append((_G(n, n, rng.integers(0, 40, (1, sl))), _X(j, n, 96), None, None, None, False))
     order = list(range(len(entries)))
     items, seg_ptr, n_seg = ops._quad_segments(entries, order, 96)
     _coverage(entries, order, items, seg_ptr)
     # several column blocks: phases of at most 128 units
-    entries = [(_G(5201, 5201, rng.integers(0, 90, (3, 326))), _X(9, 5201, 2089), None, None, None, False)]
+    entries = [(_G(5201, 5201, rng.integers(0, 90, (3, 328))), _X(9, 5201, 2089), None, None, None, False)]
     items, seg_ptr, n_seg = ops._quad_segments(entries, [0], 2089)
     _coverage(entries, [0], items, seg_ptr)
-    assert all(ue - ub <= 128 for _, _, ub, ue in items)
+    assert all(ue - ub <= 32 for _, _, ub, ue in items)

@@ -35,7 +35,8 @@ class SpmmJob(ctypes.Structure):
 
 class SpmmItem(ctypes.Structure):
     """mirror of `wdg_spmm_item` (include/wdg.h)"""
-    _fields_ = [("first_job", c_int32), ("n_jobs", c_int32), ("unit_begin", c_int32), ("unit_end", c_int32)]
+    _fields_ = [("first_job", c_int32), ("n_jobs", c_int32), ("unit_begin", c_int32), ("unit_end", c_int32),
+                ("flags", c_int32), ("reserved", c_int32)]
 
 
 class StatsJob(ctypes.Structure):

@@ -46,9 +46,22 @@ constexpr int Q_WAVES = Q_THREADS / 64;
 constexpr int Q_ROWS = 16;             // rows per unit (SELL-16 slice)
 constexpr int Q_CHUNK = 16;            // entries per row and index chunk (one 16-byte load per lane)
 constexpr int Q_CHUNK_INTS = Q_ROWS * Q_CHUNK;
+constexpr int Q_SU = 4;                // slices per super-unit (64 rows): the granule the kernel's waves are dealt
+constexpr int Q_SU_ROWS = Q_SU * Q_ROWS;
 constexpr int Q_MAX_BLOCK_COLS = 2528; // rows of a slab block: (2528 + 1 zero row) x 64 B = 158.1 KiB of the 160 KiB
 constexpr int Q_MAX_BLOCKS = 4;        // column blocks (graphs of up to 10 112 columns); more: the CSR kernels
 constexpr int Q_MAXU = 8;              // units per wave and phase when a graph has several column blocks
+
+#ifdef WDG_STAMPS  // diagnostic build only (make STAMPS=1): wave 0's clock at phase boundaries, 8 slots per workgroup
+__device__ unsigned long long wdg_q_stamp_buf[1024 * 8];
+#define Q_STAMP(k)                                                                          \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 1024)                                          \
+            wdg_q_stamp_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();        \
+    } while (0)
+#else
+#define Q_STAMP(k) do { } while (0)
+#endif
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -74,9 +87,13 @@ constexpr int Q_SORT_MAX_ROWS = 16384;
 __global__ __launch_bounds__(1024) void sell16_sort_rows(const int32_t *__restrict__ rowptr, int32_t N,
                                                          int32_t *__restrict__ perm) {
     extern __shared__ unsigned long long q_keys[];
+    const int n_slices = (N + Q_ROWS - 1) / Q_ROWS;
+    const int padded = n_slices * Q_ROWS, padded_su = (N + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU_ROWS;
     if (N > Q_SORT_MAX_ROWS) {
-        const int padded = (N + Q_ROWS - 1) / Q_ROWS * Q_ROWS;
-        for (int i = threadIdx.x; i < padded; i += 1024) perm[i] = min(i, N - 1);
+        for (int i = threadIdx.x; i < padded_su; i += 1024) {
+            const int k = i < padded ? i : (n_slices - 1) * Q_ROWS + (i % Q_ROWS);
+            perm[i] = min(k, N - 1);
+        }
         return;
     }
     for (int i = threadIdx.x; i < N; i += 1024)
@@ -109,11 +126,16 @@ __global__ __launch_bounds__(1024) void sell16_sort_rows(const int32_t *__restri
     }
     for (int i = threadIdx.x; i < N; i += 1024) perm[i] = static_cast<int32_t>(q_keys[i] & 0xffffffffull);
     __syncthreads();
-    // the slots that pad the last slice repeat the last (shortest) row: they compute and store that row's sums again
-    // (same bits to the same address), so the kernel's stores need no "is this slot a row" predicate
-    const int padded = (N + Q_ROWS - 1) / Q_ROWS * Q_ROWS;
-    if (N > 0)
+    // the slots that pad the last slice repeat the last (shortest) row, the slices that pad the last super-unit repeat the
+    // last slice: they compute and store those rows' sums again (same bits to the same address), so the kernel's stores
+    // need no "is this slot a row" predicate
+    if (N > 0) {
         for (int i = N + threadIdx.x; i < padded; i += 1024) perm[i] = static_cast<int32_t>(q_keys[N - 1] & 0xffffffffull);
+        for (int i = padded + threadIdx.x; i < padded_su; i += 1024) {
+            const int k = (n_slices - 1) * Q_ROWS + (i % Q_ROWS);
+            perm[i] = static_cast<int32_t>(q_keys[min(k, N - 1)] & 0xffffffffull);
+        }
+    }
 }
 
 // one thread per (column block, slice): width = longest in-block row segment, chunks = ceil(width / 16)
@@ -121,9 +143,12 @@ __global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__
                                                      const int32_t *__restrict__ perm, int32_t N, int32_t n_slices,
                                                      int32_t n_blocks, int32_t block_cols, int32_t *__restrict__ chunks,
                                                      int32_t *__restrict__ ext) {
+    // (n_slices here = the PADDED slice count, a multiple of Q_SU; a ghost slice repeats the last real one and owns no chunks)
     const int task = blockIdx.x * 256 + threadIdx.x;
     if (task >= n_slices * n_blocks) return;
-    const int blk = task / n_slices, slice = task % n_slices;
+    const int real_slices = (N + Q_ROWS - 1) / Q_ROWS;
+    const int blk = task / n_slices, slice = min(task % n_slices, real_slices - 1);
+    const bool ghost = task % n_slices >= real_slices;
     int width = 0;
     for (int r = 0; r < Q_ROWS; ++r) {
         const int slot = slice * Q_ROWS + r;
@@ -134,14 +159,17 @@ __global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__
         const int b = (blk + 1 == n_blocks) ? e : q_lower_bound(col, a, e, (blk + 1) * block_cols);
         width = max(width, b - a);
     }
-    chunks[task] = (width + Q_CHUNK - 1) / Q_CHUNK;
+    chunks[task] = ghost ? 0 : (width + Q_CHUNK - 1) / Q_CHUNK;
     ext[2 * task + 1] = width;
 }
 
 __global__ __launch_bounds__(256) void sell16_ext_begin(const int32_t *__restrict__ chunk_begin, int32_t n_tasks,
-                                                        int32_t *__restrict__ ext) {
+                                                        int32_t n_slices, int32_t real_slices, int32_t *__restrict__ ext) {
     const int task = blockIdx.x * 256 + threadIdx.x;
-    if (task < n_tasks) ext[2 * task] = chunk_begin[task];
+    if (task < n_tasks) {  // a ghost slice starts where the last real slice of its block starts
+        const int slice = task % n_slices;
+        ext[2 * task] = chunk_begin[slice < real_slices ? task : task - slice + real_slices - 1];
+    }
     if (task == n_tasks) {  // the trailing pair: {total chunks, 0}
         ext[2 * task] = chunk_begin[task];
         ext[2 * task + 1] = 0;
@@ -159,8 +187,9 @@ __global__ __launch_bounds__(256) void sell16_fill(const int32_t *__restrict__ r
                                                    const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
                                                    float *__restrict__ q_val, int reorder) {
     const int task = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (task >= n_slices * n_blocks) return;  // (whole waves: a task is a wave)
+    if (task >= n_slices * n_blocks) return;  // (whole waves: a task is a wave; n_slices = the padded count)
     const int blk = task / n_slices, slice = task % n_slices;
+    if (slice >= (N + Q_ROWS - 1) / Q_ROWS) return;  // a ghost slice reads the last real slice's chunks
     const int chunk0 = ext[2 * task], width = ext[2 * task + 1];
     const int n_chunks = (width + Q_CHUNK - 1) / Q_CHUNK;
     const int r = lane & 15;
@@ -234,7 +263,7 @@ struct QJob {
     global_ptr<const float> val, row_scale;
     global_ptr<float> Y;
     int64_t ldy;
-    int32_t n_rows, n_slices;
+    int32_t n_rows, n_su;  // n_su = super-units (64 rows; the ext / perm arrays are padded to whole super-units)
 };
 struct QHead {  // what a phase needs of its first job (the jobs of a phase agree in these)
     global_ptr<const void> X;
@@ -254,7 +283,7 @@ __device__ __forceinline__ QJob q_load_job(const wdg_spmm_job *jobs, const wdg_s
     v.val = to_global(j->q_val); v.row_scale = to_global(j->row_scale); v.Y = to_global(j->Y);
     v.ldy = j->ldy;
     v.n_rows = j->n_rows;
-    v.n_slices = (j->n_rows + Q_ROWS - 1) / Q_ROWS;
+    v.n_su = (j->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
     return v;
 }
 __device__ __forceinline__ QHead q_load_head(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int id, bool y_vec) {
@@ -287,27 +316,12 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
     const int F = h.n_feat;
     const int n_stage = (h.reserved & 2) ? 0 : rows * 4;  // float4 slots (reserved bit 1: timing ablation)
     const bool x_vec = sizeof(TIN) == 4 && (F % 4 == 0) && (h.ldx % 4 == 0) && (((uintptr_t)h.X & 15) == 0);
-    const bool dma = x_vec && !h.col_scale && !(h.reserved & 8);
     const global_ptr<const TIN> X = (global_ptr<const TIN>)h.X;
     if (tid < 4) xs[zero_row * 4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (dma) {
-        if constexpr (sizeof(TIN) == 4) {
-            // LDS-DMA: a wave-instruction fills 1 KiB = 16 staged rows, no data registers, every load in flight at once;
-            // chunks beyond a ragged F stay unwritten (their sums are never stored)
-            for (int i0 = wave * 64; i0 < n_stage; i0 += Q_THREADS) {
-                const int i = i0 + lane;
-                [[maybe_unused]] const int row = begin + (i >> 2);
-                const int qd = i & 3;
-                if (i < n_stage && f0 + qd * 4 < F) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    __builtin_amdgcn_global_load_lds(X + static_cast<int64_t>(row) * h.ldx + f0 + qd * 4,
-                                                     (__attribute__((address_space(3))) void *)(xs + i0), 16, 0, 0);
-#endif
-                }
-            }
-        }
-        return;
-    }
+    // Staged through registers, NOT by LDS-DMA (global_load_lds): the compiler orders every later ds_read that may alias
+    // a DMA's destination behind it with s_waitcnt vmcnt(0) - it cannot see that the phase barrier already did -, which
+    // turns every counted wait of the unit pipeline into a wait for the wave's last store.  A workgroup stages a slab once
+    // per phase (once or twice per launch), so the extra ds_write_b128 traffic is noise.
     constexpr int NL = 4;  // register-staged loads in flight per thread
     for (int i0 = 0; i0 < n_stage; i0 += Q_THREADS * NL) {
         float4 v[NL];
@@ -340,157 +354,357 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
     }
 }
 
-// one entry of all 16 rows: offset of entry (J, R) of the chunk registers, broadcast in the quad, + the lane's 16 bytes
-#define WDG_Q_STEP(J, R)                                                                        \
-    {                                                                                           \
-        const int addr = q_bcast<J>(cc[R]) + loff;                                              \
-        const f32x4_t v = *(const f32x4_t __attribute__((address_space(3))) *)(slab + addr);    \
-        if (HAS_VAL) {                                                                          \
-            const float wv = q_bcastf<J>(wc[R]);                                                \
-            a0 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{v.x, v.y}, a0);                 \
-            a1 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{v.z, v.w}, a1);                 \
-        } else {                                                                                \
-            a0 += f32x2{v.x, v.y};                                                              \
-            a1 += f32x2{v.z, v.w};                                                              \
-        }                                                                                       \
+// One entry of all 16 rows = the offset of entry (J, R) of the chunk registers, broadcast in the quad, + the lane's 16 bytes
+// -> one ds_read_b128 -> two packed adds.  A wave must keep SEVERAL reads in flight: with the two the compiler schedules on
+// its own, 16 waves x 2 reads cover about half of the LDS pipe's latency (measured: LDS 58 % busy, waves 67 % waiting).  The
+// entries are therefore read a quad at a time into four register sets, quad q + 1 requested before quad q is added
+// (scheduling barriers keep the order): four to eight reads in flight per wave.
+#define WDG_Q_READ(J, R, V)                                                                     \
+    const f32x4_t V = *(const f32x4_t __attribute__((address_space(3))) *)(slab + (q_bcast<J>(cc[R]) + loff));
+#define WDG_Q_ADD(J, R, V)                                                                      \
+    if (HAS_VAL) {                                                                              \
+        const float wv = q_bcastf<J>(wc[R]);                                                    \
+        a0 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{V.x, V.y}, a0);                     \
+        a1 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{V.z, V.w}, a1);                     \
+    } else {                                                                                    \
+        a0 += f32x2{V.x, V.y};                                                                  \
+        a1 += f32x2{V.z, V.w};                                                                  \
     }
-#define WDG_Q_QUAD(J) WDG_Q_STEP(J, 0) WDG_Q_STEP(J, 1) WDG_Q_STEP(J, 2) WDG_Q_STEP(J, 3)
+#define WDG_Q_READ4(J, P) WDG_Q_READ(J, 0, P##0) WDG_Q_READ(J, 1, P##1) WDG_Q_READ(J, 2, P##2) WDG_Q_READ(J, 3, P##3)
+#define WDG_Q_ADD4(J, P) WDG_Q_ADD(J, 0, P##0) WDG_Q_ADD(J, 1, P##1) WDG_Q_ADD(J, 2, P##2) WDG_Q_ADD(J, 3, P##3)
+// one quad of entries, on its own (partial chunks)
+#define WDG_Q_QUAD(J)        \
+    {                        \
+        WDG_Q_READ4(J, qv)   \
+        WDG_Q_ADD4(J, qv)    \
+    }
+// a whole chunk of 16 entries, software-pipelined in pairs: four reads in flight (16 data registers)
+#define WDG_Q_PAIR_READ(J, R, P) WDG_Q_READ(J, R, P##0) WDG_Q_READ(J, R + 1, P##1)
+#define WDG_Q_PAIR_ADD(J, R, P) WDG_Q_ADD(J, R, P##0) WDG_Q_ADD(J, R + 1, P##1)
+#define WDG_Q_CHUNK16                                                                                \
+    {                                                                                                \
+        WDG_Q_PAIR_READ(0, 0, pa) WDG_Q_PAIR_READ(0, 2, pb) __builtin_amdgcn_sched_barrier(0);       \
+        WDG_Q_PAIR_ADD(0, 0, pa) WDG_Q_PAIR_READ(1, 0, pc) __builtin_amdgcn_sched_barrier(0);        \
+        WDG_Q_PAIR_ADD(0, 2, pb) WDG_Q_PAIR_READ(1, 2, pd) __builtin_amdgcn_sched_barrier(0);        \
+        WDG_Q_PAIR_ADD(1, 0, pc) WDG_Q_PAIR_READ(2, 0, pe) __builtin_amdgcn_sched_barrier(0);        \
+        WDG_Q_PAIR_ADD(1, 2, pd) WDG_Q_PAIR_READ(2, 2, pf) __builtin_amdgcn_sched_barrier(0);        \
+        WDG_Q_PAIR_ADD(2, 0, pe) WDG_Q_PAIR_READ(3, 0, pg) __builtin_amdgcn_sched_barrier(0);        \
+        WDG_Q_PAIR_ADD(2, 2, pf) WDG_Q_PAIR_READ(3, 2, ph) __builtin_amdgcn_sched_barrier(0);        \
+        WDG_Q_PAIR_ADD(3, 0, pg) WDG_Q_PAIR_ADD(3, 2, ph)                                            \
+    }
 
-// the units of a wave in a phase: unit_begin + (wave + 16 n) * stride, n = 0, 1, ... < unit_end; unit u of the phase is
-// slice u - base(job) of the job it falls into (jobs first_job .. first_job + n_jobs - 1, concatenated)
-struct QCursor {
-    int job, base, last_job;
-    QJob cj;
+// ---- a phase whose graphs have ONE column block: the whole slab X[:, f0 : f0 + 16] is resident, waves run free.
+//
+// The unit of work dealt to a wave is a SUPER-UNIT: four consecutive slices (64 rows) of one job.  Measured on the first
+// version of this kernel (one slice per step): ~70 scalar + ~55 vector instructions of bookkeeping per slice against ~30
+// of sweep on the 800 set - the launch was bound by instruction issue, not by LDS or memory.  A super-unit shares the
+// bookkeeping: one request for its four extents, one for its 64 destination rows, one for their scales; per slice remain
+// the two index-chunk requests, two lane permutes (row, scale), the sweep and the store.
+//
+// The pipeline (q_units_fast).  vmcnt retires in order and counts loads and stores alike, so a wave that consumes a load
+// issued AFTER its last store waits for that store's acknowledgement.  The compiler cannot be talked out of such waits (it
+// prices every s_waitcnt vmcnt(N) by the operations CERTAIN to follow the awaited load: one conditional memory operation
+// in between, one register copy of a pending load at a loop boundary, or one LDS-DMA anywhere in the function, and N
+// becomes 0), so the pipeline's memory operations are issued from inline assembly - invisible to the compiler's
+// bookkeeping - and waited for by hand:
+//   * an iteration first issues every load of the pipeline - the index chunks and row scales of the NEXT super-unit (stage
+//     I; its extents and rows arrived during the previous iteration), then the extents and rows of the one after next
+//     (stage E) -, then sweeps its four slices, storing each slice's rows right after its sweep, then waits with vmcnt(4):
+//     all of the iteration's loads have landed, its four stores may still be in flight (they have until the end of the
+//     next iteration); only then are the next super-unit's registers copied into place, so no pending load ever crosses
+//     the loop's back edge;
+//   * every operation is issued unconditionally, a fixed number per super-unit (the count above depends on it): a
+//     super-unit past the wave's last one repeats the last one (it recomputes and stores the same bits), a narrow slice
+//     requests its second chunk anyway (the index arrays carry two chunks of slack), absent scales / values are read from
+//     some valid address and replaced afterwards; padding slots / slices repeat the last row / slice (same bits, same
+//     address);
+//   * wider slices (more than 32 entries per row; 16 with explicit values) fetch their further chunks inside the sweep,
+//     two at a time, and wait for them with vmcnt(0) (which covers the super-unit's earlier stores - by then they landed).
+// Feature groups that are ragged or whose Y cannot take 16-byte stores run the plain loop q_units_simple.
+__device__ __forceinline__ i32x4 q_ld4(global_ptr<const int32_t> base, unsigned voff) {  // 16 bytes at base + voff
+    i32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base));
+    return v;
+}
+__device__ __forceinline__ i32x4 q_ld4_1k(global_ptr<const int32_t> base, unsigned voff) {  // ... + 1024 (the next chunk)
+    i32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(v) : "v"(voff), "s"(base));
+    return v;
+}
+__device__ __forceinline__ i32x2 q_ld2(global_ptr<const int32_t> base, unsigned voff) {
+    i32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base));
+    return v;
+}
+__device__ __forceinline__ int q_ld1(global_ptr<const int32_t> base, unsigned voff) {
+    int v;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base));
+    return v;
+}
+__device__ __forceinline__ void q_st4(global_ptr<float> base, unsigned voff, f32x4_t v) {
+    // (s_nop: a VALU write of the data registers right behind a store of more than 8 bytes is a hazard the compiler
+    // resolves for its own stores, not for this one)
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
+}
+
+struct QJobE {  // what stage E needs of a job (SGPRs; re-read from the table when the stage moves to another job)
+    global_ptr<const int32_t> ext, perm;
+    int n_su;
 };
-__device__ __forceinline__ void q_seek(QCursor &c, int u, const wdg_spmm_job *jobs, const wdg_spmm_job &inl) {
-    while (u >= c.base + c.cj.n_slices && c.job < c.last_job) {
-        c.base += c.cj.n_slices;
-        ++c.job;
-        c.cj = q_load_job(jobs, inl, c.job);
+struct QJobI {
+    global_ptr<const int32_t> col, scale_or_perm, val_or_col;
+    bool has_scale, has_val;
+};
+struct QJobC {
+    global_ptr<const int32_t> col, val;
+    global_ptr<float> Y;
+    unsigned ldy4;  // bytes per row of Y
+    bool has_val;
+};
+
+template <bool HAS_VAL>
+__device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
+                                             int unit_begin, int unit_end, int stride, int f0, lds_cptr slab, bool no_sweep,
+                                             bool no_store, int wave, int lane) {
+    constexpr int NPRE = HAS_VAL ? 1 : 2;  // index chunks per slice requested one super-unit ahead
+    const int r = lane >> 2, p = lane & 3;
+    const int loff = p * 16;
+    const unsigned lane16 = lane * 16, lane4 = lane * 4, ext_lane = (lane < Q_SU ? lane : Q_SU - 1) * 8;
+    const int bperm0 = r * 4;  // ds_bpermute address of lane r: slice i's row r sits in lane 16 i + r of the 64-row registers
+    const int ustep = Q_WAVES * stride;
+    const int last_job = first_job + n_jobs - 1;
+
+    // ---- the super-unit iterator over the phase's concatenated jobs: (it_j, it_su) = job / super-unit of unit it_u;
+    //      (req_j, req_su) = what is actually requested: the iterator's while it_u is a unit, then the wave's last unit
+    int it_u = unit_begin + wave * stride, it_j = first_job, it_su;
+    int it_nsu = (q_desc(jobs, inl, it_j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+    {
+        int rest = it_u;
+        while (rest >= it_nsu && it_j < last_job) {
+            rest -= it_nsu;
+            ++it_j;
+            it_nsu = (q_desc(jobs, inl, it_j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+        }
+        it_su = rest;
+    }
+    int req_j = first_job, req_su = 0;
+    auto advance = [&]() {
+        it_u += ustep;
+        it_su += ustep;
+        while (it_su >= it_nsu && it_j < last_job) {
+            it_su -= it_nsu;
+            ++it_j;
+            it_nsu = (q_desc(jobs, inl, it_j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+        }
+    };
+
+    int ej = -1, ij = -1, cj = -1;
+    QJobE je{};
+    QJobI ji{};
+    QJobC jc{};
+    struct EStage {  // the four extents (lane i < 4: slice i) + the 64 destination rows requested
+        i32x2 ext;
+        int rows, j;
+        bool ok;
+    };
+    struct IStage {  // index chunks + row scales requested
+        i32x4 c[Q_SU][NPRE];
+        f32x4_t w[Q_SU][NPRE];
+        i32x2 ext;
+        int rows, scale_bits, j;
+        bool ok, has_scale;
+    };
+    auto issueE = [&](EStage &e) {
+        e.ok = it_u < unit_end;
+        if (e.ok) {
+            req_j = it_j;
+            req_su = it_su;
+        }
+        e.j = req_j;
+        if (e.j != ej) {
+            ej = e.j;
+            const q_desc_ptr d = q_desc(jobs, inl, ej);
+            je.ext = to_global(d->q_ext);
+            je.perm = to_global(d->q_perm);
+        }
+        e.ext = q_ld2(je.ext, static_cast<unsigned>(req_su) * (Q_SU * 8) + ext_lane);
+        e.rows = q_ld1(je.perm, static_cast<unsigned>(req_su) * (Q_SU_ROWS * 4) + lane4);
+        advance();
+    };
+    auto issueI = [&](const EStage &e, IStage &s) {
+        s.ok = e.ok;
+        s.j = e.j;
+        s.rows = e.rows;
+        s.ext = e.ext;
+        if (s.j != ij) {
+            ij = s.j;
+            const q_desc_ptr d = q_desc(jobs, inl, ij);
+            ji.col = to_global(d->q_col);
+            ji.has_scale = d->row_scale != nullptr;
+            ji.scale_or_perm = ji.has_scale ? (global_ptr<const int32_t>)to_global(d->row_scale) : to_global(d->q_perm);
+            ji.has_val = HAS_VAL && d->q_val != nullptr;
+            ji.val_or_col = ji.has_val ? (global_ptr<const int32_t>)to_global(d->q_val) : ji.col;
+        }
+#pragma unroll
+        for (int i = 0; i < Q_SU; ++i) {
+            const unsigned off = static_cast<unsigned>(__builtin_amdgcn_readlane(e.ext.x, i)) * (Q_CHUNK_INTS * 4) + lane16;
+            s.c[i][0] = q_ld4(ji.col, off);
+            if (NPRE > 1) s.c[i][NPRE - 1] = q_ld4_1k(ji.col, off);
+            if (HAS_VAL) {
+                const i32x4 wv = q_ld4(ji.val_or_col, off);
+                s.w[i][0] = f32x4_t{__int_as_float(wv.x), __int_as_float(wv.y), __int_as_float(wv.z), __int_as_float(wv.w)};
+            }
+        }
+        s.has_scale = ji.has_scale;
+        s.scale_bits = q_ld1(ji.scale_or_perm, static_cast<unsigned>(s.rows) * 4u);
+    };
+    auto sweep_and_store = [&](const IStage &cur) {
+        if (cur.j != cj) {
+            cj = cur.j;
+            const q_desc_ptr d = q_desc(jobs, inl, cj);
+            jc.col = to_global(d->q_col);
+            jc.has_val = HAS_VAL && d->q_val != nullptr;
+            jc.val = jc.has_val ? (global_ptr<const int32_t>)to_global(d->q_val) : jc.col;
+            jc.Y = to_global(d->Y);
+            jc.ldy4 = static_cast<unsigned>(d->ldy) * 4u;
+        }
+        const f32x4_t ones = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int i = 0; i < Q_SU; ++i) {
+            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+            const int width0 = no_sweep ? 0 : __builtin_amdgcn_readlane(cur.ext.y, i);
+            const int n_chunks = (width0 + Q_CHUNK - 1) / Q_CHUNK;
+            const unsigned off = static_cast<unsigned>(__builtin_amdgcn_readlane(cur.ext.x, i)) * (Q_CHUNK_INTS * 4) + lane16;
+            // chunks beyond the prefetched ones: the first is requested before the prefetched chunks are swept, each later one
+            // before the one before it is swept
+            i32x4 t0 = {0, 0, 0, 0};
+            [[maybe_unused]] i32x4 tw0 = {0, 0, 0, 0};
+            if (n_chunks > NPRE) {
+                t0 = q_ld4(jc.col, off + NPRE * 1024u);
+                if (HAS_VAL) tw0 = q_ld4(jc.val, off + NPRE * 1024u);
+            }
+            auto chunk = [&](const i32x4 &cc, [[maybe_unused]] const f32x4_t &wc, int left) {
+                if (left >= Q_CHUNK) {
+                    WDG_Q_CHUNK16
+                } else {  // a last, partial chunk: whole quads of entries (its padding entries read the zero row)
+                    WDG_Q_QUAD(0)
+                    if (left > 4) { WDG_Q_QUAD(1) }
+                    if (left > 8) { WDG_Q_QUAD(2) }
+                    if (left > 12) { WDG_Q_QUAD(3) }
+                }
+            };
+            auto as_f = [&](const i32x4 &v) {
+                return jc.has_val ? f32x4_t{__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)} : ones;
+            };
+#pragma unroll
+            for (int c = 0; c < NPRE; ++c)
+                if (width0 > c * Q_CHUNK) chunk(cur.c[i][c], (HAS_VAL && jc.has_val) ? cur.w[i][c] : ones, width0 - c * Q_CHUNK);
+            for (int ch = NPRE; ch < n_chunks; ++ch) {
+                // (nothing was issued behind this chunk: vmcnt(0) - it also covers the super-unit's earlier stores and the
+                // next super-unit's requests, all of them at least a chunk of sweeping old)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0));
+                if (HAS_VAL) asm volatile("" : "+v"(tw0));
+                const i32x4 u0 = t0;
+                [[maybe_unused]] const i32x4 uw0 = tw0;
+                if (ch + 1 < n_chunks) {
+                    t0 = q_ld4(jc.col, off + (ch + 1) * 1024u);
+                    if (HAS_VAL) tw0 = q_ld4(jc.val, off + (ch + 1) * 1024u);
+                }
+                chunk(u0, HAS_VAL ? as_f(uw0) : ones, width0 - ch * Q_CHUNK);
+            }
+            // ---- the slice's rows leave from the accumulators: the quad's four 16-byte stores are one 64-byte row segment
+            const int row = __builtin_amdgcn_ds_bpermute(bperm0 + i * (Q_ROWS * 4), cur.rows);
+            const int sb = __builtin_amdgcn_ds_bpermute(bperm0 + i * (Q_ROWS * 4), cur.scale_bits);
+            const float scale0 = cur.has_scale ? __int_as_float(sb) : 1.f;
+            const unsigned row0 = no_store ? static_cast<unsigned>(r) : static_cast<unsigned>(row);  // (timing ablation: rows 0..15)
+            q_st4(jc.Y, row0 * jc.ldy4 + static_cast<unsigned>(f0 * 4 + loff),
+                  f32x4_t{a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0});
+        }
+    };
+    // everything requested so far has landed: the registers of the stages named may be read (or copied) from here on
+    auto landed = [&](EStage &e, IStage &s) {
+        asm volatile("" : "+v"(e.ext), "+v"(e.rows), "+v"(s.scale_bits));
+#pragma unroll
+        for (int i = 0; i < Q_SU; ++i)
+#pragma unroll
+            for (int c = 0; c < NPRE; ++c) {
+                asm volatile("" : "+v"(s.c[i][c]));
+                if (HAS_VAL) asm volatile("" : "+v"(s.w[i][c]));
+            }
+    };
+
+    EStage E;
+    IStage C, N;
+#pragma unroll
+    for (int i = 0; i < Q_SU; ++i)
+#pragma unroll
+        for (int c = 0; c < NPRE; ++c) {
+            C.c[i][c] = N.c[i][c] = i32x4{0, 0, 0, 0};
+            C.w[i][c] = N.w[i][c] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+        }
+    C.scale_bits = N.scale_bits = 0;
+    issueE(E);  // super-unit 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(E, C);
+    issueI(E, C);
+    issueE(E);  // super-unit 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(E, C);
+    q_barrier_lds();  // the slab is in place for every wave; from here to the end of the phase the waves run free
+    while (C.ok) {
+        issueI(E, N);  // super-unit n + 1
+        issueE(E);     // super-unit n + 2
+        sweep_and_store(C);
+        // the iteration's loads are older than its four stores: they have all landed, the stores may be in flight
+        static_assert(Q_SU == 4, "the wait below names Q_SU");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        landed(E, N);
+        C = N;
     }
 }
 
-// ---- a phase whose graphs have ONE column block: the whole slab X[:, f0 : f0 + 16] is resident, waves run free.
-// FULL: the feature group is whole and Y takes 16-byte stores -> the unit's store is issued unconditionally (the padding
-// slots of a graph's last slice repeat its last row: same bits to the same address).  That matters beyond the branch: the
-// compiler prices every s_waitcnt vmcnt(N) by the operations that are CERTAIN to have been issued after the awaited load,
-// so only an unconditional store lets the next unit's waits leave that store in flight (vmcnt retires in order).
-template <bool HAS_VAL, bool FULL>
-__device__ __forceinline__ void q_units(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
-                                        int unit_begin, int unit_end, int stride, int f0, int F, lds_cptr slab, bool no_sweep,
-                                        int wave, int lane) {
+// the plain loop: any feature group (ragged, scalar stores), nothing requested ahead; units are super-units as well
+template <bool HAS_VAL>
+__device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
+                                               int unit_begin, int unit_end, int stride, int f0, int F, lds_cptr slab,
+                                               bool no_sweep, bool no_store, int wave, int lane) {
     const int r = lane >> 2, p = lane & 3;
     const int loff = p * 16;
-    QCursor cur;
-    cur.job = first_job;
-    cur.base = 0;
-    cur.last_job = first_job + n_jobs - 1;
-    cur.cj = q_load_job(jobs, inl, first_job);
-    const int ustep = Q_WAVES * stride;
-    int u_next = unit_begin + wave * stride;
-
-    // ---- the unit pipeline: stage 2 = located (the cursor's job), extent + destination rows requested; stage 1 = extent
-    //      known, first two index chunks + row scales requested; stage 0 = being swept.  A stage carries only what the
-    //      later stages need of its job (SGPRs are scarce: three whole descriptors would spill).
-    struct QLive {
-        global_ptr<const int32_t> col;
-        global_ptr<const float> val;
-        global_ptr<float> Y;
-        int64_t ldy;
-    };
-    QLive j1{cur.cj.col, cur.cj.val, cur.cj.Y, cur.cj.ldy}, j0 = j1;
-    bool ok2 = false, ok1 = false;
-    i32x2 ext2 = {0, 0};
-    int row2 = 0, row1 = 0, row0 = 0;
-    int chunk1 = 0, width1 = 0, chunk0 = 0, width0 = 0;
-    float scale1 = 1.f, scale0 = 1.f;
-    i32x4 c1a = {0, 0, 0, 0}, c1b = {0, 0, 0, 0}, c0a, c0b;
-    float4 w1a = make_float4(0.f, 0.f, 0.f, 0.f), w1b = w1a, w0a, w0b;
-
-    // Every vector-memory operation of the pipeline is issued UNCONDITIONALLY, a fixed number per unit (a unit past the
-    // end re-requests slice 0 of the cursor's job, a narrow unit requests its second chunk anyway - the index arrays
-    // carry two chunks of slack -, absent scales / values are read from some valid address and replaced afterwards):
-    // the compiler derives every s_waitcnt vmcnt(N) from the operations CERTAIN to follow the awaited load, and a
-    // conditional one in between would turn N into 0, i.e. into a wait for the unit's own store.
-    auto issue2 = [&]() {
-        ok2 = u_next < unit_end;
-        if (ok2) q_seek(cur, u_next, jobs, inl);
-        const int slice = ok2 ? u_next - cur.base : 0;
-        ext2 = *(global_ptr<const i32x2>)(cur.cj.ext + 2 * slice);  // one address for the wave: a broadcast load
-        row2 = cur.cj.perm[slice * Q_ROWS + r];                     // (padding slots hold the last row: always a row)
-        u_next += ustep;
-    };
-    auto promote = [&]() {  // (the cursor still stands on stage 2's job: issue2() moves it only afterwards)
-        ok1 = ok2;
-        row1 = row2;
-        j1 = QLive{cur.cj.col, cur.cj.val, cur.cj.Y, cur.cj.ldy};
-        chunk1 = __builtin_amdgcn_readfirstlane(ext2.x);
-        width1 = (no_sweep || !ok1) ? 0 : __builtin_amdgcn_readfirstlane(ext2.y);
-        const global_ptr<const int32_t> cb = j1.col + static_cast<int64_t>(chunk1) * Q_CHUNK_INTS + lane * 4;
-        c1a = *(global_ptr<const i32x4>)cb;
-        c1b = *(global_ptr<const i32x4>)(cb + Q_CHUNK_INTS);
-        if (HAS_VAL) {
-            const bool hv = j1.val != nullptr;
-            const global_ptr<const float> vb = (hv ? j1.val : (global_ptr<const float>)j1.col) + static_cast<int64_t>(chunk1) * Q_CHUNK_INTS + lane * 4;
-            const float4 va = load_f32x4(vb), vbb = load_f32x4(vb + Q_CHUNK_INTS);
-            w1a = hv ? va : make_float4(1.f, 1.f, 1.f, 1.f);
-            w1b = hv ? vbb : make_float4(1.f, 1.f, 1.f, 1.f);
+    q_barrier_lds();  // the slab is in place for every wave
+    for (int u = unit_begin + wave * stride; u < unit_end; u += Q_WAVES * stride) {
+        int j = first_job, su = u;
+        for (;;) {
+            const int nsu = (q_desc(jobs, inl, j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+            if (su < nsu || j >= first_job + n_jobs - 1) break;
+            su -= nsu;
+            ++j;
         }
-        const bool hs = cur.cj.row_scale != nullptr;
-        const float sv = (hs ? cur.cj.row_scale : (global_ptr<const float>)cur.cj.perm)[row1];
-        scale1 = hs ? sv : 1.f;
-    };
-
-    issue2();
-    promote();
-    issue2();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    q_barrier_lds();  // the slab is in place for every wave; from here to the end of the phase the waves run free
-
-    while (ok1) {
-        // stage 1 -> stage 0
-        j0 = j1; row0 = row1; scale0 = scale1; chunk0 = chunk1; width0 = width1;
-        c0a = c1a; c0b = c1b; w0a = w1a; w0b = w1b;
-        promote();
-        issue2();
-
-        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-        const int n_chunks = (width0 + Q_CHUNK - 1) / Q_CHUNK;
-        i32x4 cc = c0a, cn = c0b;
-        [[maybe_unused]] float4 wc = w0a, wn = w0b;
-        const global_ptr<const int32_t> cb = j0.col + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + lane * 4;
-        [[maybe_unused]] const global_ptr<const float> vb = j0.val + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + lane * 4;
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            i32x4 cf = cn;
-            [[maybe_unused]] float4 wf = wn;
-            if (ch + 2 < n_chunks) {  // the chunk after next: two chunks of indices are always in flight
-                cf = *(global_ptr<const i32x4>)(cb + (ch + 2) * Q_CHUNK_INTS);
-                if (HAS_VAL) wf = j0.val ? load_f32x4(vb + (ch + 2) * Q_CHUNK_INTS) : make_float4(1.f, 1.f, 1.f, 1.f);
-            }
-            const int left = width0 - ch * Q_CHUNK;  // wave-uniform
-            if (left >= Q_CHUNK) {
-                WDG_Q_QUAD(0) WDG_Q_QUAD(1) WDG_Q_QUAD(2) WDG_Q_QUAD(3)
-            } else {  // the last, partial chunk: whole quads of entries (its padding entries read the zero row)
+        const QJob job = q_load_job(jobs, inl, j);
+        const unsigned ldy = static_cast<unsigned>(job.ldy);
+        for (int i = 0; i < Q_SU; ++i) {
+            const int slice = su * Q_SU + i;
+            const i32x2 ext = *(global_ptr<const i32x2>)(job.ext + 2 * slice);
+            const int chunk0 = __builtin_amdgcn_readfirstlane(ext.x);
+            const int width0 = no_sweep ? 0 : __builtin_amdgcn_readfirstlane(ext.y);
+            const int row = job.perm[slice * Q_ROWS + r];
+            const float scale0 = job.row_scale ? job.row_scale[row] : 1.f;
+            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+            const f32x4_t ones = {1.f, 1.f, 1.f, 1.f};
+            for (int ch = 0; ch * Q_CHUNK < width0; ++ch) {
+                const i32x4 cc = *(global_ptr<const i32x4>)(job.col + static_cast<int64_t>(chunk0 + ch) * Q_CHUNK_INTS + lane * 4);
+                [[maybe_unused]] f32x4_t wc = ones;
+                if (HAS_VAL && job.val) wc = *(global_ptr<const f32x4_t>)(job.val + static_cast<int64_t>(chunk0 + ch) * Q_CHUNK_INTS + lane * 4);
+                const int left = width0 - ch * Q_CHUNK;
                 WDG_Q_QUAD(0)
                 if (left > 4) { WDG_Q_QUAD(1) }
                 if (left > 8) { WDG_Q_QUAD(2) }
                 if (left > 12) { WDG_Q_QUAD(3) }
             }
-            cc = cn;
-            cn = cf;
-            if (HAS_VAL) {
-                wc = wn;
-                wn = wf;
-            }
-        }
-        // ---- the unit's rows leave from the accumulators: the quad's four 16-byte stores are one 64-byte row segment
-        const int f = f0 + p * 4;
-        const global_ptr<float> dst = j0.Y + static_cast<int64_t>(row0) * j0.ldy + f;
-        const float4 o = make_float4(a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0);
-        if (FULL) {
-            store_f32x4(dst, o);
-        } else {
-            const bool y_vec = (F % 4 == 0) && (j0.ldy % 4 == 0) && (((uintptr_t)j0.Y & 15) == 0);
+            const int f = f0 + p * 4;
+            const int row0 = no_store ? r : row;
+            const global_ptr<float> dst = job.Y + static_cast<uint64_t>(static_cast<unsigned>(row0)) * ldy + f;
+            const float4 o = make_float4(a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0);
+            const bool y_vec = (F % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
             if (y_vec) {
                 if (f < F) store_f32x4(dst, o);
             } else {
@@ -516,15 +730,16 @@ __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const w
     if (f0 >= F) return;  // workgroup-uniform
     if (!first_phase) q_barrier_lds();  // every wave is done with the previous phase's slab
     q_stage<TIN>(head, 0, head.n_cols, head.block_cols, f0, xs, wave, lane, tid);
-    const bool no_sweep = head.reserved & 4;  // timing ablation (diagnostics)
+    const bool no_sweep = head.reserved & 4, no_store = head.reserved & 1;  // timing ablations (diagnostics)
     // whole feature group and 16-byte stores for every job of the phase (the table's flags vouch for the alignment)
-    const bool full = (f0 + 16 <= F) && head.y_vec;
-    if (full) q_units<HAS_VAL, true>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, wave, lane);
-    else q_units<HAS_VAL, false>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, wave, lane);
+    const bool full = (f0 + 16 <= F) && head.y_vec && !HAS_VAL;  // (explicit values: the plain loop)
+    if (full) q_units_fast<false>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, no_sweep, no_store, wave, lane);
+    else q_units_simple<HAS_VAL>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, no_store, wave, lane);
 }
 
 // ---- a phase whose graphs have SEVERAL column blocks (more than 2528 columns): the blocks of the slab are staged one
-//      after the other, every wave keeps the accumulators of its <= 8 units across the blocks (barriers between blocks)
+//      after the other, every wave keeps the accumulators of its <= 2 super-units (8 slices) across the blocks (barriers
+//      between blocks).  Plain loads: the sweeps of a block are short and the barriers dominate anyway.
 template <typename TIN, bool HAS_VAL>
 __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                               int unit_begin, int unit_end, int stride, int f0, float4 *xs, bool first_phase,
@@ -541,6 +756,7 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
     const lds_cptr slab = (lds_cptr)xs;
     const bool no_sweep = head.reserved & 4, no_store = head.reserved & 1;
     const int ustep = Q_WAVES * stride;
+    constexpr int MAX_SU = Q_MAXU / Q_SU;
 
     f32x2 acc0[Q_MAXU], acc1[Q_MAXU];
 #pragma unroll
@@ -550,77 +766,56 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
         if (blk > 0 || !first_phase) q_barrier_lds();  // the previous block's readers are done
         const int begin = blk * head.block_cols, rows = min(head.block_cols, head.n_cols - begin);
         q_stage<TIN>(head, begin, rows, head.block_cols, f0, xs, wave, lane, tid);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         q_barrier_lds();
-        QCursor cur;
-        cur.job = first_job;
-        cur.base = 0;
-        cur.last_job = first_job + n_jobs - 1;
-        cur.cj = q_load_job(jobs, inl, first_job);
+        int j = first_job, base = 0;
+        QJob j0 = q_load_job(jobs, inl, j);
         int u = unit_begin + wave * stride;
 #pragma unroll
-        for (int k = 0; k < Q_MAXU; ++k, u += ustep) {
+        for (int k = 0; k < MAX_SU; ++k, u += ustep) {
             if (u >= unit_end) break;  // wave-uniform
-            q_seek(cur, u, jobs, inl);
-            const QJob j0 = cur.cj;
-            const int slice = u - cur.base;
-            const int task = blk * j0.n_slices + slice;
-            const i32x2 ext = *(global_ptr<const i32x2>)(j0.ext + 2 * task);
-            const int chunk0 = __builtin_amdgcn_readfirstlane(ext.x);
-            const int width0 = no_sweep ? 0 : __builtin_amdgcn_readfirstlane(ext.y);
-            const int n_chunks = (width0 + Q_CHUNK - 1) / Q_CHUNK;
-            const global_ptr<const int32_t> cb = j0.col + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + lane * 4;
-            [[maybe_unused]] const global_ptr<const float> vb = j0.val + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + lane * 4;
-            const float4 ones = make_float4(1.f, 1.f, 1.f, 1.f);
-            i32x4 cc = {0, 0, 0, 0}, cn = {0, 0, 0, 0};
-            [[maybe_unused]] float4 wc = ones, wn = ones;
-            if (n_chunks > 0) cc = *(global_ptr<const i32x4>)cb;
-            if (n_chunks > 1) cn = *(global_ptr<const i32x4>)(cb + Q_CHUNK_INTS);
-            if (HAS_VAL && j0.val) {
-                if (n_chunks > 0) wc = load_f32x4(vb);
-                if (n_chunks > 1) wn = load_f32x4(vb + Q_CHUNK_INTS);
+            while (u >= base + j0.n_su && j < first_job + n_jobs - 1) {
+                base += j0.n_su;
+                ++j;
+                j0 = q_load_job(jobs, inl, j);
             }
-            f32x2 a0 = acc0[k], a1 = acc1[k];
-            for (int ch = 0; ch < n_chunks; ++ch) {
-                i32x4 cf = cn;
-                [[maybe_unused]] float4 wf = wn;
-                if (ch + 2 < n_chunks) {
-                    cf = *(global_ptr<const i32x4>)(cb + (ch + 2) * Q_CHUNK_INTS);
-                    if (HAS_VAL) wf = j0.val ? load_f32x4(vb + (ch + 2) * Q_CHUNK_INTS) : ones;
-                }
-                const int left = width0 - ch * Q_CHUNK;
-                if (left >= Q_CHUNK) {
-                    WDG_Q_QUAD(0) WDG_Q_QUAD(1) WDG_Q_QUAD(2) WDG_Q_QUAD(3)
-                } else {
+            const int su = u - base;
+#pragma unroll
+            for (int i = 0; i < Q_SU; ++i) {
+                const int slice = su * Q_SU + i;
+                const int task = blk * (j0.n_su * Q_SU) + slice;
+                const i32x2 ext = *(global_ptr<const i32x2>)(j0.ext + 2 * task);
+                const int chunk0 = __builtin_amdgcn_readfirstlane(ext.x);
+                const int width0 = no_sweep ? 0 : __builtin_amdgcn_readfirstlane(ext.y);
+                const f32x4_t ones = {1.f, 1.f, 1.f, 1.f};
+                f32x2 a0 = acc0[k * Q_SU + i], a1 = acc1[k * Q_SU + i];
+                for (int ch = 0; ch * Q_CHUNK < width0; ++ch) {
+                    const i32x4 cc = *(global_ptr<const i32x4>)(j0.col + static_cast<int64_t>(chunk0 + ch) * Q_CHUNK_INTS + lane * 4);
+                    [[maybe_unused]] f32x4_t wc = ones;
+                    if (HAS_VAL && j0.val) wc = *(global_ptr<const f32x4_t>)(j0.val + static_cast<int64_t>(chunk0 + ch) * Q_CHUNK_INTS + lane * 4);
+                    const int left = width0 - ch * Q_CHUNK;
                     WDG_Q_QUAD(0)
                     if (left > 4) { WDG_Q_QUAD(1) }
                     if (left > 8) { WDG_Q_QUAD(2) }
                     if (left > 12) { WDG_Q_QUAD(3) }
                 }
-                cc = cn;
-                cn = cf;
-                if (HAS_VAL) {
-                    wc = wn;
-                    wn = wf;
-                }
-            }
-            acc0[k] = a0;
-            acc1[k] = a1;
-            if (blk + 1 == head.n_blocks) {
-                const int row = j0.perm[slice * Q_ROWS + r];  // (padding slots repeat the last row: always a row)
-                if (!no_store) {
-                    const float s = j0.row_scale ? j0.row_scale[row] : 1.f;
-                    const int f = f0 + p * 4;
-                    const global_ptr<float> dst = j0.Y + static_cast<int64_t>(row) * j0.ldy + f;
-                    const float4 o = make_float4(a0.x * s, a0.y * s, a1.x * s, a1.y * s);
-                    const bool y_vec = (F % 4 == 0) && (j0.ldy % 4 == 0) && (((uintptr_t)j0.Y & 15) == 0);
-                    if (y_vec) {
-                        if (f < F) store_f32x4(dst, o);
-                    } else {
-                        if (f + 0 < F) dst[0] = o.x;
-                        if (f + 1 < F) dst[1] = o.y;
-                        if (f + 2 < F) dst[2] = o.z;
-                        if (f + 3 < F) dst[3] = o.w;
+                acc0[k * Q_SU + i] = a0;
+                acc1[k * Q_SU + i] = a1;
+                if (blk + 1 == head.n_blocks) {
+                    const int row = j0.perm[slice * Q_ROWS + r];  // (padding slots / slices repeat rows: always a row)
+                    if (!no_store) {
+                        const float sc = j0.row_scale ? j0.row_scale[row] : 1.f;
+                        const int f = f0 + p * 4;
+                        const global_ptr<float> dst = j0.Y + static_cast<int64_t>(row) * j0.ldy + f;
+                        const float4 o = make_float4(a0.x * sc, a0.y * sc, a1.x * sc, a1.y * sc);
+                        const bool y_vec = (F % 4 == 0) && (j0.ldy % 4 == 0) && (((uintptr_t)j0.Y & 15) == 0);
+                        if (y_vec) {
+                            if (f < F) store_f32x4(dst, o);
+                        } else {
+                            if (f + 0 < F) dst[0] = o.x;
+                            if (f + 1 < F) dst[1] = o.y;
+                            if (f + 2 < F) dst[2] = o.z;
+                            if (f + 3 < F) dst[3] = o.w;
+                        }
                     }
                 }
             }
@@ -642,6 +837,7 @@ __global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
     const int n_local = subs * n_groups;
     bool first_phase = true;
+    Q_STAMP(0);
     for (int lw = wg; lw < n_local; lw += wgs_per_xcd) {
         const int seg = xcd * subs + lw / n_groups;
         const int f0 = (lw % n_groups) * 16;
@@ -658,12 +854,13 @@ __global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job
             }
         } else {
             const int n_segments = kXcds * subs;
-            const int n_units = (inline_job.n_rows + Q_ROWS - 1) / Q_ROWS;
+            const int n_units = (inline_job.n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
             if (MULTI) q_phase_multi<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
             else q_phase_single<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
             first_phase = false;
         }
     }
+    Q_STAMP(1);
 }
 
 int q_block_cols_for(int n_cols) {
@@ -732,16 +929,18 @@ bool quad_eligible_single(const wdg_spmm_job &j) {
 template <typename TIN>
 int quad_single(const wdg_spmm_job &j, hipStream_t st) {
     const int n_groups = static_cast<int>(ceil_div(j.n_feat, 16));
-    const int n_units = (j.n_rows + Q_ROWS - 1) / Q_ROWS;
+    const int n_units = (j.n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;  // super-units
     const int wgs_per_xcd = std::max(wdg_device_cus(), 8) / kXcds;
-    // segments per XCD: enough (segment, group) pairs to fill the XCD's workgroups about twice, at least 16 units each
+    // segments per XCD: enough (segment, group) pairs to fill the XCD's workgroups about twice, at least 8 super-units each
     int subs = static_cast<int>(ceil_div(2 * wgs_per_xcd, n_groups));
-    subs = std::max(1, std::min(subs, static_cast<int>(ceil_div(n_units, 16 * kXcds))));
-    if (j.q_n_blocks > 1) {  // a wave keeps <= Q_MAXU units across the column blocks
-        const int need = static_cast<int>(ceil_div(n_units, static_cast<int64_t>(Q_MAXU) * Q_WAVES * kXcds));
+    subs = std::max(1, std::min(subs, static_cast<int>(ceil_div(n_units, 8 * kXcds))));
+    if (j.q_n_blocks > 1) {  // a wave keeps <= Q_MAXU slices across the column blocks
+        const int need = static_cast<int>(ceil_div(n_units, static_cast<int64_t>(Q_MAXU / Q_SU) * Q_WAVES * kXcds));
         subs = std::max(subs, need);
     }
-    const bool y_vec = (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.n_feat % 4 == 0;
+    // 16-byte stores and 32-bit byte offsets into Y and into the index arrays (what the fast loop addresses with)
+    const bool y_vec = (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.n_feat % 4 == 0 &&
+                       static_cast<int64_t>(j.n_rows) * j.ldy < (1ll << 30);
     return q_launch<TIN>(nullptr, j, nullptr, nullptr, subs, j.n_cols, j.n_feat, j.val != nullptr, y_vec, st);
 }
 int quad_single_f32(const wdg_spmm_job &j, hipStream_t st) { return quad_single<float>(j, st); }
@@ -751,10 +950,16 @@ int quad_single_bf16(const wdg_spmm_job &j, hipStream_t st) { return quad_single
 
 extern "C" {
 
+#ifdef WDG_STAMPS
+int wdg_debug_q_stamps(unsigned long long *host_out, int n_blocks) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wdg_q_stamp_buf), sizeof(unsigned long long) * 8 * n_blocks) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int32_t wdg_sell16_block_cols(int32_t n_cols) { return q_block_cols_for(n_cols); }
 
 size_t wdg_sell16_workspace_bytes(int32_t N, int32_t n_cols) {
-    const int64_t tasks = ((static_cast<int64_t>(N) + Q_ROWS - 1) / Q_ROWS) * wdg::ceil_div(n_cols > 0 ? n_cols : 1, q_block_cols_for(n_cols));
+    const int64_t tasks = ((static_cast<int64_t>(N) + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU) * wdg::ceil_div(n_cols > 0 ? n_cols : 1, q_block_cols_for(n_cols));
     return wdg::exclusive_scan_ws_bytes(tasks + 1) + static_cast<size_t>(tasks + 2) * sizeof(int32_t) + 512;
 }
 
@@ -764,7 +969,7 @@ int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N
     if (!workspace || workspace_bytes < wdg_sell16_workspace_bytes(N, n_cols))
         return wdg::fail(WDG_ERR_WORKSPACE, "csr_to_sell16: workspace too small");
     hipStream_t st = wdg::as_stream(stream);
-    const int n_slices = (N + Q_ROWS - 1) / Q_ROWS;
+    const int n_slices = (N + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU;  // padded to whole super-units
     const int block_cols = q_block_cols_for(n_cols);
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
     const int64_t tasks = static_cast<int64_t>(n_slices) * n_blocks;
@@ -788,14 +993,14 @@ int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N
     }
     if (int e = wdg::exclusive_scan_i32(chunks, tasks, chunks, nullptr, scan_ws, st)) return e;
     hipLaunchKernelGGL(sell16_ext_begin, dim3(wdg::ceil_div(tasks + 1, 256)), dim3(256), 0, st, chunks,
-                       static_cast<int32_t>(tasks), q_ext);
+                       static_cast<int32_t>(tasks), n_slices, (N + Q_ROWS - 1) / Q_ROWS, q_ext);
     return wdg::check_launch("csr_to_sell16_count");
 }
 
 int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
                            const int32_t *q_perm, const int32_t *q_ext, int32_t *q_col, float *q_val, wdg_stream_t stream) {
     WDG_REQUIRE(N >= 0 && n_cols >= 0 && q_ext && (N == 0 || q_perm), "csr_to_sell16_fill: bad arguments");
-    const int n_slices = (N + Q_ROWS - 1) / Q_ROWS;
+    const int n_slices = (N + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU;  // padded to whole super-units
     const int block_cols = q_block_cols_for(n_cols);
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
     const int64_t tasks = static_cast<int64_t>(n_slices) * n_blocks;
@@ -816,7 +1021,8 @@ int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, cons
     if (wdg::ceil_div(max_cols > 0 ? max_cols : 1, q_block_cols_for(max_cols)) > Q_MAX_BLOCKS)
         return wdg::fail(WDG_ERR_UNSUPPORTED, "spmm_quad_batched: more than %d column blocks", Q_MAX_BLOCKS);
     return q_launch<float>(jobs_dev, wdg_spmm_job{}, items_dev, seg_ptr_dev, n_segments / wdg::kXcds, max_cols, max_feat,
-                           (flags & WDG_SPMM_ANY_VAL) != 0, (flags & WDG_SPMM_DMA_OK) != 0, wdg::as_stream(stream));
+                           (flags & WDG_SPMM_ANY_VAL) != 0, (flags & WDG_SPMM_DMA_OK) != 0 && (flags & WDG_SPMM_SMALL_OFFSETS) != 0,
+                           wdg::as_stream(stream));
 }
 
 }  // extern "C"

@@ -100,10 +100,11 @@ class CsrGraph:
             self.quad = False
             return False
         dev = self.device
-        n_slices = (self.n_rows + 15) // 16
+        n_su = (self.n_rows + 63) // 64   # super-units of 64 rows: what a wave of the kernel is dealt
+        n_slices = 4 * n_su               # 16-row slices, padded to whole super-units (ghost slices repeat the last real one)
         tasks = n_slices * n_blocks
         ext = torch.empty(2 * (tasks + 1), dtype=torch.int32, device=dev)
-        perm = torch.empty(n_slices * 16, dtype=torch.int32, device=dev)  # padding slots repeat the last row
+        perm = torch.empty(n_slices * 16, dtype=torch.int32, device=dev)  # padding slots / slices repeat the last row / slice
         ws_bytes = lib.wdg_sell16_workspace_bytes(self.n_rows, self.n_cols)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         check(lib.wdg_csr_to_sell16_count(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, _ptr(perm), _ptr(ext),
@@ -121,7 +122,7 @@ class CsrGraph:
               "wdg_csr_to_sell16_fill")
         widths = ext_host[:-1, 1].reshape(n_blocks, n_slices)  # per (block, slice): the cost model of SpmmBatch reads it
         self.quad = dict(ext=ext, col=q_col, val=q_val, perm=perm, block_cols=block_cols, n_blocks=n_blocks,
-                         n_slices=n_slices, widths=widths, chunks=chunks)
+                         n_slices=n_slices, n_su=n_su, widths=widths, chunks=chunks)
         return True
 
     @property
@@ -377,29 +378,44 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
     return y
 
 
+def _quad_unit_cost(widths):
+    """modelled cost of the super-units (4 slices = 64 rows each) of a graph from its slices' entries per row (summed over
+    column blocks): the sweep is LDS-bound in the entries; a narrow slice is bound by its store and the pipeline's fixed
+    work instead (WDG_QUAD_WMIN, default 8), plus a constant per slice (WDG_QUAD_ALPHA, default 4)"""
+    alpha = float(os.environ.get("WDG_QUAD_ALPHA", "4"))
+    wmin = float(os.environ.get("WDG_QUAD_WMIN", "8"))
+    per_slice = np.maximum(widths.sum(0).astype(np.float64), wmin) + alpha
+    return per_slice.reshape(-1, 4).sum(1)
+
+
 def _quad_segments(entries, order, n_feat, cus=256):
-    """Cut the tape of 16-row units of the jobs (in table order `order`) into 8 x S segments of equal modelled cost and
-    split every segment into phases (runs of jobs that aggregate the same X); -> (items [(first_job, n_jobs, unit_begin,
-    unit_end)], seg_ptr, n_segments).  Cost of a unit = its entries per row (all column blocks) + WDG_QUAD_ALPHA (the
-    store and the per-unit overhead, in entries; default 6)."""
-    alpha = float(os.environ.get("WDG_QUAD_ALPHA", "6"))
+    """Cut the tape of super-units (64 rows) of the jobs (in table order `order`) into 8 x S segments of equal modelled cost
+    and split every segment into items; -> (items [(first_job, n_jobs, unit_begin, unit_end)], seg_ptr, n_segments).
+
+    The tape is the concatenation of the PHASE GROUPS' super-units: a phase group is a run of consecutive jobs that aggregate
+    the same X (same X, ldx, n_cols, n_feat, col_scale); an item is a range of one phase group's super-units."""
     n_groups = (n_feat + 15) // 16
     per_xcd = max(cus // 8, 1)
-    costs, job_off, group_id = [], [0], []
-    keys = {}
-    multi = False
+    keys = []
     for i in order:
         g, x, _y, _rs, cs = entries[i][:5]
-        q = g.quad
-        costs.append(q["widths"].sum(0).astype(np.float64) + alpha)
-        job_off.append(job_off[-1] + q["n_slices"])
-        key = (x.data_ptr(), _ld(x), g.n_cols, x.shape[1], 0 if cs is None else cs.data_ptr())
-        group_id.append(keys.setdefault(key, len(keys)))
-        multi = multi or q["n_blocks"] > 1
-    n_units = job_off[-1]
+        keys.append((x.data_ptr(), _ld(x), g.n_cols, x.shape[1], 0 if cs is None else cs.data_ptr()))
+    groups, costs, multi = [], [], False  # groups: (first position in `order`, n_jobs, n_units)
+    pos = 0
+    while pos < len(order):
+        end = pos + 1
+        while end < len(order) and keys[end] == keys[pos]:
+            end += 1
+        qs = [entries[order[k]][0].quad for k in range(pos, end)]
+        multi = multi or any(q["n_blocks"] > 1 for q in qs)
+        seq = np.concatenate([_quad_unit_cost(q["widths"]) for q in qs])
+        groups.append((pos, end - pos, len(seq)))
+        costs.append(seq)
+        pos = end
+    n_units = sum(g[2] for g in groups)
     cum = np.concatenate([[0.0], np.cumsum(np.concatenate(costs))]) if costs else np.zeros(1)
     # segments per XCD: one (segment, feature group) pair per workgroup when there are fewer groups than workgroups per XCD,
-    # else the S in 1..4 that leaves the least idle tail; never more segments than 16-unit bundles
+    # else the S in 1..4 that leaves the least idle tail; never more segments than 8-super-unit bundles
     if n_groups >= per_xcd:
         subs = min(range(1, 5), key=lambda s_: (-(-s_ * n_groups // per_xcd) / (s_ * n_groups / per_xcd), s_))
     else:
@@ -407,27 +423,23 @@ def _quad_segments(entries, order, n_feat, cus=256):
     forced = os.environ.get("WDG_QUAD_SUBS")
     if forced:
         subs = int(forced)
-    subs = max(1, min(subs, max(1, n_units // (8 * 16))))
-    if multi:  # a wave keeps at most 8 units across the column blocks: phases of <= 128 units
-        subs = max(subs, -(-n_units // (8 * 128)))
+    subs = max(1, min(subs, max(1, n_units // (8 * 8))))
+    if multi:  # a wave keeps at most 2 super-units across the column blocks: items of <= 32 super-units
+        subs = max(subs, -(-n_units // (8 * 32)))
     n_seg = 8 * subs
     cuts = np.searchsorted(cum, cum[-1] * np.arange(1, n_seg) / n_seg, side="left")
-    cuts = np.concatenate([[0], np.clip(cuts, 0, n_units), [n_units]])
-    cuts = np.maximum.accumulate(cuts)
-    job_off_a = np.asarray(job_off)
+    cuts = np.maximum.accumulate(np.concatenate([[0], np.clip(cuts, 0, n_units), [n_units]]))
+    g_off = np.concatenate([[0], np.cumsum([g[2] for g in groups])]).astype(np.int64)
     items, seg_ptr = [], [0]
     for s_ in range(n_seg):
         a, b = int(cuts[s_]), int(cuts[s_ + 1])
         while a < b:
-            j0 = int(np.searchsorted(job_off_a, a, side="right") - 1)
-            j1 = j0
-            while j1 + 1 < len(order) and job_off[j1 + 1] < b and group_id[j1 + 1] == group_id[j0]:
-                j1 += 1
-            end = min(b, job_off[j1 + 1])
+            gi = int(np.searchsorted(g_off, a, side="right") - 1)
+            end = min(b, int(g_off[gi + 1]))
             if multi:
-                end = min(end, a + 128)
-                j1 = int(np.searchsorted(job_off_a, end - 1, side="right") - 1)
-            items.append((j0, j1 - j0 + 1, a - job_off[j0], end - job_off[j0]))
+                end = min(end, a + 32)
+            first, nj, _n = groups[gi]
+            items.append((first, nj, a - int(g_off[gi]), end - int(g_off[gi])))
             a = end
         seg_ptr.append(len(items))
     return items, seg_ptr, n_seg
@@ -488,6 +500,8 @@ class SpmmBatch:
         if self.run >= 2 and all_sell and dma_ok:
             self.flags |= (self.run & 0xff) << 8  # WDG_SPMM_SHARED_X(run)
         if self.quad:
+            if all(e[0].n_rows * _ld(e[2]) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 for e in entries):
+                self.flags |= SPMM_SMALL_OFFSETS
             items, seg_ptr, self.n_segments = _quad_segments(entries, order, self.max_feat, max(lib.wdg_device_cus(), 8))
             iarr = (SpmmItem * max(len(items), 1))()
             for it, (fj, nj, ub, ue) in zip(iarr, items):
@@ -522,7 +536,7 @@ class SpmmBatch:
                 5: f"spmm_quad_kernel<float,{val},{'true' if self.max_cols > 2528 else 'false'}>"}.get(fam, f"family {fam}")
 
 
-SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK = 1, 2, 4
+SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS = 1, 2, 4, 8
 GEMM_A_VEC4 = 1
 
 
