@@ -114,6 +114,8 @@ int wdg_unpack_bits_f32(const uint32_t *words, int64_t ldw, int32_t N, int32_t F
  * replaces: torch.spmm / torch.mm(adj, X) - utils/homophily_metrics.py:192,199,200,234,235,299,315;
  *           utils/homophily_plot.py:196,246,320,336.
  */
+#define WDG_SELL16_CONT (1 << 30) /* flag in the width word of a q_ext pair */
+#define WDG_SELL16_SPLIT 1        /* wdg_spmm_job.q_flags */
 typedef struct wdg_spmm_job {
     const int32_t *rowptr;
     const int32_t *col;
@@ -135,18 +137,23 @@ typedef struct wdg_spmm_job {
     const int32_t *sell_perm; /* [n_rows] SELL slot -> row (rows sorted by length, longest first); NULL = identity */
     /* optional SELL-16 copy of the same pattern (wdg_csr_to_sell16_*): enables the quad-row kernel (a quad of lanes per
        row, 16-row slices; graphs of up to 4 column blocks of 2528 columns); NULL = none */
-    const int32_t *q_ext;  /* [q_n_blocks * S + 1] pairs {first chunk, width} per (block, slice), block-major, S = 4 ceil(n_rows/64)
-                              slices (the slices that pad the last super-unit repeat the last real slice); the trailing
-                              pair = {chunk count, 0} */
+    const int32_t *q_ext;  /* [q_n_blocks * q_n_entries + 1] pairs {first chunk, width | flags} per (block, entry), block-major;
+                              an ENTRY is what a wave sweeps and stores in one go: a slice, or - split form - one of the
+                              <= 32-entries-per-row pieces of a slice (WDG_SELL16_CONT: the piece continues the slice of
+                              the entry before it; CONT with width 0: a ghost that pads a super-unit of four entries);
+                              the trailing pair = {chunk count, q_n_entries | WDG_SELL16_CONT if split}                  */
     const int32_t *q_col;  /* chunk c = 256 ints: entry e (0..15) of slice row r at q_col[256 c + 16 r + e], value = 64 x
                               (column - block * q_block_cols) = byte offset of the source row in the staged slab block;
-                              padding = 64 x q_block_cols (an all-zero row the kernel appends)                           */
+                              padding = 64 x q_block_cols (an all-zero row the kernel appends); a slice's chunks are
+                              consecutive (a split entry covers two of them)                                             */
     const float *q_val;    /* same layout, needed when `val` is given (padding 0)                                        */
-    const int32_t *q_perm; /* [64 ceil(n_rows/64)] slot -> row (rows by length, longest first; the slots that pad the last slice
-                              repeat the last row, the slices that pad the last super-unit repeat the last slice: they
-                              store those rows' sums a second time)                                                      */
+    const int32_t *q_perm; /* [16 ceil(n_rows/16)] slot -> row (rows by length, longest first; the slots that pad the last
+                              slice repeat the last row: they store that row's sums a second time)                       */
+    const int32_t *q_rows; /* [16 q_n_entries] the destination rows of every entry (q_perm expanded per entry)            */
     int32_t q_block_cols;  /* columns per block = wdg_sell16_block_cols(n_cols)                                          */
     int32_t q_n_blocks;    /* ceil(n_cols / q_block_cols), 1 .. 4                                                        */
+    int32_t q_n_entries;   /* entries per column block, a multiple of 4 (four entries = a super-unit = what a wave is dealt) */
+    int32_t q_flags;       /* WDG_SELL16_SPLIT: split form (one column block, every entry <= 32 entries per row)           */
 } wdg_spmm_job;
 
 int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream);
@@ -163,8 +170,9 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
 #define WDG_SPMM_DMA_OK 4   /* every job: X and Y 16-byte aligned, ldx, ldy and n_feat multiples of 4, col_scale NULL:
                                X rows may be staged by LDS-DMA; with WDG_SPMM_PIPELINED=1 in the environment such
                                batches run the pipelined row-lane kernel (family 3), an opt-in schedule */
-#define WDG_SPMM_SMALL_OFFSETS 8 /* every job: n_rows x ldy < 2^30 elements and fewer than 2^22 index chunks (byte offsets into Y and
-                                   into q_col / q_val fit 32 bits): with WDG_SPMM_DMA_OK the quad-row kernel's pipelined loop */
+#define WDG_SPMM_SMALL_OFFSETS 8 /* every job: n_rows x ldy < 2^30 elements, fewer than 2^22 index chunks (byte offsets into Y and
+                                   into q_col / q_val fit 32 bits) and a SELL-16 copy in split form (WDG_SELL16_SPLIT): with
+                                   WDG_SPMM_DMA_OK the quad-row kernel's pipelined loop */
 #define WDG_SPMM_SHARED_X(r) (((r) & 0xff) << 8) /* every aligned group of r (2..255) consecutive jobs of the table has the
                                same X, ldx, n_cols and n_feat (the h-levels of one seed): with WDG_SPMM_ALL_SELL |
                                WDG_SPMM_DMA_OK, <= 2032 columns and <= 2048 rows the shared-X row-lane kernel (family 4)
@@ -205,21 +213,26 @@ int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float 
  * 16-feature slab of X occupies in LDS), entries in chunks of 16 per row.  Inside a (row, block) segment the entries are
  * stored in a bank-aware order (the four rows an LDS service group reads together get columns of different classes mod 4
  * wherever the rows allow it), which fixes the order of the row's sum; WDG_SELL_ORDER=0 in the environment of the fill
- * call keeps column order (the sequential CSR order).  Two calls: count fills q_perm (64 ceil(N/64) entries) and q_ext
- * (read the trailing pair's chunk count back to size q_col / q_val: 256 entries per chunk, PLUS two chunks of slack that
- * the kernel may read but never uses), then fill.  One-time per graph.
+ * call keeps column order (the sequential CSR order).  The slices are then laid out as ENTRIES, four per super-unit (see
+ * wdg_spmm_job.q_ext): graphs with one column block and at most 128 entries per row and block in split form.
+ * Two calls: count fills q_perm (16 ceil(N/16) entries), q_ext and q_rows - sized for M = wdg_sell16_max_entries(N) entries per
+ * block: q_ext 2 (n_blocks M + 1) ints, q_rows 16 M ints; the pair {chunk count, entries per block | WDG_SELL16_CONT if
+ * split} is stored behind the entries AND at pair index n_blocks M, where the caller reads it back to size q_col / q_val:
+ * 256 entries per chunk PLUS two chunks of slack that the kernel may read but never uses; then fill.  One-time per graph.
  */
 int32_t wdg_sell16_block_cols(int32_t n_cols);
+int64_t wdg_sell16_max_entries(int32_t N);
 size_t wdg_sell16_workspace_bytes(int32_t N, int32_t n_cols);
 int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *q_perm,
-                            int32_t *q_ext, void *workspace, size_t workspace_bytes, wdg_stream_t stream);
+                            int32_t *q_ext, int32_t *q_rows, void *workspace, size_t workspace_bytes, wdg_stream_t stream);
 int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
-                           const int32_t *q_perm, const int32_t *q_ext, int32_t *q_col, float *q_val, wdg_stream_t stream);
+                           const int32_t *q_rows, const int32_t *q_ext, int32_t n_entries, int32_t *q_col, float *q_val,
+                           wdg_stream_t stream);
 
 /*
  * The batched aggregation on the quad-row kernel (every job carries its SELL-16 copy).  The caller lays the jobs'
- * super-units (64 rows = four 16-row slices: what a wave is dealt) out as one tape (jobs in table order, job j contributes
- * ceil(n_rows_j / 64) of them) and cuts it into n_segments
+ * super-units (four entries of the SELL-16 copy: what a wave is dealt) out as one tape (jobs in table order, job j
+ * contributes q_n_entries_j / 4 of them) and cuts it into n_segments
  * (a multiple of 8) segments of about equal cost; segment s consists of the phases items[seg_ptr[s] .. seg_ptr[s + 1]):
  * a phase is a run of consecutive jobs that aggregate the SAME X (same X, ldx, n_cols, n_feat, col_scale) and the unit
  * range [unit_begin, unit_end) of their concatenated units it covers.  XCD x of the chip processes segments

@@ -555,16 +555,37 @@ def _skewed_graph(rng, n, e):
     return src.astype(np.int64), rng.integers(0, n, e).astype(np.int64)
 
 
+CONT = 1 << 30
+
+
+def _expected_entries(widths_blk0, n_blocks):
+    """the packing rule of sell16_pack: (slice, piece k | -1 for a ghost) per entry, and whether the graph is split"""
+    split = n_blocks == 1 and (len(widths_blk0) == 0 or max(widths_blk0) <= 128)
+    ent = []
+    for s_, w in enumerate(widths_blk0):
+        n = max(1, -(-int(w) // 32)) if split else 1
+        if len(ent) % 4 + n > 4:
+            while len(ent) % 4:
+                ent.append((s_ - 1, -1))
+        ent.extend((s_, k) for k in range(n))
+    while len(ent) % 4:
+        ent.append((len(widths_blk0) - 1, -1))
+    return ent, split
+
+
 @pytest.mark.parametrize("column_order", [False, True])
 def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
     """wdg_csr_to_sell16_*: rows by length (ties by id), slices of 16, column blocks of <= 2528, chunks of 16 entries per
     row; every (row, block) segment holds exactly the row's entries of that block as pre-scaled local offsets - in column
-    order with WDG_SELL_ORDER=0, in the bank-aware order otherwise - and pads with the zero row's offset / value 0."""
+    order with WDG_SELL_ORDER=0, in the bank-aware order otherwise - and pads with the zero row's offset / value 0; the
+    slices are laid out as entries, four per super-unit: split into pieces of <= 32 entries per row (CONT) when the graph
+    has one column block and no slice wider than 128, ghosts filling up super-units."""
     if column_order:
         monkeypatch.setenv("WDG_SELL_ORDER", "0")
     rng = np.random.default_rng(32)
     for n, m, e, skew in ((1, 1, 1, False), (16, 16, 100, False), (17, 40, 300, False), (2000, 2000, 60000, False),
-                          (130, 130, 0, False), (5201, 5201, 50000, True), (3000, 2529, 9000, False), (700, 9000, 20000, True)):
+                          (130, 130, 0, False), (5201, 5201, 50000, True), (3000, 2529, 9000, False), (700, 9000, 20000, True),
+                          (2000, 2000, 90000, True), (300, 2000, 30000, False)):
         src, dst = _skewed_graph(rng, n, e) if skew else _rand_graph(rng, n, e)
         dst = dst % m
         key = np.unique(src * m + dst)
@@ -576,37 +597,60 @@ def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
             assert col.shape[0] == 0
             continue
         q = g.quad
-        bc, nb, ns = q["block_cols"], q["n_blocks"], q["n_slices"]
-        real = (n + 15) // 16  # ns = the slices padded to whole super-units of four
-        assert bc % 4 == 0 and bc <= 2528 and nb == (m + bc - 1) // bc and ns == (n + 63) // 64 * 4
+        bc, nb, ne = q["block_cols"], q["n_blocks"], q["n_entries"]
+        real = (n + 15) // 16
+        assert bc % 4 == 0 and bc <= 2528 and nb == (m + bc - 1) // bc and ne % 4 == 0
         lens = np.diff(rowptr)
         perm_all = _np(q["perm"])
         perm = perm_all[:n]
         np.testing.assert_array_equal(perm, np.argsort(-lens, kind="stable"))
-        assert perm_all.shape[0] == ns * 16 and (perm_all[n:real * 16] == perm[-1]).all()  # padding slots repeat the last row
-        for gs in range(real, ns):  # ghost slices repeat the last real slice
-            np.testing.assert_array_equal(perm_all[gs * 16:gs * 16 + 16], perm_all[(real - 1) * 16:real * 16])
+        assert perm_all.shape[0] == real * 16 and (perm_all[n:] == perm[-1]).all()  # padding slots repeat the last row
         ext = _np(q["ext"]).reshape(-1, 2)
+        qrows = _np(q["rows"]).reshape(ne, 16)
         qc, qv = _np(q["col"]), _np(q["val"])
+        # per (block, slice): width and the slice's rows
+        rows_of = [perm_all[s_ * 16:s_ * 16 + 16] for s_ in range(real)]
+        width = np.zeros((nb, real), int)
+        for b in range(nb):
+            for s_ in range(real):
+                for r in rows_of[s_]:
+                    cr = col[rowptr[r]:rowptr[r + 1]]
+                    width[b, s_] = max(width[b, s_], int(((cr >= b * bc) & (cr < (b + 1) * bc)).sum()))
+        ent, split = _expected_entries(width[0], nb)
+        assert len(ent) == ne and q["split"] == split
         chunk = 0
         for b in range(nb):
-            for sl in range(ns):
-                c0, width = ext[b * ns + sl]
-                if sl >= real:  # a ghost slice: the last real slice's extent
-                    assert tuple(ext[b * ns + sl]) == tuple(ext[b * ns + real - 1])
-                    continue
-                assert c0 == chunk
-                rws = perm[sl * 16:min(n, sl * 16 + 16)]
-                n_chunks = (width + 15) // 16
+            first_chunk = {}
+            for s_ in range(real):
+                first_chunk[s_] = chunk
+                chunk += -(-width[b, s_] // 16)
+            for e_i, (s_, k) in enumerate(ent):
+                c0, word = ext[b * ne + e_i]
+                np.testing.assert_array_equal(qrows[e_i], rows_of[s_])
+                if k < 0:
+                    assert word == CONT and c0 == first_chunk[s_]
+                elif split:
+                    w = min(32, width[b, s_] - 32 * k) if width[b, s_] else 0
+                    assert c0 == first_chunk[s_] + 2 * k and word == (w | (CONT if k else 0)), (n, m, e_i, c0, word, w)
+                else:
+                    assert c0 == first_chunk[s_] and word == width[b, s_]
+            # the chunks of every slice: the rows' entries of this block
+            for s_ in range(real):
+                n_chunks = -(-width[b, s_] // 16)
+                c0 = first_chunk[s_]
                 blk_c = qc[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)
                 blk_v = qv[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)
-                longest = 0
-                for r16, r in enumerate(rws):
+                seen_first = {}
+                for r16, r in enumerate(rows_of[s_]):
                     cr, vr = col[rowptr[r]:rowptr[r + 1]], val[rowptr[r]:rowptr[r + 1]]
                     sel = (cr >= b * bc) & (cr < (b + 1) * bc)
                     l = int(sel.sum())
-                    longest = max(longest, l)
                     want_off = (cr[sel] - b * bc) * 64
+                    if int(r) in seen_first:  # a padding slot: the last row's entries in the last row's order
+                        np.testing.assert_array_equal(blk_c[r16], blk_c[seen_first[int(r)]])
+                        np.testing.assert_array_equal(blk_v[r16], blk_v[seen_first[int(r)]])
+                        continue
+                    seen_first[int(r)] = r16
                     if column_order:
                         np.testing.assert_array_equal(blk_c[r16, :l], want_off)
                         np.testing.assert_array_equal(blk_v[r16, :l], vr[sel])
@@ -615,12 +659,7 @@ def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
                         np.testing.assert_array_equal(blk_c[r16, :l][o], want_off)
                         np.testing.assert_array_equal(blk_v[r16, :l][o], vr[sel])
                     assert (blk_c[r16, l:] == bc * 64).all() and (blk_v[r16, l:] == 0).all()
-                assert width == longest
-                for r16 in range(rws.size, 16):  # padding slots: the last row's entries in the last row's order
-                    np.testing.assert_array_equal(blk_c[r16], blk_c[rws.size - 1])
-                    np.testing.assert_array_equal(blk_v[r16], blk_v[rws.size - 1])
-                chunk += n_chunks
-        assert tuple(ext[-1]) == (chunk, 0) and q["chunks"] == chunk
+        assert tuple(ext[nb * ne]) == (chunk, ne | (CONT if split else 0)) and q["chunks"] == chunk
 
 
 def test_sell16_bank_aware_order_reduces_conflicts(ops, oracle):
@@ -633,8 +672,11 @@ def test_sell16_bank_aware_order_reduces_conflicts(ops, oracle):
     q = g.quad
     ext, qc = _np(q["ext"]).reshape(-1, 2), _np(q["col"])
     cycles, steps = 0, 0
-    for sl in range(125):
+    for sl in range(q["n_entries"]):
         c0, width = ext[sl]
+        if width & CONT:  # (h = 0.3, k = 10: 34 entries per row - every slice is two entries; take whole slices)
+            continue
+        width = 34
         n_chunks = (width + 15) // 16
         blk = qc[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)[:, :width]
         cls = (blk // 64) & 3

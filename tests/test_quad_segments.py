@@ -25,7 +25,8 @@ class _G:
         """widths: [n_blocks, padded slices] (a multiple of 4 slices = whole super-units)"""
         assert widths.shape[1] % 4 == 0
         self.n_rows, self.n_cols = n_rows, n_cols
-        self.quad = dict(widths=widths, n_slices=widths.shape[1], n_su=widths.shape[1] // 4, n_blocks=widths.shape[0])
+        self.quad = dict(widths=widths, n_slices=widths.shape[1], n_entries=widths.shape[1], n_su=widths.shape[1] // 4,
+                         n_blocks=widths.shape[0])
 
 
 def _units_of(entries, order, item):
@@ -74,10 +75,9 @@ def test_segments_cover_every_unit_once(n_feat):
         c = 0.0
         for item in items[seg_ptr[s]:seg_ptr[s + 1]]:
             for pos, su in _units_of(entries, order, item):
-                w = entries[order[pos]][0].quad["widths"][:, 4 * su:4 * su + 4].sum(0)
-                c += (np.maximum(w, 8) + 4).sum()
+                c += ops._quad_unit_cost(entries[order[pos]][0].quad["widths"][:, 4 * su:4 * su + 4])[0]
         costs.append(c)
-    assert max(costs) <= 1.03 * np.mean(costs) + 4 * 80
+    assert max(costs) <= 1.03 * np.mean(costs) + 4 * 3800
 
 
 def test_segments_ragged_and_multiblock():

@@ -29,8 +29,8 @@ class SpmmJob(ctypes.Structure):
                 ("n_rows", c_int32), ("n_cols", c_int32), ("n_feat", c_int32), ("reserved", c_int32),
                 ("sell_ptr", c_void_p), ("sell_col", c_void_p), ("sell_val", c_void_p),
                 ("sell_block_cols", c_int32), ("sell_n_blocks", c_int32), ("sell_perm", c_void_p),
-                ("q_ext", c_void_p), ("q_col", c_void_p), ("q_val", c_void_p), ("q_perm", c_void_p),
-                ("q_block_cols", c_int32), ("q_n_blocks", c_int32)]
+                ("q_ext", c_void_p), ("q_col", c_void_p), ("q_val", c_void_p), ("q_perm", c_void_p), ("q_rows", c_void_p),
+                ("q_block_cols", c_int32), ("q_n_blocks", c_int32), ("q_n_entries", c_int32), ("q_flags", c_int32)]
 
 
 class SpmmItem(ctypes.Structure):
@@ -76,9 +76,10 @@ SIGNATURES = {
                                      c_void_p, c_void_p]),
     "wdg_sell16_block_cols": (c_int32, [c_int32]),
     "wdg_sell16_workspace_bytes": (c_size_t, [c_int32, c_int32]),
-    "wdg_csr_to_sell16_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
+    "wdg_sell16_max_entries": (c_int64, [c_int32]),
+    "wdg_csr_to_sell16_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                         c_void_p]),
-    "wdg_csr_to_sell16_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+    "wdg_csr_to_sell16_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                        c_void_p, c_void_p]),
     "wdg_spmm_quad_batched_f32": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int,
                                           c_void_p]),

@@ -87,13 +87,9 @@ constexpr int Q_SORT_MAX_ROWS = 16384;
 __global__ __launch_bounds__(1024) void sell16_sort_rows(const int32_t *__restrict__ rowptr, int32_t N,
                                                          int32_t *__restrict__ perm) {
     extern __shared__ unsigned long long q_keys[];
-    const int n_slices = (N + Q_ROWS - 1) / Q_ROWS;
-    const int padded = n_slices * Q_ROWS, padded_su = (N + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU_ROWS;
+    const int padded = (N + Q_ROWS - 1) / Q_ROWS * Q_ROWS;
     if (N > Q_SORT_MAX_ROWS) {
-        for (int i = threadIdx.x; i < padded_su; i += 1024) {
-            const int k = i < padded ? i : (n_slices - 1) * Q_ROWS + (i % Q_ROWS);
-            perm[i] = min(k, N - 1);
-        }
+        for (int i = threadIdx.x; i < padded; i += 1024) perm[i] = min(i, N - 1);
         return;
     }
     for (int i = threadIdx.x; i < N; i += 1024)
@@ -126,29 +122,20 @@ __global__ __launch_bounds__(1024) void sell16_sort_rows(const int32_t *__restri
     }
     for (int i = threadIdx.x; i < N; i += 1024) perm[i] = static_cast<int32_t>(q_keys[i] & 0xffffffffull);
     __syncthreads();
-    // the slots that pad the last slice repeat the last (shortest) row, the slices that pad the last super-unit repeat the
-    // last slice: they compute and store those rows' sums again (same bits to the same address), so the kernel's stores
-    // need no "is this slot a row" predicate
-    if (N > 0) {
+    // the slots that pad the last slice repeat the last (shortest) row: they compute and store that row's sums again (same
+    // bits to the same address), so the kernel's stores need no "is this slot a row" predicate
+    if (N > 0)
         for (int i = N + threadIdx.x; i < padded; i += 1024) perm[i] = static_cast<int32_t>(q_keys[N - 1] & 0xffffffffull);
-        for (int i = padded + threadIdx.x; i < padded_su; i += 1024) {
-            const int k = (n_slices - 1) * Q_ROWS + (i % Q_ROWS);
-            perm[i] = static_cast<int32_t>(q_keys[min(k, N - 1)] & 0xffffffffull);
-        }
-    }
 }
 
-// one thread per (column block, slice): width = longest in-block row segment, chunks = ceil(width / 16)
+// one thread per (column block, REAL slice): width = longest in-block row segment, chunks = ceil(width / 16)
 __global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                      const int32_t *__restrict__ perm, int32_t N, int32_t n_slices,
                                                      int32_t n_blocks, int32_t block_cols, int32_t *__restrict__ chunks,
-                                                     int32_t *__restrict__ ext) {
-    // (n_slices here = the PADDED slice count, a multiple of Q_SU; a ghost slice repeats the last real one and owns no chunks)
+                                                     int32_t *__restrict__ widths) {
     const int task = blockIdx.x * 256 + threadIdx.x;
     if (task >= n_slices * n_blocks) return;
-    const int real_slices = (N + Q_ROWS - 1) / Q_ROWS;
-    const int blk = task / n_slices, slice = min(task % n_slices, real_slices - 1);
-    const bool ghost = task % n_slices >= real_slices;
+    const int blk = task / n_slices, slice = task % n_slices;
     int width = 0;
     for (int r = 0; r < Q_ROWS; ++r) {
         const int slot = slice * Q_ROWS + r;
@@ -159,52 +146,114 @@ __global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__
         const int b = (blk + 1 == n_blocks) ? e : q_lower_bound(col, a, e, (blk + 1) * block_cols);
         width = max(width, b - a);
     }
-    chunks[task] = ghost ? 0 : (width + Q_CHUNK - 1) / Q_CHUNK;
-    ext[2 * task + 1] = width;
+    chunks[task] = (width + Q_CHUNK - 1) / Q_CHUNK;
+    widths[task] = width;
 }
 
-__global__ __launch_bounds__(256) void sell16_ext_begin(const int32_t *__restrict__ chunk_begin, int32_t n_tasks,
-                                                        int32_t n_slices, int32_t real_slices, int32_t *__restrict__ ext) {
-    const int task = blockIdx.x * 256 + threadIdx.x;
-    if (task < n_tasks) {  // a ghost slice starts where the last real slice of its block starts
-        const int slice = task % n_slices;
-        ext[2 * task] = chunk_begin[slice < real_slices ? task : task - slice + real_slices - 1];
+// The ENTRIES the kernel's waves work through, four per super-unit.  A graph with one column block whose slices hold at most
+// 128 entries per row is laid out in SPLIT form: a slice of more than 32 entries per row becomes 2 .. 4 consecutive entries
+// of <= 32 (two index chunks: what the kernel's pipeline requests ahead), the later ones flagged CONT - the wave keeps the
+// slice's accumulators and stores the running sums after each entry, the last store carrying the final ones.  A slice's
+// entries never straddle a super-unit: the super-unit is filled up with GHOST entries (CONT, width 0, the rows of the slice
+// before: they store its sums once more).  Other graphs: one entry per slice, ghosts pad the last super-unit.
+// One thread: the walk is sequential and a graph has a few hundred slices.
+constexpr int Q_CONT = 1 << 30;
+constexpr int Q_SPLIT_WIDTH = 2 * Q_CHUNK;  // entries per row of a split entry
+__global__ void sell16_pack(const int32_t *__restrict__ widths, int32_t n_slices, int32_t n_blocks,
+                            int32_t *__restrict__ entry_slice, int32_t *__restrict__ entry_k, int32_t *__restrict__ info) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int wmax = 0;
+    for (int i = 0; i < n_slices * n_blocks; ++i) wmax = max(wmax, widths[i]);
+    const bool split = n_blocks == 1 && wmax <= Q_SU * Q_SPLIT_WIDTH;
+    int cur = 0;
+    for (int s = 0; s < n_slices; ++s) {
+        const int n = split ? max(1, (widths[s] + Q_SPLIT_WIDTH - 1) / Q_SPLIT_WIDTH) : 1;
+        if ((cur & (Q_SU - 1)) + n > Q_SU)
+            while (cur & (Q_SU - 1)) {
+                entry_slice[cur] = s - 1;
+                entry_k[cur++] = -1;
+            }
+        for (int k = 0; k < n; ++k) {
+            entry_slice[cur] = s;
+            entry_k[cur++] = k;
+        }
     }
-    if (task == n_tasks) {  // the trailing pair: {total chunks, 0}
-        ext[2 * task] = chunk_begin[task];
-        ext[2 * task + 1] = 0;
+    while (cur & (Q_SU - 1)) {
+        entry_slice[cur] = n_slices - 1;
+        entry_k[cur++] = -1;
     }
+    info[0] = cur;            // entries per column block (a multiple of 4)
+    info[1] = split ? 1 : 0;  // every entry <= 32 wide: the kernel's pipelined loop applies
 }
 
-// One wave per (column block, slice); lane r < 16 orders row r's segment.  Bank-aware order (reorder != 0): the sweep
-// reads, for entry e of all 16 rows, the 64-byte LDS row of each row's column; the four rows of a service group collide
-// when their columns agree mod 4 (64-byte rows: a row's bank window is 16 (column mod 4) .. + 15).  The order of a row's
-// entries inside a block is free, so the rows of a group choose step by step, in rank order, a remaining entry whose
+// q_ext / q_rows from the packed entries; the trailing pair of q_ext = {total chunks, entries per block | split << 30}
+__global__ __launch_bounds__(256) void sell16_entries(const int32_t *__restrict__ widths, const int32_t *__restrict__ chunk_begin,
+                                                      const int32_t *__restrict__ entry_slice, const int32_t *__restrict__ entry_k,
+                                                      const int32_t *__restrict__ info, const int32_t *__restrict__ perm,
+                                                      int32_t n_slices, int32_t n_blocks, int32_t max_entries,
+                                                      int32_t *__restrict__ ext, int32_t *__restrict__ rows) {
+    const int n_entries = info[0], split = info[1];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) {  // {chunk count, entries per block | split}: behind the entries, and at the end of the caller's buffer
+        ext[2 * n_blocks * n_entries] = ext[2 * n_blocks * max_entries] = chunk_begin[n_slices * n_blocks];
+        ext[2 * n_blocks * n_entries + 1] = ext[2 * n_blocks * max_entries + 1] = n_entries | (split ? Q_CONT : 0);
+    }
+    if (t < n_blocks * n_entries) {
+        const int blk = t / n_entries, e = t % n_entries;
+        const int s = entry_slice[e], k = entry_k[e];
+        const int w = widths[blk * n_slices + s], c0 = chunk_begin[blk * n_slices + s];
+        int chunk, width;
+        if (k < 0) {  // ghost
+            chunk = c0;
+            width = Q_CONT;
+        } else if (split) {
+            chunk = c0 + 2 * k;
+            width = min(Q_SPLIT_WIDTH, w - Q_SPLIT_WIDTH * k) | (k > 0 ? Q_CONT : 0);
+            if (w == 0) width = 0;
+        } else {
+            chunk = c0;
+            width = w;
+        }
+        ext[2 * t] = chunk;
+        ext[2 * t + 1] = width;
+    }
+    if (t < n_entries * Q_ROWS) rows[t] = perm[entry_slice[t / Q_ROWS] * Q_ROWS + t % Q_ROWS];
+}
+
+// One wave per (column block, entry that starts a slice); lane r < 16 orders row r's segment.  Bank-aware order (reorder != 0):
+// the sweep reads, for entry e of all 16 rows, the 64-byte LDS row of each row's column; the four rows of a service group
+// collide when their columns agree mod 4 (64-byte rows: a row's bank window is 16 (column mod 4) .. + 15).  The order of a
+// row's entries inside a block is free, so the rows of a group choose step by step, in rank order, a remaining entry whose
 // class is not taken yet in this step (the class they hold most of first; the first remaining entry of that class).
 __global__ __launch_bounds__(256) void sell16_fill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                   const float *__restrict__ val, const int32_t *__restrict__ perm,
-                                                   int32_t N, int32_t n_slices, int32_t n_blocks, int32_t block_cols,
+                                                   const float *__restrict__ val, const int32_t *__restrict__ rows,
+                                                   int32_t n_entries, int32_t n_blocks, int32_t block_cols,
                                                    const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
                                                    float *__restrict__ q_val, int reorder) {
     const int task = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (task >= n_slices * n_blocks) return;  // (whole waves: a task is a wave; n_slices = the padded count)
-    const int blk = task / n_slices, slice = task % n_slices;
-    if (slice >= (N + Q_ROWS - 1) / Q_ROWS) return;  // a ghost slice reads the last real slice's chunks
-    const int chunk0 = ext[2 * task], width = ext[2 * task + 1];
-    const int n_chunks = (width + Q_CHUNK - 1) / Q_CHUNK;
+    if (task >= n_entries * n_blocks) return;  // (whole waves: a task is a wave)
+    const int blk = task / n_entries, entry = task % n_entries;
+    if (ext[2 * task + 1] & Q_CONT) return;  // a continuation / ghost entry: its slice's first entry fills the chunks
+    const int chunk0 = ext[2 * task];
     const int r = lane & 15;
     const bool worker = lane < 16;
-    const int slot = slice * Q_ROWS + r;  // (perm has ceil(N / 16) * 16 entries: padding slots repeat the last row)
-    const bool ghost = slot >= N;         // a padding slot: it must repeat the last row's entries in the SAME order
-    const int last_lane = (N - 1) & 15;   // (only the last slice has ghosts: the lane of slot N - 1)
-    const int row = worker ? perm[slot] : -1;
+    const int row = rows[entry * Q_ROWS + r];
+    // the slots that pad a graph's last slice repeat its last row: they must hold that row's entries in the SAME order
+    const int row_prev = __shfl(row, (lane & 48) + max(r - 1, 0));
+    const bool ghost = r > 0 && row == row_prev;
+    const unsigned long long first_mask = __ballot(worker && row == __shfl(row, 15) && !ghost);
+    const int last_lane = first_mask ? __ffsll(static_cast<long long>(first_mask)) - 1 : 15;
     int a = 0, len = 0;
-    if (row >= 0) {
+    {
         const int s = rowptr[row], e = rowptr[row + 1];
         a = n_blocks == 1 ? s : q_lower_bound(col, s, e, blk * block_cols);
         const int b = (blk + 1 == n_blocks) ? e : q_lower_bound(col, a, e, (blk + 1) * block_cols);
         len = b - a;
     }
+    int width = worker ? len : 0;
+    for (int o = 8; o > 0; o >>= 1) width = max(width, __shfl_xor(width, o));
+    width = __shfl(width, 0);
+    const int n_chunks = (width + Q_CHUNK - 1) / Q_CHUNK;
     const int col0 = blk * block_cols;
     const int zero_off = block_cols * 64;  // the all-zero row behind the block's rows
     // service groups of ds_read_b128 in quads (= rows): {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}
@@ -263,7 +312,7 @@ struct QJob {
     global_ptr<const float> val, row_scale;
     global_ptr<float> Y;
     int64_t ldy;
-    int32_t n_rows, n_su;  // n_su = super-units (64 rows; the ext / perm arrays are padded to whole super-units)
+    int32_t n_rows, n_su;  // n_su = super-units = q_n_entries / 4
 };
 struct QHead {  // what a phase needs of its first job (the jobs of a phase agree in these)
     global_ptr<const void> X;
@@ -279,11 +328,11 @@ __device__ __forceinline__ q_desc_ptr q_desc(const wdg_spmm_job *jobs, const wdg
 __device__ __forceinline__ QJob q_load_job(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int id) {
     const q_desc_ptr j = q_desc(jobs, inl, id);
     QJob v;
-    v.ext = to_global(j->q_ext); v.col = to_global(j->q_col); v.perm = to_global(j->q_perm);
+    v.ext = to_global(j->q_ext); v.col = to_global(j->q_col); v.perm = to_global(j->q_rows);
     v.val = to_global(j->q_val); v.row_scale = to_global(j->row_scale); v.Y = to_global(j->Y);
     v.ldy = j->ldy;
     v.n_rows = j->n_rows;
-    v.n_su = (j->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+    v.n_su = j->q_n_entries / Q_SU;
     return v;
 }
 __device__ __forceinline__ QHead q_load_head(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int id, bool y_vec) {
@@ -452,21 +501,19 @@ struct QJobE {  // what stage E needs of a job (SGPRs; re-read from the table wh
     int n_su;
 };
 struct QJobI {
-    global_ptr<const int32_t> col, scale_or_perm, val_or_col;
-    bool has_scale, has_val;
+    global_ptr<const int32_t> col, scale_or_perm;
+    bool has_scale;
 };
 struct QJobC {
-    global_ptr<const int32_t> col, val;
     global_ptr<float> Y;
     unsigned ldy4;  // bytes per row of Y
-    bool has_val;
 };
 
-template <bool HAS_VAL>
 __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                              int unit_begin, int unit_end, int stride, int f0, lds_cptr slab, bool no_sweep,
                                              bool no_store, int wave, int lane) {
-    constexpr int NPRE = HAS_VAL ? 1 : 2;  // index chunks per slice requested one super-unit ahead
+    constexpr int NPRE = 2;        // index chunks per entry (all of them), requested one super-unit ahead
+    constexpr bool HAS_VAL = false;  // (explicit values run the plain loop)
     const int r = lane >> 2, p = lane & 3;
     const int loff = p * 16;
     const unsigned lane16 = lane * 16, lane4 = lane * 4, ext_lane = (lane < Q_SU ? lane : Q_SU - 1) * 8;
@@ -477,13 +524,13 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
     // ---- the super-unit iterator over the phase's concatenated jobs: (it_j, it_su) = job / super-unit of unit it_u;
     //      (req_j, req_su) = what is actually requested: the iterator's while it_u is a unit, then the wave's last unit
     int it_u = unit_begin + wave * stride, it_j = first_job, it_su;
-    int it_nsu = (q_desc(jobs, inl, it_j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+    int it_nsu = q_desc(jobs, inl, it_j)->q_n_entries / Q_SU;
     {
         int rest = it_u;
         while (rest >= it_nsu && it_j < last_job) {
             rest -= it_nsu;
             ++it_j;
-            it_nsu = (q_desc(jobs, inl, it_j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+            it_nsu = q_desc(jobs, inl, it_j)->q_n_entries / Q_SU;
         }
         it_su = rest;
     }
@@ -494,7 +541,7 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
         while (it_su >= it_nsu && it_j < last_job) {
             it_su -= it_nsu;
             ++it_j;
-            it_nsu = (q_desc(jobs, inl, it_j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+            it_nsu = q_desc(jobs, inl, it_j)->q_n_entries / Q_SU;
         }
     };
 
@@ -509,7 +556,6 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
     };
     struct IStage {  // index chunks + row scales requested
         i32x4 c[Q_SU][NPRE];
-        f32x4_t w[Q_SU][NPRE];
         i32x2 ext;
         int rows, scale_bits, j;
         bool ok, has_scale;
@@ -525,7 +571,7 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
             ej = e.j;
             const q_desc_ptr d = q_desc(jobs, inl, ej);
             je.ext = to_global(d->q_ext);
-            je.perm = to_global(d->q_perm);
+            je.perm = to_global(d->q_rows);
         }
         e.ext = q_ld2(je.ext, static_cast<unsigned>(req_su) * (Q_SU * 8) + ext_lane);
         e.rows = q_ld1(je.perm, static_cast<unsigned>(req_su) * (Q_SU_ROWS * 4) + lane4);
@@ -541,19 +587,13 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
             const q_desc_ptr d = q_desc(jobs, inl, ij);
             ji.col = to_global(d->q_col);
             ji.has_scale = d->row_scale != nullptr;
-            ji.scale_or_perm = ji.has_scale ? (global_ptr<const int32_t>)to_global(d->row_scale) : to_global(d->q_perm);
-            ji.has_val = HAS_VAL && d->q_val != nullptr;
-            ji.val_or_col = ji.has_val ? (global_ptr<const int32_t>)to_global(d->q_val) : ji.col;
+            ji.scale_or_perm = ji.has_scale ? (global_ptr<const int32_t>)to_global(d->row_scale) : to_global(d->q_rows);
         }
 #pragma unroll
         for (int i = 0; i < Q_SU; ++i) {
             const unsigned off = static_cast<unsigned>(__builtin_amdgcn_readlane(e.ext.x, i)) * (Q_CHUNK_INTS * 4) + lane16;
             s.c[i][0] = q_ld4(ji.col, off);
             if (NPRE > 1) s.c[i][NPRE - 1] = q_ld4_1k(ji.col, off);
-            if (HAS_VAL) {
-                const i32x4 wv = q_ld4(ji.val_or_col, off);
-                s.w[i][0] = f32x4_t{__int_as_float(wv.x), __int_as_float(wv.y), __int_as_float(wv.z), __int_as_float(wv.w)};
-            }
         }
         s.has_scale = ji.has_scale;
         s.scale_bits = q_ld1(ji.scale_or_perm, static_cast<unsigned>(s.rows) * 4u);
@@ -562,57 +602,32 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
         if (cur.j != cj) {
             cj = cur.j;
             const q_desc_ptr d = q_desc(jobs, inl, cj);
-            jc.col = to_global(d->q_col);
-            jc.has_val = HAS_VAL && d->q_val != nullptr;
-            jc.val = jc.has_val ? (global_ptr<const int32_t>)to_global(d->q_val) : jc.col;
             jc.Y = to_global(d->Y);
             jc.ldy4 = static_cast<unsigned>(d->ldy) * 4u;
         }
-        const f32x4_t ones = {1.f, 1.f, 1.f, 1.f};
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+        [[maybe_unused]] const f32x4_t wc = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int i = 0; i < Q_SU; ++i) {
-            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-            const int width0 = no_sweep ? 0 : __builtin_amdgcn_readlane(cur.ext.y, i);
-            const int n_chunks = (width0 + Q_CHUNK - 1) / Q_CHUNK;
-            const unsigned off = static_cast<unsigned>(__builtin_amdgcn_readlane(cur.ext.x, i)) * (Q_CHUNK_INTS * 4) + lane16;
-            // chunks beyond the prefetched ones: the first is requested before the prefetched chunks are swept, each later one
-            // before the one before it is swept
-            i32x4 t0 = {0, 0, 0, 0};
-            [[maybe_unused]] i32x4 tw0 = {0, 0, 0, 0};
-            if (n_chunks > NPRE) {
-                t0 = q_ld4(jc.col, off + NPRE * 1024u);
-                if (HAS_VAL) tw0 = q_ld4(jc.val, off + NPRE * 1024u);
-            }
-            auto chunk = [&](const i32x4 &cc, [[maybe_unused]] const f32x4_t &wc, int left) {
+            // an entry: at most 32 entries per row (the two prefetched chunks); CONT: it continues the slice of the entry
+            // before it - the accumulators stay, the store below replaces that entry's running sums by this one's
+            const int wf = __builtin_amdgcn_readlane(cur.ext.y, i);
+            const int width0 = no_sweep ? 0 : (wf & 0xffff);
+            if (!(wf & Q_CONT)) a0 = a1 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NPRE; ++c) {
+                const int left = width0 - c * Q_CHUNK;  // wave-uniform
+                const i32x4 cc = cur.c[i][c];
                 if (left >= Q_CHUNK) {
                     WDG_Q_CHUNK16
-                } else {  // a last, partial chunk: whole quads of entries (its padding entries read the zero row)
+                } else if (left > 0) {  // a partial chunk: whole quads of entries (its padding entries read the zero row)
                     WDG_Q_QUAD(0)
                     if (left > 4) { WDG_Q_QUAD(1) }
                     if (left > 8) { WDG_Q_QUAD(2) }
                     if (left > 12) { WDG_Q_QUAD(3) }
                 }
-            };
-            auto as_f = [&](const i32x4 &v) {
-                return jc.has_val ? f32x4_t{__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)} : ones;
-            };
-#pragma unroll
-            for (int c = 0; c < NPRE; ++c)
-                if (width0 > c * Q_CHUNK) chunk(cur.c[i][c], (HAS_VAL && jc.has_val) ? cur.w[i][c] : ones, width0 - c * Q_CHUNK);
-            for (int ch = NPRE; ch < n_chunks; ++ch) {
-                // (nothing was issued behind this chunk: vmcnt(0) - it also covers the super-unit's earlier stores and the
-                // next super-unit's requests, all of them at least a chunk of sweeping old)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0));
-                if (HAS_VAL) asm volatile("" : "+v"(tw0));
-                const i32x4 u0 = t0;
-                [[maybe_unused]] const i32x4 uw0 = tw0;
-                if (ch + 1 < n_chunks) {
-                    t0 = q_ld4(jc.col, off + (ch + 1) * 1024u);
-                    if (HAS_VAL) tw0 = q_ld4(jc.val, off + (ch + 1) * 1024u);
-                }
-                chunk(u0, HAS_VAL ? as_f(uw0) : ones, width0 - ch * Q_CHUNK);
             }
-            // ---- the slice's rows leave from the accumulators: the quad's four 16-byte stores are one 64-byte row segment
+            // ---- the entry's rows leave from the accumulators: the quad's four 16-byte stores are one 64-byte row segment
             const int row = __builtin_amdgcn_ds_bpermute(bperm0 + i * (Q_ROWS * 4), cur.rows);
             const int sb = __builtin_amdgcn_ds_bpermute(bperm0 + i * (Q_ROWS * 4), cur.scale_bits);
             const float scale0 = cur.has_scale ? __int_as_float(sb) : 1.f;
@@ -627,10 +642,7 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
 #pragma unroll
         for (int i = 0; i < Q_SU; ++i)
 #pragma unroll
-            for (int c = 0; c < NPRE; ++c) {
-                asm volatile("" : "+v"(s.c[i][c]));
-                if (HAS_VAL) asm volatile("" : "+v"(s.w[i][c]));
-            }
+            for (int c = 0; c < NPRE; ++c) asm volatile("" : "+v"(s.c[i][c]));
     };
 
     EStage E;
@@ -638,10 +650,7 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
 #pragma unroll
     for (int i = 0; i < Q_SU; ++i)
 #pragma unroll
-        for (int c = 0; c < NPRE; ++c) {
-            C.c[i][c] = N.c[i][c] = i32x4{0, 0, 0, 0};
-            C.w[i][c] = N.w[i][c] = f32x4_t{1.f, 1.f, 1.f, 1.f};
-        }
+        for (int c = 0; c < NPRE; ++c) C.c[i][c] = N.c[i][c] = i32x4{0, 0, 0, 0};
     C.scale_bits = N.scale_bits = 0;
     issueE(E);  // super-unit 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -663,7 +672,9 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
     }
 }
 
-// the plain loop: any feature group (ragged, scalar stores), nothing requested ahead; units are super-units as well
+// the plain loop: any feature group (ragged, scalar stores), any entry width, explicit values; nothing requested ahead.
+// Units are super-units of four entries as well; a CONT entry keeps the accumulators of the entry before it, and the rows
+// are stored once, after the slice's last entry (ghost entries: nothing to do).
 template <bool HAS_VAL>
 __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                                int unit_begin, int unit_end, int stride, int f0, int F, lds_cptr slab,
@@ -674,21 +685,21 @@ __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const w
     for (int u = unit_begin + wave * stride; u < unit_end; u += Q_WAVES * stride) {
         int j = first_job, su = u;
         for (;;) {
-            const int nsu = (q_desc(jobs, inl, j)->n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+            const int nsu = q_desc(jobs, inl, j)->q_n_entries / Q_SU;
             if (su < nsu || j >= first_job + n_jobs - 1) break;
             su -= nsu;
             ++j;
         }
         const QJob job = q_load_job(jobs, inl, j);
         const unsigned ldy = static_cast<unsigned>(job.ldy);
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
         for (int i = 0; i < Q_SU; ++i) {
-            const int slice = su * Q_SU + i;
-            const i32x2 ext = *(global_ptr<const i32x2>)(job.ext + 2 * slice);
+            const int entry = su * Q_SU + i;
+            const i32x2 ext = *(global_ptr<const i32x2>)(job.ext + 2 * entry);
             const int chunk0 = __builtin_amdgcn_readfirstlane(ext.x);
-            const int width0 = no_sweep ? 0 : __builtin_amdgcn_readfirstlane(ext.y);
-            const int row = job.perm[slice * Q_ROWS + r];
-            const float scale0 = job.row_scale ? job.row_scale[row] : 1.f;
-            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+            const int wf = __builtin_amdgcn_readfirstlane(ext.y);
+            const int width0 = no_sweep ? 0 : (wf & (Q_CONT - 1));
+            if (!(wf & Q_CONT)) a0 = a1 = f32x2{0.f, 0.f};
             const f32x4_t ones = {1.f, 1.f, 1.f, 1.f};
             for (int ch = 0; ch * Q_CHUNK < width0; ++ch) {
                 const i32x4 cc = *(global_ptr<const i32x4>)(job.col + static_cast<int64_t>(chunk0 + ch) * Q_CHUNK_INTS + lane * 4);
@@ -700,6 +711,12 @@ __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const w
                 if (left > 8) { WDG_Q_QUAD(2) }
                 if (left > 12) { WDG_Q_QUAD(3) }
             }
+            // the slice is complete when the super-unit ends or the next entry starts a slice of its own
+            bool last = i + 1 == Q_SU;
+            if (!last) last = !(__builtin_amdgcn_readfirstlane((*(global_ptr<const i32x2>)(job.ext + 2 * (entry + 1))).y) & Q_CONT);
+            if (!last) continue;
+            const int row = job.perm[entry * Q_ROWS + r];
+            const float scale0 = job.row_scale ? job.row_scale[row] : 1.f;
             const int f = f0 + p * 4;
             const int row0 = no_store ? r : row;
             const global_ptr<float> dst = job.Y + static_cast<uint64_t>(static_cast<unsigned>(row0)) * ldy + f;
@@ -732,8 +749,9 @@ __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const w
     q_stage<TIN>(head, 0, head.n_cols, head.block_cols, f0, xs, wave, lane, tid);
     const bool no_sweep = head.reserved & 4, no_store = head.reserved & 1;  // timing ablations (diagnostics)
     // whole feature group and 16-byte stores for every job of the phase (the table's flags vouch for the alignment)
-    const bool full = (f0 + 16 <= F) && head.y_vec && !HAS_VAL;  // (explicit values: the plain loop)
-    if (full) q_units_fast<false>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, no_sweep, no_store, wave, lane);
+    // (y_vec: the launcher's promise - 16-byte stores, 32-bit offsets, every job in split form; explicit values: plain loop)
+    const bool full = (f0 + 16 <= F) && head.y_vec && !HAS_VAL;
+    if (full) q_units_fast(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, no_sweep, no_store, wave, lane);
     else q_units_simple<HAS_VAL>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, no_store, wave, lane);
 }
 
@@ -781,11 +799,13 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
             const int su = u - base;
 #pragma unroll
             for (int i = 0; i < Q_SU; ++i) {
-                const int slice = su * Q_SU + i;
+                const int slice = su * Q_SU + i;  // (graphs of several column blocks: one entry per slice)
                 const int task = blk * (j0.n_su * Q_SU) + slice;
                 const i32x2 ext = *(global_ptr<const i32x2>)(j0.ext + 2 * task);
                 const int chunk0 = __builtin_amdgcn_readfirstlane(ext.x);
-                const int width0 = no_sweep ? 0 : __builtin_amdgcn_readfirstlane(ext.y);
+                const int wf = __builtin_amdgcn_readfirstlane(ext.y);
+                if (wf & Q_CONT) continue;  // a ghost entry (it pads the last super-unit): wave-uniform
+                const int width0 = no_sweep ? 0 : wf;
                 const f32x4_t ones = {1.f, 1.f, 1.f, 1.f};
                 f32x2 a0 = acc0[k * Q_SU + i], a1 = acc1[k * Q_SU + i];
                 for (int ch = 0; ch * Q_CHUNK < width0; ++ch) {
@@ -854,7 +874,7 @@ __global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job
             }
         } else {
             const int n_segments = kXcds * subs;
-            const int n_units = (inline_job.n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;
+            const int n_units = inline_job.q_n_entries / Q_SU;
             if (MULTI) q_phase_multi<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
             else q_phase_single<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
             first_phase = false;
@@ -921,7 +941,7 @@ namespace wdg {
 bool quad_eligible_single(const wdg_spmm_job &j) {
     if (const char *s = getenv("WDG_SPMM_NO_QUAD"))
         if (atoi(s)) return false;
-    if (!j.q_ext || !j.q_col || !j.q_perm || (j.val && !j.q_val)) return false;
+    if (!j.q_ext || !j.q_col || !j.q_rows || j.q_n_entries <= 0 || (j.val && !j.q_val)) return false;
     if (j.n_feat < 8 || j.q_n_blocks < 1 || j.q_n_blocks > Q_MAX_BLOCKS) return false;
     return true;
 }
@@ -929,7 +949,7 @@ bool quad_eligible_single(const wdg_spmm_job &j) {
 template <typename TIN>
 int quad_single(const wdg_spmm_job &j, hipStream_t st) {
     const int n_groups = static_cast<int>(ceil_div(j.n_feat, 16));
-    const int n_units = (j.n_rows + Q_SU_ROWS - 1) / Q_SU_ROWS;  // super-units
+    const int n_units = j.q_n_entries / Q_SU;  // super-units
     const int wgs_per_xcd = std::max(wdg_device_cus(), 8) / kXcds;
     // segments per XCD: enough (segment, group) pairs to fill the XCD's workgroups about twice, at least 8 super-units each
     int subs = static_cast<int>(ceil_div(2 * wgs_per_xcd, n_groups));
@@ -940,7 +960,7 @@ int quad_single(const wdg_spmm_job &j, hipStream_t st) {
     }
     // 16-byte stores and 32-bit byte offsets into Y and into the index arrays (what the fast loop addresses with)
     const bool y_vec = (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.n_feat % 4 == 0 &&
-                       static_cast<int64_t>(j.n_rows) * j.ldy < (1ll << 30);
+                       static_cast<int64_t>(j.n_rows) * j.ldy < (1ll << 30) && (j.q_flags & WDG_SELL16_SPLIT) != 0;
     return q_launch<TIN>(nullptr, j, nullptr, nullptr, subs, j.n_cols, j.n_feat, j.val != nullptr, y_vec, st);
 }
 int quad_single_f32(const wdg_spmm_job &j, hipStream_t st) { return quad_single<float>(j, st); }
@@ -958,56 +978,72 @@ int wdg_debug_q_stamps(unsigned long long *host_out, int n_blocks) {
 
 int32_t wdg_sell16_block_cols(int32_t n_cols) { return q_block_cols_for(n_cols); }
 
+static int64_t q_real_slices(int32_t N) { return (static_cast<int64_t>(N) + Q_ROWS - 1) / Q_ROWS; }
+
+int64_t wdg_sell16_max_entries(int32_t N) { return Q_SU * q_real_slices(N) + Q_SU; }
+
 size_t wdg_sell16_workspace_bytes(int32_t N, int32_t n_cols) {
-    const int64_t tasks = ((static_cast<int64_t>(N) + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU) * wdg::ceil_div(n_cols > 0 ? n_cols : 1, q_block_cols_for(n_cols));
-    return wdg::exclusive_scan_ws_bytes(tasks + 1) + static_cast<size_t>(tasks + 2) * sizeof(int32_t) + 512;
+    const int64_t tasks = q_real_slices(N) * wdg::ceil_div(n_cols > 0 ? n_cols : 1, q_block_cols_for(n_cols));
+    // chunks / chunk_begin [tasks + 2], widths [tasks], entry_slice + entry_k [max entries each], info, the scan's workspace
+    return wdg::exclusive_scan_ws_bytes(tasks + 1) + static_cast<size_t>(2 * tasks + 2 * wdg_sell16_max_entries(N) + 16) * sizeof(int32_t) + 2048;
 }
 
 int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *q_perm,
-                            int32_t *q_ext, void *workspace, size_t workspace_bytes, wdg_stream_t stream) {
-    WDG_REQUIRE(N >= 0 && n_cols >= 0 && q_ext && (N == 0 || (rowptr && q_perm)), "csr_to_sell16_count: bad arguments");
+                            int32_t *q_ext, int32_t *q_rows, void *workspace, size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && n_cols >= 0 && q_ext && (N == 0 || (rowptr && q_perm && q_rows)), "csr_to_sell16_count: bad arguments");
     if (!workspace || workspace_bytes < wdg_sell16_workspace_bytes(N, n_cols))
         return wdg::fail(WDG_ERR_WORKSPACE, "csr_to_sell16: workspace too small");
     hipStream_t st = wdg::as_stream(stream);
-    const int n_slices = (N + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU;  // padded to whole super-units
+    const int n_slices = static_cast<int>(q_real_slices(N));
     const int block_cols = q_block_cols_for(n_cols);
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
     const int64_t tasks = static_cast<int64_t>(n_slices) * n_blocks;
+    const int64_t max_entries = wdg_sell16_max_entries(N);
     char *ws = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
-    int32_t *chunks = reinterpret_cast<int32_t *>(ws);
-    void *scan_ws = ws + ((static_cast<size_t>(tasks + 2) * sizeof(int32_t) + 255) & ~static_cast<size_t>(255));
-    if (tasks > 0) {
-        static thread_local int configured_dev = -1;
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (configured_dev != dev) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(sell16_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    Q_SORT_MAX_ROWS * 8) != hipSuccess)
-                return wdg::fail(WDG_ERR_LAUNCH, "csr_to_sell16: cannot raise the dynamic LDS limit");
-            configured_dev = dev;
-        }
-        const size_t sort_lds = N <= Q_SORT_MAX_ROWS ? static_cast<size_t>(N) * 8 : 0;
-        hipLaunchKernelGGL(sell16_sort_rows, dim3(1), dim3(1024), sort_lds, st, rowptr, N, q_perm);
-        hipLaunchKernelGGL(sell16_widths, dim3(wdg::ceil_div(tasks, 256)), dim3(256), 0, st, rowptr, col, q_perm, N, n_slices,
-                           n_blocks, block_cols, chunks, q_ext);
+    auto take = [&](size_t ints) {
+        int32_t *ptr = reinterpret_cast<int32_t *>(ws);
+        ws += (ints * sizeof(int32_t) + 255) & ~static_cast<size_t>(255);
+        return ptr;
+    };
+    int32_t *chunks = take(tasks + 2), *widths = take(tasks + 1), *entry_slice = take(max_entries), *entry_k = take(max_entries),
+            *info = take(4);
+    void *scan_ws = ws;
+    if (tasks == 0) {  // an empty graph: {0 chunks, 0 entries}
+        hipMemsetAsync(q_ext, 0, 2 * sizeof(int32_t), st);
+        return WDG_OK;
     }
+    static thread_local int configured_dev = -1;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (configured_dev != dev) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sell16_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Q_SORT_MAX_ROWS * 8) != hipSuccess)
+            return wdg::fail(WDG_ERR_LAUNCH, "csr_to_sell16: cannot raise the dynamic LDS limit");
+        configured_dev = dev;
+    }
+    const size_t sort_lds = N <= Q_SORT_MAX_ROWS ? static_cast<size_t>(N) * 8 : 0;
+    hipLaunchKernelGGL(sell16_sort_rows, dim3(1), dim3(1024), sort_lds, st, rowptr, N, q_perm);
+    hipLaunchKernelGGL(sell16_widths, dim3(wdg::ceil_div(tasks, 256)), dim3(256), 0, st, rowptr, col, q_perm, N, n_slices, n_blocks,
+                       block_cols, chunks, widths);
     if (int e = wdg::exclusive_scan_i32(chunks, tasks, chunks, nullptr, scan_ws, st)) return e;
-    hipLaunchKernelGGL(sell16_ext_begin, dim3(wdg::ceil_div(tasks + 1, 256)), dim3(256), 0, st, chunks,
-                       static_cast<int32_t>(tasks), n_slices, (N + Q_ROWS - 1) / Q_ROWS, q_ext);
+    hipLaunchKernelGGL(sell16_pack, dim3(1), dim3(64), 0, st, widths, n_slices, n_blocks, entry_slice, entry_k, info);
+    const int64_t threads = std::max<int64_t>(max_entries * n_blocks, max_entries * Q_ROWS);
+    hipLaunchKernelGGL(sell16_entries, dim3(wdg::ceil_div(threads, 256)), dim3(256), 0, st, widths, chunks, entry_slice, entry_k, info,
+                       q_perm, n_slices, n_blocks, static_cast<int32_t>(max_entries), q_ext, q_rows);
     return wdg::check_launch("csr_to_sell16_count");
 }
 
 int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
-                           const int32_t *q_perm, const int32_t *q_ext, int32_t *q_col, float *q_val, wdg_stream_t stream) {
-    WDG_REQUIRE(N >= 0 && n_cols >= 0 && q_ext && (N == 0 || q_perm), "csr_to_sell16_fill: bad arguments");
-    const int n_slices = (N + Q_SU_ROWS - 1) / Q_SU_ROWS * Q_SU;  // padded to whole super-units
+                           const int32_t *q_rows, const int32_t *q_ext, int32_t n_entries, int32_t *q_col, float *q_val,
+                           wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && n_cols >= 0 && n_entries >= 0 && q_ext && (N == 0 || q_rows), "csr_to_sell16_fill: bad arguments");
     const int block_cols = q_block_cols_for(n_cols);
     const int n_blocks = static_cast<int>(wdg::ceil_div(n_cols > 0 ? n_cols : 1, block_cols));
-    const int64_t tasks = static_cast<int64_t>(n_slices) * n_blocks;
+    const int64_t tasks = static_cast<int64_t>(n_entries) * n_blocks;
     if (tasks == 0) return WDG_OK;
     WDG_REQUIRE(rowptr && q_col, "csr_to_sell16_fill: null rowptr / q_col");
     hipLaunchKernelGGL(sell16_fill, dim3(wdg::ceil_div(tasks * 64, 256)), dim3(256), 0, wdg::as_stream(stream), rowptr, col, val,
-                       q_perm, N, n_slices, n_blocks, block_cols, q_ext, q_col, q_val, q_reorder_enabled() ? 1 : 0);
+                       q_rows, n_entries, n_blocks, block_cols, q_ext, q_col, q_val, q_reorder_enabled() ? 1 : 0);
     return wdg::check_launch("csr_to_sell16_fill");
 }
 

@@ -100,29 +100,32 @@ class CsrGraph:
             self.quad = False
             return False
         dev = self.device
-        n_su = (self.n_rows + 63) // 64   # super-units of 64 rows: what a wave of the kernel is dealt
-        n_slices = 4 * n_su               # 16-row slices, padded to whole super-units (ghost slices repeat the last real one)
-        tasks = n_slices * n_blocks
-        ext = torch.empty(2 * (tasks + 1), dtype=torch.int32, device=dev)
-        perm = torch.empty(n_slices * 16, dtype=torch.int32, device=dev)  # padding slots / slices repeat the last row / slice
+        max_entries = int(lib.wdg_sell16_max_entries(self.n_rows))
+        ext = torch.empty(2 * (n_blocks * max_entries + 1), dtype=torch.int32, device=dev)
+        rows = torch.empty(16 * max_entries, dtype=torch.int32, device=dev)
+        perm = torch.empty((self.n_rows + 15) // 16 * 16, dtype=torch.int32, device=dev)  # padding slots repeat the last row
         ws_bytes = lib.wdg_sell16_workspace_bytes(self.n_rows, self.n_cols)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         check(lib.wdg_csr_to_sell16_count(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, _ptr(perm), _ptr(ext),
-                                          _ptr(ws), ws_bytes, stream_handle()), "wdg_csr_to_sell16_count")
+                                          _ptr(rows), _ptr(ws), ws_bytes, stream_handle()), "wdg_csr_to_sell16_count")
         ext_host = ext.cpu().numpy().reshape(-1, 2)  # the one host sync of the build: sizes the index arrays
-        chunks = int(ext_host[-1, 0])
+        chunks, word = int(ext_host[-1, 0]), int(ext_host[-1, 1])
+        n_entries, split = word & 0x3fffffff, bool(word & (1 << 30))
+        tasks = n_entries * n_blocks
         if chunks * 256 > max_padding * self.nnz + 256 * tasks:
             self.quad = False  # very skewed rows: the CSR kernels are the better fit (remembered)
             return False
-        # (+ 2 chunks of slack: the kernel requests a unit's first two chunks unconditionally)
+        # (+ 2 chunks of slack: the kernel requests an entry's two chunks unconditionally)
         q_col = torch.zeros((chunks + 2) * 256, dtype=torch.int32, device=dev)
         q_val = torch.zeros((chunks + 2) * 256, dtype=torch.float32, device=dev) if self.val is not None else None
         check(lib.wdg_csr_to_sell16_fill(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), self.n_rows, self.n_cols,
-                                         _ptr(perm), _ptr(ext), _ptr(q_col), _ptr(q_val), stream_handle()),
+                                         _ptr(rows), _ptr(ext), n_entries, _ptr(q_col), _ptr(q_val), stream_handle()),
               "wdg_csr_to_sell16_fill")
-        widths = ext_host[:-1, 1].reshape(n_blocks, n_slices)  # per (block, slice): the cost model of SpmmBatch reads it
-        self.quad = dict(ext=ext, col=q_col, val=q_val, perm=perm, block_cols=block_cols, n_blocks=n_blocks,
-                         n_slices=n_slices, n_su=n_su, widths=widths, chunks=chunks)
+        # per (block, entry) width: the cost model of SpmmBatch reads it (flags masked off)
+        widths = (ext_host[:tasks, 1] & 0x3fffffff).reshape(n_blocks, n_entries).copy()
+        self.quad = dict(ext=ext[:2 * (tasks + 1)], col=q_col, val=q_val, perm=perm, rows=rows[:16 * n_entries],
+                         block_cols=block_cols, n_blocks=n_blocks, n_entries=n_entries, n_su=n_entries // 4, split=split,
+                         widths=widths, chunks=chunks, n_slices=n_entries)
         return True
 
     @property
@@ -298,11 +301,13 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     q = g.quad
     if q and (not wants_val or q["val"] is not None):
         job.q_ext, job.q_col, job.q_perm = q["ext"].data_ptr(), q["col"].data_ptr(), q["perm"].data_ptr()
+        job.q_rows = q["rows"].data_ptr()
         job.q_val = q["val"].data_ptr() if (wants_val and q["val"] is not None) else 0
         job.q_block_cols, job.q_n_blocks = q["block_cols"], q["n_blocks"]
+        job.q_n_entries, job.q_flags = q["n_entries"], (1 if q["split"] else 0)
     else:
-        job.q_ext = job.q_col = job.q_val = job.q_perm = 0
-        job.q_block_cols = job.q_n_blocks = 0
+        job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0
+        job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
     return job
 
 
@@ -378,13 +383,22 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
     return y
 
 
+# measured cost of a 16-row slice as a function of its entries per row (scripts/calibrate_quad.py, ns per slice and wave on
+# homogeneous batches of N = 2000 graphs, F = 512): flat while the slice's store bounds it, then ~43 ns per entry (LDS)
+_QUAD_COST_W = np.array([0, 3, 7, 11, 13, 15, 17, 21, 26, 34, 41, 51, 67], np.float64)
+_QUAD_COST_NS = np.array([1590, 1590, 1619, 1668, 1756, 1768, 1908, 1980, 2076, 2457, 2667, 3027, 3780], np.float64)
+
+
 def _quad_unit_cost(widths):
     """modelled cost of the super-units (4 slices = 64 rows each) of a graph from its slices' entries per row (summed over
-    column blocks): the sweep is LDS-bound in the entries; a narrow slice is bound by its store and the pipeline's fixed
-    work instead (WDG_QUAD_WMIN, default 8), plus a constant per slice (WDG_QUAD_ALPHA, default 4)"""
-    alpha = float(os.environ.get("WDG_QUAD_ALPHA", "4"))
-    wmin = float(os.environ.get("WDG_QUAD_WMIN", "8"))
-    per_slice = np.maximum(widths.sum(0).astype(np.float64), wmin) + alpha
+    column blocks): the measured table above, extended linearly; WDG_QUAD_ALPHA / WDG_QUAD_WMIN (entries) select the
+    two-parameter model max(width, wmin) + alpha instead (experiments)"""
+    w = widths.sum(0).astype(np.float64)
+    if "WDG_QUAD_ALPHA" in os.environ or "WDG_QUAD_WMIN" in os.environ:
+        per_slice = np.maximum(w, float(os.environ.get("WDG_QUAD_WMIN", "8"))) + float(os.environ.get("WDG_QUAD_ALPHA", "4"))
+    else:
+        per_slice = np.where(w <= _QUAD_COST_W[-1], np.interp(w, _QUAD_COST_W, _QUAD_COST_NS),
+                             _QUAD_COST_NS[-1] + 43.0 * (w - _QUAD_COST_W[-1]))
     return per_slice.reshape(-1, 4).sum(1)
 
 
@@ -500,7 +514,7 @@ class SpmmBatch:
         if self.run >= 2 and all_sell and dma_ok:
             self.flags |= (self.run & 0xff) << 8  # WDG_SPMM_SHARED_X(run)
         if self.quad:
-            if all(e[0].n_rows * _ld(e[2]) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 for e in entries):
+            if all(e[0].n_rows * _ld(e[2]) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 and e[0].quad["split"] for e in entries):
                 self.flags |= SPMM_SMALL_OFFSETS
             items, seg_ptr, self.n_segments = _quad_segments(entries, order, self.max_feat, max(lib.wdg_device_cus(), 8))
             iarr = (SpmmItem * max(len(items), 1))()
