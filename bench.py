@@ -56,7 +56,9 @@ def launch_workers(args, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+    # exactly the JSON line: libraries (RCCL) write to the workers' stdout as well
+    lines = [l for l in out.splitlines() if l.lstrip().startswith("{")]
+    sys.stdout.write("".join(l + "\n" for l in lines[-1:]))
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -227,6 +229,8 @@ def main():
                             "graphs_per_s": m2["n_graphs"] * steps2 / m2["elapsed"],
                             "roofline": roofline_of(args, m2)}
         del m2
+    if world > 1:
+        dist.destroy_process_group()  # (before the line: RCCL writes its library path to stdout when it shuts down)
     if rank == 0:
         if world == 1 and args.cpu_budget > 0:
             from oracle import cpu_ref
@@ -235,8 +239,6 @@ def main():
             sample = sweep.make_jobs(h_levels, [0], k=args.k, n_nodes=args.nodes)
             out["cpu_baseline"] = cpu_ref.baseline_record(sample, args.feat, args.cpu_budget)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

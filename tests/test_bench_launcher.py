@@ -1,0 +1,56 @@
+"""bench.py --gpus N without a launcher (the driver's `python3 bench.py --gpus 8`): the parent starts N workers - one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set - before anything touches the GPU, forwards rank 0's JSON line and returns
+non-zero when a worker fails.  A stand-in worker (WDG_BENCH_WORKER) replaces the GPU half here."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, worker_src, gpus):
+    worker = tmp_path / "worker.py"
+    worker.write_text(textwrap.dedent(worker_src))
+    env = dict(os.environ, WDG_BENCH_WORKER=str(worker), WDG_TEST_DIR=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1"],
+                          env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_launcher_starts_one_worker_per_gpu_and_forwards_rank0(tmp_path):
+    res = _run(tmp_path, """
+        import json, os, sys
+        rank = int(os.environ["RANK"])
+        rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        rec["argv"] = sys.argv[1:]
+        open(os.path.join(os.environ["WDG_TEST_DIR"], f"rank{rank}.json"), "w").write(json.dumps(rec))
+        print(json.dumps({"metric": "stub", "rank": rank}))   # every rank prints: only rank 0's line may reach stdout
+        """, gpus=2)
+    assert res.returncode == 0, res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "stub", "rank": 0}
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r, rec in enumerate(recs):
+        assert rec["RANK"] == str(r) and rec["LOCAL_RANK"] == str(r) and rec["WORLD_SIZE"] == "2"
+        assert rec["MASTER_ADDR"] == "127.0.0.1" and rec["MASTER_PORT"].isdigit()
+        assert rec["argv"] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert recs[0]["MASTER_PORT"] == recs[1]["MASTER_PORT"]
+
+
+def test_launcher_propagates_worker_failure(tmp_path):
+    res = _run(tmp_path, """
+        import os, sys
+        print('{"metric": "stub"}')
+        sys.exit(3 if os.environ["RANK"] == "1" else 0)
+        """, gpus=2)
+    assert res.returncode != 0
+    assert "workers failed" in res.stderr
+
+
+def test_single_gpu_and_torchrun_paths_do_not_relaunch():
+    """--gpus 1, or WORLD_SIZE already set by torch.distributed.run: bench.py is the worker itself"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"WORLD_SIZE" not in os.environ and args.gpus > 1' in src

@@ -99,8 +99,10 @@ def test_batched_gemm_and_las_mixed_shapes(oracle):
         assert abs(int(got[i, 0]) - s) <= 1 and abs(int(got[i, 1]) - hd) <= 1
 
 
-@pytest.mark.parametrize("variant,env,family", [("default", {"WDG_SPMM_RUN": "0"}, 2), ("shared-X", {}, 4),
-                                                ("pipelined", {"WDG_SPMM_RUN": "0", "WDG_SPMM_PIPELINED": "1"}, 3)])
+@pytest.mark.parametrize("variant,env,family", [("row-lane", {"WDG_SPMM_NO_QUAD": "1", "WDG_SPMM_RUN": "0"}, 2),
+                                                ("shared-X", {"WDG_SPMM_NO_QUAD": "1"}, 4),
+                                                ("pipelined", {"WDG_SPMM_NO_QUAD": "1", "WDG_SPMM_RUN": "0", "WDG_SPMM_PIPELINED": "1"}, 3),
+                                                ("quad-row", {}, 5)])
 def test_full_sweep_batch_every_item_exactly_once(monkeypatch, variant, env, family):
     """The bench-size batch (100 graphs, 1 600 / 3 200 / 640 queue items over 256 persistent workgroups, with stealing at
     the end): every (graph, feature group) item must be produced by every launch - outputs are pre-filled with NaN - and
@@ -124,6 +126,82 @@ def test_full_sweep_batch_every_item_exactly_once(monkeypatch, variant, env, fam
             assert not bool(torch.isnan(y).any()), (variant, launch, i)
             if i in want:
                 assert torch.equal(y, want[i]), (variant, launch, i)
+
+
+@pytest.mark.parametrize("seeds", [5, 10])
+def test_full_c3_sweep_shard_on_the_quad_kernel(oracle, seeds):
+    """BASELINE config C3 at full size - the `data_synthesis/4000`-equivalent shard the bench times: 10 h-levels (k = 10: 12 .. 67
+    stored entries per row, the wide graphs split into CONT entries) x 5 (10) seeds, N = 2000, F = 500 (+ the label columns):
+    every (graph, feature group) item is produced by every launch (outputs pre-filled with NaN), repeated launches are
+    bitwise equal to the single-graph calls, and sampled graphs match the oracle within 1e-5."""
+    from wdg_amd import ops, sweep, synth
+    jobs = sweep.make_jobs(synth.H_LEVELS_10_K10, range(seeds), k=10)
+    sb = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0)
+    assert sb.spmm.plan()[0] == 5 and sb.spmm.quad and sb.spmm.flags & ops.SPMM_SMALL_OFFSETS
+    assert sb.edges == seeds * 2000 * sum(int(10 / h) + 1 for h in synth.H_LEVELS_10_K10)
+    sample = sorted({0, 3, 9, len(jobs) // 2, len(jobs) - 7, len(jobs) - 1})
+    want = {}
+    for i in sample:
+        g, x, _y, d, _cs, _uv = sb.spmm.keep[i]
+        want[i] = ops.spmm(g, x, row_scale=d, use_values=False).clone()
+    for launch in range(4):
+        for y in sb.y_agg:
+            y.fill_(float("nan"))
+        sb.spmm.launch()
+        torch.cuda.synchronize()
+        for i, (_g, _x, y, _d, _cs, _uv) in enumerate(sb.spmm.keep):
+            assert not bool(torch.isnan(y).any()), (launch, i)
+            if i in want:
+                assert torch.equal(y, want[i]), (launch, i)
+    for i in sample:  # against the oracle: D^-1 (A + I) [X | onehot | 0]
+        j = jobs[i]
+        src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+        rowptr, col, val = oracle.coo_to_csr(src, dst, j.n_nodes, None, oracle.ADD_SELF_LOOPS)
+        vhat = oracle.normalised_csr(rowptr, col, val, 0, oracle.PREC_F32)
+        y_ref = oracle.spmm_csr(rowptr, col, vhat, synth.features(j.n_nodes, 500, j.seed))
+        np.testing.assert_allclose(sb.y[i].cpu().numpy(), y_ref, rtol=1e-5, atol=1e-6 * np.abs(y_ref).max())
+        h_ref = oracle.spmm_csr(rowptr, col, vhat, np.eye(j.n_classes, dtype=np.float32)[lab])
+        np.testing.assert_allclose(sb.h_las[i].cpu().numpy(), h_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_sweep_exchange_under_an_initialised_process_group(tmp_path):
+    """SweepBatch + broadcast_jobs + gather_results together under an initialised `nccl` (= RCCL) process group - world size 1,
+    what a one-GPU box can run; the world-size-2 logic is covered with gloo in tests/test_sweep_dist.py."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "one_rank.py"
+    script.write_text("""
+import os, sys, json
+sys.path.insert(0, os.environ["WDG_ROOT"])
+import torch, torch.distributed as dist
+from wdg_amd import sweep, synth
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+jobs = sweep.make_jobs(synth.H_LEVELS_10_K10[:4], range(2), k=10, n_nodes=1000)
+got = sweep.broadcast_jobs(jobs if dist.get_rank() == 0 else [], dev)
+mine = sweep.shard_jobs(got, dist.get_world_size(), dist.get_rank())
+batch = sweep.SweepBatch(mine, n_feat=64, gcn_hidden=16)
+batch.step()
+rows = batch.results()
+gathered = sweep.gather_results(rows, dev)
+dist.barrier()
+torch.cuda.synchronize()
+assert len(gathered) == 1 and torch.equal(gathered[0].cpu(), rows.cpu())
+print(json.dumps({"jobs": len(mine), "rows": list(rows.shape), "edge_homo": rows[:, 0].cpu().tolist()}))
+dist.destroy_process_group()
+""")
+    env = dict(os.environ, WDG_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    import json
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])  # (RCCL prints its library path, too)
+    from wdg_amd import sweep, synth
+    assert out["jobs"] == 8 and out["rows"] == [8, len(sweep.METRIC_NAMES)]
+    want = [10 / int(10 / h) for h in synth.H_LEVELS_10_K10[:4]] * 2  # edge homophily of the generator: k / int(k / h)
+    np.testing.assert_allclose(out["edge_homo"], want, rtol=1e-6)
 
 
 @pytest.mark.parametrize("kind", ["sgc", "gcn"])

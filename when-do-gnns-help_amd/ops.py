@@ -255,6 +255,8 @@ def normalise_values(g, mode=NORM_RW, prec=PREC_F32):
     """A_hat's stored values as the reference materialises them (D^-1 A or D^-1/2 A D^-1/2) -> new CsrGraph."""
     d = degree_norm(g, mode, prec)
     out = torch.empty(g.nnz, dtype=torch.float32, device=g.device)
+    if g.nnz == 0:  # nothing stored: nothing to scale (empty tensors have no device pointer to hand over)
+        return g.with_values(out)
     check(lib.wdg_normalise_values(_ptr(g.rowptr), _ptr(g.col), _ptr(g.val), g.n_rows, mode, prec, _ptr(d["dinv"]),
                                    _ptr(d["dinv64"]), _ptr(out), stream_handle()), "wdg_normalise_values")
     return g.with_values(out)
