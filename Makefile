@@ -13,9 +13,12 @@ $(LIB): $(OBJS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
 
+# (the compiler's per-kernel resource report - registers, spills, scratch - is kept beside the object: tests/test_abi.py
+# checks that no shipped kernel spills vector registers)
 build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/wdg.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> build/$*.rsrc || (cat build/$*.rsrc; exit 1)
+	@grep -E "warning:|error:" build/$*.rsrc || true
 
 oracle: oracle/_build/libwdg_oracle.so
 

@@ -47,10 +47,57 @@ def test_host_side_queries_need_no_gpu():
     assert L.lib.wdg_spmm_plan(1, 200000, 200000, 7, 0, ctypes.byref(slab), ctypes.byref(thr)) == 1  # row gather
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """every job / item struct of include/wdg.h: size and field offsets as gcc lays them out == the ctypes mirrors"""
     import wdg_amd._lib as L
-    assert ctypes.sizeof(L.SpmmJob) == 7 * 8 + 2 * 8 + 4 * 4 + 3 * 8 + 2 * 4 + 8
-    assert ctypes.sizeof(L.StatsJob) == 9 * 8 + 2 * 4
+    mirrors = {"wdg_spmm_job": L.SpmmJob, "wdg_spmm_item": L.SpmmItem, "wdg_stats_job": L.StatsJob, "wdg_las_job": L.LasJob,
+               "wdg_gemm_job": L.GemmJob, "wdg_mlp2_job": L.Mlp2Job}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wdg.h"', 'int main(void) {']
+    for cname, mirror in mirrors.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, field, value = line.split()
+        got[(cname, field)] = int(value)
+    for cname, mirror in mirrors.items():
+        assert got[(cname, "size")] == ctypes.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert got[(cname, fname)] == getattr(mirror, fname).offset, (cname, fname)
+
+
+def test_no_shipped_kernel_spills_vector_registers():
+    """the compiler's resource report of every translation unit (build/*.rsrc, written by the Makefile): no kernel of the
+    library may spill VGPRs to scratch (a spill inside the aggregation loops also breaks their hand-counted vmcnt waits)"""
+    import glob
+    reports = sorted(glob.glob(os.path.join(ROOT, "build", "*.rsrc")))
+    if not reports:
+        pytest.skip("no resource reports (the library was built without the Makefile)")
+    # known and bounded (DESIGN.md 4.4): the two 64-column B-resident MFMA kernels sit at the 128-register cap of a
+    # 1024-thread workgroup and spill a handful of registers outside their K loop's MFMA chain
+    allowed = {"gemm_bres_kernelILi2E": 13, "mlp2_bres_kernelILi2E": 9}
+    seen = 0
+    for path in reports:
+        name = None
+        for line in open(path):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"VGPRs Spill: (\d+)", line)
+            if m and name:
+                seen += 1
+                limit = next((v for k, v in allowed.items() if k in name), 0)
+                assert int(m.group(1)) <= limit, f"{os.path.basename(path)}: {name} spills {m.group(1)} VGPRs"
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and name and not any(k in name for k in allowed):
+                assert int(m.group(1)) == 0, f"{os.path.basename(path)}: {name} uses {m.group(1)} bytes of scratch per lane"
+    assert seen >= 20
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

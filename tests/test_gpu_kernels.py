@@ -376,7 +376,7 @@ def test_sell_layout_matches_csr(ops, oracle, monkeypatch, column_order):
     if column_order:
         monkeypatch.setenv("WDG_SELL_ORDER", "0")
     rng = np.random.default_rng(31)
-    for n, e in ((1, 1), (64, 500), (65, 700), (2000, 20000), (4096, 9000), (130, 0), (5201, 40000), (6144, 7000)):
+    for n, e in ((1, 1), (64, 500), (65, 700), (2000, 20000), (3000, 9000), (130, 0), (2561, 40000), (3072, 7000)):
         src, dst = _rand_graph(rng, n, e)
         rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
         g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, n)
@@ -423,8 +423,8 @@ def test_sell_layout_matches_csr(ops, oracle, monkeypatch, column_order):
 
 
 @pytest.mark.parametrize("n,f,e", [(2000, 500, 20000), (2000, 500, 82000), (2708, 1433, 13264), (1000, 32, 6000),
-                                   (4096, 64, 30000), (3000, 17, 20000), (100, 8, 300), (2048, 100, 2048), (1025, 33, 9000),
-                                   (4000, 500, 100000), (64, 129, 64)])
+                                   (3072, 64, 30000), (3000, 17, 20000), (100, 8, 300), (2048, 100, 2048), (1025, 33, 9000),
+                                   (2700, 500, 100000), (64, 129, 64)])
 def test_spmm_rowlane_family_shapes(ops, oracle, n, f, e, old_families):
     rng = np.random.default_rng(n * 7 + f)
     src, dst = _rand_graph(rng, n, e)
@@ -474,7 +474,7 @@ def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch, old_families):
 
 
 @pytest.mark.parametrize("n,f,e,power_law", [(2000, 500, 20000, False), (1000, 64, 9000, False), (3000, 100, 30000, False),
-                                              (4096, 36, 50000, True), (700, 16, 0, False), (2277, 2324, 60000, True)])
+                                              (3072, 36, 50000, True), (700, 16, 0, False), (2277, 2324, 60000, True)])
 def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power_law, old_families):
     """The opt-in pipelined schedule (WDG_SPMM_PIPELINED=1, family 3) sums in the same order as the default row-lane
     kernel: bit-identical results, single-graph and batched, with and without explicit values."""

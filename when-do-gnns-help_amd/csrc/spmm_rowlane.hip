@@ -1,5 +1,5 @@
 // Row-lane aggregation kernels + the sorted, column-blocked SELL-64 index layout they read (the fast path of the
-// homophily sweep; graphs of <= 6144 rows).
+// homophily sweep; graphs of <= 3072 rows).
 //
 // replaces: torch.spmm / torch.mm(adj, X) - same call sites as csrc/spmm.hip.
 //
@@ -48,7 +48,7 @@ using namespace wdg;
 
 constexpr int RL_THREADS = 1024;
 constexpr int RL_WAVES = RL_THREADS / 64;
-constexpr int RL_MAX_ROWS = 6 * RL_THREADS;  // 6 rows per thread at 4 float4 accumulators each
+constexpr int RL_MAX_ROWS = 3 * RL_THREADS;  // 3 rows per thread (more rows per thread spill; such graphs run the quad-row or the CSR kernels)
 constexpr int SELL_SENTINEL = 0x7fffffff;  // padding entry
 
 #ifdef WDG_STAMPS  // diagnostic build only (make STAMPS=1): wave 0's clock at phase boundaries, one 16-slot record per
@@ -1318,7 +1318,7 @@ template <int RPT>
 int launch_rowlane_shared(const wdg_spmm_job *jobs, int n_jobs, int run_len, int max_cols, int max_feat, bool has_val,
                           hipStream_t st) {
     const bool narrow_env = getenv("WDG_SPMM_SHARED8") != nullptr;  // opt-in: 8-feature items, two workgroups per CU (slower)
-    const bool narrow = narrow_env && static_cast<size_t>(max_cols) * 32 + RL_WAVES * 64 * 16 + 64 <= kLdsBytes / 2;
+    const bool narrow = narrow_env && !has_val && static_cast<size_t>(max_cols) * 32 + RL_WAVES * 64 * 16 + 64 <= kLdsBytes / 2;
     const int quads = narrow ? 2 : 4;
     const int n_groups = static_cast<int>(ceil_div(max_feat, quads * 4));
     const int n_runs = n_jobs / run_len;
@@ -1327,19 +1327,17 @@ int launch_rowlane_shared(const wdg_spmm_job *jobs, int n_jobs, int run_len, int
     const int x_slots = max_cols * quads;  // all source rows, 64 (32) B each
     const size_t lds = (static_cast<size_t>(x_slots) + RL_WAVES * 32 * quads) * 16;
     if (narrow) {
-        auto k8v = spmm_rowlane_shared8_kernel<RPT, true>;
-        auto k8n = spmm_rowlane_shared8_kernel<RPT, false>;
+        auto k8n = spmm_rowlane_shared8_kernel<RPT, false>;  // (pattern-only tables: with values the variant would spill)
         static thread_local bool configured8 = false;
         if (!configured8) {
-            for (const void *k : {reinterpret_cast<const void *>(k8v), reinterpret_cast<const void *>(k8n)})
-                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes / 2)) != hipSuccess)
-                    return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k8n), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(kLdsBytes / 2)) != hipSuccess)
+                return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
             configured8 = true;
         }
         const dim3 grid8(static_cast<unsigned>(std::min<int64_t>(n_items, 2 * resident_grid(n_items))));
         const int slot8 = static_cast<int>(next_queue_slot());
-        if (has_val) hipLaunchKernelGGL(k8v, grid8, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot8, x_slots);
-        else hipLaunchKernelGGL(k8n, grid8, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot8, x_slots);
+        hipLaunchKernelGGL(k8n, grid8, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot8, x_slots);
         return check_launch("spmm_rowlane_shared8_kernel");
     }
     auto kv = spmm_rowlane_shared_kernel<RPT, true>;
@@ -1367,8 +1365,12 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
     size_t lds = static_cast<size_t>(std::min(sell_block_cap(max_rows), max_cols)) * QUADS * 16;  // bound of the jobs' block sizes
     const size_t tr_bytes = static_cast<size_t>(RL_WAVES) * 64 * QUADS * 16;
     if (lds < tr_bytes) lds = tr_bytes;
-    auto kv = spmm_rowlane_kernel<QUADS, RPT, TIN, true>;
+    // (32-feature items with two rows per thread AND explicit values would spill: the dispatcher sends such tables here
+    // with 16-feature items, so that instantiation does not exist)
+    constexpr bool kWithValues = !(QUADS == 8 && RPT == 2);
     auto kn = spmm_rowlane_kernel<QUADS, RPT, TIN, false>;
+    auto kv = spmm_rowlane_kernel<QUADS, RPT, TIN, kWithValues>;
+    if (has_val && !kWithValues) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: no 32-feature kernel with explicit values");
     static thread_local bool configured = false;
     if (!configured) {
         for (const void *k : {reinterpret_cast<const void *>(kv), reinterpret_cast<const void *>(kn)})
@@ -1385,7 +1387,7 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
 
 bool pipelined_enabled(int max_rows) {
     const char *e = getenv("WDG_SPMM_PIPELINED");
-    return e && atoi(e) && ceil_div(max_rows, RL_THREADS) <= 4;
+    return e && atoi(e) && ceil_div(max_rows, RL_THREADS) <= 3;
 }
 
 // Jobs that share X in aligned runs (WDG_SPMM_SHARED_X) and fit the shared-X kernel: LDS-DMA-able, all source rows of a
@@ -1405,19 +1407,19 @@ int rowlane_dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jo
         if (rpt == 1) return launch_rowlane_shared<1>(jobs, n_jobs, run_len, max_cols, max_feat, has_val, st);
         return launch_rowlane_shared<2>(jobs, n_jobs, run_len, max_cols, max_feat, has_val, st);
     }
-    const bool wide = (rpt <= 2) && max_feat > 16;  // 32-feature items need 8 float4 accumulators per row
+    // 32-feature items need 8 float4 accumulators per row (with explicit values on top, two rows per thread would spill)
+    const bool wide = (rpt <= 2) && max_feat > 16 && !(has_val && rpt == 2);
     // The pipelined variant is opt-in (WDG_SPMM_PIPELINED=1): on the sweep workload it measures 288 us against the 259 us
     // of the single-buffer kernel - its per-item costs are paid twice as often (16-feature items).
     if (dma_ok && sizeof(TIN) == 4 && pipelined_enabled(max_rows)) {
 #define WDG_RL_PIPE_CASE(R) \
     if (rpt == R) return launch_rowlane_pipe<4, R>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
-        WDG_RL_PIPE_CASE(1) WDG_RL_PIPE_CASE(2) WDG_RL_PIPE_CASE(3) WDG_RL_PIPE_CASE(4)  // more rows per thread: no room
+        WDG_RL_PIPE_CASE(1) WDG_RL_PIPE_CASE(2) WDG_RL_PIPE_CASE(3)  // more rows per thread: no room
 #undef WDG_RL_PIPE_CASE
     }
 #define WDG_RL_CASE(Q, R) \
     if ((wide ? 8 : 4) == Q && rpt == R) return launch_rowlane<Q, R, TIN>(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
-    WDG_RL_CASE(8, 1) WDG_RL_CASE(8, 2) WDG_RL_CASE(4, 1) WDG_RL_CASE(4, 2) WDG_RL_CASE(4, 3) WDG_RL_CASE(4, 4)
-    WDG_RL_CASE(4, 5) WDG_RL_CASE(4, 6)
+    WDG_RL_CASE(8, 1) WDG_RL_CASE(8, 2) WDG_RL_CASE(4, 1) WDG_RL_CASE(4, 2) WDG_RL_CASE(4, 3)
 #undef WDG_RL_CASE
     return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: no kernel for rows=%d feat=%d", max_rows, max_feat);
 }

@@ -46,7 +46,7 @@ class CsrGraph:
     reference gets from `.coalesce()` on a torch COO tensor, with 4-byte instead of 8-byte indices.
     """
 
-    SELL_MAX_ROWS = 6144  # the row-lane kernel keeps every row of a graph in one workgroup's registers
+    SELL_MAX_ROWS = 3072  # the row-lane kernel keeps every row of a graph in one workgroup's registers (3 per thread)
 
     def __init__(self, rowptr, col, val, n_rows, n_cols):
         self.rowptr, self.col, self.val = rowptr, col, val
@@ -378,7 +378,7 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
     y = out if out is not None else torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=dev)
     row_scale, col_scale = _dev(row_scale, torch.float32, dev), _dev(col_scale, torch.float32, dev)
     if x.shape[1] >= 8 and not g.ensure_quad():  # one-time SELL-16 copy -> quad-row kernel (<= 10 112 columns)
-        g.ensure_sell()  # else the SELL-64 copy -> row-lane kernels for graphs of <= 6144 rows
+        g.ensure_sell()  # else the SELL-64 copy -> row-lane kernels for graphs of <= 3072 rows
     job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values)
     fn = lib.wdg_spmm_csr_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_csr_f32
     check(fn(ctypes.byref(job), stream_handle()), "wdg_spmm_csr")
