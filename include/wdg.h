@@ -371,6 +371,50 @@ typedef struct wdg_mlp2_job {
 int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
                          int32_t max_C, wdg_stream_t stream);
 
+/* ------------------------------------------------------------------ kernel-regression metric (Gram kernels + solver) */
+/*
+ * K = map(A A^T) for ALL n rows of A [n, F] (the aggregated features A_hat X of a graph, or X itself), the map fused into
+ * the MFMA launch as its epilogue; either output may be NULL:
+ *   K_linear = G / 2                                                           (n_layers = 0)
+ *   K_arccos = (G (pi - acos(G / nu)) + sqrt(nu^2 - G^2)) / (2 pi),  nu = max(|a_i| |a_j|, 1e-8), NaN -> 0   (n_layers = 1)
+ * with |a_i|^2 = G_ii (computed as the same k-ordered fp32 fma chain; norm2 [n] is scratch the call fills).
+ * replaces: gntk_homophily_ utils/homophily_metrics.py:232-257 (utils/homophily_plot.py:238-268).  The reference maps the
+ *           Gram of the rows SAMPLED in an epoch; the map is elementwise in (G_ij, |a_i| |a_j|), so that kernel is the
+ *           sub-block [sample, sample] of this one - computed once per graph instead of once per epoch.
+ */
+typedef struct wdg_gram_job {
+    const float *A;   /* [n, F] */
+    float *norm2;     /* [n] scratch: |a_i|^2 */
+    float *K_linear;  /* [n, n] or NULL */
+    float *K_arccos;  /* [n, n] or NULL */
+    int64_t lda, ldk;
+    int32_t n, F;
+} wdg_gram_job;
+int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream);
+
+/*
+ * Batched kernel regression: for every job, alpha = K[train, train]^-1 onehot(labels[train]) by a register-resident Cholesky
+ * factorisation (n_train <= wdg_kernel_regress_max_train() = 320, n_classes <= 8), predictions K[val, train] alpha, and
+ * *correct_out = #{v in val : argmax_c prediction == labels[v]} (first maximum, like torch.argmax); -1 for shapes out of range.
+ * replaces: `K_val_train @ (np.linalg.pinv(K_train_train) @ label_onehot[idx_train])`, `.argmax(1).eq(labels[idx_val])`
+ *           utils/homophily_metrics.py:283-297 (utils/homophily_plot.py:296-310), once per (graph, classifier, epoch,
+ *           kernel) - all of a sweep shard's problems in one launch.  For a positive definite train block the result IS the
+ *           pseudo-inverse's; a non-positive pivot (rank-deficient block) is replaced by 1e-6 x the largest diagonal entry
+ *           where pinv would cut the direction (documented deviation).
+ * `train` / `val` index rows of K; `labels` is indexed like K's rows.
+ */
+typedef struct wdg_kr_job {
+    const float *K;         /* [n, n] kernel of all nodes (a wdg_gram_map_batched_f32 output), leading dimension ldk */
+    const int32_t *train;   /* [n_train] */
+    const int32_t *val;     /* [n_val] */
+    const int32_t *labels;  /* [n] */
+    int32_t *correct_out;   /* [1] */
+    int64_t ldk;
+    int32_t n_train, n_val, n_classes, reserved;
+} wdg_kr_job;
+int32_t wdg_kernel_regress_max_train(void);
+int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1130,6 +1130,73 @@ def test_gram_matches_oracle(ops, oracle):
     np.testing.assert_allclose(gram, oracle.gram(x, smp), rtol=1e-6, atol=1e-6)
 
 
+# --------------------------------------------------------------------------------------------- kernel-regression metric
+def _arccos_map(g, n_layers):
+    """the reference's map (utils/homophily_metrics.py:236-244) in numpy fp32"""
+    if n_layers != 1:
+        return g / 2
+    d = np.sqrt(np.diag(g))
+    nu = d[:, None] * d[None, :]
+    nu = np.where(nu > 1e-8, nu, np.float32(1e-8))
+    with np.errstate(invalid="ignore"):
+        ac = np.nan_to_num(np.arccos(g / nu), nan=0.0)
+        sq = np.nan_to_num(np.sqrt(nu * nu - g * g), nan=0.0)
+    return (np.float32(1 / np.pi) * (g * (np.float32(np.pi) - ac) + sq) / 2).astype(np.float32)
+
+
+def test_gram_map_fused_epilogue(ops, oracle):
+    """wdg_gram_map_batched_f32: K = map(A A^T) for all rows, linear and arc-cosine in one launch: the Gram part is the
+    k-ordered fp32 chain (bitwise = wdg_gemm_f32 with transb), the map within 2e-6 of the largest entry of numpy's fp32."""
+    rng = np.random.default_rng(12)
+    mats = [rng.random((n, f), dtype=np.float32) * (rng.random((n, f)) < 0.3) for n, f in ((300, 50), (1, 7), (130, 500), (257, 64))]
+    mats[0][5] = 0.0  # a zero row: nu clamps to 1e-8, acos(0 / 1e-8) = pi / 2
+    dev = [torch.from_numpy(a.astype(np.float32)).cuda() for a in mats]
+    gb = ops.GramBatch(dev)
+    gb.launch()
+    torch.cuda.synchronize()
+    for a, t, kl, ka in zip(mats, dev, gb.k_linear, gb.k_arccos):
+        g = _np(ops.gemm(t, t, transb=True))
+        assert np.array_equal(_np(kl), g / 2)
+        want = _arccos_map(g, 1)
+        np.testing.assert_allclose(_np(ka), want, rtol=2e-5, atol=2e-6 * max(float(np.abs(want).max()), 1e-30))
+    only = ops.GramBatch(dev[:1], linear=False)
+    only.launch()
+    torch.cuda.synchronize()
+    assert only.k_linear[0] is None and torch.equal(only.k_arccos[0], gb.k_arccos[0])
+
+
+@pytest.mark.parametrize("n,nt,nv,c", [(500, 300, 200, 5), (183, 110, 73, 5), (400, 320, 80, 8), (64, 33, 31, 2), (50, 1, 49, 3)])
+def test_kernel_regression_solver_against_lapack(ops, n, nt, nv, c):
+    """wdg_kernel_regress_batched_f32 on well-conditioned kernels: per problem, the number of validation rows whose arg-max
+    prediction is right must be within 2 rows of the host LAPACK path the reference takes (fp64 solve of the fp32 block)."""
+    rng = np.random.default_rng(n + nt)
+    problems, want = [], []
+    for p in range(6):
+        h = rng.standard_normal((n, 40)).astype(np.float32)
+        lab = rng.integers(0, c, n).astype(np.int32)
+        h += np.eye(c, 40, dtype=np.float32)[lab] * 2.0  # class signal: predictions are not coin flips
+        t = torch.from_numpy(h).cuda()
+        gb = ops.GramBatch([t], linear=False)
+        gb.launch()
+        k = gb.k_arccos[0]
+        kk = _np(k).astype(np.float64) + 0  # (the solver reads the same fp32 kernel)
+        perm = rng.permutation(n)
+        tr, va = np.sort(perm[:nt]).astype(np.int32), np.sort(perm[nt:nt + nv]).astype(np.int32)
+        alpha = np.linalg.pinv(kk[np.ix_(tr, tr)]) @ np.eye(c)[lab[tr]]
+        pred = (kk[np.ix_(va, tr)] @ alpha).argmax(1)
+        want.append(int((pred == lab[va]).sum()))
+        problems.append((k, torch.from_numpy(tr).cuda(), torch.from_numpy(va).cuda(), torch.from_numpy(lab).cuda()))
+    kb = ops.KrBatch(problems, c)
+    kb.launch()
+    torch.cuda.synchronize()
+    got = kb.correct[:len(problems)].cpu().numpy()
+    assert (np.abs(got - np.asarray(want)) <= 2).all(), (got, want)
+    kb.launch()  # relaunch: same answers
+    torch.cuda.synchronize()
+    assert np.array_equal(kb.correct[:len(problems)].cpu().numpy(), got)
+    assert ((got >= 0) & (got <= nv)).all() and np.mean(np.asarray(want)) > nv / c  # (the problems carry signal)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_spmm_fuzz_shapes_and_batches(ops, oracle, seed):
     """Random shapes through whatever family the plan picks: rectangular patterns, empty rows, ragged F, explicit values,

@@ -97,7 +97,22 @@ SIGNATURES = {
     "wdg_gemm_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
     "wdg_mlp2_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_las_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_gram_map_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    "wdg_kernel_regress_max_train": (c_int32, []),
+    "wdg_kernel_regress_batched_f32": (c_int, [c_void_p, c_int32, c_void_p]),
 }
+
+
+class GramJob(ctypes.Structure):
+    """mirror of `wdg_gram_job` (include/wdg.h)"""
+    _fields_ = [("A", c_void_p), ("norm2", c_void_p), ("K_linear", c_void_p), ("K_arccos", c_void_p), ("lda", c_int64),
+                ("ldk", c_int64), ("n", c_int32), ("F", c_int32)]
+
+
+class KrJob(ctypes.Structure):
+    """mirror of `wdg_kr_job` (include/wdg.h)"""
+    _fields_ = [("K", c_void_p), ("train", c_void_p), ("val", c_void_p), ("labels", c_void_p), ("correct_out", c_void_p),
+                ("ldk", c_int64), ("n_train", c_int32), ("n_val", c_int32), ("n_classes", c_int32), ("reserved", c_int32)]
 
 
 class LasJob(ctypes.Structure):

@@ -1,0 +1,373 @@
+// Kernel-regression metric on the device: the Gram / arc-cosine kernels of a whole graph in one MFMA
+// launch with the map fused as its epilogue, and a batched symmetric solver for the per-epoch regressions.
+//
+// replaces: gntk_homophily_ (utils/homophily_metrics.py:232-257, utils/homophily_plot.py:238-268) and the kernel-regression
+//           branch of classifier_based_performance_metric (utils/homophily_metrics.py:283-297, utils/homophily_plot.py:
+//           296-310: `K_val_train @ (np.linalg.pinv(K_train_train) @ onehot[idx_train])`, argmax, accuracy).
+//
+// The reference recomputes, in each of its 100 epochs, the aggregation, the Gram of the sampled rows and its arc-cosine map,
+// moves the kernels to the host and pseudo-inverts the train block with LAPACK (>95 % of the sweep's wall time, SURVEY.md
+// 3.3).  None of that depends on the epoch except WHICH rows are sampled: the map is elementwise in (G_ij, |h_i| |h_j|), so
+// the kernel of a sample is a sub-block of the kernel of all nodes.  Here:
+//   * gram_map_kernel   K = map(A A^T) for ALL nodes of a graph, once: the tile loop of gemm_f32_kernel (v_mfma_f32_32x32x2_f32,
+//                       the k-ordered fp32 fma chain) with the map as epilogue - linear (G / 2) and / or arc-cosine
+//                       ((G (pi - acos(G / nu)) + sqrt(nu^2 - G^2)) / (2 pi), nu = max(|h_i| |h_j|, 1e-8), NaN -> 0);
+//   * row_norm2_kernel  |h_i|^2 as the same fma chain (= the Gram's diagonal, bit for bit);
+//   * kr_solve_kernel   one workgroup per (graph, classifier, epoch, kernel) problem: gathers the train block K[tr, tr] from
+//                       the graph's kernel into REGISTERS (2-D cyclic over 32 x 32 threads, up to 320 x 320), factors it
+//                       (right-looking Cholesky, one LDS broadcast of the pivot column and one barrier per step), solves
+//                       for the one-hot labels, multiplies the validation rows through and counts correct arg-max
+//                       predictions.  For a symmetric positive definite block the Cholesky solution IS pinv(K) Y; pivots
+//                       that come out non-positive (a rank-deficient block: pinv would cut those directions) are
+//                       replaced by a ridge of 1e-6 x the largest diagonal entry - a documented deviation.
+#include <type_traits>
+
+#include "wdg_common.h"
+
+namespace {
+
+using namespace wdg;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------ row norms
+__global__ __launch_bounds__(256) void row_norm2_kernel(const wdg_gram_job *__restrict__ jobs, int max_n) {
+    const desc_ptr<wdg_gram_job> job = (desc_ptr<wdg_gram_job>)(jobs + blockIdx.y);
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= job->n) return;
+    const global_ptr<const float> a = to_global(job->A) + static_cast<int64_t>(row) * job->lda;
+    float acc = 0.f;
+    for (int k = 0; k < job->F; ++k) acc = fmaf(a[k], a[k], acc);  // the k-ordered chain of the MFMA: = G_ii
+    to_global(job->norm2)[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ Gram + map
+constexpr int GBM = 128, GBN = 64, GBK = 16, GTHREADS = 256;
+constexpr int GLD = GBK + 1;
+
+__global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *__restrict__ jobs) {
+    __shared__ float As[GBM * GLD];
+    __shared__ float Bs[GBN * GLD];
+    const desc_ptr<wdg_gram_job> job = (desc_ptr<wdg_gram_job>)(jobs + blockIdx.z);
+    const global_ptr<const float> A = to_global(job->A), norm2 = to_global(job->norm2);
+    const global_ptr<float> Klin = to_global(job->K_linear), Karc = to_global(job->K_arccos);
+    const int64_t lda = job->lda, ldk = job->ldk;
+    const int n = job->n, K = job->F;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
+    if (m0 >= n || n0 >= n) return;
+
+    constexpr int A_PER = GBM * GBK / GTHREADS, B_PER = GBN * GBK / GTHREADS;
+    float ra[A_PER], rb[B_PER];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int e = tid + i * GTHREADS, k = e % GBK, m = e / GBK;
+            const int gm = m0 + m, gk = k0 + k;
+            ra[i] = (gm < n && gk < K) ? A[static_cast<int64_t>(gm) * lda + gk] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int e = tid + i * GTHREADS, k = e % GBK, c = e / GBK;
+            const int gn = n0 + c, gk = k0 + k;
+            rb[i] = (gn < n && gk < K) ? A[static_cast<int64_t>(gn) * lda + gk] : 0.f;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int e = tid + i * GTHREADS;
+            As[(e / GBK) * GLD + e % GBK] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int e = tid + i * GTHREADS;
+            Bs[(e / GBK) * GLD + e % GBK] = rb[i];
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int li = lane & 31, lk = lane >> 5;
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += GBK) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + GBK < K) load_tiles(k0 + GBK);
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2) {
+            const float a = As[(wave * 32 + li) * GLD + kk + lk];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float b = Bs[(t * 32 + li) * GLD + kk + lk];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: C/D map of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const float pi = 3.14159265358979323846f;
+    const int row0 = m0 + wave * 32;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gn = n0 + t * 32 + li;
+        if (gn >= n) continue;
+        const float dn = Karc ? sqrtf(norm2[gn]) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = row0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (gm >= n) continue;
+            const float g = acc[t][r];
+            if (Klin) Klin[static_cast<int64_t>(gm) * ldk + gn] = g * 0.5f;
+            if (Karc) {
+                float nu = sqrtf(norm2[gm]) * dn;
+                nu = nu > 1e-8f ? nu : 1e-8f;
+                float ac = acosf(g / nu);
+                float sq = sqrtf(nu * nu - g * g);
+                ac = ac != ac ? 0.f : ac;
+                sq = sq != sq ? 0.f : sq;
+                Karc[static_cast<int64_t>(gm) * ldk + gn] = (1.f / pi) * (g * (pi - ac) + sq) * 0.5f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ batched kernel regression
+constexpr int KR_THREADS = 1024, KR_T = 32, KR_B = 10;  // 32 x 32 threads, 10 x 10 elements each: blocks of up to 320 x 320
+constexpr int KR_MAX_N = KR_T * KR_B, KR_MAX_C = 8;
+constexpr int KR_COL_LD = 12;  // a thread's 10 column values, padded to three ds_read_b128
+
+__global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *__restrict__ jobs) {
+    __shared__ float colbuf[2][KR_T * KR_COL_LD];     // the pivot column of a step, [i % 32][i / 32] (double-buffered)
+    __shared__ float rhs[KR_MAX_N * KR_MAX_C];        // one-hot labels -> y -> alpha, [i][c]
+    __shared__ int tr_idx[KR_MAX_N];
+    __shared__ float part[4][256][KR_MAX_C];          // partial predictions of the validation rows
+    __shared__ float bcast[KR_MAX_C + 2];
+    __shared__ int correct;
+
+    const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + blockIdx.x);
+    const global_ptr<const float> K = to_global(job->K);
+    const global_ptr<const int32_t> train = to_global(job->train), val = to_global(job->val), labels = to_global(job->labels);
+    const int64_t ldk = job->ldk;
+    const int nt = job->n_train, nv = job->n_val, C = job->n_classes;
+    const int tid = threadIdx.x, tc = tid & 31, trw = tid >> 5;
+    if (nt <= 0 || nt > KR_MAX_N || C <= 0 || C > KR_MAX_C) {
+        if (tid == 0 && job->correct_out) *to_global(job->correct_out) = -1;
+        return;
+    }
+    for (int i = tid; i < KR_MAX_N; i += KR_THREADS) tr_idx[i] = i < nt ? train[i] : -1;
+    for (int i = tid; i < KR_MAX_N * KR_MAX_C; i += KR_THREADS) {
+        const int row = i / KR_MAX_C, c = i % KR_MAX_C;
+        rhs[i] = (row < nt && labels[train[row]] == c) ? 1.f : 0.f;
+    }
+    if (tid == 0) correct = 0;
+    __syncthreads();
+
+    // ---- gather the train block's LOWER block triangle: thread (trw, tc) holds element (trw, tc) of every 32 x 32 block
+    //      (A, B) with A >= B - 55 registers (the strictly upper parts of the diagonal blocks ride along unused); element
+    //      (i, j) = (trw + 32 A, tc + 32 B); rows / columns beyond n_train: identity
+    constexpr int KR_TRI = KR_B * (KR_B + 1) / 2;
+    float m[KR_TRI];
+#define KR_M(A, B) m[(A) * ((A) + 1) / 2 + (B)]
+    float dmax = 0.f;
+#pragma unroll
+    for (int a = 0; a < KR_B; ++a) {
+        const int i = trw + KR_T * a;
+        const int gi = tr_idx[i];
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int j = tc + KR_T * b;
+            const int gj = tr_idx[j];
+            KR_M(a, b) = (gi >= 0 && gj >= 0) ? K[static_cast<int64_t>(gi) * ldk + gj] : (i == j ? 1.f : 0.f);
+            if (i == j && gi >= 0) dmax = fmaxf(dmax, KR_M(a, b));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one block row's gathers (and their addresses) in flight at a time
+    }
+    for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+    if ((tid & 63) == 0) part[0][tid >> 6][0] = dmax;
+    __syncthreads();
+    if (tid == 0) {
+        float d = 0.f;
+        for (int w = 0; w < KR_THREADS / 64; ++w) d = fmaxf(d, part[0][w][0]);
+        bcast[KR_MAX_C] = d;
+    }
+    __syncthreads();
+    const float ridge = 1e-6f * bcast[KR_MAX_C];
+
+    // ---- right-looking Cholesky: step k = 32 kb + kk; the owners of column k (tc == kk, their register column kb) publish
+    //      it, everyone reads the pivot, its 10 row values and its 10 column values, scales, and updates its 10 x 10 block
+    //      with the vectors masked to i > k / j > k (the finished columns of L stay untouched)
+    // (the block index of the pivot is a compile-time constant of each copy of the step - the register block is indexed
+    // statically or it would live in scratch)
+    auto chol_block = [&](auto kb_const) {
+        constexpr int kb = decltype(kb_const)::value;
+        if (kb * KR_T >= nt) return;  // (uniform; the identity padding needs no work)
+        for (int kk = 0; kk < KR_T; ++kk) {
+            const int k = kb * KR_T + kk;
+            float *cb = colbuf[k & 1];
+            if (tc == kk) {
+#pragma unroll
+                for (int a = 0; a < KR_B; ++a) cb[trw * KR_COL_LD + a] = a >= kb ? KR_M(a >= kb ? a : kb, kb) : 0.f;
+            }
+            __syncthreads();
+            float piv = cb[kk * KR_COL_LD + kb];
+            piv = piv > ridge ? piv : ridge;  // (a rank-deficient block: pinv would cut the direction; see the header)
+            const float inv = 1.f / sqrtf(piv);
+            float lj[KR_B];
+#pragma unroll
+            for (int b = 0; b < KR_B; ++b) lj[b] = (tc + KR_T * b) > k ? cb[tc * KR_COL_LD + b] * inv : 0.f;
+#pragma unroll
+            for (int a = 0; a < KR_B; ++a) {
+                if (a < kb) continue;  // (static after unrolling: rows above the pivot's block are finished)
+                const float li = (trw + KR_T * a) > k ? cb[trw * KR_COL_LD + a] * inv : 0.f;
+#pragma unroll
+                for (int b = 0; b <= a; ++b)
+                    if (b >= kb) KR_M(a, b) = fmaf(-li, lj[b], KR_M(a, b));
+                if (tc == kk) {  // column k of L: l_kk = sqrt(pivot), l_ik below it
+                    const int i = trw + KR_T * a;
+                    KR_M(a, kb) = i > k ? li : (i == k ? piv * inv : KR_M(a, kb));
+                }
+            }
+        }
+    };
+#define KR_EACH_BLOCK(F)                                                                                               \
+    F(std::integral_constant<int, 0>{}); F(std::integral_constant<int, 1>{}); F(std::integral_constant<int, 2>{});     \
+    F(std::integral_constant<int, 3>{}); F(std::integral_constant<int, 4>{}); F(std::integral_constant<int, 5>{});     \
+    F(std::integral_constant<int, 6>{}); F(std::integral_constant<int, 7>{}); F(std::integral_constant<int, 8>{});     \
+    F(std::integral_constant<int, 9>{});
+#define KR_EACH_BLOCK_DOWN(F)                                                                                          \
+    F(std::integral_constant<int, 9>{}); F(std::integral_constant<int, 8>{}); F(std::integral_constant<int, 7>{});     \
+    F(std::integral_constant<int, 6>{}); F(std::integral_constant<int, 5>{}); F(std::integral_constant<int, 4>{});     \
+    F(std::integral_constant<int, 3>{}); F(std::integral_constant<int, 2>{}); F(std::integral_constant<int, 1>{});     \
+    F(std::integral_constant<int, 0>{});
+    static_assert(KR_B == 10, "KR_EACH_BLOCK lists the ten blocks");
+    KR_EACH_BLOCK(chol_block)
+    __syncthreads();
+
+    // ---- forward substitution L y = B (column form): y_k = b_k / l_kk, then b_i -= l_ik y_k for i > k
+    auto fwd_block = [&](auto kb_const) {
+        constexpr int kb = decltype(kb_const)::value;
+        if (kb * KR_T >= nt) return;
+        for (int kk = 0; kk < KR_T; ++kk) {
+            const int k = kb * KR_T + kk;
+            if (tc == kk && trw == kk) {  // the owner of (k, k)
+                const float d = KR_M(kb, kb);
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) {
+                    const float y = rhs[k * KR_MAX_C + c] / d;
+                    rhs[k * KR_MAX_C + c] = y;
+                    bcast[c] = y;
+                }
+            }
+            __syncthreads();
+            if (tc == kk) {
+#pragma unroll
+                for (int a = 0; a < KR_B; ++a) {
+                    const int i = trw + KR_T * a;
+                    if (a >= kb && i > k && i < nt) {
+                        const float l = KR_M(a >= kb ? a : kb, kb);
+#pragma unroll
+                        for (int c = 0; c < KR_MAX_C; ++c) rhs[i * KR_MAX_C + c] = fmaf(-l, bcast[c], rhs[i * KR_MAX_C + c]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    KR_EACH_BLOCK(fwd_block)
+    // ---- backward substitution L^T alpha = y (row form): alpha_k = y_k / l_kk, then y_j -= l_kj alpha_k for j < k
+    auto bwd_block = [&](auto ka_const) {
+        constexpr int ka = decltype(ka_const)::value;
+        if (ka * KR_T >= nt) return;
+        for (int kk = KR_T - 1; kk >= 0; --kk) {
+            const int k = ka * KR_T + kk;
+            if (k >= nt) continue;  // uniform
+            if (tc == kk && trw == kk) {
+                const float d = KR_M(ka, ka);
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) {
+                    const float al = rhs[k * KR_MAX_C + c] / d;
+                    rhs[k * KR_MAX_C + c] = al;
+                    bcast[c] = al;
+                }
+            }
+            __syncthreads();
+            if (trw == kk) {  // the owners of row k of L
+#pragma unroll
+                for (int b = 0; b < KR_B; ++b) {
+                    const int j = tc + KR_T * b;
+                    if (b <= ka && j < k) {
+                        const float l = KR_M(ka, b <= ka ? b : ka);
+#pragma unroll
+                        for (int c = 0; c < KR_MAX_C; ++c) rhs[j * KR_MAX_C + c] = fmaf(-l, bcast[c], rhs[j * KR_MAX_C + c]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    KR_EACH_BLOCK_DOWN(bwd_block)
+
+    // ---- predictions of the validation rows: p_v = sum_t K[val_v, train_t] alpha_t, arg-max, count the hits
+    for (int v0 = 0; v0 < nv; v0 += 256) {
+        const int v = v0 + (tid & 255), q = tid >> 8;  // four threads per validation row, a quarter of the train rows each
+        float p[KR_MAX_C];
+#pragma unroll
+        for (int c = 0; c < KR_MAX_C; ++c) p[c] = 0.f;
+        if (v < nv) {
+            const global_ptr<const float> krow = K + static_cast<int64_t>(val[v]) * ldk;
+            const int per = (nt + 3) / 4, t0 = q * per, t1 = min(nt, t0 + per);
+            for (int t = t0; t < t1; ++t) {
+                const float kv = krow[tr_idx[t]];
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) p[c] = fmaf(kv, rhs[t * KR_MAX_C + c], p[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KR_MAX_C; ++c) part[q][tid & 255][c] = p[c];
+        __syncthreads();
+        if (q == 0 && v < nv) {
+            int best = 0;
+            float bv = -3.4e38f;
+            for (int c = 0; c < C; ++c) {
+                const float s = ((part[0][tid][c] + part[1][tid][c]) + part[2][tid][c]) + part[3][tid][c];
+                if (s > bv) {  // first maximum, like torch.argmax
+                    bv = s;
+                    best = c;
+                }
+            }
+            if (best == labels[val[v]]) atomicAdd(&correct, 1);
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && job->correct_out) *to_global(job->correct_out) = correct;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_n >= 0, "gram_map_batched: negative size");
+    if (n_jobs == 0 || max_n == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "gram_map_batched: null job table");
+    hipStream_t st = wdg::as_stream(stream);
+    hipLaunchKernelGGL(row_norm2_kernel, dim3(wdg::ceil_div(max_n, 256), n_jobs), dim3(256), 0, st, jobs_dev, max_n);
+    hipLaunchKernelGGL(gram_map_kernel, dim3(wdg::ceil_div(max_n, GBM), wdg::ceil_div(max_n, GBN), n_jobs), dim3(GTHREADS), 0, st,
+                       jobs_dev);
+    return wdg::check_launch("gram_map_kernel");
+}
+
+int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0, "kernel_regress_batched: negative size");
+    if (n_jobs == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "kernel_regress_batched: null job table");
+    hipLaunchKernelGGL(kr_solve_kernel, dim3(n_jobs), dim3(KR_THREADS), 0, wdg::as_stream(stream), jobs_dev);
+    return wdg::check_launch("kr_solve_kernel");
+}
+
+int32_t wdg_kernel_regress_max_train(void) { return KR_MAX_N; }
+
+}  // extern "C"

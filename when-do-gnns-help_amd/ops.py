@@ -731,6 +731,66 @@ class Mlp2Batch:
                                        stream_handle()), "wdg_mlp2_batched_f32")
 
 
+# ------------------------------------------------------------------------------------------- kernel-regression metric
+def _table(arr):
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(require_gpu()) if len(arr) else torch.empty(0, dtype=torch.uint8)
+
+
+class GramBatch:
+    """Job table for wdg_gram_map_batched_f32: K = map(A A^T) of every A of a batch (all nodes), linear and / or arc-cosine."""
+
+    def __init__(self, mats, linear=True, arccos=True):
+        """mats: list of A [n, F] fp32 device tensors (unit inner stride) -> self.k_linear[i], self.k_arccos[i] ([n, n] or None)"""
+        dev = require_gpu()
+        self.keep = mats
+        self.n_jobs = len(mats)
+        self.max_n = max([a.shape[0] for a in mats], default=0)
+        self.norm2 = [torch.empty(a.shape[0], dtype=torch.float32, device=dev) for a in mats]
+        self.k_linear = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if linear else None for a in mats]
+        self.k_arccos = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if arccos else None for a in mats]
+        arr = (_lib.GramJob * self.n_jobs)()
+        for job, a, n2, kl, ka in zip(arr, mats, self.norm2, self.k_linear, self.k_arccos):
+            if a.dtype != torch.float32 or a.stride(1) != 1:
+                raise ValueError("GramBatch: A must be fp32 with unit inner stride")
+            job.A, job.norm2 = a.data_ptr(), n2.data_ptr()
+            job.K_linear = 0 if kl is None else kl.data_ptr()
+            job.K_arccos = 0 if ka is None else ka.data_ptr()
+            job.lda, job.ldk, job.n, job.F = _ld(a), a.shape[0], a.shape[0], a.shape[1]
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_gram_map_batched_f32(_ptr(self.table), self.n_jobs, self.max_n, stream_handle()), "wdg_gram_map_batched_f32")
+
+
+class KrBatch:
+    """Job table for wdg_kernel_regress_batched_f32: many (kernel, train rows, validation rows) problems in one launch."""
+
+    MAX_TRAIN = 320
+
+    def __init__(self, problems, n_classes):
+        """problems: list of (K [n, n] fp32 device, train int32 device [nt], val int32 device [nv], labels int32 device [n])
+        -> self.correct [n_problems] int32 after launch()"""
+        dev = require_gpu()
+        self.keep = problems
+        self.n_jobs = len(problems)
+        self.correct = torch.zeros(max(self.n_jobs, 1), dtype=torch.int32, device=dev)
+        self.n_val = torch.tensor([p[2].shape[0] for p in problems], dtype=torch.float32, device=dev)
+        arr = (_lib.KrJob * self.n_jobs)()
+        for i, (job, (k, tr, va, lab)) in enumerate(zip(arr, problems)):
+            if tr.shape[0] > self.MAX_TRAIN:
+                raise ValueError(f"KrBatch: {tr.shape[0]} train rows, the solver holds blocks of <= {self.MAX_TRAIN}")
+            job.K, job.train, job.val, job.labels = k.data_ptr(), tr.data_ptr(), va.data_ptr(), lab.data_ptr()
+            job.correct_out = self.correct.data_ptr() + 4 * i
+            job.ldk, job.n_train, job.n_val, job.n_classes = _ld(k), tr.shape[0], va.shape[0], int(n_classes)
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")
+
+    def accuracy(self):
+        return self.correct[:self.n_jobs].to(torch.float32) / self.n_val
+
+
 # ------------------------------------------------------------------------------------------- per-edge cosine
 def edge_cosine(g, x, entries=None, skip_self=True):
     """fp32 cosine similarity of the endpoints of every stored entry (or of the listed entry ids); wdg_edge_cosine_f32."""
