@@ -393,14 +393,35 @@ typedef struct wdg_gram_job {
 int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream);
 
 /*
+ * Generalized edge homophily from a Gram: mean over the stored non-loop entries (u, v) of cos(x_u, x_v) = 2 K_linear[u, v] /
+ * sqrt(norm2[u] norm2[v]) (NaN -> 0), K_linear / norm2 = a wdg_gram_map_batched_f32 output of the feature matrix.
+ * replaces: generalized_edge_homophily utils/homophily_plot.py:56-66 (utils/homophily_metrics.py:164-187, below sample_max):
+ *           the dense N x N sklearn cosine matrix masked by the adjacency.  Deterministic (fixed summation order).
+ * workspace: wdg_edge_gram_workspace_bytes(n_jobs, max_rows).
+ */
+typedef struct wdg_edge_gram_job {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const float *K_linear; /* [n, n] = X X^T / 2 */
+    const float *norm2;    /* [n] |x_i|^2 */
+    double *mean_out;      /* [1] */
+    int64_t ldk;
+    int32_t n_rows, reserved;
+} wdg_edge_gram_job;
+size_t wdg_edge_gram_workspace_bytes(int32_t n_jobs, int32_t max_rows);
+int wdg_edge_gram_mean_batched_f32(const wdg_edge_gram_job *jobs_dev, int32_t n_jobs, int32_t max_rows, void *workspace,
+                                   size_t workspace_bytes, wdg_stream_t stream);
+
+/*
  * Batched kernel regression: for every job, alpha = K[train, train]^-1 onehot(labels[train]) by a register-resident Cholesky
  * factorisation (n_train <= wdg_kernel_regress_max_train() = 320, n_classes <= 8), predictions K[val, train] alpha, and
  * *correct_out = #{v in val : argmax_c prediction == labels[v]} (first maximum, like torch.argmax); -1 for shapes out of range.
  * replaces: `K_val_train @ (np.linalg.pinv(K_train_train) @ label_onehot[idx_train])`, `.argmax(1).eq(labels[idx_val])`
  *           utils/homophily_metrics.py:283-297 (utils/homophily_plot.py:296-310), once per (graph, classifier, epoch,
  *           kernel) - all of a sweep shard's problems in one launch.  For a positive definite train block the result IS the
- *           pseudo-inverse's; a non-positive pivot (rank-deficient block) is replaced by 1e-6 x the largest diagonal entry
- *           where pinv would cut the direction (documented deviation).
+ *           pseudo-inverse's; when a pivot falls to rounding level (<= n eps max K_ii: rank-deficient block, duplicate nodes)
+ *           the block is refactored once as K + 8 n eps max K_ii I - the pseudo-inverse's least-squares predictions to within
+ *           rounding (documented deviation in the coefficients).
  * `train` / `val` index rows of K; `labels` is indexed like K's rows.
  */
 typedef struct wdg_kr_job {

@@ -162,10 +162,11 @@ def test_classifier_metric_seeded(mods, name, clf):
 
 @pytest.mark.parametrize("clf", ["kernel_reg1", "kernel_reg0"])
 def test_classifier_metric_device_solver(mods, clf):
-    """solver="device" (SURVEY.md 8(f) N1): batched symmetric-eigendecomposition pseudo-inverse on the GPU.  Same splits
-    as the host solver (same torch CPU RNG stream); with the well-conditioned arc-cosine kernel the per-epoch
-    accuracies match the host LAPACK path to a few validation nodes, the rank-deficient linear kernel only has to
-    produce a valid p-value (both solvers invert rounding noise there)."""
+    """solver="device" (the default): kernels of all nodes from the fused Gram + map launch, every epoch's
+    regressions in one launch of the register-resident Cholesky solver.  Same node sets as the host solver (same torch CPU
+    RNG stream); with the well-conditioned arc-cosine kernel the per-epoch accuracies match the host LAPACK path to a few
+    validation nodes, the rank-deficient linear kernel only has to produce a valid p-value (the host path inverts its
+    rounding noise there, the device path regularises the non-positive pivots)."""
     _, hm, _ = mods
     g0 = load("real_texas")
     adj_raw, features, labels = _raw(g0)
@@ -175,11 +176,15 @@ def test_classifier_metric_device_solver(mods, clf):
         accs = []
         orig = hm.accuracy
         hm.accuracy = lambda lab, out, _o=orig, _a=accs: (_a.append(float(_o(lab, out))), _o(lab, out))[1]
+        hm.LAST_KR_ACCURACIES = None
         try:
             p, secs = hm.classifier_based_performance_metric(features, adj_raw, labels, 200.0, base_classifier=clf, epochs=6,
                                                              solver=solver)
         finally:
             hm.accuracy = orig
+        if solver == "device":
+            assert not accs and hm.LAST_KR_ACCURACIES is not None  # (no host regression ran)
+            accs = hm.LAST_KR_ACCURACIES.reshape(-1).tolist()
         assert 0.0 <= p <= 1.0 and secs > 0 and len(accs) == 12
         seen[solver] = (p, np.array(accs))
     if clf == "kernel_reg1":

@@ -19,7 +19,7 @@ def test_sweep_step_against_oracle(oracle, symmetric, fused_mlp, ride_labels, mo
     batch.step()  # relaunch must give the same answers (counters re-zeroed)
     torch.cuda.synchronize()
     rows = batch.results().cpu().numpy()
-    assert rows.shape == (len(jobs), len(sweep.METRIC_NAMES))
+    assert rows.shape == (len(jobs), sweep.STEP_METRICS) and len(sweep.METRIC_NAMES) == 9
     assert (batch.spmm_las is None) == (ride_labels == "1") and batch.agg_feat == (112 if ride_labels == "1" else 96)
     for i, j in enumerate(jobs):
         src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
@@ -164,6 +164,49 @@ def test_full_c3_sweep_shard_on_the_quad_kernel(oracle, seeds):
         np.testing.assert_allclose(sb.h_las[i].cpu().numpy(), h_ref, rtol=1e-5, atol=1e-6)
 
 
+def test_sweep_all_nine_scalars_against_golden():
+    """The batched sweep job - all nine scalars of synthetic_plot.py:94-109 - on the reference's own `data_synthesis` fixtures
+    (five graphs, one batch): the six counter-based metrics, generalized edge homophily (gathered from the features' Gram) and
+    the kernel-regression p-values KR_L / KR_NL (kernels of all nodes in one fused MFMA launch, every (graph, classifier,
+    epoch, kernel) regression in one launch of the register-resident Cholesky solver) against the golden scalars the real
+    reference produced (seed 5, 4 epochs, sample_max 500; node sets drawn with the reference's RNG routine)."""
+    from _golden import SYN, dense_features, load
+    from wdg_amd import sweep
+    from wdg_amd.utils import util_funcs as uf
+    names = SYN
+    jobs, inputs, gold = [], [], []
+    for i, name in enumerate(names):
+        g0 = load(name)
+        n = int(g0["n_nodes"])
+        x = uf.preprocess_features(torch.from_numpy(dense_features(g0))).cpu().numpy()  # synthetic_plot.py:81-83
+        k = 10 if "_4000_" in name else 2
+        jobs.append(sweep.Job(float(name.split("_")[2]), 100 + i, k, n, int(g0["labels"].max()) + 1))
+        inputs.append((g0["adj_row"].astype(np.int64), g0["adj_col"].astype(np.int64), g0["labels"], x))
+        gold.append(g0)
+    sb = sweep.SweepBatch(jobs, n_feat=inputs[0][3].shape[1], gcn_hidden=0, inputs=inputs)
+    sb.prepare_full(epochs=4, sample_max=500, seed_of=lambda ji, clf: 5)
+    sb.step()
+    sb.launch_full()
+    torch.cuda.synchronize()
+    rows = sb.full_metrics().numpy()
+    assert rows.shape == (len(jobs), 9)
+    for r, g0, j in zip(rows, gold, jobs):
+        assert r[0] == pytest.approx(float(g0["m_edge_homo"]), rel=1e-6)
+        assert r[1] == pytest.approx(float(g0["m_node_homo"]), rel=1e-6)
+        assert r[2] == pytest.approx(float(g0["m_class_homo"]), rel=1e-5, abs=1e-7)
+        assert r[3] == pytest.approx(float(g0["m_adj_homo"]), rel=1e-4, abs=2e-7)
+        assert r[4] == pytest.approx(float(g0["m_label_info"]), rel=2e-3, abs=2e-6)
+        assert abs(r[5] - float(g0["m_soft_las"])) <= 2.01 / j.n_nodes
+        assert r[6] == pytest.approx(float(g0["m_ge_homo"]), rel=2e-5)
+        # p-values of a Welch test over 4 epochs: a single validation node decided differently moves them; same order of
+        # magnitude bound as the per-graph API test (tests/test_gpu_api.py)
+        assert abs(r[7] - float(g0["m_cpm_kernel_reg0_seed5_e4_s500"])) <= 0.15
+        assert abs(r[8] - float(g0["m_cpm_kernel_reg1_seed5_e4_s500"])) <= 0.15
+    # the accuracies behind the p-values: every (job, classifier, epoch, kernel) regression ran and is a plausible accuracy
+    acc = sb.kr.accuracy().cpu().numpy()
+    assert acc.shape == (len(jobs) * 2 * 4 * 2,) and (acc >= 0.0).all() and (acc <= 1.0).all() and acc.max() > 0.5
+
+
 def test_sweep_exchange_under_an_initialised_process_group(tmp_path):
     """SweepBatch + broadcast_jobs + gather_results together under an initialised `nccl` (= RCCL) process group - world size 1,
     what a one-GPU box can run; the world-size-2 logic is covered with gloo in tests/test_sweep_dist.py."""
@@ -199,7 +242,7 @@ dist.destroy_process_group()
     import json
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])  # (RCCL prints its library path, too)
     from wdg_amd import sweep, synth
-    assert out["jobs"] == 8 and out["rows"] == [8, len(sweep.METRIC_NAMES)]
+    assert out["jobs"] == 8 and out["rows"] == [8, sweep.STEP_METRICS]
     want = [10 / int(10 / h) for h in synth.H_LEVELS_10_K10[:4]] * 2  # edge homophily of the generator: k / int(k / h)
     np.testing.assert_allclose(out["edge_homo"], want, rtol=1e-6)
 

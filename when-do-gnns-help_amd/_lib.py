@@ -99,6 +99,8 @@ SIGNATURES = {
     "wdg_las_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_gram_map_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "wdg_kernel_regress_max_train": (c_int32, []),
+    "wdg_edge_gram_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "wdg_edge_gram_mean_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "wdg_kernel_regress_batched_f32": (c_int, [c_void_p, c_int32, c_void_p]),
 }
 
@@ -107,6 +109,12 @@ class GramJob(ctypes.Structure):
     """mirror of `wdg_gram_job` (include/wdg.h)"""
     _fields_ = [("A", c_void_p), ("norm2", c_void_p), ("K_linear", c_void_p), ("K_arccos", c_void_p), ("lda", c_int64),
                 ("ldk", c_int64), ("n", c_int32), ("F", c_int32)]
+
+
+class EdgeGramJob(ctypes.Structure):
+    """mirror of `wdg_edge_gram_job` (include/wdg.h)"""
+    _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("K_linear", c_void_p), ("norm2", c_void_p), ("mean_out", c_void_p),
+                ("ldk", c_int64), ("n_rows", c_int32), ("reserved", c_int32)]
 
 
 class KrJob(ctypes.Structure):

@@ -17,9 +17,10 @@
 //                       the graph's kernel into REGISTERS (2-D cyclic over 32 x 32 threads, up to 320 x 320), factors it
 //                       (right-looking Cholesky, one LDS broadcast of the pivot column and one barrier per step), solves
 //                       for the one-hot labels, multiplies the validation rows through and counts correct arg-max
-//                       predictions.  For a symmetric positive definite block the Cholesky solution IS pinv(K) Y; pivots
-//                       that come out non-positive (a rank-deficient block: pinv would cut those directions) are
-//                       replaced by a ridge of 1e-6 x the largest diagonal entry - a documented deviation.
+//                       predictions.  For a symmetric positive definite block the Cholesky solution IS pinv(K) Y; when a pivot
+//                       falls to rounding level (<= n eps max K_ii: a rank-deficient block, e.g. duplicate nodes) the block
+//                       is refactored once with a ridge at that level: the least-squares answer of the pseudo-inverse to
+//                       within rounding in the predictions - a documented deviation in the coefficients.
 #include <type_traits>
 
 #include "wdg_common.h"
@@ -134,6 +135,65 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
     }
 }
 
+// ------------------------------------------------------------------------------------------------ mean edge cosine from a Gram
+// generalized edge homophily (utils/homophily_plot.py:56-66, utils/homophily_metrics.py:164-187) when the features' Gram is at
+// hand anyway (the kernel-regression metric computes K_linear = X X^T / 2 per feature matrix): cos(x_u, x_v) =
+// G_uv / (|x_u| |x_v|) gathered per stored non-loop entry - no N x N cosine matrix, no per-edge dot products.
+// Fixed summation order: a wave's shuffle tree per row, then rows in index order per thread and an LDS tree per graph.
+__global__ __launch_bounds__(256) void edge_gram_rows_kernel(const wdg_edge_gram_job *__restrict__ jobs, int max_rows,
+                                                             float *__restrict__ row_sum, int32_t *__restrict__ row_cnt) {
+    const desc_ptr<wdg_edge_gram_job> job = (desc_ptr<wdg_edge_gram_job>)(jobs + blockIdx.y);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= job->n_rows) return;  // (whole waves)
+    const global_ptr<const int32_t> rowptr = to_global(job->rowptr), col = to_global(job->col);
+    const global_ptr<const float> K = to_global(job->K_linear), n2 = to_global(job->norm2);
+    const int s = rowptr[row], e = rowptr[row + 1];
+    const float nu = sqrtf(n2[row]);
+    float acc = 0.f;
+    int cnt = 0;
+    for (int p = s + lane; p < e; p += 64) {
+        const int c = col[p];
+        if (c == row) continue;
+        const float den = nu * sqrtf(n2[c]);
+        float v = 2.f * K[static_cast<int64_t>(row) * job->ldk + c] / den;
+        v = (v != v || den == 0.f) ? 0.f : v;  // NaN -> 0 (a zero feature row)
+        acc += v;
+        ++cnt;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    if (lane == 0) {
+        row_sum[static_cast<int64_t>(blockIdx.y) * max_rows + row] = acc;
+        row_cnt[static_cast<int64_t>(blockIdx.y) * max_rows + row] = cnt;
+    }
+}
+__global__ __launch_bounds__(256) void edge_gram_reduce_kernel(const wdg_edge_gram_job *__restrict__ jobs, int max_rows,
+                                                               const float *__restrict__ row_sum,
+                                                               const int32_t *__restrict__ row_cnt) {
+    __shared__ double ssum[256];
+    __shared__ long long scnt[256];
+    const desc_ptr<wdg_edge_gram_job> job = (desc_ptr<wdg_edge_gram_job>)(jobs + blockIdx.x);
+    double a = 0.0;
+    long long c = 0;
+    for (int r = threadIdx.x; r < job->n_rows; r += 256) {
+        a += static_cast<double>(row_sum[static_cast<int64_t>(blockIdx.x) * max_rows + r]);
+        c += row_cnt[static_cast<int64_t>(blockIdx.x) * max_rows + r];
+    }
+    ssum[threadIdx.x] = a;
+    scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + o];
+            scnt[threadIdx.x] += scnt[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *to_global(job->mean_out) = scnt[0] > 0 ? ssum[0] / static_cast<double>(scnt[0]) : 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------ batched kernel regression
 constexpr int KR_THREADS = 1024, KR_T = 32, KR_B = 10;  // 32 x 32 threads, 10 x 10 elements each: blocks of up to 320 x 320
 constexpr int KR_MAX_N = KR_T * KR_B, KR_MAX_C = 8;
@@ -143,6 +203,7 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
     __shared__ float colbuf[2][KR_T * KR_COL_LD];     // the pivot column of a step, [i % 32][i / 32] (double-buffered)
     __shared__ float rhs[KR_MAX_N * KR_MAX_C];        // one-hot labels -> y -> alpha, [i][c]
     __shared__ int tr_idx[KR_MAX_N];
+    __shared__ int deficient;                         // a pivot fell to rounding level: redo on K + lambda I
     __shared__ float part[4][256][KR_MAX_C];          // partial predictions of the validation rows
     __shared__ float bcast[KR_MAX_C + 2];
     __shared__ int correct;
@@ -171,6 +232,8 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
     constexpr int KR_TRI = KR_B * (KR_B + 1) / 2;
     float m[KR_TRI];
 #define KR_M(A, B) m[(A) * ((A) + 1) / 2 + (B)]
+    float ridge = 0.f;  // second attempt only (below)
+    for (int attempt = 0; attempt < 2; ++attempt) {
     float dmax = 0.f;
 #pragma unroll
     for (int a = 0; a < KR_B; ++a) {
@@ -181,7 +244,10 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
             const int j = tc + KR_T * b;
             const int gj = tr_idx[j];
             KR_M(a, b) = (gi >= 0 && gj >= 0) ? K[static_cast<int64_t>(gi) * ldk + gj] : (i == j ? 1.f : 0.f);
-            if (i == j && gi >= 0) dmax = fmaxf(dmax, KR_M(a, b));
+            if (i == j && gi >= 0) {
+                dmax = fmaxf(dmax, KR_M(a, b));
+                KR_M(a, b) += ridge;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);  // one block row's gathers (and their addresses) in flight at a time
     }
@@ -194,7 +260,14 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
         bcast[KR_MAX_C] = d;
     }
     __syncthreads();
-    const float ridge = 1e-6f * bcast[KR_MAX_C];
+    // A pivot at rounding level (<= n eps max_i K_ii, the usual rank tolerance: the row is a combination of earlier ones -
+    // duplicate nodes, a rank-deficient kernel) means the block is not positive definite in fp32.  The pseudo-inverse
+    // answers such a system in the least-squares sense; so does, to the same predictions within rounding, the ridge system
+    // (K + lambda I) alpha = Y with lambda at that tolerance (for a PSD kernel the validation rows annihilate the null
+    // space of the train block): the factorisation is redone ONCE on K + 8 n eps max K_ii I, pivots clamped to lambda.
+    const float drop_below = static_cast<float>(nt) * 1.1920929e-7f * bcast[KR_MAX_C];
+    if (tid == 0) deficient = 0;
+    __syncthreads();
 
     // ---- right-looking Cholesky: step k = 32 kb + kk; the owners of column k (tc == kk, their register column kb) publish
     //      it, everyone reads the pivot, its 10 row values and its 10 column values, scales, and updates its 10 x 10 block
@@ -213,7 +286,9 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
             }
             __syncthreads();
             float piv = cb[kk * KR_COL_LD + kb];
-            piv = piv > ridge ? piv : ridge;  // (a rank-deficient block: pinv would cut the direction; see the header)
+            const bool low = !(piv > drop_below) && k < nt;  // (also catches NaN)
+            if (low && tid == 0) deficient = 1;
+            piv = low ? fmaxf(ridge, drop_below) : piv;
             const float inv = 1.f / sqrtf(piv);
             float lj[KR_B];
 #pragma unroll
@@ -245,6 +320,10 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
     static_assert(KR_B == 10, "KR_EACH_BLOCK lists the ten blocks");
     KR_EACH_BLOCK(chol_block)
     __syncthreads();
+    if (!deficient || attempt == 1) break;  // (uniform)
+    ridge = 8.f * drop_below;
+    __syncthreads();
+    }  // attempt
 
     // ---- forward substitution L y = B (column form): y_k = b_k / l_kk, then b_i -= l_ik y_k for i > k
     auto fwd_block = [&](auto kb_const) {
@@ -369,5 +448,27 @@ int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, w
 }
 
 int32_t wdg_kernel_regress_max_train(void) { return KR_MAX_N; }
+
+size_t wdg_edge_gram_workspace_bytes(int32_t n_jobs, int32_t max_rows) {
+    return static_cast<size_t>(n_jobs > 0 ? n_jobs : 0) * static_cast<size_t>(max_rows > 0 ? max_rows : 0) * 8 + 512;
+}
+
+int wdg_edge_gram_mean_batched_f32(const wdg_edge_gram_job *jobs_dev, int32_t n_jobs, int32_t max_rows, void *workspace,
+                                   size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0, "edge_gram_mean_batched: negative size");
+    if (n_jobs == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "edge_gram_mean_batched: null job table");
+    if (!workspace || workspace_bytes < wdg_edge_gram_workspace_bytes(n_jobs, max_rows))
+        return wdg::fail(WDG_ERR_WORKSPACE, "edge_gram_mean_batched: workspace too small");
+    hipStream_t st = wdg::as_stream(stream);
+    char *ws = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+    float *row_sum = reinterpret_cast<float *>(ws);
+    int32_t *row_cnt = reinterpret_cast<int32_t *>(ws + static_cast<size_t>(n_jobs) * max_rows * 4);
+    if (max_rows > 0)
+        hipLaunchKernelGGL(edge_gram_rows_kernel, dim3(wdg::ceil_div(max_rows, 4), n_jobs), dim3(256), 0, st, jobs_dev, max_rows,
+                           row_sum, row_cnt);
+    hipLaunchKernelGGL(edge_gram_reduce_kernel, dim3(n_jobs), dim3(256), 0, st, jobs_dev, max_rows, row_sum, row_cnt);
+    return wdg::check_launch("edge_gram_mean");
+}
 
 }  // extern "C"

@@ -762,6 +762,31 @@ class GramBatch:
         check(lib.wdg_gram_map_batched_f32(_ptr(self.table), self.n_jobs, self.max_n, stream_handle()), "wdg_gram_map_batched_f32")
 
 
+class EdgeGramBatch:
+    """Job table for wdg_edge_gram_mean_batched_f32: mean edge cosine (generalized edge homophily) of many graphs from the Grams
+    of their feature matrices."""
+
+    def __init__(self, problems):
+        """problems: list of (CsrGraph, K_linear [n, n], norm2 [n]) -> self.mean [n_problems] fp64 after launch()"""
+        dev = require_gpu()
+        self.keep = problems
+        self.n_jobs = len(problems)
+        self.max_rows = max([p[0].n_rows for p in problems], default=0)
+        self.mean = torch.zeros(max(self.n_jobs, 1), dtype=torch.float64, device=dev)
+        self.ws_bytes = lib.wdg_edge_gram_workspace_bytes(self.n_jobs, self.max_rows)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        arr = (_lib.EdgeGramJob * self.n_jobs)()
+        for i, (job, (g, k, n2)) in enumerate(zip(arr, problems)):
+            job.rowptr, job.col, job.K_linear, job.norm2 = g.rowptr.data_ptr(), g.col.data_ptr(), k.data_ptr(), n2.data_ptr()
+            job.mean_out = self.mean.data_ptr() + 8 * i
+            job.ldk, job.n_rows = _ld(k), g.n_rows
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_edge_gram_mean_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, _ptr(self.ws), self.ws_bytes,
+                                                 stream_handle()), "wdg_edge_gram_mean_batched_f32")
+
+
 class KrBatch:
     """Job table for wdg_kernel_regress_batched_f32: many (kernel, train rows, validation rows) problems in one launch."""
 

@@ -18,7 +18,10 @@ import torch
 
 from . import synth
 
-METRIC_NAMES = ("edge_homo", "node_homo", "class_homo", "adj_homo", "label_info", "soft_las")
+# the nine scalars of a sweep job (synthetic_plot.py:94-109).  results() returns the first six (one integer pass + LAS: what
+# a bench step computes); full_metrics() adds generalized edge homophily and the two kernel-regression p-values
+METRIC_NAMES = ("edge_homo", "node_homo", "class_homo", "adj_homo", "label_info", "soft_las", "ge_homo", "kr_l", "kr_nl")
+STEP_METRICS = 6
 
 
 @dataclass(frozen=True)
@@ -95,10 +98,14 @@ def gather_results(local_rows, device):
 class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
-    def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64):
+    def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None):
+        """jobs: list of Job (graph + features come from the generator of synth.py) - or, with `inputs`, a list of the same
+        length of (src, dst, labels, features [n, n_feat] fp32 numpy) tuples to run instead (real / fixture graphs; jobs that
+        share a feature matrix must pass the same array object and carry the same `seed`)."""
         from . import ops
         self.ops = ops
         self.jobs = list(jobs)
+        self.inputs = inputs
         dev = ops.require_gpu()
         self.n_feat = n_feat
         n_classes = max([j.n_classes for j in self.jobs], default=0)
@@ -114,10 +121,15 @@ class SweepBatch:
         self.alg_feat = n_feat + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
         feats, self.graphs, self.dinv, self.labels, self.y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
-        for j in self.jobs:
-            src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+        for ji, j in enumerate(self.jobs):
+            if inputs is not None:
+                src, dst, lab, x_host = inputs[ji]
+                lab = np.asarray(lab)
+            else:
+                src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+                x_host = None
             if j.seed not in feats:
-                x = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed)).to(dev)
+                x = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed) if x_host is None else np.ascontiguousarray(x_host, np.float32)).to(dev)
                 if ride:
                     xa = torch.zeros((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev)
                     xa[:, :n_feat] = x
@@ -294,6 +306,57 @@ class SweepBatch:
         li = 2 - (pc * torch.log(pc)).sum((1, 2)) / (p_bar * torch.log(p_bar)).sum(1)
         soft_las = self.las.counts[:, 0].to(torch.float32) / self.las.n
         return torch.stack([edge, node, cls, adj, li, soft_las], 1)
+
+    # -- the remaining three scalars: generalized edge homophily + the kernel-regression p-values ------
+    def prepare_full(self, epochs=100, sample_max=500, seed_of=None):
+        """Set up the batched kernel-regression metric for every job: the Gram / arc-cosine kernels of the aggregated features
+        (per job) and of the raw features (per feature matrix) - all nodes, once -, and, per job x classifier (kernel_reg0 /
+        kernel_reg1) x epoch, the train / validation node sets of the reference's sampling routine drawn on the host with
+        torch.manual_seed(seed_of(job index, classifier index)) (default 1000 job + classifier); both kernels of an epoch
+        share its node sets.  One-time per batch: the node sets are inputs like the graphs."""
+        from .utils.util_funcs import kernel_regression_epoch_indices
+        ops = self.ops
+        dev = self.graphs[0].device if self.graphs else ops.require_gpu()
+        seeds = list(self.x)
+        self.kr_epochs, self.kr_sample_max = epochs, sample_max
+        # kernels: [aggregated features of every job] + [raw features of every feature matrix], linear and arc-cosine
+        self.gram = ops.GramBatch([self.y[i] for i in range(len(self.jobs))] + [self.x[s] for s in seeds])
+        x_slot = {s: len(self.jobs) + i for i, s in enumerate(seeds)}
+        self.ge = ops.EdgeGramBatch([(g, self.gram.k_linear[x_slot[j.seed]], self.gram.norm2[x_slot[j.seed]])
+                                     for j, g in zip(self.jobs, self.graphs)])
+        seed_of = seed_of or (lambda ji, clf: 1000 * ji + clf)
+        problems = []
+        rng_state = torch.get_rng_state()
+        for ji, (j, lab) in enumerate(zip(self.jobs, self.labels)):
+            lab_host = lab.cpu().long()
+            for clf in (0, 1):
+                torch.manual_seed(seed_of(ji, clf))
+                kern = (self.gram.k_linear, self.gram.k_arccos)[clf]
+                for train, val in kernel_regression_epoch_indices(lab_host, sample_max, epochs):
+                    tr, va = train.to(dev, torch.int32), val.to(dev, torch.int32)
+                    problems.append((kern[ji], tr, va, lab))                   # the aggregated features' kernel
+                    problems.append((kern[x_slot[j.seed]], tr, va, lab))       # the raw features' kernel
+        torch.set_rng_state(rng_state)
+        self.kr = ops.KrBatch(problems, self.n_classes)
+
+    def launch_full(self):
+        """the launches of the three extra scalars (after the aggregation: they read Y): Gram + maps, edge cosines, regressions"""
+        self.gram.launch()
+        self.ge.launch()
+        self.kr.launch()
+
+    def full_metrics(self):
+        """[jobs, 9] fp64: results() + ge_homo + the p-values KR_L (kernel_reg0) and KR_NL (kernel_reg1) of the Welch t-test
+        over the epochs' accuracies (scipy on the host for the t distribution, as in the reference)"""
+        from scipy.stats import ttest_ind
+        base = self.results().to(torch.float64).cpu()
+        ge = self.ge.mean[:len(self.jobs)].cpu()
+        acc = self.kr.accuracy().cpu().reshape(len(self.jobs), 2, self.kr_epochs, 2).numpy()  # [job, classifier, epoch, (graph, features)]
+        g_res, x_res = acc[..., 0], acc[..., 1]
+        _, p = ttest_ind(x_res, g_res, axis=2, equal_var=False, nan_policy="propagate")  # one call for every (job, classifier)
+        better = (g_res > x_res).astype(np.float32).mean(2)
+        pvals = torch.from_numpy(np.where(better <= 0.5, p / 2, 1 - p / 2))
+        return torch.cat([base, ge[:, None], pvals], 1)
 
 
 class TrainBatch:

@@ -196,19 +196,12 @@ def similarity(features, adj, label, hard=None, LP=1, ifsum=1, idx_train=None):
 
 
 # ------------------------------------------------------------------------------------------- A13
-def _arccos_kernel(gram, n_layers):
-    """GNTK-style map of a Gram matrix.  reference: utils/homophily_metrics.py:236-244."""
-    eps = 1e-8
-    d = torch.sqrt(torch.diag(gram))
-    nrm = d.reshape(-1, 1) * d.reshape(1, -1)
-    nrm = (nrm > eps) * nrm + eps * (nrm <= eps)
-    if n_layers != 1:
-        return gram
-    arccos = torch.acos(torch.div(gram, nrm))
-    sqrt = torch.sqrt(torch.square(nrm) - torch.square(gram))
-    arccos = torch.where(torch.isnan(arccos), torch.zeros_like(arccos), arccos)
-    sqrt = torch.where(torch.isnan(sqrt), torch.zeros_like(sqrt), sqrt)
-    return 1 / pi * (gram * (pi - arccos) + sqrt)
+def _gram_kernel(a, n_layers):
+    """K / 2 of utils/homophily_metrics.py:234-257 for the rows of `a`: the Gram on the matrix pipe with the arc-cosine map
+    (n_layers == 1) or the halving (n_layers == 0) fused as the launch's epilogue (wdg_gram_map_batched_f32)."""
+    gb = ops.GramBatch([a.contiguous()], linear=n_layers != 1, arccos=n_layers == 1)
+    gb.launch()
+    return gb.k_arccos[0] if n_layers == 1 else gb.k_linear[0]
 
 
 def _as_index(idx, dev):
@@ -223,10 +216,7 @@ def _gntk_from_aggregate(h, features, sample, n_layers):
     smp = torch.as_tensor(np.asarray(sample.cpu() if isinstance(sample, torch.Tensor) else sample), device=h.device)
     if smp.dtype == torch.bool:
         smp = torch.nonzero(smp).view(-1)
-    hs, xs = h[smp].contiguous(), features[smp].contiguous()
-    g_gram = ops.gemm(hs, hs, transb=True)
-    x_gram = ops.gemm(xs, xs, transb=True)
-    return _arccos_kernel(g_gram, n_layers) / 2, _arccos_kernel(x_gram, n_layers) / 2
+    return _gram_kernel(h[smp], n_layers), _gram_kernel(features[smp], n_layers)
 
 
 def gntk_homophily_(features, adj, sample, n_layers):
@@ -238,6 +228,50 @@ def gntk_homophily_(features, adj, sample, n_layers):
     return _gntk_from_aggregate(h, features, sample, n_layers)
 
 
+FULL_KERNEL_MAX_NODES = 16384  # n x n fp32 kernels of all nodes: 1 GiB each at this size
+LAST_KR_ACCURACIES = None
+
+
+def _kernel_regression_on_device(features, adj, labels, sample_max, base_classifier, epochs):
+    """the kernel-regression branch of classifier_based_performance_metric entirely on the GPU -> (p_value, seconds), or
+    None when a train block exceeds the solver's 320 rows"""
+    from .util_funcs import kernel_regression_epoch_indices
+    t_time = time.time()
+    g = _graph(adj)
+    dev = g.device
+    features = features.to(dev, torch.float32)
+    labels = labels.to(dev).flatten()
+    lab32 = labels.to(torch.int32)
+    n_cls = int(labels.max().item()) + 1
+    n_layers = 0 if base_classifier == 'kernel_reg0' else 1
+    node_sets = kernel_regression_epoch_indices(labels, sample_max, epochs)  # (the generator is consumed as in the reference)
+    if max(tr.shape[0] for tr, _ in node_sets) > ops.KrBatch.MAX_TRAIN:
+        return None
+    h_agg = ops.spmm(g, features)
+    problems = []
+    if labels.shape[0] <= FULL_KERNEL_MAX_NODES:
+        k_g, k_x = _gram_kernel(h_agg, n_layers), _gram_kernel(features, n_layers)
+        for tr, va in node_sets:
+            tr, va = tr.to(dev, torch.int32), va.to(dev, torch.int32)
+            problems += [(k_g, tr, va, lab32), (k_x, tr, va, lab32)]
+    else:  # kernels of each epoch's sample only (rows: train first, then validation)
+        for tr, va in node_sets:
+            rows = torch.cat([tr, va]).to(dev)
+            k_g, k_x = _gram_kernel(h_agg[rows], n_layers), _gram_kernel(features[rows], n_layers)
+            lt = torch.arange(tr.shape[0], dtype=torch.int32, device=dev)
+            lv = torch.arange(tr.shape[0], rows.shape[0], dtype=torch.int32, device=dev)
+            problems += [(k_g, lt, lv, lab32[rows]), (k_x, lt, lv, lab32[rows])]
+    kb = ops.KrBatch(problems, n_cls)
+    kb.launch()
+    acc = kb.accuracy().cpu().reshape(epochs, 2)
+    global LAST_KR_ACCURACIES
+    LAST_KR_ACCURACIES = acc.clone()  # [epoch, (graph-aware, features only)]: diagnostics / tests
+    G_results, X_results = acc[:, 0], acc[:, 1]
+    _, p = ttest_ind(X_results, G_results, axis=0, equal_var=False, nan_policy='propagate')
+    p = p / 2 if torch.mean((G_results > X_results).float()) <= 0.5 else 1 - p / 2
+    return p, time.time() - t_time
+
+
 def classifier_based_performance_metric(features, adj, labels, sample_max, base_classifier='kernel_reg1', epochs=100,
                                         solver=None):
     """Classifier-based performance metric -> (p_value, seconds).  reference: utils/homophily_metrics.py:260-349.
@@ -247,18 +281,22 @@ def classifier_based_performance_metric(features, adj, labels, sample_max, base_
     Host, exactly as in the reference: split sampling from torch's CPU generator, `np.linalg.pinv` (the reference
     moves the kernels to the CPU for it, :286-290), sklearn GNB/SVM, scipy's Welch t-test.
 
-    solver="device" (or WDG_KR_SOLVER=device) keeps the kernel regression on the GPU: the kernels
-    never leave the device, the two train blocks of an epoch are pseudo-inverted by one batched symmetric
-    eigendecomposition (`torch.linalg.pinv(hermitian=True)`, rocSOLVER underneath) and the predictions are two MFMA
-    products.  For a symmetric matrix V diag(1/lambda) V^T IS the SVD pseudo-inverse.  Cut-off: |lambda| <=
-    n eps |lambda|_max (torch's default) instead of numpy's 1e-15 sigma_max - the null space of a kernel with zero or
-    duplicate rows comes out of LAPACK's SVD as exact zeros (cut either way) but out of an fp32 eigensolver as
-    +-1e-6 lambda_max noise, which numpy's cut-off would invert.  Per-epoch accuracies then match the host path to a
-    few validation nodes on well-conditioned kernels (tests/test_gpu_api.py); on rank-deficient linear kernels
-    (kernel_reg0, F < n_train) the host path inverts ITS rounding noise and the two agree only statistically."""
-    solver = solver or os.environ.get("WDG_KR_SOLVER", "host")
+    solver="device" (the default for the kernel-regression classifiers when a train block fits the solver: <= 320 rows;
+    WDG_KR_SOLVER=host restores the reference's host path) keeps the metric on the GPU: the kernels of
+    ALL nodes are computed once per call (the map is elementwise, so an epoch's kernel is a sub-block; graphs of more than
+    16 384 nodes: the Gram of each epoch's sample instead), every epoch's node sets are drawn first - same generator, same
+    order as the reference -, and all 2 x epochs regressions run in ONE launch of the register-resident Cholesky solver
+    (wdg_kernel_regress_batched_f32).  For a positive definite train block the Cholesky solution is the pseudo-inverse's;
+    per-epoch accuracies match the host path to a few validation nodes on well-conditioned kernels
+    (tests/test_gpu_api.py); a rank-deficient block is refactored with a ridge at rounding level (include/wdg.h)."""
+    solver = solver or os.environ.get("WDG_KR_SOLVER", "device")
     if solver not in ("host", "device"):
         raise ValueError(f"unknown solver {solver!r}")
+    if base_classifier in {'kernel_reg0', 'kernel_reg1'} and solver == "device":
+        res = _kernel_regression_on_device(features, adj, labels, sample_max, base_classifier, epochs)
+        if res is not None:
+            return res
+        solver = "host"  # (a train block larger than the solver holds)
     from sklearn import svm
     from sklearn.naive_bayes import GaussianNB
 
@@ -293,22 +331,14 @@ def classifier_based_performance_metric(features, adj, labels, sample_max, base_
                 K_graph, K = fixed_kernels
             else:
                 K_graph, K = _gntk_from_aggregate(h_agg, features, sample, nlayers)
-                if solver == "host":
-                    K_graph, K = K_graph.cpu(), K.cpu()
+                K_graph, K = K_graph.cpu(), K.cpu()
                 if nnodes <= sample_max:
                     fixed_kernels = (K_graph, K)
             preds = []
-            if solver == "device":
-                tr, va = _as_index(idx_train, dev), _as_index(idx_val, dev)
-                k_tt = torch.stack([kern[tr][:, tr] for kern in (K_graph, K)])
-                coef = torch.linalg.pinv(k_tt, hermitian=True) @ label_onehot[idx_train].to(dev)
-                for kern, cf in zip((K_graph, K), coef):
-                    preds.append(ops.gemm(kern[va][:, tr].contiguous(), cf.contiguous()).cpu())
-            else:
-                for kern in (K_graph, K):
-                    k_tt = kern[idx_train, :][:, idx_train]
-                    k_vt = kern[idx_val, :][:, idx_train]
-                    preds.append(k_vt @ (torch.tensor(np.linalg.pinv(k_tt.numpy())) @ label_onehot[idx_train]))
+            for kern in (K_graph, K):
+                k_tt = kern[idx_train, :][:, idx_train]
+                k_vt = kern[idx_val, :][:, idx_train]
+                preds.append(k_vt @ (torch.tensor(np.linalg.pinv(k_tt.numpy())) @ label_onehot[idx_train]))
             acc_g = accuracy(labels_sample[idx_val], preds[0])
             acc_x = accuracy(labels_sample[idx_val], preds[1])
         else:

@@ -105,15 +105,10 @@ def index_to_mask(index, size):
     return mask
 
 
-def random_disassortative_splits(labels, num_classes, training_percentage=0.6):
-    """Class-balanced train / 20 % val / rest test boolean masks.  reference: utils/util_funcs.py:454-475.
-
-    Host logic (no kernel): it draws from torch's global CPU generator in the same order as the reference
-    (one `randperm` per class, then one over the remainder), so a given `torch.manual_seed` yields the
-    reference's masks.  `num_classes` is a tensor or int; Python `round` (banker's) as in the reference."""
-    labels = labels.cpu()
+def _disassortative_split_indices(labels, c, training_percentage=0.6):
+    """(train, val, test) index tensors on the host, drawn from torch's global CPU generator exactly like the reference's
+    routine (utils/util_funcs.py:454-475): one `randperm` per class, then one over the remainder."""
     n = labels.shape[0]
-    c = int(num_classes.item()) if isinstance(num_classes, torch.Tensor) else int(num_classes)
     per_class = []
     for k in range(c):
         members = torch.nonzero(labels == k).view(-1)
@@ -123,8 +118,43 @@ def random_disassortative_splits(labels, num_classes, training_percentage=0.6):
     train = torch.cat([p[:n_train] for p in per_class])
     rest = torch.cat([p[n_train:] for p in per_class])
     rest = rest[torch.randperm(rest.shape[0])]
-    masks = [index_to_mask(ix, n) for ix in (train, rest[:n_val], rest[n_val:])]
+    return train, rest[:n_val], rest[n_val:]
+
+
+def random_disassortative_splits(labels, num_classes, training_percentage=0.6):
+    """Class-balanced train / 20 % val / rest test boolean masks.  reference: utils/util_funcs.py:454-475.
+
+    Host logic (no kernel): it draws from torch's global CPU generator in the same order as the reference
+    (one `randperm` per class, then one over the remainder), so a given `torch.manual_seed` yields the
+    reference's masks.  `num_classes` is a tensor or int; Python `round` (banker's) as in the reference."""
+    labels = labels.cpu()
+    n = labels.shape[0]
+    c = int(num_classes.item()) if isinstance(num_classes, torch.Tensor) else int(num_classes)
+    masks = [index_to_mask(ix, n) for ix in _disassortative_split_indices(labels, c, training_percentage)]
     return tuple(m.to(device) for m in masks)
+
+
+def kernel_regression_epoch_indices(labels, sample_max, epochs):
+    """The node sets of every epoch of classifier_based_performance_metric (utils/homophily_metrics.py:268-281): per epoch the
+    class-balanced sample (all nodes when nnodes <= sample_max), its train rows and its validation (val + test) rows, as
+    ascending NODE ids - drawn from torch's global CPU generator in the reference's order (seed it before the call).
+    -> list of (train int64 [n_train], val int64 [n_val]) host tensors."""
+    labels = labels.cpu().flatten()
+    n = labels.shape[0]
+    c = int(labels.max().item()) + 1
+    out = []
+    for _ in range(epochs):
+        if n <= sample_max:
+            sample = torch.arange(n)
+        else:
+            smp, _, _ = _disassortative_split_indices(labels, c, sample_max / n)
+            sample = torch.sort(smp).values  # (a boolean mask in the reference: ascending node order)
+        lab_s = labels[sample]
+        tr, va, te = _disassortative_split_indices(lab_s, int(lab_s.max().item()) + 1)
+        train = sample[torch.sort(tr).values]
+        val = sample[torch.sort(torch.cat([va, te])).values]
+        out.append((train, val))
+    return out
 
 
 def rand_train_test_idx(label, train_prop=.6, valid_prop=.2, ignore_negative=True):
