@@ -125,6 +125,36 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
                 n_graphs=sum(g.shape[0] for g in gathered), spmm_ms=spmm_ms, k=k, seeds=seeds, steps=steps)
 
 
+def measure_full(args, dev):
+    """The whole sweep job of synthetic_plot.py:92-109 for the shard - all nine scalars: a step's aggregation + counters + LAS,
+    then the Gram / arc-cosine kernels of every graph, the edge cosines and every kernel regression of every epoch - as
+    graphs/s.  The epochs' node sets are drawn on the host beforehand (inputs, like the graphs)."""
+    import torch
+    from wdg_amd import sweep, synth
+    h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
+    jobs = sweep.make_jobs(h_levels, range(args.seeds), k=args.k, n_nodes=args.nodes)
+    sb = sweep.SweepBatch(jobs, n_feat=args.feat, gcn_hidden=0)
+    sb.prepare_full(epochs=args.kr_epochs, sample_max=500)
+    sb.step()
+    sb.launch_full()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sb.step()
+        sb.launch_full()
+    torch.cuda.synchronize()
+    dev_s = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    rows = sb.full_metrics()
+    tail_s = time.perf_counter() - t0
+    return {"workload": f"all nine scalars of the sweep job for {len(jobs)} graphs (k={args.k}, {args.seeds} seeds): + generalized edge "
+                        f"homophily, KR_L and KR_NL with {args.kr_epochs} epochs each (sample_max 500: 300 train / 200 validation "
+                        f"rows per regression, {sb.kr.n_jobs} regressions per batch)",
+            "graphs_per_s": len(jobs) / (dev_s + tail_s), "device_ms_per_batch": dev_s * 1e3, "host_tail_ms": tail_s * 1e3,
+            "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, rows.mean(0).tolist())}}
+
+
 def traffic_for(n_graphs, n_feat, k):
     """PMC-derived HBM bytes per aggregation launch of the same workload (profiles/traffic.json: one record per k)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -179,6 +209,9 @@ def main():
     ap.add_argument("--k", type=int, default=10, help="same-class out-neighbours per node (10 = `4000` set, 2 = `800` set)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--secondary", type=int, default=1, help="1: also time the `800` set (k=2, 10 seeds) and report it as `secondary` (N=1 only)")
+    ap.add_argument("--full-metrics", type=int, default=1, help="1: also time the whole nine-scalar sweep job batch (adds generalized edge "
+                    "homophily and the kernel-regression p-values, --kr-epochs epochs) and report it as `sweep_full` (N=1 only)")
+    ap.add_argument("--kr-epochs", type=int, default=100)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -231,6 +264,8 @@ def main():
         del m2
     if world > 1:
         dist.destroy_process_group()  # (before the line: RCCL writes its library path to stdout when it shuts down)
+    if world == 1 and args.full_metrics:
+        out["sweep_full"] = measure_full(args, dev)
     if rank == 0:
         if world == 1 and args.cpu_budget > 0:
             from oracle import cpu_ref
