@@ -137,7 +137,7 @@ def measure_full(args, dev):
     sb.prepare_full(epochs=args.kr_epochs, sample_max=500)
     sb.step()
     sb.launch_full()
-    torch.cuda.synchronize()
+    sb.full_metrics()  # (scipy import, pinned staging)
     reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
