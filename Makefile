@@ -2,7 +2,7 @@
 PKG      := when-do-gnns-help_amd
 CSRC     := $(PKG)/csrc
 HIPCC    ?= /opt/rocm/bin/hipcc
-HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value $(if $(STAMPS),-DWDG_STAMPS,) $(if $(DEPTH),-DWDG_PREFETCH_DEPTH=$(DEPTH),)
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value $(if $(STAMPS),-DWDG_STAMPS,) $(if $(DEPTH),-DWDG_PREFETCH_DEPTH=$(DEPTH),) $(EXTRA)
 SRCS     := $(wildcard $(CSRC)/*.hip)
 OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 LIB      := $(PKG)/lib/libwdg_hip.so

@@ -154,6 +154,12 @@ typedef struct wdg_spmm_job {
     int32_t q_n_blocks;    /* ceil(n_cols / q_block_cols), 1 .. 4                                                        */
     int32_t q_n_entries;   /* entries per column block, a multiple of 4 (four entries = a super-unit = what a wave is dealt) */
     int32_t q_flags;       /* WDG_SELL16_SPLIT: split form (one column block, every entry <= 32 entries per row)           */
+    /* optional band plan of the same pattern (wdg_csr_band_plan): enables the band kernel of the single-graph entry points
+       (a wave per row and band of 64..256 features gathered from L2; wide features, any skew, any column count); NULL = none */
+    const int32_t *band_perm; /* [wdg_csr_band_perm_len(n_rows)] rows by length, longest first; the first band_n_hub are the hub rows */
+    const int32_t *band_cuts; /* [18] cost cuts of the hub rows [0..8] and of the other rows [9..17]                            */
+    int32_t band_n_hub;       /* rows of more than 128 entries (each is swept by a whole workgroup)                              */
+    int32_t band_reserved;    /* 0 */
 } wdg_spmm_job;
 
 int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream);
@@ -228,6 +234,20 @@ int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N
 int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
                            const int32_t *q_rows, const int32_t *q_ext, int32_t n_entries, int32_t *q_col, float *q_val,
                            wdg_stream_t stream);
+
+/*
+ * Band plan of a CSR pattern (the row schedule of the band kernel, csrc/spmm_band.hip; the single-graph entry points
+ * wdg_spmm_csr_f32 run that kernel for fp32 X of >= 16 features when the job carries the plan and no SELL-16 copy in split
+ * form): band_perm = the rows by length, longest first (<= 16 384 rows: ties by row index; more: rows of equal length in no
+ * particular order - the order only schedules, every row's sum has a fixed order), wdg_csr_band_perm_len(N) ints;
+ * band_cuts = 18 ints; *n_hub_host = the number of rows with more than 128 entries (a prefix of band_perm), read back on
+ * `stream` (the call synchronises it).  One-time per graph; nothing of the plan depends on the feature width.
+ * Replaces, with wdg_spmm_csr_f32, `torch.spmm(adj, x)` of models/baseline_models.py:62-75 for single wide-feature graphs.
+ */
+size_t wdg_csr_band_plan_workspace_bytes(int32_t N);
+int32_t wdg_csr_band_perm_len(int32_t N);
+int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, int32_t *n_hub_host,
+                      void *workspace, size_t workspace_bytes, wdg_stream_t stream);
 
 /*
  * The batched aggregation on the quad-row kernel (every job carries its SELL-16 copy).  The caller lays the jobs'

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""One JSON line per BASELINE.json config (C1..C5): the aggregation launch of that config timed with HIP events on the
+stream it runs on, priced by SURVEY 8(d)'s algorithmic bytes (rowptr + col + dinv + X read once + Y written once).
+
+    python3 scripts/bench_configs.py [--out profiles/r02_configs.jsonl] [--reps 30]
+
+C1  Cora (real topology + real features, tests/golden/real_cora.npz), SGC-1 forward: D^-1/2 (A+I) D^-1/2 X, then X W
+C2  synthetic N=2000 k=2, 10 h-levels x 10 seeds as one batched launch (the `800` set; bench.py --k 2 --seeds 10)
+C3  synthetic N=2000 k=10, 10 h-levels x 5 seeds as one batched launch (the `4000` set; the bench.py headline)
+C4  squirrel + chameleon real topology (tests/golden/topo_*.npz), synthetic features of the real widths, fp32
+C5  twitch-gamers scale (168 114 nodes, 13.76 M stored entries incl. loops), F = 7 bf16 features
+Real node features of C4 / the twitch csv are absent from the reference checkout, hence synthetic of the right shape.
+Nothing here touches oracle/ or /root/reference."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+HBM_PEAK_GBS = 8000.0
+
+
+def timed(fn, reps, warm=5):
+    import torch
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ms) / len(ms) * 1e3, ms[len(ms) // 2] * 1e3  # mean, median in us
+
+
+def line(config, workload, kernel, alg_bytes, edges, us_mean, us_med, **extra):
+    rec = {"config": config, "workload": workload, "kernel": kernel, "edges_per_launch": edges,
+           "edges_per_s": edges / (us_mean * 1e-6),
+           "roofline": {"bound": "hbm", "achieved": alg_bytes / (us_mean * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / (us_mean * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": us_mean, "median_launch_us": us_med, "algorithmic_bytes_per_launch": alg_bytes}}
+    rec.update(extra)
+    return rec
+
+
+def single_graph(config, workload, g, x, reps, elem=4, **extra):
+    import torch
+    from wdg_amd import ops
+    d = ops.degree_norm(g, 1, ops.PREC_F32)["dinv"]
+    y = ops.spmm(g, x, row_scale=d, col_scale=d)
+    us, med = timed(lambda: ops.spmm(g, x, row_scale=d, col_scale=d, out=y), reps)
+    n, f, e = g.n_rows, x.shape[1], g.nnz
+    alg = 4 * (n + 1) + 4 * e + 4 * n + elem * n * f + y.element_size() * n * f
+    quad = getattr(g, "quad", None)
+    if quad:
+        kernel = f"spmm_quad_kernel ({quad['n_blocks']} column block(s) of {quad['block_cols']})"
+    else:
+        flags = ops.SPMM_ALL_SELL if getattr(g, "sell", None) else 0
+        fam = ops.spmm_plan(n, g.n_cols, f, 1, flags)
+        kernel = {0: "spmm_slab_kernel", 1: "spmm_gather_kernel", 2: "spmm_rowlane_kernel", 3: "spmm_rowlane_kernel (pipelined)"}.get(fam[0], str(fam))
+    return line(config, workload, kernel, alg, e, us, med, **extra)
+
+
+def c1(reps):
+    import torch
+    from _golden import load
+    from wdg_amd import ops
+    d = load("real_cora")
+    n, f = int(d["n_nodes"]), int(d["n_feat"])
+    g = ops.CsrGraph.from_coo(d["adj_row"], d["adj_col"], n, None, ops.COO_ADD_SELF_LOOPS)
+    import scipy.sparse as sp
+    x = torch.from_numpy(sp.csr_matrix((d["featn_data"], d["feat_indices"], d["feat_indptr"]), (n, f)).toarray().astype(np.float32)).cuda()
+    rec = single_graph("C1", f"Cora real topology + row-normalised real features: N={n}, F={f}, {g.nnz} stored entries (A+I), "
+                       "SGC-1 aggregation D^-1/2 (A+I) D^-1/2 X, fp32", g, x, reps)
+    w = torch.randn(f, 7, device="cuda")
+    dn = ops.degree_norm(g, 1, ops.PREC_F32)["dinv"]
+    y = ops.spmm(g, x, row_scale=dn, col_scale=dn)
+    us, med = timed(lambda: ops.gemm(y, w), reps)
+    rec["classifier_gemm_us"] = us
+    return rec
+
+
+def sweep(config, k, seeds, reps):
+    import torch
+    from wdg_amd import sweep as sw, synth
+    h_levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
+    jobs = sw.make_jobs(h_levels, range(seeds), k=k, n_nodes=2000)
+    sb = sw.SweepBatch(jobs, n_feat=500, gcn_hidden=64)
+    us, med = timed(sb.spmm.launch, reps)
+    edges = sum(g.nnz for g in sb.graphs)
+    us_step, _ = timed(sb.step, reps)
+    return line(config, f"synthetic sweep shard: 10 h-levels x {seeds} seeds = {len(jobs)} graphs in ONE launch, N=2000, k={k}, "
+                f"F=500 (+5 one-hot label columns), fp32", sb.spmm.kernel_name(), sb.spmm_algorithmic_bytes(), edges, us, med,
+                whole_step_us=us_step, graphs_per_s_step=len(jobs) / (us_step * 1e-6))
+
+
+def c4(name, f, reps):
+    import torch
+    from _golden import load
+    from wdg_amd import ops
+    g0 = load("topo_" + name)
+    n = int(g0["n_nodes"])
+    g = ops.CsrGraph.from_coo(g0["adj_row"], g0["adj_col"], n, None, ops.COO_ADD_SELF_LOOPS)
+    rng = np.random.default_rng(17)
+    x = torch.from_numpy(((rng.random((n, f), dtype=np.float32) < 0.02) * rng.random((n, f), dtype=np.float32))).cuda()
+    deg = np.diff(g.rowptr.cpu().numpy())
+    return single_graph("C4", f"{name} real topology: N={n}, {g.nnz} stored entries (A+I), max row {int(deg.max())}, "
+                        f"F={f} synthetic fp32 features, D^-1/2 (A+I) D^-1/2 X", g, x, reps)
+
+
+def c5(reps):
+    import torch
+    from wdg_amd import ops
+    n, e_und, f = 168114, 6797557, 7
+    from wdg_amd import synth
+    rng = np.random.default_rng(6)
+    src, dst = synth.random_graph(n, e_und, seed=5)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_ADD_SELF_LOOPS)
+    x = torch.from_numpy(rng.standard_normal((n, f), dtype=np.float32)).cuda().to(torch.bfloat16)
+    return single_graph("C5", f"twitch-gamers scale: N={n}, {g.nnz} stored entries (A+I, duplicates merged), F={f} bf16 features, "
+                        "fp32 accumulation, D^-1/2 (A+I) D^-1/2 X", g, x, reps, elem=2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import torch
+    import wdg_amd  # noqa: F401  (fails loudly without the HIP library)
+    todo = [("C1", lambda: c1(args.reps)), ("C2", lambda: sweep("C2", 2, 10, args.reps)), ("C3", lambda: sweep("C3", 10, 5, args.reps)),
+            ("C4", lambda: c4("squirrel", 2089, args.reps)), ("C4", lambda: c4("chameleon", 2325, args.reps)), ("C5", lambda: c5(args.reps))]
+    out = open(args.out, "w") if args.out else None
+    for tag, fn in todo:
+        if args.only and tag not in args.only.split(","):
+            continue
+        rec = fn()
+        rec["device"] = torch.cuda.get_device_name(0)
+        s = json.dumps(rec)
+        print(s, flush=True)
+        if out:
+            out.write(s + "\n")
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

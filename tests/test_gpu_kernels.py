@@ -23,6 +23,7 @@ def ops():
 def old_families(monkeypatch):
     """keep a test on the round-1 kernel families (slab / gather / row-lane): the quad-row kernel would take the call"""
     monkeypatch.setenv("WDG_SPMM_NO_QUAD", "1")
+    monkeypatch.setenv("WDG_SPMM_BAND", "0")
 
 
 def _np(t):
@@ -693,9 +694,10 @@ QUAD_SHAPES = [(2000, 2000, 512, 60000), (2000, 2000, 500, 20000), (2708, 2708, 
 
 
 @pytest.mark.parametrize("n,m,f,e", QUAD_SHAPES)
-def test_spmm_quad_family_shapes(ops, oracle, n, m, f, e):
+def test_spmm_quad_family_shapes(ops, oracle, monkeypatch, n, m, f, e):
     """the quad-row kernel through the single-graph entry: one and several column blocks, ragged feature groups, feature
     counts that are not multiples of 4 (scalar staging / stores), explicit values, row / column scales, bf16 input"""
+    monkeypatch.setenv("WDG_SPMM_BAND", "0")  # (wide features on skewed or many-column graphs would go to the band kernel)
     rng = np.random.default_rng(n * 11 + f)
     src, dst = _rand_graph(rng, n, e)
     dst = dst % m
@@ -1324,3 +1326,113 @@ def test_fuzz_build_stats_las_gemm(ops, oracle, seed):
     np.testing.assert_allclose(_np(got), ref, rtol=1e-5, atol=1e-5 * max(float(np.abs(ref).max()), 1e-30))
     got_t = ops.gemm(at[:, :kk], torch.from_numpy(np.ascontiguousarray(b.T)).cuda(), transb=True)
     np.testing.assert_array_equal(_np(got_t), plain)
+
+
+# ---- the band kernel (csrc/spmm_band.hip): wide features gathered from L2, a wave per row and band ------------------------
+def _band_case(rng, n, m, e, hubs=0, hub_len=0):
+    """CSR pattern with explicit values; `hubs` rows get `hub_len` extra entries (hub rows of the plan: > 256 entries)"""
+    src, dst = rng.integers(0, n, e), rng.integers(0, m, e)
+    if hubs:
+        hs = np.repeat(rng.choice(n, hubs, replace=False), hub_len)
+        src, dst = np.concatenate([src, hs]), np.concatenate([dst, rng.integers(0, m, hs.shape[0])])
+    key = np.unique(src.astype(np.int64) * m + dst)
+    rows, col = key // m, (key % m).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    return rowptr, col
+
+
+BAND_SHAPES = [  # (rows, columns, features, random entries, hub rows, entries per hub row)
+    (5201, 5201, 2089, 150000, 40, 1500), (2277, 2277, 2325, 60000, 8, 600), (2708, 2708, 1433, 11000, 0, 0),
+    (300, 7000, 257, 3000, 3, 3000), (64, 64, 16, 200, 0, 0), (1, 5, 100, 3, 0, 0), (1000, 1000, 129, 0, 2, 400),
+    (20000, 20000, 64, 150000, 5, 5000), (4096, 512, 384, 30000, 0, 0), (33, 9000, 192, 2000, 33, 300)]
+
+
+@pytest.mark.parametrize("n,m,f,e,hubs,hub_len", BAND_SHAPES)
+def test_spmm_band_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, hub_len):
+    """the band kernel through the single-graph entry: every lane width (VEC 4 / 2 / 1 by feature count), ragged last band,
+    feature counts and leading dimensions that are not multiples of 4 (unaligned rows), hub rows swept by a whole workgroup,
+    empty rows, more rows than the in-LDS row sort takes (bucket sort), explicit values, row / column scales, strided X, Y"""
+    monkeypatch.setenv("WDG_SPMM_BAND", "1")
+    rng = np.random.default_rng(n * 7 + f)
+    rowptr, col = _band_case(rng, n, m, e, hubs, hub_len)
+    if col.shape[0] == 0:
+        pytest.skip("empty pattern")
+    val = rng.random(col.shape[0], dtype=np.float32)
+    x = rng.standard_normal((m, f + 3)).astype(np.float32)
+    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, m)
+    xt_full = torch.from_numpy(x).cuda()
+    deg = np.diff(rowptr)
+
+    def run(use_values, rs, cs, strided):
+        xt = xt_full[:, 1:1 + f] if strided else xt_full[:, :f].contiguous()
+        out = torch.full((n, f + 5), 7.0, device="cuda") if strided else None
+        y = ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
+                     col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values,
+                     out=None if out is None else out[:, 2:2 + f])
+        assert g.band and g.quad is None and g.sell is None, "the call must have gone to the band kernel"
+        assert g.band["n_hub"] == int((deg > 256).sum())
+        if out is not None:
+            assert float(out[:, :2].min()) == 7.0 and float(out[:, 2 + f:].min()) == 7.0  # nothing written beside Y
+        v = val.copy() if use_values else np.ones_like(val)
+        if cs is not None:
+            v = v * cs[col]
+        xr = _np(xt)
+        ref, ref64 = oracle.spmm_csr(rowptr, col, v, xr), oracle.spmm_csr(rowptr, col, v, xr, f64acc=True)
+        if rs is not None:
+            ref, ref64 = ref * rs[:, None], ref64 * rs[:, None]
+        scale = np.abs(ref64).max() + 1e-30
+        np.testing.assert_allclose(_np(y), ref64, rtol=1e-5, atol=2e-6 * scale)
+        np.testing.assert_allclose(_np(y), ref, rtol=2e-5, atol=4e-6 * scale)
+
+    d, dc = rng.random(n, dtype=np.float32), rng.random(m, dtype=np.float32)
+    run(True, None, None, False)
+    run(False, d, None, True)
+    run(False, d, dc, False)
+    run(True, d, dc, True)
+
+
+def test_spmm_band_plan_orders_rows_and_cuts_by_cost(ops):
+    """wdg_csr_band_plan: band_perm is a permutation with non-increasing row lengths whose first n_hub rows are exactly the
+    rows of more than 256 entries; the cuts of both row classes are monotone, start at 0, end at the class size, and split
+    the class's cost (entries + 8 per row) into eighths within one row's cost"""
+    rng = np.random.default_rng(5)
+    for n, m, e, hubs, hub_len in ((3000, 3000, 40000, 30, 900), (30000, 30000, 200000, 9, 2000), (10, 10, 30, 0, 0)):
+        rowptr, col = _band_case(rng, n, m, e, hubs, hub_len)
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), None, n, m)
+        assert g.ensure_band()
+        deg = np.diff(rowptr).astype(np.int64)
+        perm, cuts, n_hub = _np(g.band["perm"])[:n], _np(g.band["cuts"]), g.band["n_hub"]
+        assert sorted(perm.tolist()) == list(range(n))
+        assert (np.diff(deg[perm]) <= 0).all()
+        assert n_hub == int((deg > 256).sum())
+        for cls, (first, count) in enumerate(((0, n_hub), (n_hub, n - n_hub))):
+            c = cuts[9 * cls:9 * cls + 9]
+            assert c[0] == 0 and c[8] == count and (np.diff(c) >= 0).all()
+            cost = deg[perm[first:first + count]] + 8
+            cum = np.concatenate([[0], np.cumsum(cost)])
+            for k in range(1, 8):
+                if count:
+                    assert abs(cum[c[k]] - cum[-1] * k / 8) <= cost.max()
+
+
+def test_spmm_band_is_deterministic_and_sums_in_csr_order(ops, monkeypatch):
+    """two launches give the same bits; without values and scales the sum of a row that is not a hub row is the sequential
+    fp32 sum of its source rows in CSR order, bit for bit (what a CPU sweep over the coalesced COO produces)"""
+    rng = np.random.default_rng(9)
+    n, f = 1500, 300
+    rowptr, col = _band_case(rng, n, n, 30000, 4, 700)
+    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), None, n, n)
+    x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
+    monkeypatch.setenv("WDG_SPMM_BAND", "1")
+    a = ops.spmm(g, x).clone()
+    b = ops.spmm(g, x)
+    assert g.band and g.band["n_hub"] == 4
+    assert torch.equal(a, b)
+    # (np.cumsum adds sequentially in fp32, np.sum would add pairwise)
+    xh, ah = _np(x), _np(a)
+    for r in range(n):
+        s, e = rowptr[r], rowptr[r + 1]
+        if 0 < e - s <= 256:
+            np.testing.assert_array_equal(ah[r], np.cumsum(xh[col[s:e]], axis=0, dtype=np.float32)[-1], err_msg=f"row {r}")
+        elif e == s:
+            assert not ah[r].any()

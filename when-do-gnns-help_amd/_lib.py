@@ -30,7 +30,8 @@ class SpmmJob(ctypes.Structure):
                 ("sell_ptr", c_void_p), ("sell_col", c_void_p), ("sell_val", c_void_p),
                 ("sell_block_cols", c_int32), ("sell_n_blocks", c_int32), ("sell_perm", c_void_p),
                 ("q_ext", c_void_p), ("q_col", c_void_p), ("q_val", c_void_p), ("q_perm", c_void_p), ("q_rows", c_void_p),
-                ("q_block_cols", c_int32), ("q_n_blocks", c_int32), ("q_n_entries", c_int32), ("q_flags", c_int32)]
+                ("q_block_cols", c_int32), ("q_n_blocks", c_int32), ("q_n_entries", c_int32), ("q_flags", c_int32),
+                ("band_perm", c_void_p), ("band_cuts", c_void_p), ("band_n_hub", c_int32), ("band_reserved", c_int32)]
 
 
 class SpmmItem(ctypes.Structure):
@@ -81,6 +82,9 @@ SIGNATURES = {
                                         c_void_p]),
     "wdg_csr_to_sell16_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                        c_void_p, c_void_p]),
+    "wdg_csr_band_plan_workspace_bytes": (c_size_t, [c_int32]),
+    "wdg_csr_band_perm_len": (c_int32, [c_int32]),
+    "wdg_csr_band_plan": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wdg_spmm_quad_batched_f32": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int,
                                           c_void_p]),
     "wdg_edge_label_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

@@ -31,6 +31,8 @@ bool rowlane_shared_x(int n_jobs, int max_rows, int max_cols, int max_feat, int 
 int rowlane_dispatch_bf16(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
 // quad-row family (spmm_quad.hip)
 bool quad_eligible_single(const wdg_spmm_job &j);
+bool band_eligible_single(const wdg_spmm_job &j);
+int band_single_f32(const wdg_spmm_job &j, hipStream_t st);
 int quad_single_f32(const wdg_spmm_job &j, hipStream_t st);
 int quad_single_bf16(const wdg_spmm_job &j, hipStream_t st);
 }  // namespace wdg
@@ -499,6 +501,10 @@ int single(const wdg_spmm_job *job_host, wdg_stream_t stream) {
     if (sizeof(TIN) == 4 && !job_host->col_scale && aligned16(job_host->X) && aligned16(job_host->Y) &&
         job_host->ldx % 4 == 0 && job_host->ldy % 4 == 0 && job_host->n_feat % 4 == 0)
         flags |= WDG_SPMM_DMA_OK;
+    // a band plan and no SELL-16 copy in split form (wide features; several column blocks or rows too long for slices)
+    if (sizeof(TIN) == 4 && band_eligible_single(*job_host) &&
+        !(quad_eligible_single(*job_host) && (job_host->q_flags & WDG_SELL16_SPLIT)))
+        return band_single_f32(*job_host, as_stream(stream));
     if (quad_eligible_single(*job_host))  // the SELL-16 copy is there: quad-row kernel (csrc/spmm_quad.hip)
         return sizeof(TIN) == 4 ? quad_single_f32(*job_host, as_stream(stream)) : quad_single_bf16(*job_host, as_stream(stream));
     return dispatch<TIN>(nullptr, *job_host, 1, job_host->n_rows, job_host->n_cols, job_host->n_feat, flags,

@@ -35,6 +35,7 @@
 namespace wdg {
 int exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int64_t *total64, void *ws, hipStream_t st);
 size_t exclusive_scan_ws_bytes(int64_t n);
+int sort_rows_by_length_small(const int32_t *rowptr, int32_t N, int32_t *perm, hipStream_t st);
 }  // namespace wdg
 
 namespace {
@@ -937,6 +938,24 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
 
 namespace wdg {
 
+// rows by length, longest first, ties by row index (one workgroup, keys in LDS); more than sort_rows_small_limit() rows: identity.
+// perm has 16 ceil(N / 16) slots, the padding repeats the last row.  Shared with the band plan (spmm_band.hip).
+int sort_rows_small_limit() { return Q_SORT_MAX_ROWS; }
+int sort_rows_by_length_small(const int32_t *rowptr, int32_t N, int32_t *perm, hipStream_t st) {
+    static thread_local int configured_dev = -1;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (configured_dev != dev) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sell16_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Q_SORT_MAX_ROWS * 8) != hipSuccess)
+            return fail(WDG_ERR_LAUNCH, "row sort: cannot raise the dynamic LDS limit");
+        configured_dev = dev;
+    }
+    const size_t sort_lds = N <= Q_SORT_MAX_ROWS ? static_cast<size_t>(N) * 8 : 0;
+    hipLaunchKernelGGL(sell16_sort_rows, dim3(1), dim3(1024), sort_lds, st, rowptr, N, perm);
+    return check_launch("sell16_sort_rows");
+}
+
 // single-graph entry (wdg_spmm_csr_*): the by-value descriptor, implicit segments (units dealt round-robin)
 bool quad_eligible_single(const wdg_spmm_job &j) {
     if (const char *s = getenv("WDG_SPMM_NO_QUAD"))
@@ -1012,17 +1031,7 @@ int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N
         hipMemsetAsync(q_ext, 0, 2 * sizeof(int32_t), st);
         return WDG_OK;
     }
-    static thread_local int configured_dev = -1;
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (configured_dev != dev) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sell16_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Q_SORT_MAX_ROWS * 8) != hipSuccess)
-            return wdg::fail(WDG_ERR_LAUNCH, "csr_to_sell16: cannot raise the dynamic LDS limit");
-        configured_dev = dev;
-    }
-    const size_t sort_lds = N <= Q_SORT_MAX_ROWS ? static_cast<size_t>(N) * 8 : 0;
-    hipLaunchKernelGGL(sell16_sort_rows, dim3(1), dim3(1024), sort_lds, st, rowptr, N, q_perm);
+    if (int e = wdg::sort_rows_by_length_small(rowptr, N, q_perm, st)) return e;
     hipLaunchKernelGGL(sell16_widths, dim3(wdg::ceil_div(tasks, 256)), dim3(256), 0, st, rowptr, col, q_perm, N, n_slices, n_blocks,
                        block_cols, chunks, widths);
     if (int e = wdg::exclusive_scan_i32(chunks, tasks, chunks, nullptr, scan_ws, st)) return e;

@@ -53,6 +53,7 @@ class CsrGraph:
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.sell = None  # (sell_ptr, sell_col, sell_val|None): SELL-64 copy of the pattern, built on demand
         self.quad = None  # SELL-16 copy (dict) for the quad-row kernel, built on demand; False = decided against
+        self.band = None  # band plan (dict) for the band kernel, built on demand; False = not applicable
 
     def ensure_sell(self, max_padding=3.0):
         """Build the SELL-64 copy (wdg_csr_to_sell_*) that the row-lane SpMM consumes.  One-time per graph.
@@ -83,6 +84,39 @@ class CsrGraph:
               "wdg_csr_to_sell_fill")
         self.sell = (sell_ptr, sell_col, sell_val, block_cols, n_blocks, sell_perm)
         return True
+
+    QUAD_SLAB_COLS = 2528  # columns of X the quad-row kernel holds in LDS at once (one column block)
+
+    def ensure_band(self):
+        """Build the band plan (wdg_csr_band_plan): rows by length, hub count, cost cuts.  One-time per graph, one host sync."""
+        if self.band is not None:
+            return self.band is not False
+        if self.n_rows == 0 or self.nnz == 0 or self.n_cols == 0:
+            self.band = False
+            return False
+        dev = self.device
+        perm = torch.empty(int(lib.wdg_csr_band_perm_len(self.n_rows)), dtype=torch.int32, device=dev)
+        cuts = torch.empty(18, dtype=torch.int32, device=dev)
+        ws_bytes = lib.wdg_csr_band_plan_workspace_bytes(self.n_rows)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        n_hub = ctypes.c_int32(0)
+        check(lib.wdg_csr_band_plan(_ptr(self.rowptr), self.n_rows, _ptr(perm), _ptr(cuts), ctypes.byref(n_hub), _ptr(ws), ws_bytes,
+                                    stream_handle()), "wdg_csr_band_plan")
+        self.band = dict(perm=perm, cuts=cuts, n_hub=int(n_hub.value))
+        return True
+
+    def prefers_band(self, n_feat):
+        """the band kernel (L2 gathers, a wave per row) rather than the quad-row kernel (LDS slabs) for a single aggregation:
+        wide features and either more columns than one LDS slab holds or rows too long for 16-row slices (> 128 entries).
+        WDG_SPMM_BAND=1 / 0 forces / forbids it."""
+        force = os.environ.get("WDG_SPMM_BAND", "")
+        if force == "0" or n_feat < 16:
+            return False
+        if not self.ensure_band():
+            return False
+        if force not in ("", "0"):
+            return True
+        return n_feat >= 64 and (self.n_cols > self.QUAD_SLAB_COLS or self.band["n_hub"] > 0)
 
     QUAD_MAX_BLOCKS = 4  # column blocks of <= 2528 columns the quad-row kernel sweeps (csrc/spmm_quad.hip)
 
@@ -282,7 +316,7 @@ def unpack_bits(words, n_feat, row_normalise=False):
 
 
 # ------------------------------------------------------------------------------------------- aggregation
-def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
+def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
     job.rowptr, job.col = g.rowptr.data_ptr(), g.col.data_ptr()
     job.val = g.val.data_ptr() if (use_values and g.val is not None) else 0
     job.row_scale = 0 if row_scale is None else row_scale.data_ptr()
@@ -310,6 +344,15 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True):
     else:
         job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0
         job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
+    if band and g.band:
+        job.band_perm, job.band_cuts, job.band_n_hub = g.band["perm"].data_ptr(), g.band["cuts"].data_ptr(), g.band["n_hub"]
+        # (the single-graph entry point prefers a split-form SELL-16 copy: this call asked for the band kernel)
+        job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0
+        job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
+    else:
+        job.band_perm = job.band_cuts = 0
+        job.band_n_hub = 0
+    job.band_reserved = 0
     return job
 
 
@@ -377,9 +420,10 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
         raise ValueError(f"spmm: X has {x.shape[0]} rows, adjacency has {g.n_cols} columns")
     y = out if out is not None else torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=dev)
     row_scale, col_scale = _dev(row_scale, torch.float32, dev), _dev(col_scale, torch.float32, dev)
-    if x.shape[1] >= 8 and not g.ensure_quad():  # one-time SELL-16 copy -> quad-row kernel (<= 10 112 columns)
+    band = x.dtype == torch.float32 and g.prefers_band(x.shape[1])  # one-time plan -> band kernel (wide features, skew)
+    if not band and x.shape[1] >= 8 and not g.ensure_quad():  # one-time SELL-16 copy -> quad-row kernel (<= 10 112 columns)
         g.ensure_sell()  # else the SELL-64 copy -> row-lane kernels for graphs of <= 3072 rows
-    job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values)
+    job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values, band=band)
     fn = lib.wdg_spmm_csr_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_csr_f32
     check(fn(ctypes.byref(job), stream_handle()), "wdg_spmm_csr")
     return y
