@@ -448,6 +448,50 @@ def _quad_unit_cost(widths):
     return per_slice.reshape(-1, 4).sum(1)
 
 
+# what a phase costs a workgroup beside its super-units: staging the slab, two barriers, the pipeline's prologue and the
+# ragged end of the 16 waves (measured as the extra time of XCDs whose segment holds two phases)
+_QUAD_PHASE_NS = 0.0
+
+
+def _quad_cut(cum, g_off, n_seg, phase):
+    """cut positions [n_seg + 1] of the tape (cum = cumulative super-unit cost, g_off = phase-group boundaries) such that
+    every segment's cost + `phase` per phase group it touches is the same (the smallest such bound, by bisection)"""
+    n_units = len(cum) - 1
+    if phase <= 0 or n_units == 0:
+        cuts = np.searchsorted(cum, cum[-1] * np.arange(1, n_seg) / n_seg, side="left")
+        return np.maximum.accumulate(np.concatenate([[0], np.clip(cuts, 0, n_units), [n_units]]))
+
+    def fill(bound):
+        cuts, a = [0], 0
+        for _ in range(n_seg):
+            cap = bound
+            while a < n_units:
+                cap -= phase
+                if cap <= 0:
+                    break
+                gi = int(np.searchsorted(g_off, a, side="right") - 1)
+                gb = int(g_off[gi + 1])
+                fit = int(np.searchsorted(cum, cum[a] + cap, side="right") - 1)
+                if fit < gb:
+                    a = max(fit, a)
+                    break
+                cap -= cum[gb] - cum[a]
+                a = gb
+            cuts.append(a)
+        return cuts
+
+    lo, hi = cum[-1] / n_seg, cum[-1] / n_seg + phase * (len(g_off) + 1) + cum[-1] / max(n_units, 1) * 2
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        if fill(mid)[-1] >= n_units:
+            hi = mid
+        else:
+            lo = mid
+    cuts = fill(hi)
+    cuts[-1] = n_units
+    return np.maximum.accumulate(np.asarray(cuts, np.int64))
+
+
 def _quad_segments(entries, order, n_feat, cus=256):
     """Cut the tape of super-units (64 rows) of the jobs (in table order `order`) into 8 x S segments of equal modelled cost
     and split every segment into items; -> (items [(first_job, n_jobs, unit_begin, unit_end)], seg_ptr, n_segments).
@@ -487,9 +531,9 @@ def _quad_segments(entries, order, n_feat, cus=256):
     if multi:  # a wave keeps at most 2 super-units across the column blocks: items of <= 32 super-units
         subs = max(subs, -(-n_units // (8 * 32)))
     n_seg = 8 * subs
-    cuts = np.searchsorted(cum, cum[-1] * np.arange(1, n_seg) / n_seg, side="left")
-    cuts = np.maximum.accumulate(np.concatenate([[0], np.clip(cuts, 0, n_units), [n_units]]))
     g_off = np.concatenate([[0], np.cumsum([g[2] for g in groups])]).astype(np.int64)
+    phase = float(os.environ.get("WDG_QUAD_PHASE_NS", _QUAD_PHASE_NS)) * 16  # (the table prices a wave, a workgroup has 16)
+    cuts = _quad_cut(cum, g_off, n_seg, phase)
     items, seg_ptr = [], [0]
     for s_ in range(n_seg):
         a, b = int(cuts[s_]), int(cuts[s_ + 1])
