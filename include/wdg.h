@@ -170,6 +170,11 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
  * (needed on the host to size the grid and LDS without reading the table back).
  * Jobs are started in table order by persistent workgroups: put the jobs with the most stored entries first
  * so that no long job starts last (results do not depend on the order).
+ * The row-lane kernels behind this entry (and behind wdg_spmm_csr_* for jobs with a SELL-64 copy) draw their items from
+ * work-queue counters in one of 256 device-resident slots, given to a launch when it is enqueued (a launch recorded into a
+ * hipGraph keeps its slot for every replay; recorded and eager launches draw from different halves).  The caller keeps:
+ * at most 128 such launches in flight at a time, at most 128 recorded per process, and no recorded launch running
+ * concurrently with itself on two streams.  The quad-row and band kernels have no queues and no such limits.
  */
 #define WDG_SPMM_ALL_SELL 1 /* every job of the table carries sell_ptr / sell_col            */
 #define WDG_SPMM_ANY_VAL 2  /* some job has explicit values (then sell_val must be set too) */

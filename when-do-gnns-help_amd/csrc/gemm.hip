@@ -413,12 +413,12 @@ int bres_parts(int n_jobs, int max_M) {
 }
 
 int launch_bres(const wdg_gemm_job *jobs, const wdg_gemm_job &inl, int n_jobs, int max_M, int max_N, int K, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
+    static thread_local int configured_dev = -1;
+    if (configured_dev != current_device()) {
         for (const void *k : {reinterpret_cast<const void *>(gemm_bres_kernel<1>), reinterpret_cast<const void *>(gemm_bres_kernel<2>)})
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
-        configured = true;
+        configured_dev = wdg::current_device();
     }
     const int parts = bres_parts(n_jobs, max_M);
     const size_t lds = static_cast<size_t>(ceil_div(K, 32) * 32) * BRES_COLS * 4;
@@ -495,12 +495,12 @@ int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t m
         return wdg::fail(WDG_ERR_UNSUPPORTED, "mlp2_batched: needs H <= 64, C <= 8, 0 < K <= 512, K % 4 == 0 (use two wdg_gemm calls)");
     WDG_REQUIRE(static_cast<int64_t>(n_jobs) * 16 <= 0x7fffffffLL, "mlp2_batched: too many jobs");
     const size_t lds_max = 128 * 1024 + (BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static thread_local int configured_dev = -1;
+    if (configured_dev != wdg::current_device()) {
         for (const void *k : {reinterpret_cast<const void *>(mlp2_bres_kernel<1>), reinterpret_cast<const void *>(mlp2_bres_kernel<2>)})
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_max)) != hipSuccess)
                 return wdg::fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
-        configured = true;
+        configured_dev = wdg::current_device();
     }
     const int parts = bres_parts(n_jobs, max_M);
     const size_t lds = (static_cast<size_t>(wdg::ceil_div(max_K, 32) * 32) * BRES_COLS + BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);

@@ -506,13 +506,13 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
         if (N > 0) {
             hipLaunchKernelGGL(sort_rows_wave, dim3(wave_rows_grid(N)), dim3(256), 0, st, ws.rowstart, N, ws.bucket,
                                ws.long_rows, ws.long_count);
-            static thread_local bool configured = false;
-            if (!configured) {
+            static thread_local int configured_dev = -1;
+            if (configured_dev != current_device()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(sort_rows_block),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         LONG_LDS_KEYS * static_cast<int>(sizeof(u64))) != hipSuccess)
                     return fail(WDG_ERR_LAUNCH, "coo_to_csr: cannot raise dynamic LDS limit");
-                configured = true;
+                configured_dev = current_device();
             }
             hipLaunchKernelGGL(sort_rows_block, dim3(256), dim3(LONG_THREADS), LONG_LDS_KEYS * sizeof(u64), st,
                                ws.rowstart, ws.bucket, ws.long_rows, ws.long_count);

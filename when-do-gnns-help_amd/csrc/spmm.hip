@@ -426,12 +426,12 @@ int launch_slab(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, i
     size_t lds = static_cast<size_t>(max_cols + 1) * SLAB * 4 + (static_cast<size_t>(max_rows) + 1) * 8 + 32;
     if (env_int("WDG_SPMM_ABLATE", 0) & 8) lds += static_cast<size_t>(max_rows) * SLAB * 4 + 16;  // experiment: Y staging
     auto kern = spmm_slab_kernel<SLAB, THREADS, TIN>;
-    static thread_local size_t configured = 0;
-    if (lds > configured) {
+    static thread_local int configured_dev = -1;
+    if (configured_dev != current_device()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(kLdsBytes - 256)) != hipSuccess)
             return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
-        configured = kLdsBytes;
+        configured_dev = current_device();
     }
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(xcd_grid_size(n_items))), dim3(THREADS), lds, st, jobs,
                        inl, n_slabs, static_cast<long long>(n_items));

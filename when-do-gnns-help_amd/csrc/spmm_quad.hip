@@ -909,8 +909,7 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
                               reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, true>),
                               reinterpret_cast<const void *>(spmm_quad_kernel<TIN, true, true>)};
     static thread_local int configured_dev = -1;
-    int dev = 0;
-    hipGetDevice(&dev);
+    const int dev = current_device();
     if (configured_dev != dev) {
         for (const void *k : kernels)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes) - 1024) != hipSuccess)
@@ -943,8 +942,7 @@ namespace wdg {
 int sort_rows_small_limit() { return Q_SORT_MAX_ROWS; }
 int sort_rows_by_length_small(const int32_t *rowptr, int32_t N, int32_t *perm, hipStream_t st) {
     static thread_local int configured_dev = -1;
-    int dev = 0;
-    hipGetDevice(&dev);
+    const int dev = current_device();
     if (configured_dev != dev) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(sell16_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 Q_SORT_MAX_ROWS * 8) != hipSuccess)

@@ -1279,9 +1279,17 @@ int sell_block_cols_for(int n_rows, int n_cols) {
     return std::min(cap, (even + 3) & ~3);  // a multiple of 4: a column's bank class (col mod 4) is the same in every block
 }
 
-unsigned next_queue_slot() {
-    static std::atomic<unsigned> launches{0};
-    return launches.fetch_add(1) % RL_QUEUE_SLOTS;
+// A launch's queue counters live in the slot it is given here, for as long as it runs (its last workgroup re-arms them).
+// Eager launches draw from the lower half of the slots round-robin; a launch recorded into a hipGraph keeps ITS slot for
+// every replay, so it draws from the upper half: an eager launch can then never share counters with a replay running on
+// another stream.  Still the caller's to respect (wdg.h): at most 128 launches of these kernels in flight at a time, at
+// most 128 of them captured per process, and a captured launch never runs concurrently with itself.
+unsigned next_queue_slot(hipStream_t st) {
+    static std::atomic<unsigned> eager{0}, captured{0};
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    const bool capturing = st && hipStreamIsCapturing(st, &status) == hipSuccess && status == hipStreamCaptureStatusActive;
+    constexpr unsigned half = RL_QUEUE_SLOTS / 2;
+    return capturing ? half + captured.fetch_add(1) % half : eager.fetch_add(1) % half;
 }
 
 int64_t resident_grid(int64_t n_items) {  // 1 workgroup per CU (LDS), persistent over items
@@ -1300,15 +1308,15 @@ int launch_rowlane_pipe(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n
     const size_t lds = (static_cast<size_t>(buf_slots) * 2 + RL_WAVES * 128) * 16;
     auto kv = spmm_rowlane_pipe_kernel<QUADS, RPT, true>;
     auto kn = spmm_rowlane_pipe_kernel<QUADS, RPT, false>;
-    static thread_local bool configured = false;
-    if (!configured) {
+    static thread_local int configured_dev = -1;
+    if (configured_dev != current_device()) {
         for (const void *k : {reinterpret_cast<const void *>(kv), reinterpret_cast<const void *>(kn)})
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes) - 1024) != hipSuccess)
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
-        configured = true;
+        configured_dev = current_device();
     }
     const dim3 grid(static_cast<unsigned>(resident_grid(n_items)));
-    const int slot = static_cast<int>(next_queue_slot());
+    const int slot = static_cast<int>(next_queue_slot(st));
     if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, n_jobs, slot, buf_slots);
     else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, n_jobs, slot, buf_slots);
     return check_launch("spmm_rowlane_pipe_kernel");
@@ -1328,29 +1336,29 @@ int launch_rowlane_shared(const wdg_spmm_job *jobs, int n_jobs, int run_len, int
     const size_t lds = (static_cast<size_t>(x_slots) + RL_WAVES * 32 * quads) * 16;
     if (narrow) {
         auto k8n = spmm_rowlane_shared8_kernel<RPT, false>;  // (pattern-only tables: with values the variant would spill)
-        static thread_local bool configured8 = false;
-        if (!configured8) {
+        static thread_local int configured8_dev = -1;
+        if (configured8_dev != current_device()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k8n), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(kLdsBytes / 2)) != hipSuccess)
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
-            configured8 = true;
+            configured8_dev = current_device();
         }
         const dim3 grid8(static_cast<unsigned>(std::min<int64_t>(n_items, 2 * resident_grid(n_items))));
-        const int slot8 = static_cast<int>(next_queue_slot());
+        const int slot8 = static_cast<int>(next_queue_slot(st));
         hipLaunchKernelGGL(k8n, grid8, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot8, x_slots);
         return check_launch("spmm_rowlane_shared8_kernel");
     }
     auto kv = spmm_rowlane_shared_kernel<RPT, true>;
     auto kn = spmm_rowlane_shared_kernel<RPT, false>;
-    static thread_local bool configured = false;
-    if (!configured) {
+    static thread_local int configured_dev = -1;
+    if (configured_dev != current_device()) {
         for (const void *k : {reinterpret_cast<const void *>(kv), reinterpret_cast<const void *>(kn)})
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes) - 1024) != hipSuccess)
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
-        configured = true;
+        configured_dev = current_device();
     }
     const dim3 grid(static_cast<unsigned>(resident_grid(n_items)));
-    const int slot = static_cast<int>(next_queue_slot());
+    const int slot = static_cast<int>(next_queue_slot(st));
     if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot, x_slots);
     else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, n_groups, n_runs, run_len, slot, x_slots);
     return check_launch("spmm_rowlane_shared_kernel");
@@ -1371,15 +1379,15 @@ int launch_rowlane(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs
     auto kn = spmm_rowlane_kernel<QUADS, RPT, TIN, false>;
     auto kv = spmm_rowlane_kernel<QUADS, RPT, TIN, kWithValues>;
     if (has_val && !kWithValues) return fail(WDG_ERR_UNSUPPORTED, "spmm rowlane: no 32-feature kernel with explicit values");
-    static thread_local bool configured = false;
-    if (!configured) {
+    static thread_local int configured_dev = -1;
+    if (configured_dev != current_device()) {
         for (const void *k : {reinterpret_cast<const void *>(kv), reinterpret_cast<const void *>(kn)})
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes) - 1024) != hipSuccess)  // 1 KiB left for static LDS
                 return fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
-        configured = true;
+        configured_dev = current_device();
     }
     const dim3 grid(static_cast<unsigned>(resident_grid(n_items)));
-    const int slot = static_cast<int>(next_queue_slot());
+    const int slot = static_cast<int>(next_queue_slot(st));
     if (has_val) hipLaunchKernelGGL(kv, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items), slot);
     else hipLaunchKernelGGL(kn, grid, dim3(RL_THREADS), lds, st, jobs, inl, n_groups, static_cast<long long>(n_items), slot);
     return check_launch("spmm_rowlane_kernel");

@@ -26,6 +26,14 @@ inline int check_launch(const char *what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Function attributes (the raised dynamic-LDS limit) are per DEVICE: launchers keep `static thread_local int configured_dev = -1`
+// and set them again when the calling thread's current device is not the one they were set for.
+inline int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev;
+}
+
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Map a launch's linear block id
 // to a work item so that each XCD walks a CONTIGUOUS range of items: neighbouring items (adjacent feature
 // slabs of one graph, graphs sharing a feature matrix) then share one L2.  Speed only, never correctness.
