@@ -157,7 +157,8 @@ typedef struct wdg_spmm_job {
     /* optional band plan of the same pattern (wdg_csr_band_plan): enables the band kernel of the single-graph entry points
        (a wave per row and band of 64..256 features gathered from L2; wide features, any skew, any column count); NULL = none */
     const int32_t *band_perm; /* [wdg_csr_band_perm_len(n_rows)] rows by length, longest first; the first band_n_hub are the hub rows */
-    const int32_t *band_cuts; /* [18] cost cuts of the hub rows [0..8] and of the other rows [9..17]                            */
+    const int32_t *band_cuts; /* [24] cost cuts of the hub rows [0..8] and of the other rows [9..17]; [18], [19] = rows of more than
+                                 2048 / 128 entries (the narrow kernel's row classes); the rest 0                                  */
     int32_t band_n_hub;       /* rows of more than 128 entries (each is swept by a whole workgroup)                              */
     int32_t band_reserved;    /* 0 */
 } wdg_spmm_job;
@@ -245,7 +246,7 @@ int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const floa
  * wdg_spmm_csr_f32 run that kernel for fp32 X of >= 16 features when the job carries the plan and no SELL-16 copy in split
  * form): band_perm = the rows by length, longest first (<= 16 384 rows: ties by row index; more: rows of equal length in no
  * particular order - the order only schedules, every row's sum has a fixed order), wdg_csr_band_perm_len(N) ints;
- * band_cuts = 18 ints; *n_hub_host = the number of rows with more than 128 entries (a prefix of band_perm), read back on
+ * band_cuts = 24 ints; *n_hub_host = the number of rows with more than 256 entries (a prefix of band_perm), read back on
  * `stream` (the call synchronises it).  One-time per graph; nothing of the plan depends on the feature width.
  * Replaces, with wdg_spmm_csr_f32, `torch.spmm(adj, x)` of models/baseline_models.py:62-75 for single wide-feature graphs.
  */
@@ -253,6 +254,26 @@ size_t wdg_csr_band_plan_workspace_bytes(int32_t N);
 int32_t wdg_csr_band_perm_len(int32_t N);
 int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, int32_t *n_hub_host,
                       void *workspace, size_t workspace_bytes, wdg_stream_t stream);
+
+/*
+ * The aggregation for ONE graph with at most 8 features (csrc/spmm_narrow.hip; config C5: twitch-gamers scale with 7 bf16
+ * features): the job carries a band plan; `workspace` (wdg_spmm_narrow_workspace_bytes(n_rows, n_cols) bytes) receives the
+ * packed sources cs[c] X[c, 0..7] as fp32 - column scale, conversion and padding once per column - and every stored entry
+ * then costs one 32-byte gather.  When the packed table exceeds what an XCD's L2 holds (wdg_spmm_narrow_parts(n_cols) =
+ * 2, 4 or 8 > 1) the columns are cut into that many ranges, each swept by its own XCDs, and the partial rows are summed in
+ * range order: the call then needs `part_ptr` = the split positions of every row ([n_rows x (parts - 1)] ints, filled once
+ * per graph by wdg_spmm_narrow_plan; NULL when parts is 1).  Sums in a fixed order (lanes split a row's entries, fixed
+ * butterfly, parts ascending).
+ * Replaces `torch.spmm(adj, label_onehot)` utils/homophily_metrics.py:199 and the SGC-1 aggregation on large graphs.
+ */
+int32_t wdg_spmm_narrow_parts(int32_t n_cols);
+size_t wdg_spmm_narrow_workspace_bytes(int32_t n_rows, int32_t n_cols);
+int wdg_spmm_narrow_plan(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *part_ptr,
+                         wdg_stream_t stream);
+int wdg_spmm_narrow_f32(const wdg_spmm_job *job_host, const int32_t *part_ptr, void *workspace, size_t workspace_bytes,
+                        wdg_stream_t stream);
+int wdg_spmm_narrow_bf16(const wdg_spmm_job *job_host, const int32_t *part_ptr, void *workspace, size_t workspace_bytes,
+                         wdg_stream_t stream);
 
 /*
  * The batched aggregation on the quad-row kernel (every job carries its SELL-16 copy).  The caller lays the jobs'

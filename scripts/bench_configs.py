@@ -57,7 +57,9 @@ def single_graph(config, workload, g, x, reps, elem=4, **extra):
     n, f, e = g.n_rows, x.shape[1], g.nnz
     alg = 4 * (n + 1) + 4 * e + 4 * n + elem * n * f + y.element_size() * n * f
     quad = getattr(g, "quad", None)
-    if getattr(g, "band", None) and not quad:
+    if getattr(g, "narrow_ws", None) is not None:
+        kernel = "narrow_pack + spmm_narrow_kernel"
+    elif getattr(g, "band", None) and not quad:
         kernel = f"spmm_band_kernel ({g.band['n_hub']} hub rows)"
     elif quad:
         kernel = f"spmm_quad_kernel ({quad['n_blocks']} column block(s) of {quad['block_cols']})"

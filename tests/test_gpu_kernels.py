@@ -1436,3 +1436,57 @@ def test_spmm_band_is_deterministic_and_sums_in_csr_order(ops, monkeypatch):
             np.testing.assert_array_equal(ah[r], np.cumsum(xh[col[s:e]], axis=0, dtype=np.float32)[-1], err_msg=f"row {r}")
         elif e == s:
             assert not ah[r].any()
+
+
+# ---- the narrow kernel (csrc/spmm_narrow.hip): <= 8 features, lanes split a row's entries ----------------------------------
+NARROW_SHAPES = [  # (rows, columns, features, random entries, hub rows, entries per hub row)
+    (30000, 30000, 7, 600000, 3, 5000), (5000, 9000, 8, 40000, 40, 300), (2000, 2000, 1, 30000, 0, 0),
+    (100, 50, 3, 400, 1, 40), (17, 4000, 5, 0, 17, 2100), (70000, 70000, 4, 300000, 0, 0)]
+
+
+@pytest.mark.parametrize("n,m,f,e,hubs,hub_len", NARROW_SHAPES)
+@pytest.mark.parametrize("parts", [0, 4])
+def test_spmm_narrow_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, hub_len, parts):
+    """the narrow kernel through ops.spmm: all three row classes (16 lanes / a wave / a workgroup per row), every feature
+    count, fp32 and bf16 sources with any leading dimension, explicit values, row / column scales, strided Y, empty rows;
+    one column range and several (partial rows combined in range order)"""
+    monkeypatch.setattr(ops, "NARROW_MIN_ENTRIES", 0)
+    if parts:  # force the column-part variant (else only tables beyond an XCD's L2 take it: 70 000 columns here do)
+        monkeypatch.setenv("WDG_NARROW_PARTS", str(parts))
+    rng = np.random.default_rng(n + 13 * f)
+    rowptr, col = _band_case(rng, n, m, e, hubs, hub_len)
+    val = rng.random(col.shape[0], dtype=np.float32)
+    x = rng.standard_normal((m, f + 2)).astype(np.float32)
+    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, m)
+    deg = np.diff(rowptr)
+
+    def run(use_values, rs, cs, dtype, strided):
+        xt = torch.from_numpy(x).cuda().to(dtype)
+        xt = xt[:, 1:1 + f] if strided else xt[:, :f].contiguous()
+        out = torch.full((n, f + 3), 7.0, device="cuda") if strided else None
+        y = ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
+                     col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values,
+                     out=None if out is None else out[:, 1:1 + f])
+        assert g.narrow_ws is not None and g.quad is None and g.sell is None, "the call must have gone to the narrow kernel"
+        cuts = _np(g.band["cuts"])
+        assert cuts[18] == int((deg > 2048).sum()) and cuts[19] == int((deg > 128).sum())
+        if out is not None:
+            assert float(out[:, :1].min()) == 7.0 and float(out[:, 1 + f:].min()) == 7.0
+        v = val.copy() if use_values else np.ones_like(val)
+        if cs is not None:
+            v = v * cs[col]
+        xr = _np(xt.float())
+        ref64 = oracle.spmm_csr(rowptr, col, v, xr, f64acc=True)
+        if rs is not None:
+            ref64 = ref64 * rs[:, None]
+        scale = np.abs(ref64).max() + 1e-30
+        np.testing.assert_allclose(_np(y), ref64, rtol=2e-5, atol=4e-6 * scale)
+
+    d, dc = rng.random(n, dtype=np.float32), rng.random(m, dtype=np.float32)
+    run(True, None, None, torch.float32, False)
+    run(False, d, dc, torch.float32, True)
+    run(False, d, dc, torch.bfloat16, False)
+    run(True, d, None, torch.bfloat16, True)
+    a = ops.spmm(g, torch.from_numpy(x[:, :f].copy()).cuda(), use_values=False).clone()
+    b = ops.spmm(g, torch.from_numpy(x[:, :f].copy()).cuda(), use_values=False)
+    assert torch.equal(a, b)  # fixed summation order: two launches, same bits

@@ -278,16 +278,23 @@ __global__ __launch_bounds__(1024) void band_cuts_kernel(const int32_t *__restri
     __shared__ long long total_s;
     __shared__ int hub_s;
     const int t = threadIdx.x;
-    if (t == 0) hub_s = 0;
-    if (t < 18) cuts[t] = 0;
+    __shared__ int class_s[2];
+    if (t == 0) hub_s = class_s[0] = class_s[1] = 0;
+    if (t < 24) cuts[t] = 0;
     __syncthreads();
-    int local = 0;
+    int local = 0, wg_rows = 0, wave_rows = 0;
     for (int i = t; i < N; i += 1024) {
         const int row = perm[i];
-        local += (rowptr[row + 1] - rowptr[row]) > hub_len;
+        const int len = rowptr[row + 1] - rowptr[row];
+        local += len > hub_len;
+        wg_rows += len > 2048;  // the narrow kernel's row classes (csrc/spmm_narrow.hip): a workgroup per row,
+        wave_rows += len > 128; // a wave per row, 16 lanes per row
     }
     atomicAdd(&hub_s, local);
+    atomicAdd(&class_s[0], wg_rows);
+    atomicAdd(&class_s[1], wave_rows);
     __syncthreads();
+    if (t == 0) cuts[18] = class_s[0], cuts[19] = class_s[1];
     const int R = hub_s;
     if (t == 0) *n_hub_out = R;
     for (int cls = 0; cls < 2; ++cls) {

@@ -54,6 +54,8 @@ class CsrGraph:
         self.sell = None  # (sell_ptr, sell_col, sell_val|None): SELL-64 copy of the pattern, built on demand
         self.quad = None  # SELL-16 copy (dict) for the quad-row kernel, built on demand; False = decided against
         self.band = None  # band plan (dict) for the band kernel, built on demand; False = not applicable
+        self.narrow_ws = None  # packed-source workspace of the narrow kernel (one per graph: calls on one stream)
+        self.narrow_parts = None  # (parts, split positions of every row) when the packed sources exceed an XCD's L2
 
     def ensure_sell(self, max_padding=3.0):
         """Build the SELL-64 copy (wdg_csr_to_sell_*) that the row-lane SpMM consumes.  One-time per graph.
@@ -96,7 +98,7 @@ class CsrGraph:
             return False
         dev = self.device
         perm = torch.empty(int(lib.wdg_csr_band_perm_len(self.n_rows)), dtype=torch.int32, device=dev)
-        cuts = torch.empty(18, dtype=torch.int32, device=dev)
+        cuts = torch.empty(24, dtype=torch.int32, device=dev)
         ws_bytes = lib.wdg_csr_band_plan_workspace_bytes(self.n_rows)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         n_hub = ctypes.c_int32(0)
@@ -316,6 +318,9 @@ def unpack_bits(words, n_feat, row_normalise=False):
 
 
 # ------------------------------------------------------------------------------------------- aggregation
+NARROW_MIN_ENTRIES = 1 << 18  # below that a launch is latency-bound whatever the kernel: keep the general families
+
+
 def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
     job.rowptr, job.col = g.rowptr.data_ptr(), g.col.data_ptr()
     job.val = g.val.data_ptr() if (use_values and g.val is not None) else 0
@@ -420,6 +425,21 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
         raise ValueError(f"spmm: X has {x.shape[0]} rows, adjacency has {g.n_cols} columns")
     y = out if out is not None else torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=dev)
     row_scale, col_scale = _dev(row_scale, torch.float32, dev), _dev(col_scale, torch.float32, dev)
+    if x.shape[1] <= 8 and g.nnz >= NARROW_MIN_ENTRIES and os.environ.get("WDG_SPMM_NARROW", "1") != "0" and g.ensure_band():
+        # few features on a large graph: packed sources, lanes split the entries (csrc/spmm_narrow.hip)
+        job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values, band=True)
+        ws_bytes = lib.wdg_spmm_narrow_workspace_bytes(g.n_rows, g.n_cols)
+        if g.narrow_ws is None or g.narrow_ws.numel() < ws_bytes:
+            g.narrow_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        parts = int(lib.wdg_spmm_narrow_parts(g.n_cols))
+        if parts > 1 and (g.narrow_parts is None or g.narrow_parts[0] != parts):  # one-time: every row's split positions
+            pp = torch.empty(g.n_rows * (parts - 1), dtype=torch.int32, device=dev)
+            check(lib.wdg_spmm_narrow_plan(_ptr(g.rowptr), _ptr(g.col), g.n_rows, g.n_cols, _ptr(pp), stream_handle()), "wdg_spmm_narrow_plan")
+            g.narrow_parts = (parts, pp)
+        part_ptr = g.narrow_parts[1] if parts > 1 else None
+        fn = lib.wdg_spmm_narrow_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_narrow_f32
+        check(fn(ctypes.byref(job), _ptr(part_ptr), _ptr(g.narrow_ws), ws_bytes, stream_handle()), "wdg_spmm_narrow")
+        return y
     band = x.dtype == torch.float32 and g.prefers_band(x.shape[1])  # one-time plan -> band kernel (wide features, skew)
     if not band and x.shape[1] >= 8 and not g.ensure_quad():  # one-time SELL-16 copy -> quad-row kernel (<= 10 112 columns)
         g.ensure_sell()  # else the SELL-64 copy -> row-lane kernels for graphs of <= 3072 rows
