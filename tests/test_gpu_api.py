@@ -239,3 +239,27 @@ def test_synthetic_generator_known_answers(mods):
         lab = torch.from_numpy(labels)
         assert _f(hp.edge_homophily(adj, torch.eye(5)[lab])) == pytest.approx(k / d, rel=1e-7)
         assert _f(hp.node_homophily(adj, lab)) == pytest.approx((k + 1) / (d + 1), rel=1e-6)
+
+
+def test_csr_tag_survives_the_round_trip_through_a_torch_sparse_tensor():
+    """homophily_tests.py hands the normalised adjacency to the metric functions as a torch sparse tensor; the CSR it was
+    made from rides along, so the metric functions do not rebuild it (and a coalesced copy, which drops the tag, still works)"""
+    from wdg_amd import ops
+    rng = np.random.default_rng(3)
+    n = 300
+    src, dst = rng.integers(0, n, 2000), rng.integers(0, n, 2000)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+    t = g.to_torch_sparse()
+    assert ops.CsrGraph.from_any(t) is g
+    g2 = ops.CsrGraph.from_any(t.coalesce() * 1.0)
+    assert g2 is not g
+    assert torch.equal(g2.rowptr, g.rowptr) and torch.equal(g2.col, g.col)
+
+
+def test_row_l1_normalise_is_torch_normalize_p1():
+    from wdg_amd import ops
+    x = torch.randn(500, 37, device="cuda")
+    x[7] = 0
+    want = torch.nn.functional.normalize(x, p=1, dim=1)
+    got = ops.row_l1_normalise(x, use_abs=True)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)

@@ -201,7 +201,9 @@ constexpr int KR_COL_LD = 12;  // a thread's 10 column values, padded to three d
 
 __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *__restrict__ jobs) {
     __shared__ float colbuf[2][KR_T * KR_COL_LD];     // the pivot column of a step, [i % 32][i / 32] (double-buffered)
-    __shared__ float rhs[KR_MAX_N * KR_MAX_C];        // one-hot labels -> y -> alpha, [i][c]
+    __shared__ float rhs[KR_MAX_N * KR_MAX_C];        // one-hot labels, reduced step by step; later alpha, [i][c]
+    __shared__ float ysol[KR_MAX_N * KR_MAX_C];       // y = L^-1 B, written as the factorisation goes
+    __shared__ float dblk[KR_T * (KR_T + 1)];         // a diagonal block of L for the blocked back substitution
     __shared__ int tr_idx[KR_MAX_N];
     __shared__ int deficient;                         // a pivot fell to rounding level: redo on K + lambda I
     __shared__ float part[4][256][KR_MAX_C];          // partial predictions of the validation rows
@@ -219,10 +221,6 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
         return;
     }
     for (int i = tid; i < KR_MAX_N; i += KR_THREADS) tr_idx[i] = i < nt ? train[i] : -1;
-    for (int i = tid; i < KR_MAX_N * KR_MAX_C; i += KR_THREADS) {
-        const int row = i / KR_MAX_C, c = i % KR_MAX_C;
-        rhs[i] = (row < nt && labels[train[row]] == c) ? 1.f : 0.f;
-    }
     if (tid == 0) correct = 0;
     __syncthreads();
 
@@ -234,6 +232,11 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
 #define KR_M(A, B) m[(A) * ((A) + 1) / 2 + (B)]
     float ridge = 0.f;  // second attempt only (below)
     for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int i = tid; i < KR_MAX_N * KR_MAX_C; i += KR_THREADS) {  // (the forward substitution below consumes it: per attempt)
+        const int row = i / KR_MAX_C, c = i % KR_MAX_C;
+        rhs[i] = (row < nt && labels[tr_idx[row]] == c) ? 1.f : 0.f;
+        ysol[i] = 0.f;
+    }
     float dmax = 0.f;
 #pragma unroll
     for (int a = 0; a < KR_B; ++a) {
@@ -305,6 +308,17 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
                     KR_M(a, kb) = i > k ? li : (i == k ? piv * inv : KR_M(a, kb));
                 }
             }
+            // the forward substitution L y = B rides along (column form): y_k = b_k / l_kk, b_i -= l_ik y_k for i > k.  Row k
+            // of B is final here (its last update was published by this step's barrier); eight threads per row.
+            if (k < nt) {
+                const int c = tid & (KR_MAX_C - 1);
+                const float yk = rhs[k * KR_MAX_C + c] * inv;  // (1 / l_kk = 1 / sqrt(pivot))
+                if (tid < KR_MAX_C) ysol[k * KR_MAX_C + c] = yk;
+                for (int i = k + 1 + (tid >> 3); i < nt; i += KR_THREADS / KR_MAX_C) {
+                    const float lik = cb[(i & (KR_T - 1)) * KR_COL_LD + (i >> 5)] * inv;
+                    rhs[i * KR_MAX_C + c] = fmaf(-lik, yk, rhs[i * KR_MAX_C + c]);
+                }
+            }
         }
     };
 #define KR_EACH_BLOCK(F)                                                                                               \
@@ -325,67 +339,61 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
     __syncthreads();
     }  // attempt
 
-    // ---- forward substitution L y = B (column form): y_k = b_k / l_kk, then b_i -= l_ik y_k for i > k
-    auto fwd_block = [&](auto kb_const) {
+    // ---- back substitution L^T alpha = y, one 32-column block at a time (30 barriers instead of two per column):
+    //      z = y_kb - sum over the blocks A > kb of L[A, kb]^T alpha_A (every thread multiplies the <= 9 elements it holds,
+    //      the 32 threads of a column are summed through LDS in a fixed order), then wave 0 solves the 32 x 32 triangle
+    //      L[kb, kb]^T alpha_kb = z by itself (lane = column, the two half-waves take four right-hand sides each).
+    float(*const zpart)[KR_T][KR_MAX_C] = reinterpret_cast<float(*)[KR_T][KR_MAX_C]>(&part[0][0][0]);  // [16 waves][32][8]
+    const int n_blocks = (nt + KR_T - 1) / KR_T;
+    auto bwd_block = [&](auto kb_const) {
         constexpr int kb = decltype(kb_const)::value;
-        if (kb * KR_T >= nt) return;
-        for (int kk = 0; kk < KR_T; ++kk) {
-            const int k = kb * KR_T + kk;
-            if (tc == kk && trw == kk) {  // the owner of (k, k)
-                const float d = KR_M(kb, kb);
+        if (kb >= n_blocks) return;  // (uniform)
+        float z[KR_MAX_C];
 #pragma unroll
-                for (int c = 0; c < KR_MAX_C; ++c) {
-                    const float y = rhs[k * KR_MAX_C + c] / d;
-                    rhs[k * KR_MAX_C + c] = y;
-                    bcast[c] = y;
-                }
-            }
-            __syncthreads();
-            if (tc == kk) {
+        for (int c = 0; c < KR_MAX_C; ++c) z[c] = 0.f;
 #pragma unroll
-                for (int a = 0; a < KR_B; ++a) {
-                    const int i = trw + KR_T * a;
-                    if (a >= kb && i > k && i < nt) {
-                        const float l = KR_M(a >= kb ? a : kb, kb);
+        for (int a = kb + 1; a < KR_B; ++a) {
+            if (a >= n_blocks) continue;
+            const float l = KR_M(a, kb);
+            const float *al = rhs + (trw + KR_T * a) * KR_MAX_C;  // alpha of the blocks below: already solved
 #pragma unroll
-                        for (int c = 0; c < KR_MAX_C; ++c) rhs[i * KR_MAX_C + c] = fmaf(-l, bcast[c], rhs[i * KR_MAX_C + c]);
-                    }
-                }
-            }
-            __syncthreads();
+            for (int c = 0; c < KR_MAX_C; ++c) z[c] = fmaf(l, al[c], z[c]);
         }
-    };
-    KR_EACH_BLOCK(fwd_block)
-    // ---- backward substitution L^T alpha = y (row form): alpha_k = y_k / l_kk, then y_j -= l_kj alpha_k for j < k
-    auto bwd_block = [&](auto ka_const) {
-        constexpr int ka = decltype(ka_const)::value;
-        if (ka * KR_T >= nt) return;
-        for (int kk = KR_T - 1; kk >= 0; --kk) {
-            const int k = ka * KR_T + kk;
-            if (k >= nt) continue;  // uniform
-            if (tc == kk && trw == kk) {
-                const float d = KR_M(ka, ka);
 #pragma unroll
-                for (int c = 0; c < KR_MAX_C; ++c) {
-                    const float al = rhs[k * KR_MAX_C + c] / d;
-                    rhs[k * KR_MAX_C + c] = al;
-                    bcast[c] = al;
-                }
-            }
-            __syncthreads();
-            if (trw == kk) {  // the owners of row k of L
+        for (int c = 0; c < KR_MAX_C; ++c) z[c] += __shfl_xor(z[c], 32);  // the wave's two rows
+        if ((tid & 32) == 0) {
 #pragma unroll
-                for (int b = 0; b < KR_B; ++b) {
-                    const int j = tc + KR_T * b;
-                    if (b <= ka && j < k) {
-                        const float l = KR_M(ka, b <= ka ? b : ka);
-#pragma unroll
-                        for (int c = 0; c < KR_MAX_C; ++c) rhs[j * KR_MAX_C + c] = fmaf(-l, bcast[c], rhs[j * KR_MAX_C + c]);
-                    }
-                }
-            }
-            __syncthreads();
+            for (int c = 0; c < KR_MAX_C; ++c) zpart[tid >> 6][tc][c] = z[c];
         }
+        dblk[trw * (KR_T + 1) + tc] = KR_M(kb, kb);
+        __syncthreads();
+        if (tid < KR_T * KR_MAX_C) {  // 256 threads: (column j, right-hand side c)
+            const int j = tid >> 3, c = tid & 7;
+            float sum = zpart[0][j][c];
+#pragma unroll
+            for (int w = 1; w < KR_THREADS / 64; ++w) sum += zpart[w][j][c];
+            ysol[(kb * KR_T + j) * KR_MAX_C + c] -= sum;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int j = tid & 31, c0 = (tid >> 5) * 4;
+            float zz[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zz[c] = ysol[(kb * KR_T + j) * KR_MAX_C + c0 + c];
+            for (int k = KR_T - 1; k >= 0; --k) {
+                const float dinv = 1.f / dblk[k * (KR_T + 1) + k];
+                const float lkj = j < k ? dblk[k * (KR_T + 1) + j] : 0.f;  // row k of L = column k of L^T
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float ak = __shfl(zz[c], (tid & 32) + k) * dinv;
+                    if (j == k) zz[c] = ak;
+                    zz[c] = fmaf(-lkj, ak, zz[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rhs[(kb * KR_T + j) * KR_MAX_C + c0 + c] = (kb * KR_T + j) < nt ? zz[c] : 0.f;
+        }
+        __syncthreads();
     };
     KR_EACH_BLOCK_DOWN(bwd_block)
 

@@ -21,6 +21,7 @@ import os
 import numpy as np
 import torch
 
+from . import ops
 from .utils import homophily_metrics as hm
 from .utils import util_funcs as uf
 
@@ -74,7 +75,7 @@ def run(dataset_path, homophily_metric, symmetric=0, sample_max=500, base_classi
         features = uf.normalize_tensor(features_raw.to(device))
         adj = uf.normalized_adjacency_csr(adj_raw, symmetric=int(symmetric), prec=0).to_torch_sparse()
     else:                      # homophily_tests.py:87-110 (fp64 scipy coefficients, F.normalize on features)
-        features = torch.nn.functional.normalize(features_raw.to(device), p=1, dim=1)
+        features = ops.row_l1_normalise(features_raw.to(device), use_abs=True)  # f.normalize(features, p=1, dim=1)
         adj = uf.normalized_adjacency_csr(adj_raw, symmetric=int(symmetric), prec=1).to_torch_sparse()
     labels = labels_raw.to(device).flatten()
 

@@ -241,6 +241,9 @@ class CsrGraph:
             return a
         if isinstance(a, torch.Tensor):
             if a.layout == torch.sparse_coo:
+                g = getattr(a, "_wdg_csr", None)  # tagged by to_torch_sparse()
+                if g is not None and flags == 0 and (g.n_rows, g.n_cols) == tuple(a.shape) and g.nnz == a._nnz():
+                    return g
                 return CsrGraph.from_torch_sparse(a, flags)
             if a.dim() == 2 and a.shape[0] == 2 and not a.is_floating_point():
                 raise TypeError("edge-index tensors need an explicit node count: use CsrGraph.from_coo")
@@ -268,7 +271,11 @@ class CsrGraph:
     def to_torch_sparse(self):
         idx = torch.stack([self.row_indices(), self.col.to(torch.int64)])
         val = self.val if self.val is not None else torch.ones(self.nnz, device=self.device)
-        return torch.sparse_coo_tensor(idx, val, (self.n_rows, self.n_cols)).coalesce()
+        t = torch.sparse_coo_tensor(idx, val, (self.n_rows, self.n_cols)).coalesce()
+        # the API twins hand this tensor straight back to functions that need the CSR: from_any() finds it here instead of
+        # running the COO -> CSR build again (the tensor is a view of the same pattern; .coalesce() / arithmetic drop the tag)
+        t._wdg_csr = self
+        return t
 
     def with_values(self, val):  # (neither SELL copy is shared: both hold values)
         return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)  # SELL copy (holds values) not shared
