@@ -512,7 +512,7 @@ struct QJobC {
 
 __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                              int unit_begin, int unit_end, int stride, int f0, lds_cptr slab, bool no_sweep,
-                                             bool no_store, int wave, int lane) {
+                                             bool no_store, bool no_idx, int wave, int lane) {
     constexpr int NPRE = 2;        // index chunks per entry (all of them), requested one super-unit ahead
     constexpr bool HAS_VAL = false;  // (explicit values run the plain loop)
     const int r = lane >> 2, p = lane & 3;
@@ -592,7 +592,8 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
         }
 #pragma unroll
         for (int i = 0; i < Q_SU; ++i) {
-            const unsigned off = static_cast<unsigned>(__builtin_amdgcn_readlane(e.ext.x, i)) * (Q_CHUNK_INTS * 4) + lane16;
+            // (no_sweep with bit 3 of the ablation word: every chunk request goes to chunk 0 - what the index stream costs)
+            const unsigned off = (no_idx ? 0u : static_cast<unsigned>(__builtin_amdgcn_readlane(e.ext.x, i)) * (Q_CHUNK_INTS * 4)) + lane16;
             s.c[i][0] = q_ld4(ji.col, off);
             if (NPRE > 1) s.c[i][NPRE - 1] = q_ld4_1k(ji.col, off);
         }
@@ -752,7 +753,7 @@ __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const w
     // whole feature group and 16-byte stores for every job of the phase (the table's flags vouch for the alignment)
     // (y_vec: the launcher's promise - 16-byte stores, 32-bit offsets, every job in split form; explicit values: plain loop)
     const bool full = (f0 + 16 <= F) && head.y_vec && !HAS_VAL;
-    if (full) q_units_fast(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, no_sweep, no_store, wave, lane);
+    if (full) q_units_fast(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, no_sweep, no_store, (head.reserved & 8) != 0, wave, lane);
     else q_units_simple<HAS_VAL>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, no_store, wave, lane);
 }
 
