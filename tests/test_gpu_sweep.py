@@ -289,3 +289,31 @@ def test_batched_training_matches_per_graph_training(kind):
             torch.testing.assert_close(g, p.detach(), rtol=2e-3, atol=2e-4)
         assert abs(float(out["val_acc"][j]) - ref["val_acc"]) <= 2.5 / tb.va.shape[1]
     assert float(out["val_acc"].mean()) > 0.3
+
+
+def test_base_sweep_shares_graphs_and_matches_the_oracle_per_base(oracle):
+    """synthetic_plot.py:64-65: the same adjacencies under several feature bases of different widths (here 3 of the 6
+    reference widths at N = 1000): graphs are built once, every base's aggregation and step scalars match the oracle"""
+    from wdg_amd import sweep, synth
+    jobs = sweep.make_jobs([0.2, 0.6], [0, 1], k=2, n_nodes=1000)
+    bases = (("pubmed", 500), ("film", 932), ("cora", 1433))
+    bs = sweep.BaseSweep(jobs, bases)
+    assert all(b.graphs[i] is bs.batches[0].graphs[i] for b in bs.batches for i in range(len(jobs)))
+    assert bs.batches[0].graphs[0].quad is not None
+    bs.step()
+    torch.cuda.synchronize()
+    res = bs.results()
+    assert tuple(res.shape) == (3, len(jobs), sweep.STEP_METRICS)
+    for bi, (name, width) in enumerate(bases):
+        b = bs.batches[bi]
+        for ji in (0, 3):
+            j = jobs[ji]
+            src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+            rowptr, col, val = oracle.coo_to_csr(src, dst, j.n_nodes, None, oracle.ADD_SELF_LOOPS)
+            vhat = oracle.normalised_csr(rowptr, col, val, 0, oracle.PREC_F32)
+            x = synth.features(j.n_nodes, width, j.seed + 1000 * bi)
+            want = oracle.spmm_csr(rowptr, col, vhat, x)
+            np.testing.assert_allclose(b.y[ji].cpu().numpy(), want, rtol=1e-5, atol=1e-6 * np.abs(want).max(), err_msg=f"{name} job {ji}")
+        # the integer metrics do not depend on the base
+        assert torch.equal(res[bi, :, :5], res[0, :, :5])
+        assert abs(float(res[bi, 0, 0]) - 2 / int(2 / 0.2)) < 1e-6  # edge homophily = k / int(k / h)

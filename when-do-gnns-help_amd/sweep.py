@@ -98,10 +98,13 @@ def gather_results(local_rows, device):
 class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
-    def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None):
+    def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None, share=None, feature_seed=0):
         """jobs: list of Job (graph + features come from the generator of synth.py) - or, with `inputs`, a list of the same
         length of (src, dst, labels, features [n, n_feat] fp32 numpy) tuples to run instead (real / fixture graphs; jobs that
-        share a feature matrix must pass the same array object and carry the same `seed`)."""
+        share a feature matrix must pass the same array object and carry the same `seed`).
+        share: another SweepBatch over the SAME jobs whose graphs (CSR, SELL-16 copy, degrees, labels) this one reuses - the
+        feature bases of synthetic_plot.py:64-65 aggregate different feature matrices over the same 300 adjacencies
+        (BaseSweep below); feature_seed offsets the generator's feature seed per base."""
         from . import ops
         self.ops = ops
         self.jobs = list(jobs)
@@ -125,11 +128,15 @@ class SweepBatch:
             if inputs is not None:
                 src, dst, lab, x_host = inputs[ji]
                 lab = np.asarray(lab)
+            elif share is not None:
+                src = dst = None
+                lab, x_host = share.labels[ji].cpu().numpy().astype(np.int64), None
             else:
                 src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
                 x_host = None
             if j.seed not in feats:
-                x = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed) if x_host is None else np.ascontiguousarray(x_host, np.float32)).to(dev)
+                x = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
+                                     else np.ascontiguousarray(x_host, np.float32)).to(dev)
                 if ride:
                     xa = torch.zeros((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev)
                     xa[:, :n_feat] = x
@@ -138,8 +145,11 @@ class SweepBatch:
                 feats[j.seed], seed_labels[j.seed] = x, lab
             elif ride and not np.array_equal(seed_labels[j.seed], lab):
                 raise ValueError("SweepBatch: jobs of one seed differ in labels; set WDG_SWEEP_RIDE_LABELS=0")
-            g = ops.CsrGraph.from_coo(src, dst, j.n_nodes, None, ops.COO_ADD_SELF_LOOPS)  # A + I (synthetic_plot.py:92)
-            d = ops.degree_norm(g, ops.NORM_SYM if symmetric else ops.NORM_RW, ops.PREC_F32, use_values=True)["dinv"]
+            if share is not None:
+                g, d = share.graphs[ji], share.dinv[ji]
+            else:
+                g = ops.CsrGraph.from_coo(src, dst, j.n_nodes, None, ops.COO_ADD_SELF_LOOPS)  # A + I (synthetic_plot.py:92)
+                d = ops.degree_norm(g, ops.NORM_SYM if symmetric else ops.NORM_RW, ops.PREC_F32, use_values=True)["dinv"]
             self.graphs.append(g)
             self.dinv.append(d)
             self.labels.append(torch.from_numpy(lab).to(dev).to(torch.int32))
@@ -357,6 +367,38 @@ class SweepBatch:
         better = (g_res > x_res).astype(np.float32).mean(2)
         pvals = torch.from_numpy(np.where(better <= 0.5, p / 2, 1 - p / 2))
         return torch.cat([base, ge[:, None], pvals], 1)
+
+
+class BaseSweep:
+    """The feature bases of the reference's sweep (synthetic_plot.py:64-65,78-82: the 300 synthetic adjacencies are paired
+    with features sampled from each of six base datasets, 1 800 jobs): one SweepBatch per base over the SAME jobs, all of
+    them sharing the graphs of the first (CSR, SELL-16 copy, degrees, labels are built once); every base has its own
+    feature width (the aggregation's grid follows it: ceil((F + C) / 16) feature groups; widths over 512 take two GEMM
+    launches for the GCN forward instead of the fused transform)."""
+
+    # (name, feature width) of the reference's bases; the real feature tables are absent from the checkout except pubmed's
+    REFERENCE_BASES = (("cora", 1433), ("citeseer", 3703), ("pubmed", 500), ("chameleon", 2325), ("squirrel", 2089), ("film", 932))
+
+    def __init__(self, jobs, bases=REFERENCE_BASES, symmetric=0, gcn_hidden=64):
+        self.bases = list(bases)
+        self.batches = []
+        for bi, (_name, width) in enumerate(self.bases):
+            self.batches.append(SweepBatch(jobs, n_feat=width, symmetric=symmetric, gcn_hidden=gcn_hidden,
+                                           share=self.batches[0] if self.batches else None, feature_seed=1000 * bi))
+        self.jobs = self.batches[0].jobs
+
+    def step(self):
+        """a step of every base (the integer edge/label pass is repeated per base: 40-60 us beside each base's GEMM)"""
+        for b in self.batches:
+            b.step()
+
+    def results(self):
+        """[bases, jobs, 6]: the step's scalars per base"""
+        return torch.stack([b.results() for b in self.batches])
+
+    @property
+    def edges(self):
+        return sum(b.edges for b in self.batches)
 
 
 class TrainBatch:
