@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 6 --warmup 2 --cpu-budget 0 $*"
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$name.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
 run fetch FETCH_SIZE

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 python3 bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 60 --warmup 10 --cpu-budget 0 --secondary 0 --full-metrics 0 "$@" > "$OUT/stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 60 --warmup 10 --cpu-budget 0 --secondary 0 --full-metrics 0 "$@" > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 cd "$ROOT"
