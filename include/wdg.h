@@ -185,6 +185,7 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
 #define WDG_SPMM_SMALL_OFFSETS 8 /* every job: n_rows x ldy < 2^30 elements, fewer than 2^22 index chunks (byte offsets into Y and
                                    into q_col / q_val fit 32 bits) and a SELL-16 copy in split form (WDG_SELL16_SPLIT): with
                                    WDG_SPMM_DMA_OK the quad-row kernel's pipelined loop */
+#define WDG_SPMM_ANY_COL_SCALE 16 /* some job has a column scale (wdg_spmm_narrow_batched_f32 gathers it per entry) */
 #define WDG_SPMM_SHARED_X(r) (((r) & 0xff) << 8) /* every aligned group of r (2..255) consecutive jobs of the table has the
                                same X, ldx, n_cols and n_feat (the h-levels of one seed): with WDG_SPMM_ALL_SELL |
                                WDG_SPMM_DMA_OK, <= 2032 columns and <= 2048 rows the shared-X row-lane kernel (family 4)
@@ -274,6 +275,15 @@ int wdg_spmm_narrow_f32(const wdg_spmm_job *job_host, const int32_t *part_ptr, v
                         wdg_stream_t stream);
 int wdg_spmm_narrow_bf16(const wdg_spmm_job *job_host, const int32_t *part_ptr, void *workspace, size_t workspace_bytes,
                          wdg_stream_t stream);
+
+/*
+ * Many graphs with at most 8 features each in one launch (the sweep's logits aggregation A_hat Z with C classes): plain CSR,
+ * 16 lanes per row, sources read IN PLACE - every job's X must be 16-byte aligned with ldx a multiple of 4 and >= 4 (>= 8
+ * when the job has more than 4 features: a source row is read as one or two float4).  flags: WDG_SPMM_ANY_VAL,
+ * WDG_SPMM_ANY_COL_SCALE.  Sums in a fixed order (lane layout + fixed butterfly).
+ */
+int wdg_spmm_narrow_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_feat, int flags,
+                                wdg_stream_t stream);
 
 /*
  * The batched aggregation on the quad-row kernel (every job carries its SELL-16 copy).  The caller lays the jobs'

@@ -1490,3 +1490,38 @@ def test_spmm_narrow_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, h
     a = ops.spmm(g, torch.from_numpy(x[:, :f].copy()).cuda(), use_values=False).clone()
     b = ops.spmm(g, torch.from_numpy(x[:, :f].copy()).cuda(), use_values=False)
     assert torch.equal(a, b)  # fixed summation order: two launches, same bits
+
+
+@pytest.mark.parametrize("f,ld", [(5, 8), (8, 8), (3, 4), (1, 12), (4, 4)])
+def test_spmm_narrow_batched_table(ops, oracle, f, ld):
+    """job tables of <= 8 features whose sources are 16-byte aligned rows of whole float4s run the batched narrow kernel
+    (sources read in place); values, row and column scales per job, jobs of different sizes, empty rows"""
+    rng = np.random.default_rng(f * 10 + ld)
+    entries, refs = [], []
+    for ji, n in enumerate((700, 64, 1500, 1)):
+        rowptr, col = _band_case(rng, n, n, 12 * n, 1 if n > 100 else 0, min(n, 300))
+        if col.shape[0] == 0:
+            rowptr, col = np.array([0, 1], np.int32), np.array([0], np.int32)
+        val = rng.random(col.shape[0], dtype=np.float32) if ji % 2 else None
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), None if val is None else torch.from_numpy(val).cuda(), n, n)
+        store = torch.from_numpy(rng.standard_normal((n, ld)).astype(np.float32)).cuda()
+        x = store[:, :f]
+        y = torch.full((n, f + 2), 3.0, device="cuda")[:, :f]
+        rs = rng.random(n, dtype=np.float32) if ji != 1 else None
+        cs = rng.random(n, dtype=np.float32) if ji >= 2 else None
+        entries.append((g, x, y, None if rs is None else torch.from_numpy(rs).cuda(), None if cs is None else torch.from_numpy(cs).cuda(), True))
+        v = val.copy() if val is not None else np.ones(col.shape[0], np.float32)
+        if cs is not None:
+            v = v * cs[col]
+        ref = oracle.spmm_csr(rowptr, col, v, _np(x), f64acc=True)
+        refs.append(ref if rs is None else ref * rs[:, None])
+    batch = ops.SpmmBatch(entries)
+    assert batch.narrow and batch.kernel_name() == "spmm_narrow_batched_kernel"
+    batch.launch()
+    torch.cuda.synchronize()
+    for (g, x, y, *_), ref in zip(entries, refs):
+        np.testing.assert_allclose(_np(y), ref, rtol=2e-5, atol=4e-6 * (np.abs(ref).max() + 1e-30))
+        assert float(y._base[:, f:].min()) == 3.0  # nothing written beside Y
+    first = [e[2].clone() for e in entries]
+    batch.launch()
+    assert all(torch.equal(a, e[2]) for a, e in zip(first, entries))

@@ -49,13 +49,17 @@ struct Acc8 {
     float v[8];
 };
 
-// partial sums of the entries b + sub, b + sub + G, ... < e of one row; four gathers in flight per lane
-template <int G, bool HAS_VAL>
+// partial sums of the entries b + sub, b + sub + G, ... < e of one row; four gathers in flight per lane.  A source row is
+// `ldq` float4s apart (2 for the packed table); WIDE: eight features (two 16-byte loads), else four (one);
+// HAS_W: explicit values and / or a column scale gathered per entry (either pointer may be null)
+template <int G, bool HAS_W, bool WIDE = true>
 __device__ __forceinline__ Acc8 narrow_sweep(global_ptr<const int32_t> col, global_ptr<const float> val,
-                                             global_ptr<const f32x4_t> T, int b, int e, int sub) {
+                                             global_ptr<const f32x4_t> T, int b, int e, int sub, int64_t ldq = 2,
+                                             global_ptr<const float> cs = nullptr) {
     Acc8 a;
 #pragma unroll
     for (int f = 0; f < 8; ++f) a.v[f] = 0.f;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     int k = b + sub;
     for (; k + 3 * G < e; k += 4 * G) {
         int idx[4];
@@ -65,27 +69,29 @@ __device__ __forceinline__ Acc8 narrow_sweep(global_ptr<const int32_t> col, glob
         for (int u = 0; u < 4; ++u) idx[u] = col[k + u * G];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            lo[u] = T[2 * static_cast<int64_t>(idx[u])];
-            hi[u] = T[2 * static_cast<int64_t>(idx[u]) + 1];
-            w[u] = HAS_VAL ? val[k + u * G] : 1.f;
+            lo[u] = T[ldq * static_cast<int64_t>(idx[u])];
+            hi[u] = WIDE ? T[ldq * static_cast<int64_t>(idx[u]) + 1] : zero;
+            w[u] = 1.f;
+            if (HAS_W) w[u] = (val ? val[k + u * G] : 1.f) * (cs ? cs[idx[u]] : 1.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                a.v[f] = HAS_VAL ? __builtin_fmaf(w[u], lo[u][f], a.v[f]) : a.v[f] + lo[u][f];
-                a.v[4 + f] = HAS_VAL ? __builtin_fmaf(w[u], hi[u][f], a.v[4 + f]) : a.v[4 + f] + hi[u][f];
+                a.v[f] = HAS_W ? __builtin_fmaf(w[u], lo[u][f], a.v[f]) : a.v[f] + lo[u][f];
+                if (WIDE) a.v[4 + f] = HAS_W ? __builtin_fmaf(w[u], hi[u][f], a.v[4 + f]) : a.v[4 + f] + hi[u][f];
             }
         }
     }
     for (; k < e; k += G) {
         const int idx = col[k];
-        const f32x4_t lo = T[2 * static_cast<int64_t>(idx)], hi = T[2 * static_cast<int64_t>(idx) + 1];
-        const float w = HAS_VAL ? val[k] : 1.f;
+        const f32x4_t lo = T[ldq * static_cast<int64_t>(idx)], hi = WIDE ? T[ldq * static_cast<int64_t>(idx) + 1] : zero;
+        float w = 1.f;
+        if (HAS_W) w = (val ? val[k] : 1.f) * (cs ? cs[idx] : 1.f);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            a.v[f] = HAS_VAL ? __builtin_fmaf(w, lo[f], a.v[f]) : a.v[f] + lo[f];
-            a.v[4 + f] = HAS_VAL ? __builtin_fmaf(w, hi[f], a.v[4 + f]) : a.v[4 + f] + hi[f];
+            a.v[f] = HAS_W ? __builtin_fmaf(w, lo[f], a.v[f]) : a.v[f] + lo[f];
+            if (WIDE) a.v[4 + f] = HAS_W ? __builtin_fmaf(w, hi[f], a.v[4 + f]) : a.v[4 + f] + hi[f];
         }
     }
     return a;
@@ -222,6 +228,28 @@ __global__ __launch_bounds__(256) void narrow_combine(const float *__restrict__ 
     Y[static_cast<int64_t>(row) * ldy + f] = sum * (rs ? rs[row] : 1.f);
 }
 
+// ---- many small graphs, <= 8 features, sources read in place (no packing: the rows must be 16-byte aligned with a leading
+//      dimension of whole float4s - the sweep's logits aggregation A_hat Z, Z = relu(Y W0) W1 with C = 5 classes, Z stored
+//      with ld 8): a workgroup takes 16 rows of one job, 16 lanes per row; rows in natural order (the sweep's rows are of
+//      about equal length); column scales, where a job has them, are gathered per entry.
+template <bool HAS_W, bool WIDE>
+__global__ __launch_bounds__(N_THREADS) void spmm_narrow_batched_kernel(const wdg_spmm_job *__restrict__ jobs, int blocks_per_job) {
+    const int job_id = blockIdx.x / blocks_per_job, rb = blockIdx.x % blocks_per_job;
+    const desc_ptr<wdg_spmm_job> job = (desc_ptr<wdg_spmm_job>)(jobs + job_id);
+    const int N = job->n_rows, F = job->n_feat;
+    const int lane = threadIdx.x & 63;
+    const int row = rb * 16 + (threadIdx.x >> 4);
+    if (rb * 16 >= N) return;  // (uniform: jobs smaller than the launch bound)
+    const global_ptr<const int32_t> rowptr = to_global(job->rowptr), col = to_global(job->col);
+    const global_ptr<const float> val = to_global(job->val), rs = to_global(job->row_scale), cs = to_global(job->col_scale);
+    const global_ptr<const f32x4_t> X = (global_ptr<const f32x4_t>)to_global(static_cast<const float *>(job->X));
+    const bool live = row < N;
+    const int b = live ? rowptr[row] : 0, e = live ? rowptr[row + 1] : 0;
+    const float total = narrow_reduce16(narrow_sweep<16, HAS_W, WIDE>(col, val, X, b, e, lane & 15, job->ldx / 4, cs), lane);
+    const int feat = (lane >> 1) & 7;
+    if (live && !(lane & 1) && feat < F) to_global(job->Y)[static_cast<int64_t>(row) * job->ldy + feat] = total * (rs ? rs[row] : 1.f);
+}
+
 constexpr int64_t N_PART_BYTES = 3 << 20;  // 3 MiB of packed sources per part: what an XCD's 4-MiB L2 keeps beside the streams (168 114 columns: 2 parts 133 us, 1 part 151, 4 parts 141)
 
 }  // namespace
@@ -297,6 +325,27 @@ int wdg_spmm_narrow_f32(const wdg_spmm_job *job_host, const int32_t *part_ptr, v
 int wdg_spmm_narrow_bf16(const wdg_spmm_job *job_host, const int32_t *part_ptr, void *workspace, size_t workspace_bytes,
                          wdg_stream_t stream) {
     return narrow_launch(job_host, true, part_ptr, workspace, workspace_bytes, stream);
+}
+
+int wdg_spmm_narrow_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_feat, int flags,
+                                wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_feat >= 0, "spmm_narrow_batched: negative size");
+    if (n_jobs == 0 || max_rows == 0 || max_feat == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "spmm_narrow_batched: null job table");
+    if (max_feat > 8) return wdg::fail(WDG_ERR_UNSUPPORTED, "spmm_narrow_batched: more than 8 features");
+    const int blocks_per_job = static_cast<int>(wdg::ceil_div(max_rows, 16));
+    WDG_REQUIRE(static_cast<int64_t>(blocks_per_job) * n_jobs < (1ll << 31), "spmm_narrow_batched: grid too large");
+    const dim3 grid(static_cast<unsigned>(blocks_per_job) * n_jobs);
+    hipStream_t st = wdg::as_stream(stream);
+    const bool has_w = (flags & (WDG_SPMM_ANY_VAL | WDG_SPMM_ANY_COL_SCALE)) != 0, wide = max_feat > 4;
+    if (has_w) {
+        if (wide) hipLaunchKernelGGL((spmm_narrow_batched_kernel<true, true>), grid, dim3(N_THREADS), 0, st, jobs_dev, blocks_per_job);
+        else hipLaunchKernelGGL((spmm_narrow_batched_kernel<true, false>), grid, dim3(N_THREADS), 0, st, jobs_dev, blocks_per_job);
+    } else {
+        if (wide) hipLaunchKernelGGL((spmm_narrow_batched_kernel<false, true>), grid, dim3(N_THREADS), 0, st, jobs_dev, blocks_per_job);
+        else hipLaunchKernelGGL((spmm_narrow_batched_kernel<false, false>), grid, dim3(N_THREADS), 0, st, jobs_dev, blocks_per_job);
+    }
+    return wdg::check_launch("spmm_narrow_batched_kernel");
 }
 
 }  // extern "C"

@@ -594,7 +594,11 @@ class SpmmBatch:
             if x.dtype != torch.float32 or x.stride(1) != 1:
                 raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
         feats = {e[1].shape[1] for e in entries}
-        self.quad = (len(entries) > 0 and not quad_disabled() and min(feats) >= 8
+        # <= 8 features read in place as one or two float4 per source row (the sweep's logits aggregation): narrow kernel
+        need_ld = 8 if max(feats, default=0) > 4 else 4
+        self.narrow = (len(entries) > 0 and max(feats) <= 8 and os.environ.get("WDG_SPMM_NARROW", "1") != "0"
+                       and all(e[1].data_ptr() % 16 == 0 and _ld(e[1]) % 4 == 0 and _ld(e[1]) >= need_ld for e in entries))
+        self.quad = (len(entries) > 0 and not self.narrow and not quad_disabled() and min(feats) >= 8
                      and all(e[0].ensure_quad() for e in entries)
                      and all((not (e[5] and e[0].val is not None)) or e[0].quad["val"] is not None for e in entries))
         # the kernels start jobs in table order: most stored entries first, so the long jobs do not end up in the tail
@@ -615,7 +619,7 @@ class SpmmBatch:
             if self.run >= 2:
                 order = _shared_x_order(entries, self.run)
         for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
-            if x.shape[1] >= 8 and not self.quad:
+            if x.shape[1] >= 8 and not self.quad and not self.narrow:
                 g.ensure_sell()
             _fill_job(job, g, x, y, rs, cs, uv)
             all_sell = all_sell and bool(job.sell_ptr)
@@ -628,6 +632,8 @@ class SpmmBatch:
         self.table = host.to(dev)
         self.edges = sum(e[0].nnz for e in entries)
         self.flags = (SPMM_ALL_SELL if all_sell else 0) | (SPMM_ANY_VAL if any_val else 0) | (SPMM_DMA_OK if dma_ok else 0)
+        if any(e[4] is not None for e in entries):
+            self.flags |= SPMM_ANY_COL_SCALE
         if self.run >= 2 and all_sell and dma_ok:
             self.flags |= (self.run & 0xff) << 8  # WDG_SPMM_SHARED_X(run)
         if self.quad:
@@ -642,6 +648,10 @@ class SpmmBatch:
             self.n_items = len(items)
 
     def launch(self):
+        if self.narrow:
+            check(lib.wdg_spmm_narrow_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, self.max_feat, self.flags,
+                                                  stream_handle()), "wdg_spmm_narrow_batched_f32")
+            return
         if self.quad:
             check(lib.wdg_spmm_quad_batched_f32(_ptr(self.table), self.n_jobs, _ptr(self.items), _ptr(self.seg_ptr),
                                                 self.n_segments, self.max_cols, self.max_feat, self.flags, stream_handle()),
@@ -651,6 +661,8 @@ class SpmmBatch:
                                        self.flags, stream_handle()), "wdg_spmm_batched_f32")
 
     def plan(self):
+        if self.narrow:
+            return 6, 16, 256
         if self.quad:
             return 5, 16, 1024
         return spmm_plan(self.max_rows, self.max_cols, self.max_feat, self.n_jobs, self.flags)
@@ -664,10 +676,11 @@ class SpmmBatch:
                 2: f"spmm_rowlane_kernel<{slab // 4},{rpt},float,{val}>",
                 3: f"spmm_rowlane_pipe_kernel<{slab // 4},{rpt},{val}>",
                 4: f"spmm_rowlane_shared_kernel<{rpt},{val}>",
-                5: f"spmm_quad_kernel<float,{val},{'true' if self.max_cols > 2528 else 'false'}>"}.get(fam, f"family {fam}")
+                5: f"spmm_quad_kernel<float,{val},{'true' if self.max_cols > 2528 else 'false'}>",
+                6: "spmm_narrow_batched_kernel"}.get(fam, f"family {fam}")
 
 
-SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS = 1, 2, 4, 8
+SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS, SPMM_ANY_COL_SCALE = 1, 2, 4, 8, 16
 GEMM_A_VEC4 = 1
 
 

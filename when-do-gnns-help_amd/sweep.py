@@ -193,7 +193,8 @@ class SweepBatch:
             w0 = [(torch.randn((n_feat, gcn_hidden), generator=gen) * (2.0 / (n_feat + gcn_hidden)) ** 0.5).to(dev) for _ in self.jobs]
             w1 = [(torch.randn((gcn_hidden, n_classes), generator=gen) * (2.0 / (gcn_hidden + n_classes)) ** 0.5).to(dev) for _ in self.jobs]
             hid = [torch.empty((j.n_nodes, gcn_hidden), dtype=torch.float32, device=dev) for j in self.jobs]
-            z2 = [torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev) for j in self.jobs]
+            # (rows of 8 floats: the logits aggregation reads a source row as two aligned float4 - ops.SpmmBatch narrow family)
+            z2 = [torch.zeros((j.n_nodes, 8 if n_classes <= 8 else n_classes), dtype=torch.float32, device=dev)[:, :n_classes] for j in self.jobs]
             out = [torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev) for j in self.jobs]
             mlp = [(y, a, None, b, None, z) for y, a, b, z in zip(self.y, w0, w1, z2)]
             fused = os.environ.get("WDG_SWEEP_FUSED_MLP", "1") != "0" and ops.Mlp2Batch.eligible(mlp)
