@@ -7,7 +7,7 @@ from wdg_amd import sweep, synth
 for k, seeds in ((10, 5), (2, 10), (10, 10)):
     levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
     jobs = sweep.make_jobs(levels, range(seeds), k=k)
-    for ph in (0, 4000, 8000, 12000, 16000, 24000):
+    for ph in (0, 6000, 9000, 12000, 15000, 18000):
         os.environ["WDG_QUAD_PHASE_NS"] = str(ph)
         b = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0)
         for _ in range(5): b.spmm.launch()

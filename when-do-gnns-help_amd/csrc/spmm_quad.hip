@@ -494,7 +494,10 @@ __device__ __forceinline__ int q_ld1(global_ptr<const int32_t> base, unsigned vo
 __device__ __forceinline__ void q_st4(global_ptr<float> base, unsigned voff, f32x4_t v) {
     // (s_nop: a VALU write of the data registers right behind a store of more than 8 bytes is a hazard the compiler
     // resolves for its own stores, not for this one)
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
+#ifndef WDG_Q_STORE_POLICY
+#define WDG_Q_STORE_POLICY ""
+#endif
+    asm volatile("global_store_dwordx4 %0, %1, %2 " WDG_Q_STORE_POLICY "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
 }
 
 struct QJobE {  // what stage E needs of a job (SGPRs; re-read from the table when the stage moves to another job)
@@ -662,6 +665,13 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed(E, C);
     q_barrier_lds();  // the slab is in place for every wave; from here to the end of the phase the waves run free
+#ifdef WDG_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {  // the slot after the phase's start stamp (whichever of 2, 4, 6 was written last)
+        unsigned long long *rec = wdg_q_stamp_buf + blockIdx.x * 8;
+        const int slot = rec[6] > rec[4] && rec[6] > rec[2] ? 7 : (rec[4] > rec[2] ? 5 : 3);
+        rec[slot] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     while (C.ok) {
         issueI(E, N);  // super-unit n + 1
         issueE(E);     // super-unit n + 2
@@ -870,6 +880,7 @@ __global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job
                 typedef const wdg_spmm_item __attribute__((address_space(4))) *iptr;
                 const iptr it = (iptr)(items + ph);
                 const int fj = it->first_job, nj = it->n_jobs, ub = it->unit_begin, ue = it->unit_end;
+                Q_STAMP(2 + 2 * min(ph - pb, 2));  // (diagnostic build: start of the phase; + 1: its staging is done)
                 if (MULTI) q_phase_multi<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, first_phase, y_vec_all != 0);
                 else q_phase_single<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, first_phase, y_vec_all != 0);
                 first_phase = false;

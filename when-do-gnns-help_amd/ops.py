@@ -519,7 +519,7 @@ def _quad_cut(cum, g_off, n_seg, phase):
     return np.maximum.accumulate(np.asarray(cuts, np.int64))
 
 
-def _quad_segments(entries, order, n_feat, cus=256):
+def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None):
     """Cut the tape of super-units (64 rows) of the jobs (in table order `order`) into 8 x S segments of equal modelled cost
     and split every segment into items; -> (items [(first_job, n_jobs, unit_begin, unit_end)], seg_ptr, n_segments).
 
@@ -559,11 +559,14 @@ def _quad_segments(entries, order, n_feat, cus=256):
         subs = max(subs, -(-n_units // (8 * 32)))
     n_seg = 8 * subs
     g_off = np.concatenate([[0], np.cumsum([g[2] for g in groups])]).astype(np.int64)
-    phase = float(os.environ.get("WDG_QUAD_PHASE_NS", _QUAD_PHASE_NS)) * 16  # (the table prices a wave, a workgroup has 16)
+    if phase_ns is None:
+        phase_ns = float(os.environ.get("WDG_QUAD_PHASE_NS", _QUAD_PHASE_NS))
+    phase = float(phase_ns) * 16  # (the table prices a wave, a workgroup has 16)
     cuts = _quad_cut(cum, g_off, n_seg, phase)
     items, seg_ptr = [], [0]
     for s_ in range(n_seg):
         a, b = int(cuts[s_]), int(cuts[s_ + 1])
+        seg_items = []
         while a < b:
             gi = int(np.searchsorted(g_off, a, side="right") - 1)
             end = min(b, int(g_off[gi + 1]))
@@ -571,7 +574,14 @@ def _quad_segments(entries, order, n_feat, cus=256):
                 end = min(end, a + 32)
             first, nj, _n = groups[gi]
             items.append((first, nj, a - int(g_off[gi]), end - int(g_off[gi])))
+            seg_items.append((float(cum[end] - cum[a]), len(items) - 1))
             a = end
+        # the phases of a segment run shortest first: staging a slab costs 8 us while the memory system is quiet and 20 - 55 us
+        # once the launch's stores have filled the write path (scripts/stamps_quad_phases.py: the later the switch, the dearer)
+        if len(seg_items) > 1 and os.environ.get("WDG_QUAD_PHASE_ORDER", "1") != "0" and not multi:
+            first_item = seg_items[0][1]
+            reordered = [items[i] for _c, i in sorted(seg_items)]
+            items[first_item:first_item + len(reordered)] = reordered
         seg_ptr.append(len(items))
     return items, seg_ptr, n_seg
 
@@ -639,13 +649,47 @@ class SpmmBatch:
         if self.quad:
             if all(e[0].n_rows * _ld(e[2]) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 and e[0].quad["split"] for e in entries):
                 self.flags |= SPMM_SMALL_OFFSETS
-            items, seg_ptr, self.n_segments = _quad_segments(entries, order, self.max_feat, max(lib.wdg_device_cus(), 8))
-            iarr = (SpmmItem * max(len(items), 1))()
-            for it, (fj, nj, ub, ue) in zip(iarr, items):
-                it.first_job, it.n_jobs, it.unit_begin, it.unit_end = fj, nj, ub, ue
-            self.items = torch.frombuffer(bytearray(bytes(iarr)), dtype=torch.uint8).to(dev)
-            self.seg_ptr = torch.tensor(seg_ptr, dtype=torch.int32, device=dev)
-            self.n_items = len(items)
+            self.order = order
+            self._set_segments(None)
+
+    def _set_segments(self, phase_ns):
+        """cut the tape (ops._quad_segments; phase_ns: what a phase switch is priced at, None = the default) and upload it"""
+        dev = self.table.device
+        items, seg_ptr, self.n_segments = _quad_segments(self.keep, self.order, self.max_feat, max(lib.wdg_device_cus(), 8), phase_ns)
+        iarr = (SpmmItem * max(len(items), 1))()
+        for it, (fj, nj, ub, ue) in zip(iarr, items):
+            it.first_job, it.n_jobs, it.unit_begin, it.unit_end = fj, nj, ub, ue
+        self.items = torch.frombuffer(bytearray(bytes(iarr)), dtype=torch.uint8).to(dev)
+        self.seg_ptr = torch.tensor(seg_ptr, dtype=torch.int32, device=dev)
+        self.n_items = len(items)
+        self.items_host, self.seg_ptr_host, self.phase_ns = items, seg_ptr, phase_ns  # (scripts/fit_quad_cost.py reads them)
+
+    def tune(self, candidates=(0, 6000, 10000, 14000), launches=6):
+        """Pick the tape cut by measurement (quad-row tables with more than one phase group only).  Where the phase switches
+        of the eight XCDs fall relative to each other decides how dear they are (a slab staged while the other XCDs' stores
+        fill the write path takes 20 - 55 us instead of 8), and that interplay is repeatable on a box but not monotone in
+        any model parameter (scripts/ab_phase_order.py): so the launch is timed for a few prices of a phase switch and the
+        best cut is kept.  Every cut computes the same bits (a row's sum order is fixed by the SELL-16 copy).  Costs
+        len(candidates) x launches launches, once per table; the outputs are (re)written with the same values."""
+        if not self.quad or self.n_items <= self.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":
+            return None
+        best = None
+        for ph in candidates:
+            self._set_segments(ph)
+            self.launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(launches):
+                self.launch()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / launches
+            if best is None or t < best[0]:
+                best = (t, ph)
+        self._set_segments(best[1])
+        self.tuned = best
+        return best
 
     def launch(self):
         if self.narrow:

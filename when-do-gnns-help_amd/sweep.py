@@ -161,6 +161,7 @@ class SweepBatch:
         entries = [(g, self.x_agg[j.seed], y, d, d if symmetric else None, False)
                    for j, g, y, d in zip(self.jobs, self.graphs, self.y_agg, self.dinv)]
         self.spmm = ops.SpmmBatch(entries)
+        self.spmm.tune()  # (quad-row tables: the tape cut is chosen by timing a few candidates on this device, once)
         self.n_classes = n_classes
         self.stats = ops.StatsBatch(self.graphs, self.labels, n_classes)
         self.edges = sum(g.nnz for g in self.graphs)
