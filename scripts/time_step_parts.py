@@ -8,7 +8,9 @@ import torch
 
 from wdg_amd import sweep, synth
 
-batch = sweep.SweepBatch(sweep.make_jobs(synth.H_LEVELS_10, range(10), k=2), n_feat=500)
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+batch = sweep.SweepBatch(sweep.make_jobs(synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10, range(seeds), k=k), n_feat=500)
 parts = [(f"spmm (F={batch.agg_feat})", batch.spmm), ("edge stats", batch.stats), ("spmm label aggregation (F=C)", batch.spmm_las),
          ("las", batch.las), ("fused relu(Y W0) W1", batch.gcn["mlp"]), ("gemm1 relu(Y W0)", batch.gcn["gemm1"]),
          ("gemm2", batch.gcn["gemm2"]), ("spmm logits (F=C)", batch.gcn["spmm"])]
