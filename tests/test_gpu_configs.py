@@ -85,8 +85,8 @@ def test_c5_twitch_scale(oracle):
     x = rng.standard_normal((n, f)).astype(np.float32)
     xb = torch.from_numpy(x).cuda().to(torch.bfloat16)
     d = ops.degree_norm(g, ops.NORM_SYM, ops.PREC_F32)["dinv"]
-    assert ops.spmm_plan(n, n, f)[0] == 1  # row-gather family
     y = ops.spmm(g, xb, row_scale=d, col_scale=d)
+    assert g.narrow_ws is not None and g.narrow_parts is not None and g.narrow_parts[0] == 2  # narrow kernel, two column ranges
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
