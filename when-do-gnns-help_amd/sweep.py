@@ -161,7 +161,6 @@ class SweepBatch:
         entries = [(g, self.x_agg[j.seed], y, d, d if symmetric else None, False)
                    for j, g, y, d in zip(self.jobs, self.graphs, self.y_agg, self.dinv)]
         self.spmm = ops.SpmmBatch(entries)
-        self.spmm.tune()  # (quad-row tables: the tape cut is chosen by timing a few candidates on this device, once)
         self.n_classes = n_classes
         self.stats = ops.StatsBatch(self.graphs, self.labels, n_classes)
         self.edges = sum(g.nnz for g in self.graphs)
@@ -206,6 +205,34 @@ class SweepBatch:
                             gemm2=ops.GemmBatch([(h, b, z, None) for h, b, z in zip(hid, w1, z2)]),
                             spmm=ops.SpmmBatch([(g, z, o, d, scale(d), False)
                                                 for g, z, o, d in zip(self.graphs, z2, out, self.dinv)]))
+
+        self.tune()
+
+    def tune(self, candidates=(0, 6000, 10000, 14000), steps=6):
+        """Pick the aggregation's tape cut by timing it INSIDE the step (ops.SpmmBatch.tune explains why it is measured):
+        between the other kernels of a step the caches are colder than in back-to-back launches of the aggregation alone,
+        and the best cut differs.  len(candidates) x (2 + steps) steps, once per batch; every cut computes the same bits."""
+        sp = self.spmm
+        if not sp.quad or sp.n_items <= sp.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":
+            return None
+        best = None
+        for ph in candidates:
+            sp._set_segments(ph)
+            for _ in range(2):
+                self.step()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            for a, b in ev:
+                a.record()
+                sp.launch()
+                b.record()
+                self.step_rest()
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(b) for a, b in ev)[steps // 2]
+            if best is None or t < best[0]:
+                best = (t, ph)
+        sp._set_segments(best[1])
+        sp.tuned = best
+        return best
 
     # -- bytes the aggregation must move (SURVEY.md 8(d), fused normalisation: no `val`, + dinv) ---------------
     def spmm_algorithmic_bytes(self):
