@@ -305,6 +305,15 @@ typedef struct wdg_spmm_item {
 int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
                               const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat, int flags,
                               wdg_stream_t stream);
+/* The same launch; wg_clock_dev (may be NULL): [2 x wdg_spmm_quad_workgroups(n_segments, max_feat)] 64-bit words that receive
+ * every workgroup's start and end on the device's 100 MHz clock (workgroup b belongs to XCD b % 8 and serves the segments
+ * of that XCD): the caller can balance the segments by what they really cost (ops.SpmmBatch.balance). */
+int wdg_spmm_quad_batched_clocked_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
+                                      const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat,
+                                      int flags, uint64_t *wg_clock_dev, wdg_stream_t stream);
+int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat);
+/* diagnostics: one thread stores the device's 100 MHz clock to out_dev, in stream order */
+int wdg_debug_clock(uint64_t *out_dev, wdg_stream_t stream);
 
 /* ------------------------------------------------------------------ edge / label statistics */
 /*

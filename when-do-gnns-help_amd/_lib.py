@@ -91,6 +91,10 @@ SIGNATURES = {
     "wdg_spmm_narrow_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wdg_spmm_narrow_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wdg_spmm_narrow_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "wdg_spmm_quad_batched_clocked_f32": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p,
+                                                  c_void_p]),
+    "wdg_spmm_quad_workgroups": (c_int32, [c_int32, c_int32]),
+    "wdg_debug_clock": (c_int, [c_void_p, c_void_p]),
     "wdg_spmm_quad_batched_f32": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int,
                                           c_void_p]),
     "wdg_edge_label_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

@@ -864,12 +864,15 @@ __global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job
                                                               const wdg_spmm_job inline_job,
                                                               const wdg_spmm_item *__restrict__ items,
                                                               const int32_t *__restrict__ seg_ptr, int subs, int n_groups,
-                                                              int y_vec_all) {
+                                                              int y_vec_all, unsigned long long *__restrict__ wg_clock) {
     extern __shared__ float4 q_lds[];
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
     const int n_local = subs * n_groups;
     bool first_phase = true;
     Q_STAMP(0);
+    // (wg_clock: optional [2 x workgroups] device buffer - the workgroup's start and end on the 100 MHz clock; the sweep driver
+    // balances the XCDs' segments with it, ops.SpmmBatch.balance)
+    if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     for (int lw = wg; lw < n_local; lw += wgs_per_xcd) {
         const int seg = xcd * subs + lw / n_groups;
         const int f0 = (lw % n_groups) * 16;
@@ -894,6 +897,7 @@ __global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job
         }
     }
     Q_STAMP(1);
+    if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 int q_block_cols_for(int n_cols) {
@@ -910,7 +914,8 @@ bool q_reorder_enabled() {  // bank-aware entry order inside (row, block) segmen
 
 template <typename TIN>
 int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_item *items, const int32_t *seg_ptr,
-             int subs, int max_cols, int max_feat, bool has_val, bool y_vec_all, hipStream_t st) {
+             int subs, int max_cols, int max_feat, bool has_val, bool y_vec_all, hipStream_t st,
+             unsigned long long *wg_clock = nullptr) {
     const int n_groups = static_cast<int>(ceil_div(max_feat, 16));
     // every job's block size is <= min(its columns rounded up to 4, 2528): the bound over the table sizes the slab
     const int block_cols = std::min(Q_MAX_BLOCK_COLS, (std::max(max_cols, 1) + 3) & ~3);
@@ -933,7 +938,7 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
     const dim3 grid(static_cast<unsigned>(wgs_per_xcd * kXcds));
 #define WDG_Q_LAUNCH(V, M)                                                                                             \
     hipLaunchKernelGGL((spmm_quad_kernel<TIN, V, M>), grid, dim3(Q_THREADS), lds, st, jobs, inl, items, seg_ptr, subs, \
-                       n_groups, y_vec_all ? 1 : 0)
+                       n_groups, y_vec_all ? 1 : 0, wg_clock)
     if (multi) {
         if (has_val) WDG_Q_LAUNCH(true, true);
         else WDG_Q_LAUNCH(false, true);
@@ -1066,9 +1071,9 @@ int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const floa
     return wdg::check_launch("csr_to_sell16_fill");
 }
 
-int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
-                              const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat, int flags,
-                              wdg_stream_t stream) {
+int wdg_spmm_quad_batched_clocked_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
+                                      const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat, int flags,
+                                      uint64_t *wg_clock_dev, wdg_stream_t stream) {
     WDG_REQUIRE(n_jobs >= 0 && n_segments >= 0 && max_cols >= 0 && max_feat >= 0, "spmm_quad_batched: negative size");
     if (n_jobs == 0 || n_segments == 0 || max_feat == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev && items_dev && seg_ptr_dev, "spmm_quad_batched: null table");
@@ -1077,7 +1082,20 @@ int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, cons
         return wdg::fail(WDG_ERR_UNSUPPORTED, "spmm_quad_batched: more than %d column blocks", Q_MAX_BLOCKS);
     return q_launch<float>(jobs_dev, wdg_spmm_job{}, items_dev, seg_ptr_dev, n_segments / wdg::kXcds, max_cols, max_feat,
                            (flags & WDG_SPMM_ANY_VAL) != 0, (flags & WDG_SPMM_DMA_OK) != 0 && (flags & WDG_SPMM_SMALL_OFFSETS) != 0,
-                           wdg::as_stream(stream));
+                           wdg::as_stream(stream), reinterpret_cast<unsigned long long *>(wg_clock_dev));
+}
+
+int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
+                              const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat, int flags,
+                              wdg_stream_t stream) {
+    return wdg_spmm_quad_batched_clocked_f32(jobs_dev, n_jobs, items_dev, seg_ptr_dev, n_segments, max_cols, max_feat, flags,
+                                             nullptr, stream);
+}
+
+int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat) {  // the grid of the batched launch (sizes wg_clock)
+    const int n_groups = static_cast<int>(wdg::ceil_div(max_feat, 16));
+    const int cus = std::max(wdg_device_cus(), 8);
+    return std::max(1, std::min(cus / wdg::kXcds, (n_segments / wdg::kXcds) * n_groups)) * wdg::kXcds;
 }
 
 }  // extern "C"

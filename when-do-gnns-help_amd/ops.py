@@ -480,18 +480,20 @@ def _quad_unit_cost(widths):
 _QUAD_PHASE_NS = 0.0
 
 
-def _quad_cut(cum, g_off, n_seg, phase):
+def _quad_cut(cum, g_off, n_seg, phase, shares=None):
     """cut positions [n_seg + 1] of the tape (cum = cumulative super-unit cost, g_off = phase-group boundaries) such that
-    every segment's cost + `phase` per phase group it touches is the same (the smallest such bound, by bisection)"""
+    segment s's cost + `phase` per phase group it touches is shares[s] of the whole (equal shares by default): the smallest
+    such bound, by bisection"""
     n_units = len(cum) - 1
-    if phase <= 0 or n_units == 0:
+    w = np.full(n_seg, 1.0) if shares is None else np.asarray(shares, np.float64) * n_seg / float(np.sum(shares))
+    if (phase <= 0 and shares is None) or n_units == 0:
         cuts = np.searchsorted(cum, cum[-1] * np.arange(1, n_seg) / n_seg, side="left")
         return np.maximum.accumulate(np.concatenate([[0], np.clip(cuts, 0, n_units), [n_units]]))
 
     def fill(bound):
         cuts, a = [0], 0
-        for _ in range(n_seg):
-            cap = bound
+        for s_ in range(n_seg):
+            cap = bound * w[s_]
             while a < n_units:
                 cap -= phase
                 if cap <= 0:
@@ -507,8 +509,8 @@ def _quad_cut(cum, g_off, n_seg, phase):
             cuts.append(a)
         return cuts
 
-    lo, hi = cum[-1] / n_seg, cum[-1] / n_seg + phase * (len(g_off) + 1) + cum[-1] / max(n_units, 1) * 2
-    for _ in range(40):
+    lo, hi = 0.0, (cum[-1] / n_seg + phase * (len(g_off) + 1) + cum[-1] / max(n_units, 1) * 2) / max(float(w.min()), 1e-3)
+    for _ in range(50):
         mid = 0.5 * (lo + hi)
         if fill(mid)[-1] >= n_units:
             hi = mid
@@ -519,7 +521,7 @@ def _quad_cut(cum, g_off, n_seg, phase):
     return np.maximum.accumulate(np.asarray(cuts, np.int64))
 
 
-def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None):
+def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
     """Cut the tape of super-units (64 rows) of the jobs (in table order `order`) into 8 x S segments of equal modelled cost
     and split every segment into items; -> (items [(first_job, n_jobs, unit_begin, unit_end)], seg_ptr, n_segments).
 
@@ -562,7 +564,9 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None):
     if phase_ns is None:
         phase_ns = float(os.environ.get("WDG_QUAD_PHASE_NS", _QUAD_PHASE_NS))
     phase = float(phase_ns) * 16  # (the table prices a wave, a workgroup has 16)
-    cuts = _quad_cut(cum, g_off, n_seg, phase)
+    if shares is not None and len(shares) != n_seg:
+        shares = None
+    cuts = _quad_cut(cum, g_off, n_seg, phase, shares)
     items, seg_ptr = [], [0]
     for s_ in range(n_seg):
         a, b = int(cuts[s_]), int(cuts[s_ + 1])
@@ -652,17 +656,27 @@ class SpmmBatch:
             self.order = order
             self._set_segments(None)
 
-    def _set_segments(self, phase_ns):
-        """cut the tape (ops._quad_segments; phase_ns: what a phase switch is priced at, None = the default) and upload it"""
+    def _set_segments(self, phase_ns, shares=None):
+        """cut the tape (ops._quad_segments; phase_ns: what a phase switch is priced at, None = the default; shares: the
+        fraction of the modelled cost every segment gets, None = equal) and upload it"""
         dev = self.table.device
-        items, seg_ptr, self.n_segments = _quad_segments(self.keep, self.order, self.max_feat, max(lib.wdg_device_cus(), 8), phase_ns)
+        items, seg_ptr, self.n_segments = _quad_segments(self.keep, self.order, self.max_feat, max(lib.wdg_device_cus(), 8), phase_ns, shares)
         iarr = (SpmmItem * max(len(items), 1))()
         for it, (fj, nj, ub, ue) in zip(iarr, items):
             it.first_job, it.n_jobs, it.unit_begin, it.unit_end = fj, nj, ub, ue
         self.items = torch.frombuffer(bytearray(bytes(iarr)), dtype=torch.uint8).to(dev)
         self.seg_ptr = torch.tensor(seg_ptr, dtype=torch.int32, device=dev)
         self.n_items = len(items)
-        self.items_host, self.seg_ptr_host, self.phase_ns = items, seg_ptr, phase_ns  # (scripts/fit_quad_cost.py reads them)
+        self.items_host, self.seg_ptr_host, self.phase_ns, self.shares = items, seg_ptr, phase_ns, shares  # (scripts read them)
+
+    def segment_spans(self, clock):
+        """[n_segments] us: how long each segment's workgroups ran in the launch that filled `clock` (launch(clock=...)): the
+        latest end of the segment's XCD minus the launch's earliest start (one segment per XCD; else None)"""
+        if self.n_segments != 8:
+            return None
+        t = clock.cpu().numpy().astype(np.float64).reshape(-1, 2) * 10e-3  # 100 MHz -> us
+        start = t[:, 0].min()
+        return np.array([t[x::8, 1].max() - start for x in range(8)])
 
     def tune(self, candidates=(0, 6000, 10000, 14000), launches=6):
         """Pick the tape cut by measurement (quad-row tables with more than one phase group only).  Where the phase switches
@@ -691,7 +705,17 @@ class SpmmBatch:
         self.tuned = best
         return best
 
-    def launch(self):
+    def new_clock(self):
+        """device buffer for launch(clock=...): start / end of every workgroup of the quad-row launch"""
+        n = int(lib.wdg_spmm_quad_workgroups(self.n_segments, self.max_feat))
+        return torch.zeros(2 * n, dtype=torch.int64, device=self.table.device)
+
+    def launch(self, clock=None):
+        if clock is not None and self.quad:
+            check(lib.wdg_spmm_quad_batched_clocked_f32(_ptr(self.table), self.n_jobs, _ptr(self.items), _ptr(self.seg_ptr),
+                                                        self.n_segments, self.max_cols, self.max_feat, self.flags, _ptr(clock),
+                                                        stream_handle()), "wdg_spmm_quad_batched_clocked_f32")
+            return
         if self.narrow:
             check(lib.wdg_spmm_narrow_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, self.max_feat, self.flags,
                                                   stream_handle()), "wdg_spmm_narrow_batched_f32")

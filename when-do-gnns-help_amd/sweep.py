@@ -208,29 +208,40 @@ class SweepBatch:
 
         self.tune()
 
-    def tune(self, candidates=(0, 6000, 10000, 14000), steps=6):
-        """Pick the aggregation's tape cut by timing it INSIDE the step (ops.SpmmBatch.tune explains why it is measured):
-        between the other kernels of a step the caches are colder than in back-to-back launches of the aggregation alone,
-        and the best cut differs.  len(candidates) x (2 + steps) steps, once per batch; every cut computes the same bits."""
+    def tune(self, rounds=6, steps=5):
+        """Balance the aggregation's eight segments (one per XCD) by what they really cost INSIDE the step.  The modelled cut
+        leaves the XCDs 25 - 40 % apart (a segment that holds two phase groups stages a second slab while the other XCDs' stores
+        fill the write path: 10 - 55 us, depending on when), and the launch ends with the slowest.  The kernel can record
+        every workgroup's start and end on the device clock (wdg_spmm_quad_batched_clocked_f32); here the step is run a few
+        times, each segment's share of the modelled cost is scaled by (mean span / its span) ^ 0.7, the tape is cut again,
+        and the cut with the shortest launch (HIP events around the launch, median over `steps` steps) is kept.
+        rounds x (2 + steps) steps, once per batch; every cut computes the same bits (a row's sum order is fixed by the
+        SELL-16 copy)."""
         sp = self.spmm
-        if not sp.quad or sp.n_items <= sp.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":
+        if not sp.quad or sp.n_segments != 8 or sp.n_items <= sp.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":
             return None
+        clock = sp.new_clock()
+        shares = np.ones(8)
         best = None
-        for ph in candidates:
-            sp._set_segments(ph)
+        for rnd in range(rounds):
+            sp._set_segments(0, None if rnd == 0 else shares)
             for _ in range(2):
                 self.step()
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            spans = np.zeros(8)
             for a, b in ev:
                 a.record()
-                sp.launch()
+                sp.launch(clock=clock)
                 b.record()
                 self.step_rest()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                spans += sp.segment_spans(clock) / steps
             t = sorted(a.elapsed_time(b) for a, b in ev)[steps // 2]
             if best is None or t < best[0]:
-                best = (t, ph)
-        sp._set_segments(best[1])
+                best = (t, None if rnd == 0 else shares.copy(), spans.copy())
+            shares = shares * (spans.mean() / spans) ** 0.7
+            shares /= shares.sum() / 8
+        sp._set_segments(0, best[1])
         sp.tuned = best
         return best
 
