@@ -96,3 +96,44 @@ def test_segments_ragged_and_multiblock():
     items, seg_ptr, n_seg = ops._quad_segments(entries, [0], 2089)
     _coverage(entries, [0], items, seg_ptr)
     assert all(ue - ub <= 32 for _, _, ub, ue in items)
+
+
+def test_segment_phases_run_shortest_first_and_shares_shift_the_cuts():
+    """a segment that touches two phase groups lists the cheaper phase first (its slab is staged while the launch's stores
+    have not yet filled the write path); `shares` moves cost between segments (the feedback balancing of SweepBatch.tune)
+    and a phase price shortens the segments that hold two phases - coverage stays exact in every case"""
+    from wdg_amd import ops
+    rng = np.random.default_rng(8)
+    entries = []
+    for seed in range(5):
+        x = _X(2000 + seed, 2000, 512)
+        for h in range(10):
+            entries.append((_G(2000, 2000, np.full((1, 128), int(rng.integers(8, 33)))), x, None, None, None, False))
+    order = list(range(len(entries)))
+
+    def seg_costs(items, seg_ptr):
+        out = []
+        for s in range(len(seg_ptr) - 1):
+            out.append([sum(ops._quad_unit_cost(entries[order[pos]][0].quad["widths"][:, 4 * su:4 * su + 4])[0]
+                            for pos, su in _units_of(entries, order, it)) for it in items[seg_ptr[s]:seg_ptr[s + 1]]])
+        return out
+
+    items, seg_ptr, n_seg = ops._quad_segments(entries, order, 512)
+    _coverage(entries, order, items, seg_ptr)
+    base = seg_costs(items, seg_ptr)
+    assert any(len(c) == 2 for c in base)
+    assert all(c == sorted(c) for c in base), "phases of a segment in ascending cost"
+    # a price per phase: two-phase segments get less of the tape than one-phase segments
+    items2, seg_ptr2, _ = ops._quad_segments(entries, order, 512, phase_ns=20000)
+    _coverage(entries, order, items2, seg_ptr2)
+    priced = seg_costs(items2, seg_ptr2)
+    one = [sum(c) for c in priced if len(c) == 1]
+    two = [sum(c) for c in priced if len(c) == 2]
+    assert one and two and max(two) < min(one)
+    # shares: segment 0 is asked to take 30 % more than the others
+    shares = np.ones(8)
+    shares[0] = 1.3
+    items3, seg_ptr3, _ = ops._quad_segments(entries, order, 512, phase_ns=0, shares=shares)
+    _coverage(entries, order, items3, seg_ptr3)
+    shared = [sum(c) for c in seg_costs(items3, seg_ptr3)]
+    assert shared[0] > 1.2 * np.mean(shared[1:])
