@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from wdg_amd import sweep, synth
 from wdg_amd.ops import lib, _ptr, stream_handle, check
+from wdg_amd import ops as _ops
+_ops.ABLATE_BITS = int(os.environ.get("WDG_GAPS_ABLATE", "0"))  # (timing-only ablations of scripts/ablate_quad.py)
 for k, seeds in ((10, 5), (2, 10)):
     levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
     b = sweep.SweepBatch(sweep.make_jobs(levels, range(seeds), k=k), n_feat=500)
