@@ -92,7 +92,7 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     # streams -> 1); measured slower than the plain launches (0.517 vs 0.486 ms per step), so off by default
     step_rest = batch.capture_rest() if os.environ.get("WDG_BENCH_GRAPH", "0") == "1" else batch.step_rest
     # HIP events around the aggregation launch of every `stride`-th step (about 50 samples over the timed region): an
-    # event pair costs ~20 us of queue markers per step (scripts/time_gaps.py: 0.443 -> 0.423 ms without them), so the
+    # event pair costs ~20 us of queue markers per step (scripts/dev/time_gaps.py: 0.443 -> 0.423 ms without them), so the
     # roofline figure is sampled instead of taxing every step; all steps run the same launches either way
     stride = max(1, steps // 50)
     ev = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in range(0, steps, stride)}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (every pass runs under `timeout 300`: some counter passes hang rocprofv3 on this pool)
 # PMC passes for the quad-row SpMM alone (run ON the GPU box, from the repo root):  bash scripts/pmc_quad.sh <tag> <k> <seeds> <ablate code>
 set -u
 TAG=${1:-pmcq}; K=${2:-10}; SEEDS=${3:-5}; AB=${4:-0}
@@ -8,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/scripts/ablate_quad.py" $K $SEEDS $AB > "$OUT/$name.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/scripts/dev/ablate_quad.py" $K $SEEDS $AB > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT

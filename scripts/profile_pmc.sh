@@ -3,6 +3,8 @@
 # One counter group per rocprofv3 run, kernel-trace only (no sys/hip/hsa tracing with --pmc on this pool).
 set -u
 TAG=${1:-pmc}; shift || true
+# a profiled process has the GPU initialised by the profiler's preload: it must not spawn torch workers (bench.py --gpus N > 1)
+case " $* " in *" --gpus "[2-9]*|*" --gpus=[2-9]"*) echo "profile one rank only: --gpus > 1 is refused under rocprofv3" >&2; exit 2;; esac
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

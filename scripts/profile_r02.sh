@@ -3,6 +3,8 @@
 # statistics of the same command, and the PMC passes (scripts/profile_pmc.sh).  usage: bash scripts/profile_r02.sh <tag> [bench args]
 set -u
 TAG=${1:-r02}; shift || true
+# a profiled process has the GPU initialised by the profiler's preload: it must not spawn torch workers (bench.py --gpus N > 1)
+case " $* " in *" --gpus "[2-9]*|*" --gpus=[2-9]"*) echo "profile one rank only: --gpus > 1 is refused under rocprofv3" >&2; exit 2;; esac
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -36,7 +36,7 @@ int wdg_device_cus(void) {
 }
 
 // one thread stores the device's 100 MHz clock: a timestamp IN stream order (diagnostics: what lies between a launch's
-// events and its workgroups' own clocks, scripts/launch_gaps.py)
+// events and its workgroups' own clocks, scripts/dev/launch_gaps.py)
 __global__ void wdg_clock_kernel(unsigned long long *out) { *out = __builtin_amdgcn_s_memrealtime(); }
 int wdg_debug_clock(uint64_t *out_dev, wdg_stream_t stream) {
     hipLaunchKernelGGL(wdg_clock_kernel, dim3(1), dim3(1), 0, wdg::as_stream(stream), reinterpret_cast<unsigned long long *>(out_dev));

@@ -581,7 +581,7 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
             seg_items.append((float(cum[end] - cum[a]), len(items) - 1))
             a = end
         # the phases of a segment run shortest first: staging a slab costs 8 us while the memory system is quiet and 20 - 55 us
-        # once the launch's stores have filled the write path (scripts/stamps_quad_phases.py: the later the switch, the dearer)
+        # once the launch's stores have filled the write path (scripts/dev/stamps_quad_phases.py: the later the switch, the dearer)
         if len(seg_items) > 1 and os.environ.get("WDG_QUAD_PHASE_ORDER", "1") != "0" and not multi:
             first_item = seg_items[0][1]
             reordered = [items[i] for _c, i in sorted(seg_items)]
@@ -682,7 +682,7 @@ class SpmmBatch:
         """Pick the tape cut by measurement (quad-row tables with more than one phase group only).  Where the phase switches
         of the eight XCDs fall relative to each other decides how dear they are (a slab staged while the other XCDs' stores
         fill the write path takes 20 - 55 us instead of 8), and that interplay is repeatable on a box but not monotone in
-        any model parameter (scripts/ab_phase_order.py): so the launch is timed for a few prices of a phase switch and the
+        any model parameter (scripts/dev/ab_phase_order.py): so the launch is timed for a few prices of a phase switch and the
         best cut is kept.  Every cut computes the same bits (a row's sum order is fixed by the SELL-16 copy).  Costs
         len(candidates) x launches launches, once per table; the outputs are (re)written with the same values."""
         if not self.quad or self.n_items <= self.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":

@@ -272,7 +272,7 @@ class SweepBatch:
         Two independent chains on two HIP streams: the metric chain (LAS, then the statistics pass) and the GCN-2 forward
         (fused feature transform + the logits aggregation).  The B-resident GEMM occupies 200 of the 256 CUs for ~150 us;
         the metric kernels use the remaining CUs meanwhile: LAS first (large workgroups, done within ~50 us), then the
-        statistics kernel, whose remainder overlaps the logits aggregation (scripts/step_timeline.py on a kernel trace).
+        statistics kernel, whose remainder overlaps the logits aggregation (scripts/dev/step_timeline.py on a kernel trace).
         Measured per step: one stream 0.47 ms, two streams statistics-first 0.439, three streams 0.425, two streams
         LAS-first 0.408.  WDG_SWEEP_STREAMS=1|3 for the other arrangements."""
         main = torch.cuda.current_stream()
