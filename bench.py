@@ -38,32 +38,67 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ach
 
 
 def launch_workers(args, argv):
-    """`python bench.py --gpus N` without a launcher: start N workers (one per GPU) from a parent that never touches the
-    GPU, forward rank 0's stdout (the JSON line), return non-zero when any worker fails.  WDG_BENCH_WORKER (tests) names a
-    stand-in worker script."""
+    """`python bench.py --gpus N` without a launcher: start N fresh workers (one per GPU) from a parent that never touches
+    the GPU, forward rank 0's stdout (the JSON line), return non-zero when any worker fails.  All workers are polled: the
+    first non-zero exit (or --timeout) terminates the siblings - they would otherwise sit in the rendezvous or a barrier
+    until RCCL's own timeout - and every rank's stderr goes to its own file so the failing rank can be read.
+    WDG_BENCH_WORKER (tests) names a stand-in worker script."""
     import socket
     import subprocess
+    import tempfile
+    preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("HSA_TOOLS_LIB", "")
+    if "rocprof" in preload:
+        # under rocprofv3 the profiler's preload has initialised the GPU in THIS process already: starting torch workers from
+        # it is the exec-after-GPU-init pattern the pool forbids.  Profile one rank: rocprofv3 ... -- python3 bench.py
+        print("bench.py: refusing to spawn workers from a profiled process; profile `bench.py --gpus 1`", file=sys.stderr)
+        return 2
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     script = os.environ.get("WDG_BENCH_WORKER", os.path.abspath(__file__))
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="wdg_bench_")
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        errs.append(open(os.path.join(logdir, f"rank{r}.err"), "w+"))
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, stderr=errs[-1],
+                                      stdout=open(os.path.join(logdir, "rank0.out"), "w+") if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + args.timeout
+    rcs = [None] * len(procs)
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if (bad or time.monotonic() > deadline) and failed is None:
+            failed = bad or ["timeout"]
+            for r, p in enumerate(procs):  # the exact children started above, nothing else
+                if rcs[r] is None:
+                    p.terminate()
+            grace = time.monotonic() + 10
+            while time.monotonic() < grace and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    out = open(os.path.join(logdir, "rank0.out")).read()
     # exactly the JSON line: libraries (RCCL) write to the workers' stdout as well
     lines = [l for l in out.splitlines() if l.lstrip().startswith("{")]
     sys.stdout.write("".join(l + "\n" for l in lines[-1:]))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: workers failed (rank, rc): {bad}", file=sys.stderr)
+    if failed is not None:
+        print(f"bench.py: workers failed (first: rank {failed}; return codes {rcs}); stderr of every rank under {logdir}", file=sys.stderr)
+        for r in (failed if failed != ["timeout"] else range(len(procs))):
+            errs[r].seek(0)
+            sys.stderr.write(f"---- rank {r} stderr (tail) ----\n" + errs[r].read()[-2000:] + "\n")
         return 1
+    for r, f in enumerate(errs):  # a clean run: the ranks' stderr is forwarded as before
+        f.seek(0)
+        sys.stderr.write(f.read())
     return 0
 
 
@@ -73,8 +108,11 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     import torch.distributed as dist
     from wdg_amd import sweep, synth
     h_levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
-    # rank 0 defines the whole job list and broadcasts it; every rank takes its shard (whole seeds)
-    jobs = sweep.make_jobs(h_levels, range(seeds * world), k=k, n_nodes=args.nodes) if rank == 0 else []
+    # rank 0 defines the whole job list and broadcasts it; every rank takes its shard (sweep.shard_jobs: single jobs, by cost)
+    # weak scaling (default): `seeds` seeds per rank; strong: the job list is fixed (BASELINE configs[2] literally: 10 h-levels
+    # x 5 seeds = 50 jobs) and sharded over however many ranks there are
+    n_seeds = seeds if args.scaling == "strong" else seeds * world
+    jobs = sweep.make_jobs(h_levels, range(n_seeds), k=k, n_nodes=args.nodes) if rank == 0 else []
     jobs = sweep.broadcast_jobs(jobs, dev)
     mine = sweep.shard_jobs(jobs, world, rank)
     batch = sweep.SweepBatch(mine, n_feat=args.feat)
@@ -190,7 +228,9 @@ def workload_text(args, m, world):
     batch = m["batch"]
     n_launches = 4 + (batch.spmm_las is not None) + (1 if batch.gcn["mlp"] is not None else 2)
     return (f"synthetic homophily sweep (data_synthesis/{m['k'] * 400}-equivalent): "
-            f"{len(m['h_levels'])} h-levels x {m['seeds']} seeds = {len(m['mine'])} graphs/GPU/step, "
+            + (f"{len(m['h_levels'])} h-levels x {m['seeds']} seeds = {len(m['h_levels']) * m['seeds']} graphs/step sharded by job over "
+               f"{world} GPU(s) ({len(m['mine'])} on rank 0), " if args.scaling == "strong" else
+               f"{len(m['h_levels'])} h-levels x {m['seeds']} seeds = {len(m['mine'])} graphs/GPU/step, ") +
             f"N={args.nodes} nodes, k={m['k']}, F={args.feat} fp32, C=5; step = batched "
             f"D^-1(A+I)X aggregation + edge/label statistics + label aggregation & LAS + "
             f"GCN-2 forward (hidden 64, per-graph weights), {n_launches} launches"
@@ -212,6 +252,9 @@ def main():
     ap.add_argument("--full-metrics", type=int, default=1, help="1: also time the whole nine-scalar sweep job batch (adds generalized edge "
                     "homophily and the kernel-regression p-values, --kr-epochs epochs) and report it as `sweep_full` (N=1 only)")
     ap.add_argument("--kr-epochs", type=int, default=100)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: --seeds seeds PER RANK (per-GPU work fixed); "
+                    "strong: --seeds seeds in all (configs[2] literally: 50 jobs), sharded over the ranks")
+    ap.add_argument("--timeout", type=float, default=1500.0, help="self-launched workers (--gpus N > 1) are stopped after this many seconds")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -241,7 +284,7 @@ def main():
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": m["elapsed"] / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_text(args, m, world),
                        "graphs_per_step_per_gpu": len(m["mine"]), "edges_per_step_per_gpu": batch.edges,

@@ -10,13 +10,13 @@ import textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, worker_src, gpus):
+def _run(tmp_path, worker_src, gpus, extra=()):
     worker = tmp_path / "worker.py"
     worker.write_text(textwrap.dedent(worker_src))
     env = dict(os.environ, WDG_BENCH_WORKER=str(worker), WDG_TEST_DIR=str(tmp_path))
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1"],
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", *extra],
                           env=env, capture_output=True, text=True, timeout=120)
 
 
@@ -48,6 +48,35 @@ def test_launcher_propagates_worker_failure(tmp_path):
         """, gpus=2)
     assert res.returncode != 0
     assert "workers failed" in res.stderr
+
+
+def test_launcher_stops_the_siblings_of_a_dead_worker(tmp_path):
+    """one rank dies while the others would wait forever (a rendezvous / barrier): the launcher terminates them and fails"""
+    import time
+    t0 = time.monotonic()
+    res = _run(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.stderr.write("rank 1: out of memory\\n")
+            sys.exit(7)
+        time.sleep(600)
+        """, gpus=3)
+    assert res.returncode != 0 and time.monotonic() - t0 < 60
+    assert "workers failed" in res.stderr and "rank 1: out of memory" in res.stderr
+
+
+def test_launcher_timeout(tmp_path):
+    res = _run(tmp_path, "import time; time.sleep(600)", gpus=2, extra=("--timeout", "2"))
+    assert res.returncode != 0 and "timeout" in res.stderr
+
+
+def test_launcher_refuses_to_spawn_from_a_profiled_process(tmp_path):
+    worker = tmp_path / "worker.py"
+    worker.write_text("print('{}')")
+    env = dict(os.environ, WDG_BENCH_WORKER=str(worker), HSA_TOOLS_LIB="/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=60)
+    assert res.returncode == 2 and "profiled process" in res.stderr
 
 
 def test_single_gpu_and_torchrun_paths_do_not_relaunch():

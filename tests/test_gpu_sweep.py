@@ -317,3 +317,21 @@ def test_base_sweep_shares_graphs_and_matches_the_oracle_per_base(oracle):
         # the integer metrics do not depend on the base
         assert torch.equal(res[bi, :, :5], res[0, :, :5])
         assert abs(float(res[bi, 0, 0]) - 2 / int(2 / 0.2)) < 1e-6  # edge homophily = k / int(k / h)
+
+
+def test_empty_shard_steps_and_gathers():
+    """more ranks than jobs (sweep.shard_jobs hands a rank nothing): SweepBatch([]) builds, steps, computes all nine scalars
+    and takes part in the result exchange without error - zero rows, same columns"""
+    from wdg_amd import sweep
+    sb = sweep.SweepBatch(sweep.shard_jobs(sweep.make_jobs([0.2, 0.5], [0], n_nodes=400), 3, 2) and [], n_feat=64, gcn_hidden=16)
+    assert sb.jobs == [] and sb.edges == 0
+    sb.step()
+    sb.step()
+    rows = sb.results()
+    assert tuple(rows.shape) == (0, sweep.STEP_METRICS)
+    sb.prepare_full(epochs=2, sample_max=50)
+    sb.launch_full()
+    torch.cuda.synchronize()
+    assert tuple(sb.full_metrics().shape) == (0, len(sweep.METRIC_NAMES))
+    assert [tuple(t.shape) for t in sweep.gather_results(rows, rows.device)] == [(0, sweep.STEP_METRICS)]
+    assert sb.spmm_algorithmic_bytes() == 0 and sb.spmm_unique_bytes() == 0

@@ -12,18 +12,40 @@ import torch.multiprocessing as mp
 from wdg_amd import sweep, synth
 
 
-def test_shard_jobs_partitions_whole_seeds():
-    jobs = sweep.make_jobs(synth.H_LEVELS_10, range(7))
-    for ws in (1, 2, 3, 8):
-        shards = [sweep.shard_jobs(jobs, ws, r) for r in range(ws)]
-        flat = [j for s in shards for j in s]
-        assert sorted(flat, key=lambda j: (j.seed, j.h)) == sorted(jobs, key=lambda j: (j.seed, j.h))
-        for s in shards:
-            seeds = {j.seed for j in s}
-            assert all(len([j for j in s if j.seed == sd]) == 10 for sd in seeds)  # a seed never splits
-        loads = [sum(j.nnz for j in s) for s in shards]
-        assert max(loads) - min(loads) <= max(j.nnz for j in jobs) * 10
+def test_shard_jobs_partitions_the_job_list():
+    """every job exactly once, deterministic, balanced by job_cost - at job granularity (a seed may split: X is 4 MB)"""
+    for hl, k, n_seeds in ((synth.H_LEVELS_10, 2, 7), (synth.H_LEVELS_10_K10, 10, 5)):
+        jobs = sweep.make_jobs(hl, range(n_seeds), k=k)
+        for ws in (1, 2, 3, 8):
+            shards = [sweep.shard_jobs(jobs, ws, r) for r in range(ws)]
+            flat = [j for s in shards for j in s]
+            assert sorted(flat, key=lambda j: (j.seed, j.h)) == sorted(jobs, key=lambda j: (j.seed, j.h))
+            assert shards == [sweep.shard_jobs(list(jobs), ws, r) for r in range(ws)]
+            for s in shards:  # the jobs of a seed stay adjacent inside a shard (they share X), in list order
+                assert s == sorted(s, key=lambda j: (j.seed, jobs.index(j)))
+            loads = [sum(sweep.job_cost(j) for j in s) for s in shards]
+            assert max(loads) <= 1.15 * min(loads), (k, ws, loads)
     assert sweep.decode_jobs(sweep.encode_jobs(jobs)) == jobs
+
+
+def test_shard_jobs_north_star_split():
+    """BASELINE configs[2] literally: 10 h x 5 seeds = 50 jobs over 8 GPUs -> 6 - 7 jobs per rank, loads within 15 %
+    (whole-seed dealing gave [10, 10, 10, 10, 10, 0, 0, 0]: three idle GPUs)"""
+    jobs = sweep.make_jobs(synth.H_LEVELS_10_K10, range(5), k=10)
+    shards = [sweep.shard_jobs(jobs, 8, r) for r in range(8)]
+    assert sorted(len(s) for s in shards) == [6, 6, 6, 6, 6, 6, 7, 7]
+    loads = [sum(sweep.job_cost(j) for j in s) for s in shards]
+    assert max(loads) / min(loads) <= 1.15
+    edges = [sum(j.nnz for j in s) for s in shards]
+    assert max(edges) / min(edges) <= 1.25  # (the cost has a per-row part: stored entries alone balance less tightly)
+
+
+def test_shard_jobs_fewer_jobs_than_ranks():
+    jobs = sweep.make_jobs([0.2, 0.5], [0], k=2, n_nodes=200)
+    shards = [sweep.shard_jobs(jobs, 3, r) for r in range(3)]
+    assert sorted(len(s) for s in shards) == [0, 1, 1]
+    assert sweep.shard_jobs([], 4, 2) == []
+    assert sweep.encode_jobs([]).shape == (0, 5) and sweep.decode_jobs(sweep.encode_jobs([])) == []
 
 
 def _free_port():
@@ -32,12 +54,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, h_levels=(0.1, 0.5, 0.9), seeds=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as orc
     dev = torch.device("cpu")
-    jobs = sweep.make_jobs([0.1, 0.5, 0.9], range(4), n_nodes=200) if rank == 0 else []
+    jobs = sweep.make_jobs(list(h_levels), range(seeds), n_nodes=200) if rank == 0 else []
     jobs = sweep.broadcast_jobs(jobs, dev)
     mine = sweep.shard_jobs(jobs, world, rank)
     rows = []
@@ -68,3 +90,18 @@ def test_two_rank_sweep_gloo(tmp_path):
             d = int(2 / h)
             assert abs(eh - 2 / d) < 1e-12 and abs(nh - 3 / (d + 1)) < 1e-6  # generator's known answers
     assert torch.equal(torch.cat(res[0]["gathered"]), torch.cat(res[1]["gathered"]))
+
+
+def test_three_ranks_two_jobs_one_empty_shard_gloo(tmp_path):
+    """more ranks than jobs: one rank's shard is empty - it still takes part in the broadcast and the all_gather"""
+    world, port = 3, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), (0.2, 0.5), 1), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    assert [r["jobs"] for r in res] == [2, 2, 2]
+    assert sorted(r["mine"] for r in res) == [0, 1, 1]
+    for r in range(world):
+        assert sorted(g.shape[0] for g in res[r]["gathered"]) == [0, 1, 1]
+        g = torch.cat(res[r]["gathered"])
+        assert g.shape == (2, 4) and sorted(g[:, 1].tolist()) == [0.2, 0.5]
+        for _seed, h, eh, _nh in g.tolist():
+            assert abs(eh - 2 / int(2 / h)) < 1e-12

@@ -42,21 +42,63 @@ def make_jobs(h_levels, seeds, k=2, n_nodes=2000, n_classes=5):
     return [Job(float(h), int(s), k, n_nodes, n_classes) for s in seeds for h in h_levels]
 
 
-def shard_jobs(jobs, world_size, rank):
-    """Static partition: whole seeds (= groups sharing X) are dealt to the least-loaded rank by stored entries
-    (longest-processing-time first); deterministic, identical on every rank."""
-    groups = {}
-    for j in jobs:
-        groups.setdefault(j.seed, []).append(j)
-    order = sorted(groups, key=lambda s: (-sum(j.nnz for j in groups[s]), s))
+# what a job costs a GPU, in units of one stored entry of A + I: the aggregation's measured price per 16-row slice is flat
+# (~1.6 us: the slice's 2-KB rows of Y) plus ~43 ns per entry of width (ops._QUAD_COST_*: 1 200 + 38.5 w ns fits the table),
+# i.e. w + 31 entries' worth per row; the feature transform and the metric kernels are per-node work as well
+JOB_ROW_COST = 32
+
+
+def job_cost(j):
+    return j.nnz + JOB_ROW_COST * j.n_nodes
+
+
+def shard_jobs(jobs, world_size, rank, slack=0.02):
+    """Static partition of the JOB list (jobs (base, h, sample) are independent, synthetic_plot.py:64-78):
+    longest-processing-time first over single jobs by job_cost; among the ranks whose load is within `slack` of a rank's
+    fair share of the lightest, one that already holds a job of the same seed is preferred (its X is resident there: 4 MB
+    saved - a tie-break, never a reason to unbalance).  Deterministic and identical on every rank; a rank may end up with
+    no job when there are fewer jobs than ranks.  The shard keeps the jobs of a seed adjacent, in list order."""
+    order = sorted(range(len(jobs)), key=lambda i: (-job_cost(jobs[i]), i))
+    fair = sum(job_cost(j) for j in jobs) / max(world_size, 1)
     load = [0] * world_size
-    mine = []
-    for s in order:
-        r = min(range(world_size), key=lambda i: (load[i], i))
-        load[r] += sum(j.nnz for j in groups[s])
-        if r == rank:
-            mine.extend(groups[s])
-    return sorted(mine, key=lambda j: (j.seed, jobs.index(j)))
+    seeds = [set() for _ in range(world_size)]
+    owner = [0] * len(jobs)
+    for i in order:
+        j = jobs[i]
+        lightest = min(load)
+        cands = [r for r in range(world_size) if load[r] <= lightest + slack * fair]
+        r = min(cands, key=lambda q: (j.seed not in seeds[q], load[q], q))
+        load[r] += job_cost(j)
+        seeds[r].add(j.seed)
+        owner[i] = r
+    # refinement: while it shortens the longest shard, move one of its jobs to - or swap one with - another rank (LPT alone
+    # leaves 50 jobs on 8 ranks 14 % apart; the sweep ends with its slowest rank)
+    for _ in range(4 * len(jobs)):
+        hi = max(range(world_size), key=lambda q: (load[q], -q))
+        best = None  # (new maximum of the pair, i, j | None, other rank)
+        for i in (i for i in order if owner[i] == hi):
+            ci = job_cost(jobs[i])
+            for q in range(world_size):
+                if q == hi:
+                    continue
+                for k in [None] + [k for k in order if owner[k] == q]:
+                    ck = 0 if k is None else job_cost(jobs[k])
+                    if ck >= ci:
+                        continue
+                    top = max(load[hi] - ci + ck, load[q] + ci - ck)
+                    if top < load[hi] and (best is None or top < best[0]):
+                        best = (top, i, k, q)
+        if best is None:
+            break
+        _top, i, k, q = best
+        ci, ck = job_cost(jobs[i]), (0 if k is None else job_cost(jobs[k]))
+        load[hi] += ck - ci
+        load[q] += ci - ck
+        owner[i] = q
+        if k is not None:
+            owner[k] = hi
+    mine = [i for i in range(len(jobs)) if owner[i] == rank]
+    return [jobs[i] for i in sorted(mine, key=lambda i: (jobs[i].seed, i))]
 
 
 def encode_jobs(jobs):
@@ -329,8 +371,10 @@ class SweepBatch:
         self.gcn["spmm"].launch()   # logits = A_hat (.)           (F = C)
 
     def results(self):
-        """[jobs, len(METRIC_NAMES)] fp32: dense-flavour metric scalars (utils/homophily_plot.py) from the counters."""
+        """[jobs, STEP_METRICS] fp32: dense-flavour metric scalars (utils/homophily_plot.py) from the counters."""
         st = self.stats
+        if not self.jobs:  # an empty shard (more ranks than jobs): no rows, same columns
+            return torch.zeros((0, STEP_METRICS), dtype=torch.float32, device=st.counters.device)
         tot = st.totals.to(torch.float32)
         edge = tot[:, 5] / tot[:, 4]
         n = st.max_rows
@@ -399,6 +443,8 @@ class SweepBatch:
         """[jobs, 9] fp64: results() + ge_homo + the p-values KR_L (kernel_reg0) and KR_NL (kernel_reg1) of the Welch t-test
         over the epochs' accuracies (scipy on the host for the t distribution, as in the reference)"""
         from scipy.stats import ttest_ind
+        if not self.jobs:
+            return torch.zeros((0, len(METRIC_NAMES)), dtype=torch.float64)
         base = self.results().to(torch.float64).cpu()
         ge = self.ge.mean[:len(self.jobs)].cpu()
         acc = self.kr.accuracy().cpu().reshape(len(self.jobs), 2, self.kr_epochs, 2).numpy()  # [job, classifier, epoch, (graph, features)]
