@@ -344,3 +344,39 @@ def gntk_kernels(features, rowptr, col, val, sample, n_layers):
         return (np.float32(1 / math.pi) * (g * (np.float32(math.pi) - ac) + sq)).astype(np.float32)
 
     return arc(gram(hagg, sample)) / np.float32(2), arc(gram(x, sample)) / np.float32(2)
+
+
+def kernel_regression_accuracies(features, rowptr, col, val, labels, node_sets, n_layers):
+    """The kernel-regression branch of one call of classifier_based_performance_metric, epoch by epoch
+    (utils/homophily_metrics.py:283-297, utils/homophily_plot.py:301-316): per epoch the kernels of the epoch's sample
+    (gntk_homophily_, :232-257), `K_val_train @ (np.linalg.pinv(K_train_train) @ onehot[train])` in fp32 with numpy's default
+    rcond (1e-15: every singular value of an fp32 block is kept), arg-max, mean hit rate on the validation rows.
+    node_sets: list of (train node ids, validation node ids) - the reference's boolean masks as ascending ids.
+    -> (G_results [epochs], X_results [epochs]) float64, like the reference's per-epoch result vectors.  Pinned per epoch
+    by tests/test_oracle_golden.py against tests/golden/kr_epochs.npz."""
+    labels = np.asarray(labels, np.int64)
+    c = int(labels.max()) + 1
+    onehot = np.eye(c, dtype=np.float32)[labels]
+    g_res, x_res = [], []
+    for train, valid in node_sets:
+        train, valid = np.asarray(train, np.int64), np.asarray(valid, np.int64)
+        sample = np.sort(np.concatenate([train, valid]))
+        pos = {int(v): i for i, v in enumerate(sample)}
+        tr = np.array([pos[int(v)] for v in train])
+        va = np.array([pos[int(v)] for v in valid])
+        accs = []
+        for kern in gntk_kernels(features, rowptr, col, val, sample, n_layers):
+            alpha = np.linalg.pinv(kern[np.ix_(tr, tr)]) @ onehot[train]
+            pred = (kern[np.ix_(va, tr)] @ alpha).argmax(1)
+            accs.append(float(np.mean((pred == labels[valid]).astype(np.float32))))
+        g_res.append(accs[0])
+        x_res.append(accs[1])
+    return np.array(g_res), np.array(x_res)
+
+
+def welch_p_value(g_results, x_results):
+    """utils/homophily_metrics.py:335-347: Welch t-test of the epochs' accuracies, folded by which side won more epochs"""
+    from scipy.stats import ttest_ind
+    g, x = np.asarray(g_results, np.float32), np.asarray(x_results, np.float32)
+    _, p = ttest_ind(x, g, axis=0, equal_var=False, nan_policy="propagate")
+    return float(p / 2 if np.mean((g > x).astype(np.float32)) <= 0.5 else 1 - p / 2)

@@ -19,3 +19,41 @@ def dense_features(g, key="feat_data"):
     rr = np.repeat(np.arange(n), np.diff(g["feat_indptr"]))
     x[rr, g["feat_indices"]] = g[key]
     return x
+
+
+KR_FIXTURES = SYN + ["real_texas", "real_cora", "real_cora_s200"]
+
+
+def load_kr(name):
+    """per-epoch kernel-regression golden of fixture `name` (make_golden_kr.py): dict(epochs, seed, sample_max and, per
+    classifier, train / val node-id lists per epoch, g_results / x_results per epoch, p)"""
+    z = np.load(os.path.join(GOLDEN_DIR, "kr_epochs.npz"))
+    out = {"epochs": int(z["epochs"]), "seed": int(z[f"{name}/seed"]), "sample_max": float(z[f"{name}/sample_max"])}
+    for clf in ("kernel_reg0", "kernel_reg1"):
+        tr, va = z[f"{name}/train_{clf}"], z[f"{name}/val_{clf}"]
+        out[clf] = dict(node_sets=[(t[t >= 0].astype(np.int64), v[v >= 0].astype(np.int64)) for t, v in zip(tr, va)],
+                        g_results=z[f"{name}/g_results_{clf}"], x_results=z[f"{name}/x_results_{clf}"], p=float(z[f"{name}/p_{clf}"]))
+    return out
+
+
+def welch_p(g, x):
+    """the metric's p-value from the epochs' accuracies (utils/homophily_metrics.py:335-347)"""
+    from scipy.stats import ttest_ind
+    g, x = np.asarray(g, np.float32), np.asarray(x, np.float32)
+    _, p = ttest_ind(x, g, axis=0, equal_var=False, nan_policy="propagate")
+    return float(p / 2 if np.mean((g > x).astype(np.float32)) <= 0.5 else 1 - p / 2)
+
+
+def p_tolerance(g_ref, x_ref, n_val, rows, trials=400, seed=0):
+    """How far the Welch p-value can move when every epoch's accuracy is off by at most `rows` validation rows: the largest
+    deviation over `trials` random perturbations of that size (both result vectors) - the p-value bound that a per-epoch
+    accuracy bound of rows / n_val implies for THESE accuracies (a p-value near 0 or 1 barely moves, one near 0.5 does)."""
+    rng = np.random.default_rng(seed)
+    g_ref, x_ref = np.asarray(g_ref, np.float64), np.asarray(x_ref, np.float64)
+    p0 = welch_p(g_ref, x_ref)
+    worst = 0.0
+    for _ in range(trials):
+        dg = rng.integers(-rows, rows + 1, g_ref.shape) / n_val
+        dx = rng.integers(-rows, rows + 1, x_ref.shape) / n_val
+        worst = max(worst, abs(welch_p(np.clip(g_ref + dg, 0, 1), np.clip(x_ref + dx, 0, 1)) - p0))
+    return worst + 1e-9

@@ -149,15 +149,29 @@ def test_gntk_kernels(mods, name, nl):
 @pytest.mark.parametrize("name", ["texas", "cora"])
 @pytest.mark.parametrize("clf", ["kernel_reg0", "kernel_reg1", "gnb"])
 def test_classifier_metric_seeded(mods, name, clf):
-    """Same torch CPU RNG stream as the reference -> same splits; p-values agree unless an argmax sits on a
-    rounding boundary, so a loose tolerance (statistical parity)."""
+    """Same torch CPU RNG stream as the reference -> same node sets in every epoch.  Kernel regression: the per-epoch
+    accuracies against what the reference computed in those epochs (tests/golden/kr_epochs.npz; texas within 2, cora within 4
+    validation rows: their raw-adjacency train blocks are rank deficient - tests/test_gpu_kr_epochs.py), the p-value within
+    what that implies.  GNB runs sklearn on the host like the reference: the p-value itself."""
+    from _golden import load_kr, p_tolerance
     _, hm, _ = mods
     g0 = load("real_" + name)
     adj_raw, features, labels = _raw(g0)
     torch.manual_seed(11)
+    hm.LAST_KR_ACCURACIES = None
     p, secs = hm.classifier_based_performance_metric(features, adj_raw, labels, 200.0, base_classifier=clf, epochs=6)
     assert 0.0 <= p <= 1.0 and secs > 0
-    assert abs(p - float(g0[f"m_cpm_{clf}_seed11_e6_s200"])) <= 0.15
+    want = float(g0[f"m_cpm_{clf}_seed11_e6_s200"])
+    if clf == "gnb":
+        assert abs(p - want) <= 1e-6
+        return
+    rec = load_kr("real_texas" if name == "texas" else "real_cora_s200")[clf]  # the same call (sample_max 200, seed 11), 8 epochs
+    rows = 2 if name == "texas" else 4
+    acc = hm.LAST_KR_ACCURACIES.numpy().astype(np.float64)  # [epoch, (graph-aware, features only)]
+    n_val = float(len(rec["node_sets"][0][1]))
+    assert np.abs(acc[:, 0] - rec["g_results"][:6]).max() * n_val <= rows + 0.01
+    assert np.abs(acc[:, 1] - rec["x_results"][:6]).max() * n_val <= rows + 0.01
+    assert abs(p - want) <= p_tolerance(rec["g_results"][:6], rec["x_results"][:6], n_val, rows)
 
 
 @pytest.mark.parametrize("clf", ["kernel_reg1", "kernel_reg0"])
@@ -187,9 +201,12 @@ def test_classifier_metric_device_solver(mods, clf):
             accs = hm.LAST_KR_ACCURACIES.reshape(-1).tolist()
         assert 0.0 <= p <= 1.0 and secs > 0 and len(accs) == 12
         seen[solver] = (p, np.array(accs))
-    if clf == "kernel_reg1":
-        assert np.abs(seen["host"][1] - seen["device"][1]).max() <= 0.06  # <= 4 of the 73 validation nodes of texas
-        assert abs(seen["host"][0] - seen["device"][0]) <= 0.15
+    # host (LAPACK pinv, the reference's arithmetic) and device (Cholesky + ridge at n eps max K_ii / 8) per epoch: within 2
+    # of the 73 validation nodes of texas for both kernels - the linear one (rank-deficient train blocks) included
+    assert np.abs(seen["host"][1] - seen["device"][1]).max() <= 2.01 / 73
+    from _golden import p_tolerance
+    h = seen["host"][1].reshape(-1, 2)
+    assert abs(seen["host"][0] - seen["device"][0]) <= p_tolerance(h[:, 0], h[:, 1], 73.0, 2)
     with pytest.raises(ValueError):
         hm.classifier_based_performance_metric(features, adj_raw, labels, 200.0, solver="fpga")
 

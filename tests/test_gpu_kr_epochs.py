@@ -1,0 +1,99 @@
+"""The device kernel-regression solver against what the REFERENCE computed inside each epoch (tests/golden/kr_epochs.npz,
+recorded inside the reference's own classifier_based_performance_metric call by tests/golden/make_golden_kr.py): same node
+sets, per (fixture, classifier, epoch, kernel) the validation accuracy of the regression."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import KR_FIXTURES, dense_features, load, load_kr, p_tolerance, welch_p
+
+pytestmark = pytest.mark.gpu
+
+# validation rows (of 196 - 200; texas 73) by which an epoch's accuracy may differ from the reference's.  Well-conditioned or
+# mildly deficient blocks (the synthetic sweep graphs): 2.  The raw-adjacency kernels of the real graphs are rank deficient
+# (isolated and duplicate nodes: exactly singular train blocks); the reference's pinv keeps their rounding-level singular
+# values (rcond 1e-15), which no other factorisation reproduces - the device solver answers with a ridge at n eps max K_ii / 8
+# (csrc/kernel_reg.hip): measured deviation <= 2 rows on texas, <= 4 on cora (fp32 emulation: 0 - 2, one epoch 4).
+ROWS_OFF = {"real_texas": 2, "real_cora": 4, "real_cora_s200": 4}
+
+
+def _device_inputs(name):
+    """(h_agg, x, labels) on the GPU, built the way the reference call was fed"""
+    from wdg_amd import ops
+    g = load(name.replace("_s200", ""))
+    n = int(g["n_nodes"])
+    if name.startswith("syn_"):  # synthetic_plot.py:81-92
+        gr = ops.CsrGraph.from_coo(g["adj_row"].astype(np.int64), g["adj_col"].astype(np.int64), n, None, ops.COO_ADD_SELF_LOOPS)
+        d = ops.degree_norm(gr, ops.NORM_RW, ops.PREC_F32)["dinv"]
+        x = ops.row_l1_normalise(torch.from_numpy(dense_features(g)))
+        h = ops.spmm(gr, x, row_scale=d)
+    else:                        # homophily_tests.py:133-137: raw adjacency, raw features
+        gr = ops.CsrGraph.from_coo(g["adj_row"].astype(np.int64), g["adj_col"].astype(np.int64), n, g["adj_val"])
+        x = torch.from_numpy(dense_features(g)).cuda()
+        h = ops.spmm(gr, x)
+    return h, x, torch.from_numpy(g["labels"]).cuda().to(torch.int32)
+
+
+@pytest.mark.parametrize("name", KR_FIXTURES)
+def test_device_solver_per_epoch_against_the_reference(name):
+    from wdg_amd import ops
+    kr = load_kr(name)
+    h, x, lab = _device_inputs(name)
+    gb = ops.GramBatch([h, x])
+    gb.launch()
+    rows = ROWS_OFF.get(name, 2)
+    for clf, kern in (("kernel_reg0", gb.k_linear), ("kernel_reg1", gb.k_arccos)):
+        rec = kr[clf]
+        problems = []
+        for tr, va in rec["node_sets"]:
+            tr, va = torch.from_numpy(tr).cuda().to(torch.int32), torch.from_numpy(va).cuda().to(torch.int32)
+            problems += [(kern[0], tr, va, lab), (kern[1], tr, va, lab)]
+        kb = ops.KrBatch(problems, int(lab.max().item()) + 1)
+        kb.launch()
+        torch.cuda.synchronize()
+        acc = kb.accuracy().cpu().numpy().reshape(-1, 2).astype(np.float64)
+        n_val = np.array([len(v) for _, v in rec["node_sets"]], np.float64)
+        off_g, off_x = (acc[:, 0] - rec["g_results"]) * n_val, (acc[:, 1] - rec["x_results"]) * n_val
+        assert np.abs(off_g).max() <= rows + 0.01 and np.abs(off_x).max() <= rows + 0.01, (name, clf, np.round(off_g), np.round(off_x))
+        # the p-value: within what that accuracy bound implies for these accuracies (no fixed 0.15)
+        tol = p_tolerance(rec["g_results"], rec["x_results"], float(n_val.min()), rows)
+        assert abs(welch_p(acc[:, 0], acc[:, 1]) - rec["p"]) <= tol, (name, clf, welch_p(acc[:, 0], acc[:, 1]), rec["p"], tol)
+
+
+def test_solver_limits_are_refused_loudly():
+    """more than 8 classes / an empty train set: KrBatch raises instead of launching problems the kernel answers with -1
+    (accuracies of -1 / n_val fed the t-test a garbage p-value)"""
+    from wdg_amd import ops
+    k = torch.eye(64, device="cuda")
+    lab = (torch.arange(64, device="cuda") % 10).to(torch.int32)
+    tr, va = torch.arange(40, device="cuda", dtype=torch.int32), torch.arange(40, 64, device="cuda", dtype=torch.int32)
+    with pytest.raises(ValueError):
+        ops.KrBatch([(k, tr, va, lab)], 10)
+    with pytest.raises(ValueError):
+        ops.KrBatch([(k, tr[:0], va, lab)], 5)
+    kb = ops.KrBatch([(k, tr, va, lab % 5)], 5)
+    kb.launch()
+    assert 0.0 <= float(kb.accuracy()[0]) <= 1.0
+    kb.correct.fill_(-1)  # what the kernel writes for a refused problem
+    with pytest.raises(RuntimeError):
+        kb.accuracy()
+
+
+def test_ten_class_labels_fall_back_to_the_host_path():
+    """classifier_based_performance_metric with 10 classes: the device path declines before consuming the generator, the
+    reference's host path (np.linalg.pinv) runs on the same node sets and returns a valid p-value"""
+    from wdg_amd.utils import homophily_metrics as hm
+    rng = np.random.default_rng(3)
+    n, f, c = 300, 24, 10
+    lab = torch.from_numpy(np.arange(n) % c)
+    x = torch.from_numpy((rng.standard_normal((n, f)) + np.eye(c, f)[lab.numpy()] * 2).astype(np.float32))
+    src = rng.integers(0, n, 1500)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.stack([src, (src + c * rng.integers(1, 5, 1500)) % n])), torch.ones(1500), (n, n)).coalesce()
+    assert hm._kernel_regression_on_device(x, adj, lab, 200.0, "kernel_reg1", 3) is None
+    res = {}
+    for solver in ("device", "host"):
+        torch.manual_seed(4)
+        hm.LAST_KR_ACCURACIES = None
+        res[solver] = hm.classifier_based_performance_metric(x, adj, lab, 200.0, base_classifier="kernel_reg1", epochs=3, solver=solver)[0]
+        assert hm.LAST_KR_ACCURACIES is None  # (no device regression ran)
+    assert res["device"] == res["host"] and 0.0 <= res["host"] <= 1.0

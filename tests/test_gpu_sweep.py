@@ -198,13 +198,18 @@ def test_sweep_all_nine_scalars_against_golden():
         assert r[4] == pytest.approx(float(g0["m_label_info"]), rel=2e-3, abs=2e-6)
         assert abs(r[5] - float(g0["m_soft_las"])) <= 2.01 / j.n_nodes
         assert r[6] == pytest.approx(float(g0["m_ge_homo"]), rel=2e-5)
-        # p-values of a Welch test over 4 epochs: a single validation node decided differently moves them; same order of
-        # magnitude bound as the per-graph API test (tests/test_gpu_api.py)
-        assert abs(r[7] - float(g0["m_cpm_kernel_reg0_seed5_e4_s500"])) <= 0.15
-        assert abs(r[8] - float(g0["m_cpm_kernel_reg1_seed5_e4_s500"])) <= 0.15
-    # the accuracies behind the p-values: every (job, classifier, epoch, kernel) regression ran and is a plausible accuracy
-    acc = sb.kr.accuracy().cpu().numpy()
-    assert acc.shape == (len(jobs) * 2 * 4 * 2,) and (acc >= 0.0).all() and (acc <= 1.0).all() and acc.max() > 0.5
+    # the accuracies behind the p-values, per (job, classifier, epoch, kernel), against what the reference computed in each of
+    # these epochs (tests/golden/kr_epochs.npz holds 8 epochs of the same seed: the first 4 are this run's): within 2 of the
+    # 200 validation rows; the p-values within what that implies for these accuracies (_golden.p_tolerance)
+    from _golden import load_kr, p_tolerance
+    acc = sb.kr.accuracy().cpu().numpy().astype(np.float64).reshape(len(jobs), 2, 4, 2)
+    for ji, (name, r, g0) in enumerate(zip(names, rows, gold)):
+        kr = load_kr(name)
+        for ci, clf in enumerate(("kernel_reg0", "kernel_reg1")):
+            g_ref, x_ref = kr[clf]["g_results"][:4], kr[clf]["x_results"][:4]
+            assert np.abs(acc[ji, ci, :, 0] - g_ref).max() <= 2.01 / 200, (name, clf, acc[ji, ci, :, 0], g_ref)
+            assert np.abs(acc[ji, ci, :, 1] - x_ref).max() <= 2.01 / 200, (name, clf, acc[ji, ci, :, 1], x_ref)
+            assert abs(r[7 + ci] - float(g0[f"m_cpm_{clf}_seed5_e4_s500"])) <= p_tolerance(g_ref, x_ref, 200.0, 2)
 
 
 def test_sweep_exchange_under_an_initialised_process_group(tmp_path):

@@ -235,3 +235,52 @@ def test_coo_to_csr_flag_semantics(oracle):
     # empty graph
     rp, col, val = oracle.coo_to_csr(np.zeros(0, np.int64), np.zeros(0, np.int64), 3, None, oracle.ADD_SELF_LOOPS)
     assert rp.tolist() == [0, 1, 2, 3] and col.tolist() == [0, 1, 2]
+
+
+# --------------------------------------------------------------------------- kernel regression, per epoch
+def _kr_inputs(oracle, name):
+    """what the reference call of make_golden_kr.py was handed: (features, rowptr, col, val, labels)"""
+    g = load(name.replace("_s200", ""))
+    n = int(g["n_nodes"])
+    if name.startswith("syn_"):  # synthetic_plot.py:81-92: row-L1 features, D^-1 (A + I)
+        rowptr, col, val = oracle.coo_to_csr(g["adj_row"], g["adj_col"], n, None, oracle.ADD_SELF_LOOPS)
+        val = oracle.normalised_csr(rowptr, col, val, oracle.NORM_RW, oracle.PREC_F32)
+        x = oracle.row_l1_normalise(dense_features(g))
+    else:                        # homophily_tests.py:133-137: raw adjacency, raw features
+        rowptr, col, val = oracle.coo_to_csr(g["adj_row"], g["adj_col"], n, g["adj_val"])
+        x = dense_features(g)
+    return x, rowptr, col, val, g["labels"]
+
+
+@pytest.mark.parametrize("name", ["syn_800_0.5_0", "syn_4000_0.2_0", "real_texas", "real_cora", "real_cora_s200"])
+def test_kernel_regression_epochs(oracle, name):
+    """The oracle's per-epoch restatement of the kernel-regression metric against what the reference computed in each epoch
+    (tests/golden/kr_epochs.npz: node sets and accuracies recorded inside the reference's own call).  Exact or one validation
+    row: the Gram's summation order differs from torch.mm's, and arg-max ties sit on rounding."""
+    from _golden import load_kr
+    kr = load_kr(name)
+    x, rowptr, col, val, labels = _kr_inputs(oracle, name)
+    for nl, clf in enumerate(("kernel_reg0", "kernel_reg1")):
+        rec = kr[clf]
+        sets = rec["node_sets"][:3]
+        g_res, x_res = oracle.kernel_regression_accuracies(x, rowptr, col, val, labels, sets, nl)
+        n_val = np.array([len(v) for _, v in sets], np.float64)
+        assert (np.abs(g_res - rec["g_results"][:3]) * n_val <= 1.01).all(), (clf, g_res, rec["g_results"][:3])
+        assert (np.abs(x_res - rec["x_results"][:3]) * n_val <= 1.01).all(), (clf, x_res, rec["x_results"][:3])
+        assert abs(oracle.welch_p_value(rec["g_results"], rec["x_results"]) - rec["p"]) <= 1e-9
+
+
+@pytest.mark.parametrize("name", ["syn_800_0.05_0", "syn_4000_0.15_2", "real_texas", "real_cora", "real_cora_s200"])
+def test_epoch_node_sets_reproduce_the_reference_stream(name):
+    """wdg_amd.utils.util_funcs.kernel_regression_epoch_indices (host logic of the product) draws, under the same
+    torch.manual_seed, exactly the node sets the reference drew in every epoch (its masks as ascending node ids)."""
+    import torch
+    from _golden import load_kr
+    from wdg_amd.utils.util_funcs import kernel_regression_epoch_indices
+    kr = load_kr(name)
+    labels = torch.from_numpy(load(name.replace("_s200", ""))["labels"])
+    for clf in ("kernel_reg0", "kernel_reg1"):
+        torch.manual_seed(kr["seed"])
+        got = kernel_regression_epoch_indices(labels, kr["sample_max"], kr["epochs"])
+        for (tr, va), (tr0, va0) in zip(got, kr[clf]["node_sets"]):
+            assert np.array_equal(tr.numpy(), tr0) and np.array_equal(va.numpy(), va0)

@@ -987,19 +987,24 @@ class KrBatch:
     """Job table for wdg_kernel_regress_batched_f32: many (kernel, train rows, validation rows) problems in one launch."""
 
     MAX_TRAIN = 320
+    MAX_CLASSES = 8  # KR_MAX_C of csrc/kernel_reg.hip: the right-hand sides a problem's workgroup carries
 
     def __init__(self, problems, n_classes):
         """problems: list of (K [n, n] fp32 device, train int32 device [nt], val int32 device [nv], labels int32 device [n])
-        -> self.correct [n_problems] int32 after launch()"""
+        -> self.correct [n_problems] int32 after launch().  Shapes the solver does not hold (more than 8 classes, more than
+        320 or fewer than 1 train rows) raise here: the kernel would answer them with the sentinel -1, and an accuracy of
+        -1 / n_val fed to the t-test is a silently wrong p-value (callers with such label sets take the host path)."""
         dev = require_gpu()
+        if not 1 <= int(n_classes) <= self.MAX_CLASSES and len(problems):
+            raise ValueError(f"KrBatch: {n_classes} classes, the solver holds 1..{self.MAX_CLASSES}")
         self.keep = problems
         self.n_jobs = len(problems)
         self.correct = torch.zeros(max(self.n_jobs, 1), dtype=torch.int32, device=dev)
         self.n_val = torch.tensor([p[2].shape[0] for p in problems], dtype=torch.float32, device=dev)
         arr = (_lib.KrJob * self.n_jobs)()
         for i, (job, (k, tr, va, lab)) in enumerate(zip(arr, problems)):
-            if tr.shape[0] > self.MAX_TRAIN:
-                raise ValueError(f"KrBatch: {tr.shape[0]} train rows, the solver holds blocks of <= {self.MAX_TRAIN}")
+            if not 1 <= tr.shape[0] <= self.MAX_TRAIN:
+                raise ValueError(f"KrBatch: {tr.shape[0]} train rows, the solver holds blocks of 1..{self.MAX_TRAIN}")
             job.K, job.train, job.val, job.labels = k.data_ptr(), tr.data_ptr(), va.data_ptr(), lab.data_ptr()
             job.correct_out = self.correct.data_ptr() + 4 * i
             job.ldk, job.n_train, job.n_val, job.n_classes = _ld(k), tr.shape[0], va.shape[0], int(n_classes)
@@ -1009,7 +1014,11 @@ class KrBatch:
         check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")
 
     def accuracy(self):
-        return self.correct[:self.n_jobs].to(torch.float32) / self.n_val
+        """[n_problems] fp32 hit rate on the validation rows; raises when the kernel refused a problem (sentinel -1)"""
+        correct = self.correct[:self.n_jobs]
+        if self.n_jobs and bool((correct < 0).any().item()):
+            raise _lib.WdgError("wdg_kernel_regress_batched_f32 refused a problem (shape outside the solver's limits)")
+        return correct.to(torch.float32) / self.n_val
 
 
 # ------------------------------------------------------------------------------------------- per-edge cosine

@@ -234,7 +234,8 @@ LAST_KR_ACCURACIES = None
 
 def _kernel_regression_on_device(features, adj, labels, sample_max, base_classifier, epochs):
     """the kernel-regression branch of classifier_based_performance_metric entirely on the GPU -> (p_value, seconds), or
-    None when a train block exceeds the solver's 320 rows"""
+    None when the solver does not hold the problem: a train block of more than 320 rows or more than 8 classes (Coauthor_CS
+    15, Amazon_Computers 10, WikiCS 10: the caller then takes the reference's host path)"""
     from .util_funcs import kernel_regression_epoch_indices
     t_time = time.time()
     g = _graph(adj)
@@ -244,8 +245,12 @@ def _kernel_regression_on_device(features, adj, labels, sample_max, base_classif
     lab32 = labels.to(torch.int32)
     n_cls = int(labels.max().item()) + 1
     n_layers = 0 if base_classifier == 'kernel_reg0' else 1
+    if n_cls > ops.KrBatch.MAX_CLASSES:
+        return None  # (before the node sets are drawn: the host path draws them itself, from the same generator state)
+    rng_state = torch.get_rng_state()
     node_sets = kernel_regression_epoch_indices(labels, sample_max, epochs)  # (the generator is consumed as in the reference)
-    if max(tr.shape[0] for tr, _ in node_sets) > ops.KrBatch.MAX_TRAIN:
+    if not 1 <= min(tr.shape[0] for tr, _ in node_sets) or max(tr.shape[0] for tr, _ in node_sets) > ops.KrBatch.MAX_TRAIN:
+        torch.set_rng_state(rng_state)  # the host path redraws the same sets
         return None
     h_agg = ops.spmm(g, features)
     problems = []
