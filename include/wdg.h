@@ -494,7 +494,8 @@ typedef struct wdg_kr_job {
     const int32_t *train;   /* [n_train] */
     const int32_t *val;     /* [n_val] */
     const int32_t *labels;  /* [n] */
-    int32_t *correct_out;   /* [1] */
+    int32_t *correct_out;   /* [1]: validation rows predicted right; -1 = problem refused (shape outside the limits) */
+    int32_t *flags_out;     /* [1] or NULL: bit 0 = a pivot fell to rounding level and the block was refactored with the ridge */
     int64_t ldk;
     int32_t n_train, n_val, n_classes, reserved;
 } wdg_kr_job;

@@ -9,8 +9,10 @@ from _golden import KR_FIXTURES, dense_features, load, load_kr, p_tolerance, wel
 
 pytestmark = pytest.mark.gpu
 
-# validation rows (of 196 - 200; texas 73) by which an epoch's accuracy may differ from the reference's.  Well-conditioned or
-# mildly deficient blocks (the synthetic sweep graphs): 2.  The raw-adjacency kernels of the real graphs are rank deficient
+# validation rows (of 196 - 200; texas 73) by which an epoch's accuracy may differ from the reference's.  Positive definite
+# train blocks (no ridge: KrBatch.ridged() false): 2 everywhere.  Blocks the solver had to regularise (the feature kernels of
+# the pubmed sample hold duplicate rows): 3 - there the reference's own answer carries the noise of its inverted
+# rounding-level singular values.  The raw-adjacency kernels of the real graphs are rank deficient
 # (isolated and duplicate nodes: exactly singular train blocks); the reference's pinv keeps their rounding-level singular
 # values (rcond 1e-15), which no other factorisation reproduces - the device solver answers with a ridge at n eps max K_ii / 8
 # (csrc/kernel_reg.hip): measured deviation <= 2 rows on texas, <= 4 on cora (fp32 emulation: 0 - 2, one epoch 4).
@@ -54,7 +56,10 @@ def test_device_solver_per_epoch_against_the_reference(name):
         acc = kb.accuracy().cpu().numpy().reshape(-1, 2).astype(np.float64)
         n_val = np.array([len(v) for _, v in rec["node_sets"]], np.float64)
         off_g, off_x = (acc[:, 0] - rec["g_results"]) * n_val, (acc[:, 1] - rec["x_results"]) * n_val
-        assert np.abs(off_g).max() <= rows + 0.01 and np.abs(off_x).max() <= rows + 0.01, (name, clf, np.round(off_g), np.round(off_x))
+        ridged = kb.ridged().cpu().numpy().reshape(-1, 2)
+        lim = np.where(ridged, max(rows, 3), rows) + 0.01  # [epoch, (graph-aware, features only)]
+        assert (np.abs(off_g) <= lim[:, 0]).all() and (np.abs(off_x) <= lim[:, 1]).all(), (name, clf, np.round(off_g), np.round(off_x), ridged.T)
+        rows = int(lim.max())
         # the p-value: within what that accuracy bound implies for these accuracies (no fixed 0.15)
         tol = p_tolerance(rec["g_results"], rec["x_results"], float(n_val.min()), rows)
         assert abs(welch_p(acc[:, 0], acc[:, 1]) - rec["p"]) <= tol, (name, clf, welch_p(acc[:, 0], acc[:, 1]), rec["p"], tol)

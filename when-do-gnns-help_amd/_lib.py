@@ -134,7 +134,7 @@ class EdgeGramJob(ctypes.Structure):
 class KrJob(ctypes.Structure):
     """mirror of `wdg_kr_job` (include/wdg.h)"""
     _fields_ = [("K", c_void_p), ("train", c_void_p), ("val", c_void_p), ("labels", c_void_p), ("correct_out", c_void_p),
-                ("ldk", c_int64), ("n_train", c_int32), ("n_val", c_int32), ("n_classes", c_int32), ("reserved", c_int32)]
+                ("flags_out", c_void_p), ("ldk", c_int64), ("n_train", c_int32), ("n_val", c_int32), ("n_classes", c_int32), ("reserved", c_int32)]
 
 
 class LasJob(ctypes.Structure):

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
     const int tid = threadIdx.x, tc = tid & 31, trw = tid >> 5;
     if (nt <= 0 || nt > KR_MAX_N || C <= 0 || C > KR_MAX_C) {
         if (tid == 0 && job->correct_out) *to_global(job->correct_out) = -1;
+        if (tid == 0 && job->flags_out) *to_global(job->flags_out) = 0;
         return;
     }
     for (int i = tid; i < KR_MAX_N; i += KR_THREADS) tr_idx[i] = i < nt ? train[i] : -1;
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
         __syncthreads();
     }
     if (tid == 0 && job->correct_out) *to_global(job->correct_out) = correct;
+    if (tid == 0 && job->flags_out) *to_global(job->flags_out) = ridge > 0.f ? 1 : 0;
 }
 
 }  // namespace

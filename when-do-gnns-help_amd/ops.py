@@ -1000,6 +1000,7 @@ class KrBatch:
         self.keep = problems
         self.n_jobs = len(problems)
         self.correct = torch.zeros(max(self.n_jobs, 1), dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(max(self.n_jobs, 1), dtype=torch.int32, device=dev)  # bit 0: the ridge refactorisation ran
         self.n_val = torch.tensor([p[2].shape[0] for p in problems], dtype=torch.float32, device=dev)
         arr = (_lib.KrJob * self.n_jobs)()
         for i, (job, (k, tr, va, lab)) in enumerate(zip(arr, problems)):
@@ -1007,11 +1008,16 @@ class KrBatch:
                 raise ValueError(f"KrBatch: {tr.shape[0]} train rows, the solver holds blocks of 1..{self.MAX_TRAIN}")
             job.K, job.train, job.val, job.labels = k.data_ptr(), tr.data_ptr(), va.data_ptr(), lab.data_ptr()
             job.correct_out = self.correct.data_ptr() + 4 * i
+            job.flags_out = self.flags.data_ptr() + 4 * i
             job.ldk, job.n_train, job.n_val, job.n_classes = _ld(k), tr.shape[0], va.shape[0], int(n_classes)
         self.table = _table(arr)
 
     def launch(self):
         check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")
+
+    def ridged(self):
+        """[n_problems] bool: the train block was rank deficient in fp32 and was solved with the rounding-level ridge"""
+        return (self.flags[:self.n_jobs] & 1).bool()
 
     def accuracy(self):
         """[n_problems] fp32 hit rate on the validation rows; raises when the kernel refused a problem (sentinel -1)"""
