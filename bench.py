@@ -115,7 +115,7 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     jobs = sweep.make_jobs(h_levels, range(n_seeds), k=k, n_nodes=args.nodes) if rank == 0 else []
     jobs = sweep.broadcast_jobs(jobs, dev)
     mine = sweep.shard_jobs(jobs, world, rank)
-    batch = sweep.SweepBatch(mine, n_feat=args.feat)
+    batch = sweep.SweepBatch(mine, n_feat=args.feat, tune=True)  # (replayed `steps` times: the feedback-balanced tape cut pays)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -166,7 +166,8 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
 def measure_full(args, dev):
     """The whole sweep job of synthetic_plot.py:92-109 for the shard - all nine scalars: a step's aggregation + counters + LAS,
     then the Gram / arc-cosine kernels of every graph, the edge cosines and every kernel regression of every epoch - as
-    graphs/s.  The epochs' node sets are drawn on the host beforehand (inputs, like the graphs)."""
+    graphs/s, REPLAYED on a resident batch (steady state; the one-pass figure is `sweep_cold`).  The epochs' node sets are drawn
+    by the device sampler inside the timed launches."""
     import torch
     from wdg_amd import sweep, synth
     h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
@@ -191,6 +192,73 @@ def measure_full(args, dev):
                         f"rows per regression, {sb.kr.n_jobs} regressions per batch)",
             "graphs_per_s": len(jobs) / (dev_s + tail_s), "device_ms_per_batch": dev_s * 1e3, "host_tail_ms": tail_s * 1e3,
             "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, rows.mean(0).tolist())}}
+
+
+def measure_cold(args, dev):
+    """The sweep as the reference runs it (synthetic_plot.py:78-109): every graph is visited ONCE.  Distinct shards, each from
+    host COO arrays (what the reference loads from `data_synthesis/*.pt`) to its metric rows on the host, EVERYTHING inside
+    the clock: upload, the batched CSR / SELL-16 build, degrees, job tables, the aggregation step, and - nine-scalar variant -
+    Gram + maps, the epochs' node sets drawn on the device, every kernel regression and the t-tests.  No tape-cut tuning
+    (a one-pass batch takes the modelled cut).  One untimed shard first (code objects, allocator pools)."""
+    import numpy as np
+    import torch
+    from wdg_amd import sweep, synth
+    h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
+    n_shards = args.cold_shards
+
+    def host_inputs(first_seed):
+        jobs = sweep.make_jobs(h_levels, range(first_seed, first_seed + args.seeds), k=args.k, n_nodes=args.nodes)
+        feats, inputs = {}, []
+        for j in jobs:
+            src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+            if j.seed not in feats:
+                feats[j.seed] = synth.features(j.n_nodes, args.feat, j.seed)
+            inputs.append((src, dst, lab, feats[j.seed]))
+        return jobs, inputs
+
+    shards = [host_inputs(1000 + args.seeds * b) for b in range(n_shards + 1)]  # (the inputs: like files on disk)
+    out = {}
+    for name, nine in (("six_scalars", False), ("nine_scalars", True)):
+        phases = {"build_ms": [], "sample_ms": [], "device_ms": [], "host_tail_ms": [], "total_ms": []}
+        graphs = 0
+        for b, (jobs, inputs) in enumerate(shards):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sb = sweep.SweepBatch(jobs, n_feat=args.feat, gcn_hidden=0, inputs=inputs)   # upload + batched build (one read-back)
+            if nine:
+                sb.prepare_full(epochs=args.kr_epochs, sample_max=500, base_seed=b)      # tables only; nothing drawn yet
+            t1 = time.perf_counter()
+            sb.step()
+            ev = None
+            if nine:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                sb.kr_sets.launch()
+                ev[1].record()
+                sb.gram.launch()
+                sb.ge.launch()
+                sb.kr.launch()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            rows = sb.full_metrics() if nine else sb.results().cpu()
+            t3 = time.perf_counter()
+            if b == 0:
+                continue  # warm-up shard
+            graphs += len(jobs)
+            phases["build_ms"].append((t1 - t0) * 1e3)
+            phases["device_ms"].append((t2 - t1) * 1e3)
+            phases["host_tail_ms"].append((t3 - t2) * 1e3)
+            phases["total_ms"].append((t3 - t0) * 1e3)
+            phases["sample_ms"].append(ev[0].elapsed_time(ev[1]) if ev else 0.0)
+            del sb
+        total_s = sum(phases["total_ms"]) * 1e-3
+        out[name] = {"graphs_per_s": graphs / total_s, **{k: sum(v) / len(v) for k, v in phases.items()},
+                     "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, rows.double().mean(0).tolist())}}
+    out["workload"] = (f"{n_shards} distinct shards of {len(shards[0][0])} graphs (k={args.k}, {args.seeds} seeds each, N={args.nodes}, "
+                       f"F={args.feat}), each visited once: host COO -> batched build -> step -> metric rows on the host; nine_scalars adds "
+                       f"Gram + maps, {args.kr_epochs} epochs of device-drawn node sets x 2 classifiers x 2 kernels = "
+                       f"{len(shards[0][0]) * args.kr_epochs * 4} regressions per shard, t-tests; per-shard averages, one warm-up shard untimed")
+    return out
 
 
 def traffic_for(n_graphs, n_feat, k):
@@ -252,6 +320,9 @@ def main():
     ap.add_argument("--full-metrics", type=int, default=1, help="1: also time the whole nine-scalar sweep job batch (adds generalized edge "
                     "homophily and the kernel-regression p-values, --kr-epochs epochs) and report it as `sweep_full` (N=1 only)")
     ap.add_argument("--kr-epochs", type=int, default=100)
+    ap.add_argument("--cold", type=int, default=1, help="1: also time the one-pass (cold) sweep - distinct shards from host COO to "
+                    "metric rows, everything inside the clock - and report it as `sweep_cold` (N=1 only)")
+    ap.add_argument("--cold-shards", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: --seeds seeds PER RANK (per-GPU work fixed); "
                     "strong: --seeds seeds in all (configs[2] literally: 50 jobs), sharded over the ranks")
     ap.add_argument("--timeout", type=float, default=1500.0, help="self-launched workers (--gpus N > 1) are stopped after this many seconds")
@@ -309,6 +380,9 @@ def main():
         dist.destroy_process_group()  # (before the line: RCCL writes its library path to stdout when it shuts down)
     if world == 1 and args.full_metrics:
         out["sweep_full"] = measure_full(args, dev)
+    if world == 1 and args.cold:
+        torch.cuda.empty_cache()
+        out["sweep_cold"] = measure_cold(args, dev)
     if rank == 0:
         if world == 1 and args.cpu_budget > 0:
             from oracle import cpu_ref

@@ -64,6 +64,27 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
                        size_t workspace_bytes, wdg_stream_t stream);
 
 /*
+ * A whole sweep shard through ONE COO -> CSR build (the reference's loop builds a graph per iteration, synthetic_plot.py:84-92;
+ * here the shard's graphs are laid out as one block-diagonal graph of sum(n_g) nodes, built by a single wdg_coo_to_csr_i32 call,
+ * and cut apart again - one launch sequence and one host read-back per shard instead of ~10 launches and a sync per graph).
+ *   wdg_coo_blockdiag_offset: the concatenated edge lists of the graphs (graph g holds entries edge_ptr[g] .. edge_ptr[g+1] - 1,
+ *     node ids local to the graph) -> ids of the block-diagonal graph, in place: id + node_ptr[g].  An id outside [0, n_g) sets
+ *     *bad_out (device int32, zeroed by the call first) to 1 and is left out of range of the whole graph.
+ *   wdg_csr_split_blockdiag: the block-diagonal CSR -> per-graph CSRs: rowptr_out (pooled: graph g's n_g + 1 offsets start at
+ *     node_ptr[g] + g, rebased to 0), col rebased IN PLACE (col -= node_ptr[g]; graph g's entries stay where they are: at
+ *     rowptr[node_ptr[g]]), nnz_out[g] = entries of graph g.  With sell_jobs_dev != NULL the rowptr / col / val fields of
+ *     job g of that wdg_sell16_job table are set to graph g's arrays (val only when val != NULL), so that
+ *     wdg_csr_to_sell16_count_batched can follow on the same stream without the host knowing where a graph's entries start.
+ * replaces: the per-iteration `adj + eye` / `.to_sparse()` / `.coalesce()` of synthetic_plot.py:85-92, homophily_tests.py:83-85.
+ */
+int wdg_coo_blockdiag_offset(int64_t *src, int64_t *dst, const int64_t *edge_ptr_dev, const int32_t *node_ptr_dev, int32_t n_graphs,
+                             int64_t n_edges, int32_t *bad_out, wdg_stream_t stream);
+struct wdg_sell16_job;
+int wdg_csr_split_blockdiag(const int32_t *rowptr, int32_t *col, const float *val, const int32_t *node_ptr_dev, int32_t n_graphs,
+                            int32_t n_nodes_total, int32_t *rowptr_out, int64_t *nnz_out, struct wdg_sell16_job *sell_jobs_dev,
+                            wdg_stream_t stream);
+
+/*
  * Dense [N,M] fp32 -> CSR of its non-zeros (the "plot" flavour hands dense adjacencies around).
  * replaces: `A.nonzero()`, `A.to_sparse().coalesce()`, `(adj > 0)` utils/homophily_plot.py:48,85,133,151.
  * Two calls: count (fills rowptr), then fill (needs col/val of rowptr[N] entries).
@@ -241,6 +262,29 @@ int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N
 int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
                            const int32_t *q_rows, const int32_t *q_ext, int32_t n_entries, int32_t *q_col, float *q_val,
                            wdg_stream_t stream);
+
+/*
+ * The same build for a table of graphs (a sweep shard): count = sort + widths + scan / pack + entries of every graph in four
+ * launches, fill in one; between the two the caller reads back every graph's {chunk count, entries | split} pair (ONE copy
+ * of the q_ext tails for the whole shard), sizes a pooled q_col / q_val and stores the pointers into the table (q_col == NULL:
+ * no copy wanted for that graph).  Buffers per job are sized as for the single-graph calls with the job's own n_rows / n_cols;
+ * workspace: wdg_sell16_workspace_bytes(n_rows, n_cols) bytes per job.  Graphs of more than 16 384 rows (unsorted layout)
+ * take the single-graph calls.  max_rows / max_cols: the largest n_rows / n_cols of the table (they size the grids).
+ */
+typedef struct wdg_sell16_job {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const float *val;      /* NULL: pattern only */
+    int32_t *q_perm, *q_ext, *q_rows;
+    int32_t *q_col;        /* fill: NULL = skip this graph */
+    float *q_val;          /* fill: NULL = no values */
+    void *workspace;
+    int32_t n_rows, n_cols;
+} wdg_sell16_job;
+int wdg_csr_to_sell16_count_batched(const wdg_sell16_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
+                                    wdg_stream_t stream);
+int wdg_csr_to_sell16_fill_batched(const wdg_sell16_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
+                                   wdg_stream_t stream);
 
 /*
  * Band plan of a CSR pattern (the row schedule of the band kernel, csrc/spmm_band.hip; the single-graph entry points
@@ -500,6 +544,30 @@ typedef struct wdg_kr_job {
     int32_t n_train, n_val, n_classes, reserved;
 } wdg_kr_job;
 int32_t wdg_kernel_regress_max_train(void);
+
+/*
+ * The node sets of the epochs, drawn on the device: per (graph, classifier, epoch) set a class-balanced sample of the nodes
+ * and, inside it, the class-balanced train rows; the rest of the sample validates.
+ * replaces: the two random_disassortative_splits calls per epoch of classifier_based_performance_metric
+ *           (utils/homophily_metrics.py:267-281, utils/homophily_plot.py:286-297; the routine: utils/util_funcs.py:454-475).
+ * Same DISTRIBUTION as the reference (per class: the first train_per_class[c] members of a uniform random permutation train,
+ * the next sample_per_class[c] - train_per_class[c] validate), a documented generator instead of torch's CPU stream:
+ * key(node) = Philox4x32-10(counter {node, set index, 0, 0}, key = seed), first output word; nodes ordered by (class, key,
+ * node).  Ids come out ascending (the reference's boolean masks).  A job = n_sets sets of one label vector; set s of the job
+ * is written to train_out + s train_stride / val_out + s val_stride (sum of train_per_class / of sample - train entries each).
+ * Grid block b serves set b - first_set of the job with first_set <= b < first_set + n_sets (jobs ascending in first_set).
+ * Limits: n <= 16 000 nodes, n_classes <= 64.  Labels outside [0, n_classes) are never drawn.
+ */
+typedef struct wdg_kr_sample_job {
+    const int32_t *labels;            /* [n] */
+    const int32_t *sample_per_class;  /* [n_classes] s_c: members of class c in an epoch's sample */
+    const int32_t *train_per_class;   /* [n_classes] t_c <= s_c */
+    int32_t *train_out;               /* [n_sets, train_stride] */
+    int32_t *val_out;                 /* [n_sets, val_stride] */
+    uint64_t seed;
+    int32_t n, n_classes, n_sets, first_set, train_stride, val_stride;
+} wdg_kr_sample_job;
+int wdg_kr_sample_sets(const wdg_kr_sample_job *jobs_dev, int32_t n_jobs, int32_t n_sets_total, int32_t max_n, wdg_stream_t stream);
 int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream);
 
 #ifdef __cplusplus

@@ -56,6 +56,10 @@ SIGNATURES = {
     "wdg_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int]),
     "wdg_coo_to_csr_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wdg_coo_blockdiag_offset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "wdg_csr_split_blockdiag": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wdg_csr_to_sell16_count_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_csr_to_sell16_fill_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_dense_to_csr_count": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wdg_dense_to_csr_fill": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wdg_scan_workspace_bytes": (c_size_t, [c_int64]),
@@ -116,7 +120,15 @@ SIGNATURES = {
     "wdg_edge_gram_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "wdg_edge_gram_mean_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "wdg_kernel_regress_batched_f32": (c_int, [c_void_p, c_int32, c_void_p]),
+    "wdg_kr_sample_sets": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
 }
+
+
+class Sell16Job(ctypes.Structure):
+    """mirror of `wdg_sell16_job` (include/wdg.h)"""
+    _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("q_perm", c_void_p), ("q_ext", c_void_p),
+                ("q_rows", c_void_p), ("q_col", c_void_p), ("q_val", c_void_p), ("workspace", c_void_p),
+                ("n_rows", c_int32), ("n_cols", c_int32)]
 
 
 class GramJob(ctypes.Structure):
@@ -135,6 +147,13 @@ class KrJob(ctypes.Structure):
     """mirror of `wdg_kr_job` (include/wdg.h)"""
     _fields_ = [("K", c_void_p), ("train", c_void_p), ("val", c_void_p), ("labels", c_void_p), ("correct_out", c_void_p),
                 ("flags_out", c_void_p), ("ldk", c_int64), ("n_train", c_int32), ("n_val", c_int32), ("n_classes", c_int32), ("reserved", c_int32)]
+
+
+class KrSampleJob(ctypes.Structure):
+    """mirror of `wdg_kr_sample_job` (include/wdg.h)"""
+    _fields_ = [("labels", c_void_p), ("sample_per_class", c_void_p), ("train_per_class", c_void_p), ("train_out", c_void_p),
+                ("val_out", c_void_p), ("seed", ctypes.c_uint64), ("n", c_int32), ("n_classes", c_int32), ("n_sets", c_int32),
+                ("first_set", c_int32), ("train_stride", c_int32), ("val_stride", c_int32)]
 
 
 class LasJob(ctypes.Structure):

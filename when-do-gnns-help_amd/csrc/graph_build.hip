@@ -317,6 +317,62 @@ __global__ void coo_finish(const int *bad, int64_t *nnz_out) {
     if (*bad) *nnz_out = -1;
 }
 
+// ------------------------------------------------------------------------------------------------ block-diagonal shards
+// graph of a position in a concatenation: the last g with ptr[g] <= pos (ptr ascending, ptr[0] = 0)
+template <typename T>
+__device__ __forceinline__ int segment_of(const T *__restrict__ ptr, int n_seg, long long pos) {
+    int lo = 0, hi = n_seg;  // invariant: ptr[lo] <= pos < ptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (static_cast<long long>(ptr[mid]) <= pos) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void blockdiag_offset_kernel(int64_t *__restrict__ src, int64_t *__restrict__ dst,
+                                                               const int64_t *__restrict__ edge_ptr,
+                                                               const int32_t *__restrict__ node_ptr, int n_graphs, long long E,
+                                                               int32_t *__restrict__ bad) {
+    const long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int g = segment_of(edge_ptr, n_graphs, e);
+    const int64_t off = node_ptr[g], n = node_ptr[g + 1] - off;
+    const int64_t s = src[e], d = dst[e];
+    if (s < 0 || d < 0 || s >= n || d >= n) {  // must not land in a neighbour's block: push it out of the whole graph
+        *bad = 1;
+        src[e] = dst[e] = -1;
+        return;
+    }
+    src[e] = s + off;
+    dst[e] = d + off;
+}
+
+// one wave per row of the block-diagonal CSR: rebased row offset, columns rebased in place; the first row of a graph also
+// records where the graph's entries start (job table) and its entry count
+__global__ __launch_bounds__(256) void blockdiag_split_kernel(const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                              const float *__restrict__ val, const int32_t *__restrict__ node_ptr,
+                                                              int n_graphs, int n_total, int32_t *__restrict__ rowptr_out,
+                                                              int64_t *__restrict__ nnz_out, wdg_sell16_job *__restrict__ jobs) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= n_total) return;
+    const int g = segment_of(node_ptr, n_graphs, row);
+    const int off = node_ptr[g], n = node_ptr[g + 1] - off;
+    const int base = rowptr[off], s = rowptr[row], e = rowptr[row + 1];
+    int32_t *out = rowptr_out + off + g;
+    if (lane == 0) out[row - off] = s - base;
+    if (row == off + n - 1 && lane == 0) out[n] = e - base;
+    if (row == off && lane == 0) {
+        if (nnz_out) nnz_out[g] = rowptr[off + n] - base;
+        if (jobs) {
+            jobs[g].rowptr = out;
+            jobs[g].col = col + base;
+            jobs[g].val = val ? val + base : nullptr;
+        }
+    }
+    for (int p = s + lane; p < e; p += 64) col[p] -= off;
+}
+
 // ------------------------------------------------------------------------------------------------ dense -> CSR
 __global__ __launch_bounds__(256) void dense_count(const float *__restrict__ A, int64_t lda, int32_t N, int32_t M,
                                                    int32_t *__restrict__ cnt) {
@@ -529,6 +585,29 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
     }
     hipLaunchKernelGGL(coo_finish, dim3(1), dim3(1), 0, st, ws.bad, nnz_out);
     return check_launch("coo_to_csr");
+}
+
+int wdg_coo_blockdiag_offset(int64_t *src, int64_t *dst, const int64_t *edge_ptr_dev, const int32_t *node_ptr_dev, int32_t n_graphs,
+                             int64_t n_edges, int32_t *bad_out, wdg_stream_t stream) {
+    WDG_REQUIRE(n_graphs >= 0 && n_edges >= 0 && bad_out, "coo_blockdiag_offset: bad arguments");
+    hipStream_t st = as_stream(stream);
+    hipMemsetAsync(bad_out, 0, sizeof(int32_t), st);
+    if (n_edges == 0 || n_graphs == 0) return WDG_OK;
+    WDG_REQUIRE(src && dst && edge_ptr_dev && node_ptr_dev, "coo_blockdiag_offset: null array");
+    hipLaunchKernelGGL(blockdiag_offset_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, st, src, dst, edge_ptr_dev, node_ptr_dev,
+                       n_graphs, static_cast<long long>(n_edges), bad_out);
+    return check_launch("coo_blockdiag_offset");
+}
+
+int wdg_csr_split_blockdiag(const int32_t *rowptr, int32_t *col, const float *val, const int32_t *node_ptr_dev, int32_t n_graphs,
+                            int32_t n_nodes_total, int32_t *rowptr_out, int64_t *nnz_out, wdg_sell16_job *sell_jobs_dev,
+                            wdg_stream_t stream) {
+    WDG_REQUIRE(n_graphs >= 0 && n_nodes_total >= 0, "csr_split_blockdiag: negative size");
+    if (n_graphs == 0 || n_nodes_total == 0) return WDG_OK;
+    WDG_REQUIRE(rowptr && node_ptr_dev && rowptr_out, "csr_split_blockdiag: null array");
+    hipLaunchKernelGGL(blockdiag_split_kernel, dim3(wave_rows_grid(n_nodes_total)), dim3(256), 0, as_stream(stream), rowptr, col, val,
+                       node_ptr_dev, n_graphs, n_nodes_total, rowptr_out, nnz_out, sell_jobs_dev);
+    return check_launch("csr_split_blockdiag");
 }
 
 int wdg_dense_to_csr_count(const float *A, int64_t lda, int32_t N, int32_t M, int32_t *rowptr, void *workspace,

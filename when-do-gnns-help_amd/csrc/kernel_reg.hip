@@ -195,6 +195,127 @@ __global__ __launch_bounds__(256) void edge_gram_reduce_kernel(const wdg_edge_gr
     if (threadIdx.x == 0) *to_global(job->mean_out) = scnt[0] > 0 ? ssum[0] / static_cast<double>(scnt[0]) : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------------ node sets of the epochs
+// The reference draws, in every epoch of classifier_based_performance_metric (utils/homophily_metrics.py:267-281,
+// utils/homophily_plot.py:286-297), a class-balanced sample of the nodes (random_disassortative_splits: per class a random
+// permutation, the first s_c members) and inside it a class-balanced train set (again per class a random permutation, the
+// first t_c); everything else of the sample validates.  Two nested uniform choices = the first t_c and the following
+// s_c - t_c members of ONE uniform random permutation of the class - which is what this kernel draws, for every (graph,
+// classifier, epoch) set of a sweep shard in one launch: key(node) = Philox4x32-10(counter = {node, set, 0, 0}, key = the
+// job's seed), the nodes sorted by (class, key, node) in LDS, roles from the rank inside the class, and an ordered compaction
+// so that the ids come out ascending like the reference's boolean masks.  Same distribution as the reference's sets, not
+// the same stream (torch's CPU generator): the host routine (utils/util_funcs.kernel_regression_epoch_indices) reproduces
+// the stream and stays the path of the golden tests.  Counter-based: a set's draw depends on (seed, set index) only.
+__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = static_cast<unsigned>(p1 >> 32) ^ c1 ^ k0, n2 = static_cast<unsigned>(p0 >> 32) ^ c3 ^ k1;
+    c1 = static_cast<unsigned>(p1);
+    c3 = static_cast<unsigned>(p0);
+    c0 = n0;
+    c2 = n2;
+}
+__device__ __forceinline__ unsigned philox4x32_10(unsigned c0, unsigned c1, unsigned k0, unsigned k1) {
+    unsigned c2 = 0, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+constexpr int KS_THREADS = 1024, KS_MAX_CLASSES = 64;
+__global__ __launch_bounds__(KS_THREADS) void kr_sample_kernel(const wdg_kr_sample_job *__restrict__ jobs, int n_jobs) {
+    extern __shared__ unsigned long long ks_keys[];  // [n] sort keys, then (aliased) the nodes' roles
+    __shared__ int cstart[KS_MAX_CLASSES + 1], scan_t[KS_THREADS], scan_v[KS_THREADS];
+    // which job: first_set ascending
+    int lo = 0, hi = n_jobs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (jobs[mid].first_set <= static_cast<int>(blockIdx.x)) lo = mid;
+        else hi = mid;
+    }
+    const wdg_kr_sample_job j = jobs[lo];
+    const int set = static_cast<int>(blockIdx.x) - j.first_set;
+    if (set >= j.n_sets) return;
+    const int n = j.n, C = j.n_classes, tid = threadIdx.x;
+    const unsigned k0 = static_cast<unsigned>(j.seed), k1 = static_cast<unsigned>(j.seed >> 32);
+    for (int i = tid; i < n; i += KS_THREADS) {
+        const int c = j.labels[i];
+        const unsigned long long cls = (c >= 0 && c < C) ? static_cast<unsigned long long>(c) : 255ull;  // unlabelled: never drawn
+        ks_keys[i] = (cls << 56) | (static_cast<unsigned long long>(philox4x32_10(static_cast<unsigned>(i), static_cast<unsigned>(set), k0, k1)) << 24) |
+                     static_cast<unsigned long long>(i);
+    }
+    if (tid <= KS_MAX_CLASSES) cstart[tid] = n;
+    __syncthreads();
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int k = 2; k <= P; k <<= 1) {  // comparator network, all ascending, virtual +inf padding (any n)
+        for (int i = tid; i < n; i += KS_THREADS) {
+            const int l = i ^ (k - 1);
+            if (l > i && l < n && ks_keys[i] > ks_keys[l]) {
+                const unsigned long long t = ks_keys[i];
+                ks_keys[i] = ks_keys[l];
+                ks_keys[l] = t;
+            }
+        }
+        __syncthreads();
+        for (int jj = k >> 2; jj > 0; jj >>= 1) {
+            for (int i = tid; i < n; i += KS_THREADS) {
+                const int l = i ^ jj;
+                if (l > i && l < n && ks_keys[i] > ks_keys[l]) {
+                    const unsigned long long t = ks_keys[i];
+                    ks_keys[i] = ks_keys[l];
+                    ks_keys[l] = t;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += KS_THREADS) {  // first position of every class present
+        const int c = static_cast<int>(ks_keys[i] >> 56);
+        if (c < C && (i == 0 || static_cast<int>(ks_keys[i - 1] >> 56) != c)) cstart[c] = i;
+    }
+    __syncthreads();
+    // role of every node by its rank inside its class: 1 = train, 2 = validation, 0 = not in this epoch's sample
+    unsigned char *role = reinterpret_cast<unsigned char *>(ks_keys + n);
+    for (int i = tid; i < n; i += KS_THREADS) {
+        const unsigned long long key = ks_keys[i];
+        const int c = static_cast<int>(key >> 56), node = static_cast<int>(key & 0xffffffull);
+        unsigned char r = 0;
+        if (c < C) {
+            const int rank = i - cstart[c];
+            r = rank < j.train_per_class[c] ? 1 : (rank < j.sample_per_class[c] ? 2 : 0);
+        }
+        role[node] = r;
+    }
+    __syncthreads();
+    // ordered compaction: a thread owns a contiguous run of node ids
+    const int per = (n + KS_THREADS - 1) / KS_THREADS, a = min(n, tid * per), b = min(n, a + per);
+    int ct = 0, cv = 0;
+    for (int i = a; i < b; ++i) {
+        ct += role[i] == 1;
+        cv += role[i] == 2;
+    }
+    scan_t[tid] = ct;
+    scan_v[tid] = cv;
+    __syncthreads();
+    for (int o = 1; o < KS_THREADS; o <<= 1) {
+        const int t = tid >= o ? scan_t[tid - o] : 0, v = tid >= o ? scan_v[tid - o] : 0;
+        __syncthreads();
+        scan_t[tid] += t;
+        scan_v[tid] += v;
+        __syncthreads();
+    }
+    int pt = scan_t[tid] - ct, pv = scan_v[tid] - cv;
+    int32_t *tr = j.train_out + static_cast<int64_t>(set) * j.train_stride, *va = j.val_out + static_cast<int64_t>(set) * j.val_stride;
+    for (int i = a; i < b; ++i) {
+        if (role[i] == 1 && pt < j.train_stride) tr[pt++] = i;
+        if (role[i] == 2 && pv < j.val_stride) va[pv++] = i;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ batched kernel regression
 constexpr int KR_THREADS = 1024, KR_T = 32, KR_B = 10;  // 32 x 32 threads, 10 x 10 elements each: blocks of up to 320 x 320
 constexpr int KR_MAX_N = KR_T * KR_B, KR_MAX_C = 8;
@@ -463,6 +584,24 @@ int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, w
 }
 
 int32_t wdg_kernel_regress_max_train(void) { return KR_MAX_N; }
+
+int wdg_kr_sample_sets(const wdg_kr_sample_job *jobs_dev, int32_t n_jobs, int32_t n_sets_total, int32_t max_n, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && n_sets_total >= 0 && max_n >= 0, "kr_sample_sets: negative size");
+    if (n_jobs == 0 || n_sets_total == 0 || max_n == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "kr_sample_sets: null job table");
+    WDG_REQUIRE(max_n <= 16000, "kr_sample_sets: graphs of more than 16 000 nodes draw their node sets on the host");
+    const size_t lds = static_cast<size_t>(max_n) * 8 + ((static_cast<size_t>(max_n) + 15) & ~static_cast<size_t>(15));
+    static thread_local int configured_dev = -1;
+    if (configured_dev != wdg::current_device()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kr_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                16000 * 9 + 16) != hipSuccess)
+            return wdg::fail(WDG_ERR_LAUNCH, "kr_sample_sets: cannot raise the dynamic LDS limit");
+        configured_dev = wdg::current_device();
+    }
+    hipLaunchKernelGGL(kr_sample_kernel, dim3(static_cast<unsigned>(n_sets_total)), dim3(KS_THREADS), lds, wdg::as_stream(stream),
+                       jobs_dev, n_jobs);
+    return wdg::check_launch("kr_sample_kernel");
+}
 
 size_t wdg_edge_gram_workspace_bytes(int32_t n_jobs, int32_t max_rows) {
     return static_cast<size_t>(n_jobs > 0 ? n_jobs : 0) * static_cast<size_t>(max_rows > 0 ? max_rows : 0) * 8 + 512;

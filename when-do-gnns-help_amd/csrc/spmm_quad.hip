@@ -53,6 +53,16 @@ constexpr int Q_MAX_BLOCK_COLS = 2528; // rows of a slab block: (2528 + 1 zero r
 constexpr int Q_MAX_BLOCKS = 4;        // column blocks (graphs of up to 10 112 columns); more: the CSR kernels
 constexpr int Q_MAXU = 8;              // units per wave and phase when a graph has several column blocks
 
+// columns per slab block: the columns cut into the fewest blocks of <= 2528, evenly, a multiple of 4 (column class mod 4 =
+// local class mod 4: what the bank-aware order of sell16_fill keys on)
+__host__ __device__ inline int q_block_cols_hd(int n_cols) {
+    const int c = n_cols > 0 ? n_cols : 1;
+    const int blocks = (c + Q_MAX_BLOCK_COLS - 1) / Q_MAX_BLOCK_COLS;
+    const int even = (c + blocks - 1) / blocks;
+    const int rounded = (even + 3) & ~3;
+    return rounded < Q_MAX_BLOCK_COLS ? rounded : Q_MAX_BLOCK_COLS;
+}
+
 #ifdef WDG_STAMPS  // diagnostic build only (make STAMPS=1): wave 0's clock at phase boundaries, 8 slots per workgroup
 __device__ unsigned long long wdg_q_stamp_buf[1024 * 8];
 #define Q_STAMP(k)                                                                          \
@@ -85,9 +95,8 @@ __device__ __forceinline__ int q_lower_bound(const int32_t *col, int lo, int hi,
 // perm[slot] = row, rows by total length (longest first, ties by row id): a slice of 16 slots holds rows of similar
 // length.  One workgroup, keys in LDS; graphs of more rows keep the identity (they pad by their skew).
 constexpr int Q_SORT_MAX_ROWS = 16384;
-__global__ __launch_bounds__(1024) void sell16_sort_rows(const int32_t *__restrict__ rowptr, int32_t N,
-                                                         int32_t *__restrict__ perm) {
-    extern __shared__ unsigned long long q_keys[];
+__device__ __forceinline__ void sell16_sort_rows_body(const int32_t *__restrict__ rowptr, int32_t N, int32_t *__restrict__ perm,
+                                                      unsigned long long *q_keys) {
     const int padded = (N + Q_ROWS - 1) / Q_ROWS * Q_ROWS;
     if (N > Q_SORT_MAX_ROWS) {
         for (int i = threadIdx.x; i < padded; i += 1024) perm[i] = min(i, N - 1);
@@ -128,13 +137,17 @@ __global__ __launch_bounds__(1024) void sell16_sort_rows(const int32_t *__restri
     if (N > 0)
         for (int i = N + threadIdx.x; i < padded; i += 1024) perm[i] = static_cast<int32_t>(q_keys[N - 1] & 0xffffffffull);
 }
+__global__ __launch_bounds__(1024) void sell16_sort_rows(const int32_t *__restrict__ rowptr, int32_t N,
+                                                         int32_t *__restrict__ perm) {
+    extern __shared__ unsigned long long q_keys[];
+    sell16_sort_rows_body(rowptr, N, perm, q_keys);
+}
 
 // one thread per (column block, REAL slice): width = longest in-block row segment, chunks = ceil(width / 16)
-__global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                     const int32_t *__restrict__ perm, int32_t N, int32_t n_slices,
-                                                     int32_t n_blocks, int32_t block_cols, int32_t *__restrict__ chunks,
-                                                     int32_t *__restrict__ widths) {
-    const int task = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void sell16_widths_body(int task, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const int32_t *__restrict__ perm, int32_t N, int32_t n_slices,
+                                                   int32_t n_blocks, int32_t block_cols, int32_t *__restrict__ chunks,
+                                                   int32_t *__restrict__ widths) {
     if (task >= n_slices * n_blocks) return;
     const int blk = task / n_slices, slice = task % n_slices;
     int width = 0;
@@ -150,6 +163,12 @@ __global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__
     chunks[task] = (width + Q_CHUNK - 1) / Q_CHUNK;
     widths[task] = width;
 }
+__global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                     const int32_t *__restrict__ perm, int32_t N, int32_t n_slices,
+                                                     int32_t n_blocks, int32_t block_cols, int32_t *__restrict__ chunks,
+                                                     int32_t *__restrict__ widths) {
+    sell16_widths_body(blockIdx.x * 256 + threadIdx.x, rowptr, col, perm, N, n_slices, n_blocks, block_cols, chunks, widths);
+}
 
 // The ENTRIES the kernel's waves work through, four per super-unit.  A graph with one column block whose slices hold at most
 // 128 entries per row is laid out in SPLIT form: a slice of more than 32 entries per row becomes 2 .. 4 consecutive entries
@@ -160,9 +179,9 @@ __global__ __launch_bounds__(256) void sell16_widths(const int32_t *__restrict__
 // One thread: the walk is sequential and a graph has a few hundred slices.
 constexpr int Q_CONT = 1 << 30;
 constexpr int Q_SPLIT_WIDTH = 2 * Q_CHUNK;  // entries per row of a split entry
-__global__ void sell16_pack(const int32_t *__restrict__ widths, int32_t n_slices, int32_t n_blocks,
-                            int32_t *__restrict__ entry_slice, int32_t *__restrict__ entry_k, int32_t *__restrict__ info) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__device__ __forceinline__ void sell16_pack_body(const int32_t *__restrict__ widths, int32_t n_slices, int32_t n_blocks,
+                                                 int32_t *__restrict__ entry_slice, int32_t *__restrict__ entry_k,
+                                                 int32_t *__restrict__ info) {
     int wmax = 0;
     for (int i = 0; i < n_slices * n_blocks; ++i) wmax = max(wmax, widths[i]);
     const bool split = n_blocks == 1 && wmax <= Q_SU * Q_SPLIT_WIDTH;
@@ -186,15 +205,19 @@ __global__ void sell16_pack(const int32_t *__restrict__ widths, int32_t n_slices
     info[0] = cur;            // entries per column block (a multiple of 4)
     info[1] = split ? 1 : 0;  // every entry <= 32 wide: the kernel's pipelined loop applies
 }
+__global__ void sell16_pack(const int32_t *__restrict__ widths, int32_t n_slices, int32_t n_blocks,
+                            int32_t *__restrict__ entry_slice, int32_t *__restrict__ entry_k, int32_t *__restrict__ info) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    sell16_pack_body(widths, n_slices, n_blocks, entry_slice, entry_k, info);
+}
 
 // q_ext / q_rows from the packed entries; the trailing pair of q_ext = {total chunks, entries per block | split << 30}
-__global__ __launch_bounds__(256) void sell16_entries(const int32_t *__restrict__ widths, const int32_t *__restrict__ chunk_begin,
-                                                      const int32_t *__restrict__ entry_slice, const int32_t *__restrict__ entry_k,
-                                                      const int32_t *__restrict__ info, const int32_t *__restrict__ perm,
-                                                      int32_t n_slices, int32_t n_blocks, int32_t max_entries,
-                                                      int32_t *__restrict__ ext, int32_t *__restrict__ rows) {
+__device__ __forceinline__ void sell16_entries_body(int t, const int32_t *__restrict__ widths, const int32_t *__restrict__ chunk_begin,
+                                                    const int32_t *__restrict__ entry_slice, const int32_t *__restrict__ entry_k,
+                                                    const int32_t *__restrict__ info, const int32_t *__restrict__ perm,
+                                                    int32_t n_slices, int32_t n_blocks, int32_t max_entries,
+                                                    int32_t *__restrict__ ext, int32_t *__restrict__ rows) {
     const int n_entries = info[0], split = info[1];
-    const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {  // {chunk count, entries per block | split}: behind the entries, and at the end of the caller's buffer
         ext[2 * n_blocks * n_entries] = ext[2 * n_blocks * max_entries] = chunk_begin[n_slices * n_blocks];
         ext[2 * n_blocks * n_entries + 1] = ext[2 * n_blocks * max_entries + 1] = n_entries | (split ? Q_CONT : 0);
@@ -220,18 +243,26 @@ __global__ __launch_bounds__(256) void sell16_entries(const int32_t *__restrict_
     }
     if (t < n_entries * Q_ROWS) rows[t] = perm[entry_slice[t / Q_ROWS] * Q_ROWS + t % Q_ROWS];
 }
+__global__ __launch_bounds__(256) void sell16_entries(const int32_t *__restrict__ widths, const int32_t *__restrict__ chunk_begin,
+                                                      const int32_t *__restrict__ entry_slice, const int32_t *__restrict__ entry_k,
+                                                      const int32_t *__restrict__ info, const int32_t *__restrict__ perm,
+                                                      int32_t n_slices, int32_t n_blocks, int32_t max_entries,
+                                                      int32_t *__restrict__ ext, int32_t *__restrict__ rows) {
+    sell16_entries_body(blockIdx.x * 256 + threadIdx.x, widths, chunk_begin, entry_slice, entry_k, info, perm, n_slices, n_blocks,
+                        max_entries, ext, rows);
+}
 
 // One wave per (column block, entry that starts a slice); lane r < 16 orders row r's segment.  Bank-aware order (reorder != 0):
 // the sweep reads, for entry e of all 16 rows, the 64-byte LDS row of each row's column; the four rows of a service group
 // collide when their columns agree mod 4 (64-byte rows: a row's bank window is 16 (column mod 4) .. + 15).  The order of a
 // row's entries inside a block is free, so the rows of a group choose step by step, in rank order, a remaining entry whose
 // class is not taken yet in this step (the class they hold most of first; the first remaining entry of that class).
-__global__ __launch_bounds__(256) void sell16_fill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                   const float *__restrict__ val, const int32_t *__restrict__ rows,
-                                                   int32_t n_entries, int32_t n_blocks, int32_t block_cols,
-                                                   const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
-                                                   float *__restrict__ q_val, int reorder) {
-    const int task = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                 const float *__restrict__ val, const int32_t *__restrict__ rows,
+                                                 int32_t n_entries, int32_t n_blocks, int32_t block_cols,
+                                                 const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
+                                                 float *__restrict__ q_val, int reorder) {
+    const int lane = threadIdx.x & 63;
     if (task >= n_entries * n_blocks) return;  // (whole waves: a task is a wave)
     const int blk = task / n_entries, entry = task % n_entries;
     if (ext[2 * task + 1] & Q_CONT) return;  // a continuation / ghost entry: its slice's first entry fills the chunks
@@ -304,6 +335,113 @@ __global__ __launch_bounds__(256) void sell16_fill(const int32_t *__restrict__ r
             if (dstv) dstv[at] = pick >= 0 ? (val ? val[a + pick] : 1.f) : 0.f;
         }
     }
+}
+__global__ __launch_bounds__(256) void sell16_fill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const float *__restrict__ val, const int32_t *__restrict__ rows,
+                                                   int32_t n_entries, int32_t n_blocks, int32_t block_cols,
+                                                   const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
+                                                   float *__restrict__ q_val, int reorder) {
+    sell16_fill_body((blockIdx.x * 256 + threadIdx.x) >> 6, rowptr, col, val, rows, n_entries, n_blocks, block_cols, ext, q_col, q_val,
+                     reorder);
+}
+
+// ---- the same build for a TABLE of graphs (wdg_sell16_job; blockIdx.y = graph): a sweep shard's SELL-16 copies in six launches
+// and one host read-back instead of ten launches and a host sync per graph (the cold, one-pass sweep: synthetic_plot.py:78-109
+// visits every graph once).  Per-graph scratch lives in the job's workspace, laid out like wdg_csr_to_sell16_count's.
+struct Sell16Ws {
+    int32_t *chunks, *widths, *entry_slice, *entry_k, *info;
+};
+__device__ __forceinline__ Sell16Ws sell16_ws(void *workspace, int64_t tasks, int64_t max_entries) {
+    char *ws = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+    auto take = [&](int64_t ints) {
+        int32_t *ptr = reinterpret_cast<int32_t *>(ws);
+        ws += (static_cast<size_t>(ints) * sizeof(int32_t) + 255) & ~static_cast<size_t>(255);
+        return ptr;
+    };
+    Sell16Ws w;
+    w.chunks = take(tasks + 2);
+    w.widths = take(tasks + 1);
+    w.entry_slice = take(max_entries);
+    w.entry_k = take(max_entries);
+    w.info = take(4);
+    return w;
+}
+struct Sell16Shape {
+    int32_t n_slices, n_blocks, block_cols;
+    int64_t tasks, max_entries;
+};
+__device__ __forceinline__ Sell16Shape sell16_shape(int32_t N, int32_t n_cols) {
+    Sell16Shape sh;
+    sh.n_slices = (N + Q_ROWS - 1) / Q_ROWS;
+    sh.block_cols = q_block_cols_hd(n_cols);
+    sh.n_blocks = (max(n_cols, 1) + sh.block_cols - 1) / sh.block_cols;
+    sh.tasks = static_cast<int64_t>(sh.n_slices) * sh.n_blocks;
+    sh.max_entries = static_cast<int64_t>(Q_SU) * sh.n_slices + Q_SU;
+    return sh;
+}
+__global__ __launch_bounds__(1024) void sell16_sort_rows_batched(const wdg_sell16_job *__restrict__ jobs) {
+    extern __shared__ unsigned long long q_keys[];
+    const wdg_sell16_job j = jobs[blockIdx.y];
+    if (j.n_rows <= 0) return;
+    sell16_sort_rows_body(j.rowptr, j.n_rows, j.q_perm, q_keys);
+}
+__global__ __launch_bounds__(256) void sell16_widths_batched(const wdg_sell16_job *__restrict__ jobs) {
+    const wdg_sell16_job j = jobs[blockIdx.y];
+    if (j.n_rows <= 0) return;
+    const Sell16Shape sh = sell16_shape(j.n_rows, j.n_cols);
+    const Sell16Ws w = sell16_ws(j.workspace, sh.tasks, sh.max_entries);
+    sell16_widths_body(blockIdx.x * 256 + threadIdx.x, j.rowptr, j.col, j.q_perm, j.n_rows, sh.n_slices, sh.n_blocks, sh.block_cols,
+                       w.chunks, w.widths);
+}
+// one workgroup per graph: exclusive scan of the (block, slice) chunk counts in place (total behind them), then the packer
+__global__ __launch_bounds__(1024) void sell16_scan_pack_batched(const wdg_sell16_job *__restrict__ jobs) {
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    const wdg_sell16_job j = jobs[blockIdx.y];
+    if (j.n_rows <= 0) {
+        if (threadIdx.x == 0 && j.q_ext) j.q_ext[0] = j.q_ext[1] = 0;  // an empty graph: {0 chunks, 0 entries}
+        return;
+    }
+    const Sell16Shape sh = sell16_shape(j.n_rows, j.n_cols);
+    const Sell16Ws w = sell16_ws(j.workspace, sh.tasks, sh.max_entries);
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < sh.tasks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < sh.tasks ? w.chunks[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+            const int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < sh.tasks) w.chunks[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        w.chunks[sh.tasks] = carry;
+        sell16_pack_body(w.widths, sh.n_slices, sh.n_blocks, w.entry_slice, w.entry_k, w.info);
+    }
+}
+__global__ __launch_bounds__(256) void sell16_entries_batched(const wdg_sell16_job *__restrict__ jobs) {
+    const wdg_sell16_job j = jobs[blockIdx.y];
+    if (j.n_rows <= 0) return;
+    const Sell16Shape sh = sell16_shape(j.n_rows, j.n_cols);
+    const Sell16Ws w = sell16_ws(j.workspace, sh.tasks, sh.max_entries);
+    sell16_entries_body(blockIdx.x * 256 + threadIdx.x, w.widths, w.chunks, w.entry_slice, w.entry_k, w.info, j.q_perm, sh.n_slices,
+                        sh.n_blocks, static_cast<int32_t>(sh.max_entries), j.q_ext, j.q_rows);
+}
+__global__ __launch_bounds__(256) void sell16_fill_batched(const wdg_sell16_job *__restrict__ jobs, int reorder) {
+    const wdg_sell16_job j = jobs[blockIdx.y];
+    if (j.n_rows <= 0 || !j.q_col) return;  // (no SELL-16 copy wanted for this graph: decided by the caller after the count)
+    const Sell16Shape sh = sell16_shape(j.n_rows, j.n_cols);
+    const int32_t n_entries = j.q_ext[2 * sh.n_blocks * sh.max_entries + 1] & 0x3fffffff;
+    sell16_fill_body((blockIdx.x * 256 + threadIdx.x) >> 6, j.rowptr, j.col, j.val, j.q_rows, n_entries, sh.n_blocks, sh.block_cols,
+                     j.q_ext, j.q_col, j.q_val, reorder);
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -900,12 +1038,7 @@ __global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job
     if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-int q_block_cols_for(int n_cols) {
-    const int c = n_cols > 0 ? n_cols : 1;
-    const int blocks = static_cast<int>(ceil_div(c, Q_MAX_BLOCK_COLS));
-    const int even = static_cast<int>(ceil_div(c, blocks));
-    return std::min(Q_MAX_BLOCK_COLS, (even + 3) & ~3);  // a multiple of 4: column class mod 4 = local class mod 4
-}
+int q_block_cols_for(int n_cols) { return q_block_cols_hd(n_cols); }
 
 bool q_reorder_enabled() {  // bank-aware entry order inside (row, block) segments: on unless WDG_SELL_ORDER=0
     const char *e = getenv("WDG_SELL_ORDER");
@@ -1069,6 +1202,45 @@ int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const floa
     hipLaunchKernelGGL(sell16_fill, dim3(wdg::ceil_div(tasks * 64, 256)), dim3(256), 0, wdg::as_stream(stream), rowptr, col, val,
                        q_rows, n_entries, n_blocks, block_cols, q_ext, q_col, q_val, q_reorder_enabled() ? 1 : 0);
     return wdg::check_launch("csr_to_sell16_fill");
+}
+
+int wdg_csr_to_sell16_count_batched(const wdg_sell16_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
+                                    wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_cols >= 0, "csr_to_sell16_count_batched: negative size");
+    if (n_jobs == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev, "csr_to_sell16_count_batched: null job table");
+    WDG_REQUIRE(max_rows <= Q_SORT_MAX_ROWS, "csr_to_sell16_count_batched: graphs of more than 16 384 rows take the single-graph build");
+    hipStream_t st = wdg::as_stream(stream);
+    static thread_local int configured_dev = -1;
+    const int dev = wdg::current_device();
+    if (configured_dev != dev) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sell16_sort_rows_batched), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Q_SORT_MAX_ROWS * 8) != hipSuccess)
+            return wdg::fail(WDG_ERR_LAUNCH, "row sort: cannot raise the dynamic LDS limit");
+        configured_dev = dev;
+    }
+    const int64_t n_slices = q_real_slices(max_rows);
+    const int64_t n_blocks = wdg::ceil_div(max_cols > 0 ? max_cols : 1, q_block_cols_for(max_cols));
+    const int64_t tasks = n_slices * n_blocks, max_entries = wdg_sell16_max_entries(max_rows);
+    const unsigned g = static_cast<unsigned>(n_jobs);
+    hipLaunchKernelGGL(sell16_sort_rows_batched, dim3(1, g), dim3(1024), static_cast<size_t>(max_rows) * 8, st, jobs_dev);
+    if (tasks > 0) hipLaunchKernelGGL(sell16_widths_batched, dim3(wdg::ceil_div(tasks, 256), g), dim3(256), 0, st, jobs_dev);
+    hipLaunchKernelGGL(sell16_scan_pack_batched, dim3(1, g), dim3(1024), 0, st, jobs_dev);
+    const int64_t threads = std::max<int64_t>(max_entries * n_blocks, max_entries * Q_ROWS);
+    hipLaunchKernelGGL(sell16_entries_batched, dim3(wdg::ceil_div(threads, 256), g), dim3(256), 0, st, jobs_dev);
+    return wdg::check_launch("csr_to_sell16_count_batched");
+}
+
+int wdg_csr_to_sell16_fill_batched(const wdg_sell16_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
+                                   wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_cols >= 0, "csr_to_sell16_fill_batched: negative size");
+    if (n_jobs == 0 || max_rows == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev, "csr_to_sell16_fill_batched: null job table");
+    const int64_t n_blocks = wdg::ceil_div(max_cols > 0 ? max_cols : 1, q_block_cols_for(max_cols));
+    const int64_t tasks = wdg_sell16_max_entries(max_rows) * n_blocks;
+    hipLaunchKernelGGL(sell16_fill_batched, dim3(wdg::ceil_div(tasks * 64, 256), static_cast<unsigned>(n_jobs)), dim3(256), 0,
+                       wdg::as_stream(stream), jobs_dev, q_reorder_enabled() ? 1 : 0);
+    return wdg::check_launch("csr_to_sell16_fill_batched");
 }
 
 int wdg_spmm_quad_batched_clocked_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,

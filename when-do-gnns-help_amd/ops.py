@@ -39,6 +39,11 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
 
 
+def _table(arr):
+    """ctypes array of job descriptors -> device bytes (an empty table stays a host tensor: its pointer is NULL)"""
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(require_gpu()) if len(arr) else torch.empty(0, dtype=torch.uint8)
+
+
 class CsrGraph:
     """Device-resident CSR adjacency: int32 rowptr[n_rows+1], int32 col[nnz], optional fp32 val[nnz].
 
@@ -279,6 +284,153 @@ class CsrGraph:
 
     def with_values(self, val):  # (neither SELL copy is shared: both hold values)
         return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)  # SELL copy (holds values) not shared
+
+
+class GraphBatch:
+    """A sweep shard's graphs built together: ONE COO -> CSR build of their block-diagonal union (wdg_coo_blockdiag_offset,
+    wdg_coo_to_csr_i32, wdg_csr_split_blockdiag), the SELL-16 copies of all of them in five more launches
+    (wdg_csr_to_sell16_count_batched / _fill_batched) and ONE host read-back for the whole shard - against ~20 launches and two
+    host syncs per graph through CsrGraph.from_coo + ensure_quad (the cold path of a one-pass sweep: synthetic_plot.py:78-109
+    visits every graph once).  The results are bit for bit the per-graph builds' (tests/test_gpu_batched_build.py).
+
+    .graphs: list of CsrGraph (views into the shard's pooled arrays; .quad set when `quad`); degree_norm(): every graph's
+    degrees / coefficients from one launch over the union."""
+
+    def __init__(self, coos, flags=0, quad=True, quad_values=False, max_padding=4.0):
+        """coos: list of (src, dst, n) or (src, dst, n, val): host arrays or tensors, node ids local to each graph."""
+        dev = require_gpu()
+        G = len(coos)
+        self.flags = flags
+        ns = [int(c[2]) for c in coos]
+        es = [int(len(c[0])) for c in coos]
+        node_ptr_h = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+        edge_ptr_h = np.concatenate([[0], np.cumsum(es)]).astype(np.int64)
+        self.n_total, e_total = int(node_ptr_h[-1]), int(edge_ptr_h[-1])
+        if self.n_total >= (1 << 31) - 1:
+            raise ValueError("GraphBatch: more than 2^31 nodes in one shard")
+        any_val = any(len(c) > 3 and c[3] is not None for c in coos)
+
+        def cat(parts, dtype):
+            if all(isinstance(p_, torch.Tensor) for p_ in parts):
+                return torch.cat([p_.to(dev, dtype) for p_ in parts]) if parts else torch.empty(0, dtype=dtype, device=dev)
+            host = np.concatenate([np.asarray(p_.cpu() if isinstance(p_, torch.Tensor) else p_) for p_ in parts]) if parts else np.empty(0)
+            return torch.from_numpy(np.ascontiguousarray(host)).to(device=dev, dtype=dtype)
+
+        src, dst = cat([c[0] for c in coos], torch.int64), cat([c[1] for c in coos], torch.int64)
+        val = None
+        if any_val:
+            val = cat([(c[3] if len(c) > 3 and c[3] is not None else np.ones(es[i], np.float32)) for i, c in enumerate(coos)], torch.float32)
+        node_ptr = torch.from_numpy(node_ptr_h.astype(np.int32)).to(dev)
+        edge_ptr = torch.from_numpy(edge_ptr_h).to(dev)
+        st = stream_handle()
+        # everything the host wants to know afterwards, in one buffer: [bad, nnz of the union, nnz per graph ...]
+        info = torch.zeros(2 + max(G, 1), dtype=torch.int64, device=dev)
+        bad = torch.zeros(2, dtype=torch.int32, device=dev)
+        check(lib.wdg_coo_blockdiag_offset(_ptr(src), _ptr(dst), _ptr(edge_ptr), _ptr(node_ptr), G, e_total, _ptr(bad), st),
+              "wdg_coo_blockdiag_offset")
+        cap = lib.wdg_coo_to_csr_capacity(e_total, self.n_total, flags)
+        self.rowptr = torch.empty(self.n_total + 1, dtype=torch.int32, device=dev)
+        self.col = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.val = torch.empty(cap, dtype=torch.float32, device=dev)
+        ws_bytes = lib.wdg_coo_to_csr_workspace_bytes(e_total, self.n_total, flags)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.wdg_coo_to_csr_i32(_ptr(src), _ptr(dst), _ptr(val), e_total, self.n_total, flags, _ptr(self.rowptr), _ptr(self.col),
+                                     _ptr(self.val), c_void_p(info.data_ptr() + 8), _ptr(ws), ws_bytes, st), "wdg_coo_to_csr_i32")
+        # per-graph buffers of the SELL-16 build, pooled; the job table's rowptr / col / val are filled in by the split kernel
+        self.rowptr_pool = torch.empty(self.n_total + G, dtype=torch.int32, device=dev)
+        quad = quad and not quad_disabled() and G > 0
+        jobs = (_lib.Sell16Job * max(G, 1))()
+        if quad:
+            n_blocks = [(max(n, 1) + lib.wdg_sell16_block_cols(n) - 1) // lib.wdg_sell16_block_cols(n) for n in ns]
+            quad = max(n_blocks) <= CsrGraph.QUAD_MAX_BLOCKS and max(ns) <= 16384
+        if quad:
+            max_e = [int(lib.wdg_sell16_max_entries(n)) for n in ns]
+            ext_len = [2 * (nb * m + 1) for nb, m in zip(n_blocks, max_e)]
+            r64 = lambda v: (v + 63) // 64 * 64  # noqa: E731  (every graph's slice of a pool starts 256-byte aligned, like its own allocation)
+            ext_off = np.concatenate([[0], np.cumsum([r64(v) for v in ext_len])]).astype(np.int64)
+            rows_off = np.concatenate([[0], np.cumsum([r64(16 * m) for m in max_e])]).astype(np.int64)
+            perm_len = [(n + 15) // 16 * 16 for n in ns]
+            perm_off = np.concatenate([[0], np.cumsum([r64(v) for v in perm_len])]).astype(np.int64)
+            ws_len = [(int(lib.wdg_sell16_workspace_bytes(n, n)) + 255) // 256 * 256 for n in ns]
+            ws_off = np.concatenate([[0], np.cumsum(ws_len)]).astype(np.int64)
+            ext = torch.empty(int(ext_off[-1]), dtype=torch.int32, device=dev)
+            rows = torch.empty(int(rows_off[-1]), dtype=torch.int32, device=dev)
+            perm = torch.empty(int(perm_off[-1]), dtype=torch.int32, device=dev)
+            qws = torch.empty(int(ws_off[-1]) + 256, dtype=torch.uint8, device=dev)
+            for g_, job in enumerate(jobs[:G]):
+                job.q_perm, job.q_ext = perm.data_ptr() + 4 * int(perm_off[g_]), ext.data_ptr() + 4 * int(ext_off[g_])
+                job.q_rows, job.workspace = rows.data_ptr() + 4 * int(rows_off[g_]), qws.data_ptr() + int(ws_off[g_])
+                job.n_rows = job.n_cols = ns[g_]
+            table = _table(jobs) if G else None
+        else:
+            table = None
+        check(lib.wdg_csr_split_blockdiag(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), _ptr(node_ptr), G, self.n_total,
+                                          _ptr(self.rowptr_pool), c_void_p(info.data_ptr() + 16), _ptr(table), st),
+              "wdg_csr_split_blockdiag")
+        if quad:
+            check(lib.wdg_csr_to_sell16_count_batched(_ptr(table), G, max(ns), max(ns), st), "wdg_csr_to_sell16_count_batched")
+        # ---- the shard's ONE host read-back
+        info[0:1].copy_(bad[0:1])
+        info_h = info.cpu().numpy()
+        if info_h[0] != 0 or info_h[1] < 0:
+            raise IndexError("edge index out of range for its graph")
+        nnz_g = info_h[2:2 + G]
+        base = np.concatenate([[0], np.cumsum(nnz_g)]).astype(np.int64)
+        self.node_ptr_host = node_ptr_h
+        self.graphs = []
+        for g_ in range(G):
+            o = int(node_ptr_h[g_]) + g_
+            self.graphs.append(CsrGraph(self.rowptr_pool[o:o + ns[g_] + 1], self.col[int(base[g_]):int(base[g_ + 1])],
+                                        self.val[int(base[g_]):int(base[g_ + 1])], ns[g_], ns[g_]))
+        if not quad:
+            return
+        ext_h = ext.cpu().numpy()
+        want, chunks_g = [], []
+        for g_ in range(G):
+            tail = ext_h[int(ext_off[g_]) + ext_len[g_] - 2:int(ext_off[g_]) + ext_len[g_]]
+            chunks, word = int(tail[0]), int(tail[1])
+            n_entries, tasks = word & 0x3fffffff, (word & 0x3fffffff) * n_blocks[g_]
+            ok = ns[g_] > 0 and nnz_g[g_] > 0 and chunks * 256 <= max_padding * nnz_g[g_] + 256 * tasks
+            want.append(ok)
+            chunks_g.append(chunks if ok else 0)
+        # (+ 2 chunks of slack per graph: the kernel requests an entry's two chunks unconditionally)
+        qoff = np.concatenate([[0], np.cumsum([(c + 2) * 256 if w else 0 for c, w in zip(chunks_g, want)])]).astype(np.int64)
+        q_col = torch.zeros(int(qoff[-1]), dtype=torch.int32, device=dev)
+        q_val = torch.zeros(int(qoff[-1]), dtype=torch.float32, device=dev) if quad_values else None
+        for g_, job in enumerate(jobs[:G]):
+            gr = self.graphs[g_]
+            job.rowptr, job.col, job.val = gr.rowptr.data_ptr(), gr.col.data_ptr() if gr.nnz else 0, gr.val.data_ptr() if gr.nnz else 0
+            job.q_col = q_col.data_ptr() + 4 * int(qoff[g_]) if want[g_] else 0
+            job.q_val = q_val.data_ptr() + 4 * int(qoff[g_]) if (want[g_] and quad_values) else 0
+        table = _table(jobs)
+        check(lib.wdg_csr_to_sell16_fill_batched(_ptr(table), G, max(ns), max(ns), st), "wdg_csr_to_sell16_fill_batched")
+        self._keep = (table, qws)
+        for g_, gr in enumerate(self.graphs):
+            if not want[g_]:
+                gr.quad = False
+                continue
+            word = int(ext_h[int(ext_off[g_]) + ext_len[g_] - 1])
+            n_entries, split = word & 0x3fffffff, bool(word & (1 << 30))
+            tasks = n_entries * n_blocks[g_]
+            eh = ext_h[int(ext_off[g_]):int(ext_off[g_]) + ext_len[g_]].reshape(-1, 2)
+            widths = (eh[:tasks, 1] & 0x3fffffff).reshape(n_blocks[g_], n_entries).copy()
+            a, b = int(qoff[g_]), int(qoff[g_ + 1])
+            gr.quad = dict(ext=ext[int(ext_off[g_]):int(ext_off[g_]) + 2 * (tasks + 1)], col=q_col[a:b],
+                           val=q_val[a:b] if quad_values else None,
+                           perm=perm[int(perm_off[g_]):int(perm_off[g_]) + perm_len[g_]], rows=rows[int(rows_off[g_]):int(rows_off[g_]) + 16 * n_entries],
+                           block_cols=int(lib.wdg_sell16_block_cols(ns[g_])), n_blocks=n_blocks[g_], n_entries=n_entries,
+                           n_su=n_entries // 4, split=split, widths=widths, chunks=chunks_g[g_], n_slices=n_entries)
+
+    def degree_norm(self, mode=NORM_RW, prec=PREC_F32, use_values=True):
+        """-> list (one dict per graph, like ops.degree_norm) of views into the union's arrays: one launch for the shard"""
+        dev = self.rowptr.device
+        n = self.n_total
+        out = dict(rowsum=torch.empty(n, dtype=torch.float32, device=dev), cnt=torch.empty(n, dtype=torch.int32, device=dev),
+                   dinv=torch.empty(n, dtype=torch.float32, device=dev), dinv64=torch.empty(n, dtype=torch.float64, device=dev))
+        check(lib.wdg_degree_norm(_ptr(self.rowptr), _ptr(self.val if use_values else None), n, mode, prec, _ptr(out["rowsum"]),
+                                  _ptr(out["cnt"]), _ptr(out["dinv"]), _ptr(out["dinv64"]), stream_handle()), "wdg_degree_norm")
+        p = self.node_ptr_host
+        return [{k: v[int(p[g_]):int(p[g_ + 1])] for k, v in out.items()} for g_ in range(len(self.graphs))]
 
 
 # ------------------------------------------------------------------------------------------- normalisation
@@ -928,10 +1080,6 @@ class Mlp2Batch:
 
 
 # ------------------------------------------------------------------------------------------- kernel-regression metric
-def _table(arr):
-    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(require_gpu()) if len(arr) else torch.empty(0, dtype=torch.uint8)
-
-
 class GramBatch:
     """Job table for wdg_gram_map_batched_f32: K = map(A A^T) of every A of a batch (all nodes), linear and / or arc-cosine."""
 
@@ -983,6 +1131,71 @@ class EdgeGramBatch:
                                                  stream_handle()), "wdg_edge_gram_mean_batched_f32")
 
 
+def kr_split_sizes(labels, sample_max):
+    """Per class: how many members an epoch's sample holds (s_c) and how many of those train (t_c) - the sizes the
+    reference's two random_disassortative_splits calls produce (utils/homophily_metrics.py:269-279 with utils/util_funcs.py:
+    454-475; Python's banker's `round`, classes counted as max label + 1, a class smaller than its share gives all it has).
+    labels: host int array -> (s_c, t_c) int32 [C]"""
+    labels = np.asarray(labels).reshape(-1)
+    n = labels.shape[0]
+    c = int(labels.max()) + 1 if n else 0
+    n_c = np.bincount(labels[labels >= 0], minlength=c).astype(np.int64)
+    if n <= sample_max:
+        s_c = n_c.copy()
+    else:
+        s_c = np.minimum(n_c, int(round((sample_max / n) * (n / c))))
+    present = np.flatnonzero(s_c)
+    c2 = int(present.max()) + 1 if present.size else 1       # labels_sample.max() + 1
+    t_c = np.minimum(s_c, int(round(0.6 * (int(s_c.sum()) / c2))))
+    return s_c.astype(np.int32), t_c.astype(np.int32)
+
+
+class KrSets:
+    """Job table for wdg_kr_sample_sets: the (train, validation) node sets of every epoch of many (graph, classifier) pairs,
+    drawn on the device in one launch (Philox4x32-10 keyed per pair; include/wdg.h documents the generator).
+    self.train [pairs, epochs, n_train], self.val [pairs, epochs, n_val] int32, ascending ids; pairs whose graphs differ in
+    class sizes are padded to the widest (self.n_train / self.n_val hold the true lengths)."""
+
+    def __init__(self, entries, epochs):
+        """entries: list of (labels int32 device [n], s_c, t_c (kr_split_sizes), seed int)"""
+        dev = require_gpu()
+        self.keep = entries
+        self.n_pairs, self.epochs = len(entries), int(epochs)
+        self.n_train = np.array([int(np.sum(t)) for _l, _s, t, _seed in entries], np.int64)
+        self.n_val = np.array([int(np.sum(s_) - np.sum(t)) for _l, s_, t, _seed in entries], np.int64)
+        self.train_stride, self.val_stride = int(self.n_train.max(initial=0)), int(self.n_val.max(initial=0))
+        self.train = torch.zeros((self.n_pairs, self.epochs, max(self.train_stride, 1)), dtype=torch.int32, device=dev)
+        self.val = torch.zeros((self.n_pairs, self.epochs, max(self.val_stride, 1)), dtype=torch.int32, device=dev)
+        self.max_n = max([int(e[0].shape[0]) for e in entries], default=0)
+        cls = np.concatenate([np.concatenate([np.asarray(s_, np.int32), np.asarray(t, np.int32)]) for _l, s_, t, _seed in entries]) \
+            if entries else np.zeros(0, np.int32)
+        self.class_tables = torch.from_numpy(cls).to(dev)
+        arr = (_lib.KrSampleJob * self.n_pairs)()
+        off = 0
+        for i, (job, (lab, s_, t, seed)) in enumerate(zip(arr, entries)):
+            c = len(s_)
+            if c > 64:
+                raise ValueError("KrSets: more than 64 classes")
+            job.labels = lab.data_ptr()
+            job.sample_per_class = self.class_tables.data_ptr() + 4 * off
+            job.train_per_class = self.class_tables.data_ptr() + 4 * (off + c)
+            off += 2 * c
+            job.train_out, job.val_out = self.train[i].data_ptr(), self.val[i].data_ptr()
+            job.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            job.n, job.n_classes, job.n_sets, job.first_set = int(lab.shape[0]), c, self.epochs, i * self.epochs
+            job.train_stride, job.val_stride = self.train.shape[2], self.val.shape[2]
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_kr_sample_sets(_ptr(self.table), self.n_pairs, self.n_pairs * self.epochs, self.max_n, stream_handle()),
+              "wdg_kr_sample_sets")
+
+
+_KR_JOB_DTYPE = np.dtype([("K", "<u8"), ("train", "<u8"), ("val", "<u8"), ("labels", "<u8"), ("correct_out", "<u8"), ("flags_out", "<u8"),
+                          ("ldk", "<i8"), ("n_train", "<i4"), ("n_val", "<i4"), ("n_classes", "<i4"), ("reserved", "<i4")])
+assert _KR_JOB_DTYPE.itemsize == ctypes.sizeof(_lib.KrJob)
+
+
 class KrBatch:
     """Job table for wdg_kernel_regress_batched_f32: many (kernel, train rows, validation rows) problems in one launch."""
 
@@ -994,23 +1207,38 @@ class KrBatch:
         -> self.correct [n_problems] int32 after launch().  Shapes the solver does not hold (more than 8 classes, more than
         320 or fewer than 1 train rows) raise here: the kernel would answer them with the sentinel -1, and an accuracy of
         -1 / n_val fed to the t-test is a silently wrong p-value (callers with such label sets take the host path)."""
-        dev = require_gpu()
-        if not 1 <= int(n_classes) <= self.MAX_CLASSES and len(problems):
-            raise ValueError(f"KrBatch: {n_classes} classes, the solver holds 1..{self.MAX_CLASSES}")
         self.keep = problems
-        self.n_jobs = len(problems)
-        self.correct = torch.zeros(max(self.n_jobs, 1), dtype=torch.int32, device=dev)
-        self.flags = torch.zeros(max(self.n_jobs, 1), dtype=torch.int32, device=dev)  # bit 0: the ridge refactorisation ran
-        self.n_val = torch.tensor([p[2].shape[0] for p in problems], dtype=torch.float32, device=dev)
-        arr = (_lib.KrJob * self.n_jobs)()
-        for i, (job, (k, tr, va, lab)) in enumerate(zip(arr, problems)):
-            if not 1 <= tr.shape[0] <= self.MAX_TRAIN:
-                raise ValueError(f"KrBatch: {tr.shape[0]} train rows, the solver holds blocks of 1..{self.MAX_TRAIN}")
-            job.K, job.train, job.val, job.labels = k.data_ptr(), tr.data_ptr(), va.data_ptr(), lab.data_ptr()
-            job.correct_out = self.correct.data_ptr() + 4 * i
-            job.flags_out = self.flags.data_ptr() + 4 * i
-            job.ldk, job.n_train, job.n_val, job.n_classes = _ld(k), tr.shape[0], va.shape[0], int(n_classes)
-        self.table = _table(arr)
+        n = len(problems)
+        col = lambda f: np.fromiter((f(p_) for p_ in problems), np.int64, n)  # noqa: E731
+        self._build(col(lambda p_: p_[0].data_ptr()), col(lambda p_: _ld(p_[0])), col(lambda p_: p_[1].data_ptr()),
+                    col(lambda p_: p_[2].data_ptr()), col(lambda p_: p_[3].data_ptr()), col(lambda p_: p_[1].shape[0]),
+                    col(lambda p_: p_[2].shape[0]), n_classes)
+
+    @classmethod
+    def from_arrays(cls, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes, keep=None):
+        """the same table from per-problem numpy columns (device addresses and sizes): a sweep shard's 20 000 problems are
+        described by arithmetic on a few base pointers, not by 20 000 tensor objects"""
+        self = cls.__new__(cls)
+        self.keep = keep
+        self._build(*(np.asarray(a, np.int64) for a in (k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val)), n_classes)
+        return self
+
+    def _build(self, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes):
+        dev = require_gpu()
+        n = self.n_jobs = int(k_ptr.shape[0])
+        if n and not 1 <= int(n_classes) <= self.MAX_CLASSES:
+            raise ValueError(f"KrBatch: {n_classes} classes, the solver holds 1..{self.MAX_CLASSES}")
+        if n and not (1 <= int(n_train.min()) and int(n_train.max()) <= self.MAX_TRAIN):
+            raise ValueError(f"KrBatch: {int(n_train.min())}..{int(n_train.max())} train rows, the solver holds blocks of 1..{self.MAX_TRAIN}")
+        self.correct = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)  # bit 0: the ridge refactorisation ran
+        self.n_val = torch.from_numpy(n_val.astype(np.float32)).to(dev)
+        tab = np.zeros(n, _KR_JOB_DTYPE)
+        tab["K"], tab["train"], tab["val"], tab["labels"] = k_ptr, train_ptr, val_ptr, labels_ptr
+        tab["correct_out"] = self.correct.data_ptr() + 4 * np.arange(n, dtype=np.int64)
+        tab["flags_out"] = self.flags.data_ptr() + 4 * np.arange(n, dtype=np.int64)
+        tab["ldk"], tab["n_train"], tab["n_val"], tab["n_classes"] = ldk, n_train, n_val, int(n_classes)
+        self.table = torch.from_numpy(tab.view(np.uint8)).to(dev) if n else torch.empty(0, dtype=torch.uint8)
 
     def launch(self):
         check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")

@@ -37,6 +37,18 @@ class Job:
         return self.n_nodes * (synth.out_degree(self.k, self.h) + 1)
 
 
+def _mix64(*words):
+    """splitmix64 over a few integers -> 64-bit key (host arithmetic; seeds the device sampler's Philox per (job, classifier))"""
+    x = 0x9E3779B97F4A7C15
+    for w in words:
+        x = (x ^ (int(w) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+        x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+    return x
+
+
 def make_jobs(h_levels, seeds, k=2, n_nodes=2000, n_classes=5):
     """seed-major order: the jobs of one seed (which share a feature matrix) are adjacent."""
     return [Job(float(h), int(s), k, n_nodes, n_classes) for s in seeds for h in h_levels]
@@ -140,13 +152,19 @@ def gather_results(local_rows, device):
 class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
-    def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None, share=None, feature_seed=0):
+    def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None, share=None, feature_seed=0, tune=False,
+                 build=None):
         """jobs: list of Job (graph + features come from the generator of synth.py) - or, with `inputs`, a list of the same
         length of (src, dst, labels, features [n, n_feat] fp32 numpy) tuples to run instead (real / fixture graphs; jobs that
         share a feature matrix must pass the same array object and carry the same `seed`).
         share: another SweepBatch over the SAME jobs whose graphs (CSR, SELL-16 copy, degrees, labels) this one reuses - the
         feature bases of synthetic_plot.py:64-65 aggregate different feature matrices over the same 300 adjacencies
-        (BaseSweep below); feature_seed offsets the generator's feature seed per base."""
+        (BaseSweep below); feature_seed offsets the generator's feature seed per base.
+        build: "batched" (default; WDG_SWEEP_BUILD) - all graphs of the shard through ops.GraphBatch: one COO -> CSR build of
+        their block-diagonal union, the SELL-16 copies in five launches, ONE host read-back; "per_graph" - round 2's
+        CsrGraph.from_coo + ensure_quad per graph (~20 launches and two host syncs each), kept for A/B runs and tests.
+        tune: balance the aggregation's tape cut by feedback (tune() below: ~40 extra steps) - worth it for a batch that is
+        replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut."""
         from . import ops
         self.ops = ops
         self.jobs = list(jobs)
@@ -164,18 +182,22 @@ class SweepBatch:
         align = int(os.environ.get("WDG_SWEEP_AGG_ALIGN", "16"))
         self.agg_feat = (n_feat + n_classes + align - 1) // align * align if ride else n_feat
         self.alg_feat = n_feat + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
+        build = build or os.environ.get("WDG_SWEEP_BUILD", "batched")
         feats, self.graphs, self.dinv, self.labels, self.y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
+        coos, labs_host = [], []
         for ji, j in enumerate(self.jobs):
             if inputs is not None:
                 src, dst, lab, x_host = inputs[ji]
                 lab = np.asarray(lab)
             elif share is not None:
                 src = dst = None
-                lab, x_host = share.labels[ji].cpu().numpy().astype(np.int64), None
+                lab, x_host = np.asarray(share.labels_host[ji]).astype(np.int64), None
             else:
                 src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
                 x_host = None
+            coos.append((src, dst, j.n_nodes))
+            labs_host.append(lab)
             if j.seed not in feats:
                 x = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
                                      else np.ascontiguousarray(x_host, np.float32)).to(dev)
@@ -187,14 +209,25 @@ class SweepBatch:
                 feats[j.seed], seed_labels[j.seed] = x, lab
             elif ride and not np.array_equal(seed_labels[j.seed], lab):
                 raise ValueError("SweepBatch: jobs of one seed differ in labels; set WDG_SWEEP_RIDE_LABELS=0")
-            if share is not None:
-                g, d = share.graphs[ji], share.dinv[ji]
-            else:
-                g = ops.CsrGraph.from_coo(src, dst, j.n_nodes, None, ops.COO_ADD_SELF_LOOPS)  # A + I (synthetic_plot.py:92)
-                d = ops.degree_norm(g, ops.NORM_SYM if symmetric else ops.NORM_RW, ops.PREC_F32, use_values=True)["dinv"]
-            self.graphs.append(g)
-            self.dinv.append(d)
-            self.labels.append(torch.from_numpy(lab).to(dev).to(torch.int32))
+        mode = ops.NORM_SYM if symmetric else ops.NORM_RW
+        if share is not None:
+            self.graphs, self.dinv = list(share.graphs), list(share.dinv)
+        elif build == "batched":
+            # A + I of every graph (synthetic_plot.py:92) in one build, the degrees of all of them in one launch
+            self.graph_batch = ops.GraphBatch(coos, ops.COO_ADD_SELF_LOOPS, quad=True)
+            self.graphs = self.graph_batch.graphs
+            self.dinv = [d["dinv"] for d in self.graph_batch.degree_norm(mode, ops.PREC_F32, use_values=True)]
+        else:
+            for src, dst, n_nodes in coos:
+                g = ops.CsrGraph.from_coo(src, dst, n_nodes, None, ops.COO_ADD_SELF_LOOPS)  # A + I (synthetic_plot.py:92)
+                self.graphs.append(g)
+                self.dinv.append(ops.degree_norm(g, mode, ops.PREC_F32, use_values=True)["dinv"])
+        # labels of every graph: one pooled upload
+        lab_ptr = np.concatenate([[0], np.cumsum([len(l) for l in labs_host])]).astype(np.int64)
+        lab_pool = torch.from_numpy(np.concatenate(labs_host).astype(np.int32) if labs_host else np.zeros(0, np.int32)).to(dev)
+        self.labels = [lab_pool[int(lab_ptr[i]):int(lab_ptr[i + 1])] for i in range(len(self.jobs))]
+        self.labels_host = labs_host
+        for j in self.jobs:
             self.y_agg.append(torch.empty((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev))
             self.y.append(self.y_agg[-1][:, :n_feat])  # the feature part (a view: leading dimension agg_feat)
         self.x_agg = feats                                        # what the aggregation reads: [X | onehot | 0]
@@ -248,7 +281,8 @@ class SweepBatch:
                             spmm=ops.SpmmBatch([(g, z, o, d, scale(d), False)
                                                 for g, z, o, d in zip(self.graphs, z2, out, self.dinv)]))
 
-        self.tune()
+        if tune or os.environ.get("WDG_QUAD_TUNE", "") == "1":
+            self.tune()
 
     def tune(self, rounds=6, steps=5):
         """Balance the aggregation's eight segments (one per XCD) by what they really cost INSIDE the step.  The modelled cut
@@ -260,7 +294,7 @@ class SweepBatch:
         rounds x (2 + steps) steps, once per batch; every cut computes the same bits (a row's sum order is fixed by the
         SELL-16 copy)."""
         sp = self.spmm
-        if not sp.quad or sp.n_segments != 8 or sp.n_items <= sp.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":
+        if not sp.quad or sp.n_segments != 8 or sp.n_items <= sp.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":  # noqa: E501
             return None
         clock = sp.new_clock()
         shares = np.ones(8)
@@ -402,39 +436,82 @@ class SweepBatch:
         return torch.stack([edge, node, cls, adj, li, soft_las], 1)
 
     # -- the remaining three scalars: generalized edge homophily + the kernel-regression p-values ------
-    def prepare_full(self, epochs=100, sample_max=500, seed_of=None):
+    def prepare_full(self, epochs=100, sample_max=500, seed_of=None, sampler=None, base_seed=0):
         """Set up the batched kernel-regression metric for every job: the Gram / arc-cosine kernels of the aggregated features
         (per job) and of the raw features (per feature matrix) - all nodes, once -, and, per job x classifier (kernel_reg0 /
-        kernel_reg1) x epoch, the train / validation node sets of the reference's sampling routine drawn on the host with
-        torch.manual_seed(seed_of(job index, classifier index)) (default 1000 job + classifier); both kernels of an epoch
-        share its node sets.  One-time per batch: the node sets are inputs like the graphs."""
+        kernel_reg1) x epoch, the train / validation node sets; both kernels of an epoch share its node sets.
+        sampler "device" (default; WDG_KR_SAMPLER): the sets of all epochs are drawn by ONE launch (ops.KrSets,
+        wdg_kr_sample_sets: Philox4x32-10 keyed by base_seed, job and classifier - the reference's distribution, a documented
+        generator) in launch_full(), inside the clock of a cold sweep.  sampler "host" (implied by seed_of): the reference's
+        own routine on torch's CPU generator seeded with seed_of(job index, classifier index) (default 1000 job + classifier) -
+        bit for bit the reference's sets (the golden tests), ~40 ms of host time per (job, classifier) at 100 epochs."""
         from .utils.util_funcs import kernel_regression_epoch_indices
         ops = self.ops
         dev = self.graphs[0].device if self.graphs else ops.require_gpu()
         seeds = list(self.x)
+        J = len(self.jobs)
         self.kr_epochs, self.kr_sample_max = epochs, sample_max
+        sampler = "host" if seed_of is not None else (sampler or os.environ.get("WDG_KR_SAMPLER", "device"))
+        if J == 0:  # an empty shard
+            self.gram, self.ge, self.kr_sets = ops.GramBatch([]), ops.EdgeGramBatch([]), None
+            self.kr = ops.KrBatch([], max(self.n_classes, 1))
+            return
+        if self.n_classes > ops.KrBatch.MAX_CLASSES:
+            raise ValueError(f"SweepBatch.prepare_full: {self.n_classes} classes, the device solver holds {ops.KrBatch.MAX_CLASSES}; "
+                             "use utils.homophily_metrics.classifier_based_performance_metric (host path) per graph")
         # kernels: [aggregated features of every job] + [raw features of every feature matrix], linear and arc-cosine
-        self.gram = ops.GramBatch([self.y[i] for i in range(len(self.jobs))] + [self.x[s] for s in seeds])
-        x_slot = {s: len(self.jobs) + i for i, s in enumerate(seeds)}
+        self.gram = ops.GramBatch([self.y[i] for i in range(J)] + [self.x[s] for s in seeds])
+        x_slot = {s: J + i for i, s in enumerate(seeds)}
         self.ge = ops.EdgeGramBatch([(g, self.gram.k_linear[x_slot[j.seed]], self.gram.norm2[x_slot[j.seed]])
                                      for j, g in zip(self.jobs, self.graphs)])
-        seed_of = seed_of or (lambda ji, clf: 1000 * ji + clf)
-        problems = []
-        rng_state = torch.get_rng_state()
-        for ji, (j, lab) in enumerate(zip(self.jobs, self.labels)):
-            lab_host = lab.cpu().long()
-            for clf in (0, 1):
-                torch.manual_seed(seed_of(ji, clf))
-                kern = (self.gram.k_linear, self.gram.k_arccos)[clf]
-                for train, val in kernel_regression_epoch_indices(lab_host, sample_max, epochs):
-                    tr, va = train.to(dev, torch.int32), val.to(dev, torch.int32)
-                    problems.append((kern[ji], tr, va, lab))                   # the aggregated features' kernel
-                    problems.append((kern[x_slot[j.seed]], tr, va, lab))       # the raw features' kernel
-        torch.set_rng_state(rng_state)
-        self.kr = ops.KrBatch(problems, self.n_classes)
+        sizes = [ops.kr_split_sizes(lab, sample_max) for lab in self.labels_host]
+        if sampler == "device":
+            # a (job, classifier) pair's key: the job's identity (not its position in this shard), so that the same job draws
+            # the same sets on whichever rank / in whichever batch it runs, and different jobs draw independent ones
+            self.kr_sets = ops.KrSets([(self.labels[ji], sizes[ji][0], sizes[ji][1],
+                                        _mix64(base_seed, j.seed, int(round(j.h * 1e6)), j.k, j.n_nodes, clf))
+                                       for ji, j in enumerate(self.jobs) for clf in (0, 1)], epochs)
+            train, val = self.kr_sets.train, self.kr_sets.val         # [J * 2, epochs, n_train / n_val], filled by launch_full()
+        else:
+            self.kr_sets = None
+            seed_of = seed_of or (lambda ji, clf: 1000 * ji + clf)
+            nt = max([int(t.sum()) for _s, t in sizes], default=1)
+            nv = max([int(s_.sum() - t.sum()) for s_, t in sizes], default=1)
+            train_h, val_h = np.zeros((J * 2, epochs, max(nt, 1)), np.int32), np.zeros((J * 2, epochs, max(nv, 1)), np.int32)
+            rng_state = torch.get_rng_state()
+            for ji, lab in enumerate(self.labels_host):
+                lab_t = torch.from_numpy(np.asarray(lab)).long()
+                for clf in (0, 1):
+                    torch.manual_seed(seed_of(ji, clf))
+                    for e, (tr, va) in enumerate(kernel_regression_epoch_indices(lab_t, sample_max, epochs)):
+                        train_h[2 * ji + clf, e, :tr.shape[0]] = tr.numpy()
+                        val_h[2 * ji + clf, e, :va.shape[0]] = va.numpy()
+            torch.set_rng_state(rng_state)
+            train, val = torch.from_numpy(train_h).to(dev), torch.from_numpy(val_h).to(dev)
+        self.kr_train, self.kr_val = train, val
+        # the problem table: p = ((job * 2 + classifier) * epochs + epoch) * 2 + (0: the aggregated features' kernel, 1: the raw
+        # features' kernel), described by arithmetic on base addresses
+        pair = np.repeat(np.arange(J * 2), epochs * 2)
+        ji, clf = pair // 2, pair % 2
+        epoch = np.tile(np.repeat(np.arange(epochs), 2), J * 2)
+        which = np.tile(np.arange(2), J * 2 * epochs)
+        k_lin = np.array([k.data_ptr() for k in self.gram.k_linear], np.int64)
+        k_arc = np.array([k.data_ptr() for k in self.gram.k_arccos], np.int64)
+        slot = np.where(which == 0, ji, np.array([x_slot[j.seed] for j in self.jobs], np.int64)[ji])
+        k_ptr = np.where(clf == 0, k_lin[slot], k_arc[slot])
+        n_nodes = np.array([j.n_nodes for j in self.jobs], np.int64)
+        n_tr = np.array([int(t.sum()) for _s, t in sizes], np.int64)
+        n_va = np.array([int(s_.sum() - t.sum()) for s_, t in sizes], np.int64)
+        lab_ptr = np.array([l.data_ptr() for l in self.labels], np.int64)
+        self.kr = ops.KrBatch.from_arrays(
+            k_ptr, n_nodes[ji], train.data_ptr() + 4 * (pair * epochs + epoch) * train.shape[2],
+            val.data_ptr() + 4 * (pair * epochs + epoch) * val.shape[2], lab_ptr[ji], n_tr[ji], n_va[ji], self.n_classes,
+            keep=(train, val, self.gram))
 
     def launch_full(self):
         """the launches of the three extra scalars (after the aggregation: they read Y): Gram + maps, edge cosines, regressions"""
+        if self.kr_sets is not None:
+            self.kr_sets.launch()   # the epochs' node sets (device sampler; a host-sampled batch uploaded them in prepare_full)
         self.gram.launch()
         self.ge.launch()
         self.kr.launch()
