@@ -22,6 +22,7 @@
 //                       block is refactored once with the ridge n eps max K_ii / 8: the least-squares answer of the
 //                       pseudo-inverse to within one or two validation rows per epoch (measured against the reference's
 //                       per-epoch accuracies) - a documented deviation in the coefficients.
+#include <cstdlib>
 #include <type_traits>
 
 #include "wdg_common.h"
@@ -560,6 +561,441 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
     if (tid == 0 && job->flags_out) *to_global(job->flags_out) = ridge > 0.f ? 1 : 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ blocked solver (round 3)
+// The same problem as kr_solve_kernel - one workgroup of 16 waves per (kernel, train rows, validation rows) regression - as a
+// right-looking BLOCKED Cholesky with 32 x 32 blocks: the trailing update, > 90 % of the flops, runs on the fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain, fixed order -> bitwise reproducible), and a regression takes ~60
+// workgroup barriers instead of ~330 (kr_solve_kernel: one per eliminated column).
+//
+//   layout   block (a, b), b <= a, of the train block lives in ONE wave's registers, TRANSPOSED in the MFMA accumulator layout:
+//            lane (i, h) = (lane & 31, lane >> 5) holds A[32 a + i][32 b + j] for the 16 columns j = jmap(h, r) = (r & 3) +
+//            8 (r >> 2) + 4 h, r = 0 .. 15 - row i of the block on the lane, the columns in the registers.  With the k index of an
+//            MFMA step dealt the same way (half h supplies k = jmap(h, s)), the update T(a, b) -= L_b L_a^T reads both panel
+//            blocks from LDS (row-major, stride 36 floats: conflict-free) with four ds_read_b128 per lane and needs no transpose.
+//   blocks   enumerated by column (last first), dealt round-robin to the 16 waves: at every step the still-active blocks are a
+//            prefix of that order, so the update is balanced to one block; a column's blocks sit on distinct waves.
+//   gather   K is symmetric: lane (i, h) reads K[tr[32 b + j]][tr[32 a + i]] - per register a wave-uniform ROW (one per lane
+//            half) and 32 ascending columns inside a ~200-column window - instead of 32 different rows per instruction.
+//   step kb  the column's blocks go to LDS (row-major); (1) the diagonal block's wave factors it: lane = row, row j of L_kk is
+//            read back from LDS (broadcast) as soon as it is complete - the same substitution loop that (2) the other blocks of
+//            the column run against the finished L_kk (X L_kk^T = A), while the diagonal wave solves z_kb = L_kk^-1 y_kb; (3)
+//            every wave updates its active blocks with 16 MFMAs each, the panel's waves subtract L_a z_kb from the right-hand
+//            sides.  The in-wave routines exist ONCE in the code (a wave's block reaches them through LDS, whatever register
+//            slot it lives in) and their solves are rolled loops: the first version unrolled them per slot, 200 KB of straight-
+//            line code that ran at the speed of instruction-cache misses (450 us per regression; this one: see DESIGN.md).
+//   then     back substitution block column by block column (the column's blocks go through LDS once more: the product with
+//            L^T sums over the lane index), predictions one wave per four validation rows.
+// Rank-deficient blocks: as in kr_solve_kernel (pivot test at n eps max K_ii / 64, one restart on K + n eps max K_ii / 8 I).
+constexpr int K2_THREADS = 1024, K2_WAVES = 16, K2_NB = 10, K2_SLOTS = 4, K2_PS = 36;
+static_assert(K2_NB * (K2_NB + 1) / 2 <= K2_WAVES * K2_SLOTS, "every block needs a register slot");
+
+__device__ __forceinline__ int k2_jmap(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float k2_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// a block's registers <-> its row-major image in LDS (lane (i, h): row i, columns 4 h + 8 q .. + 3)
+__device__ __forceinline__ void k2_store_block(const f32x16 &t, float *img, int li, int h) {
+    float *row = img + li * K2_PS + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(row + 8 * q) = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+}
+__device__ __forceinline__ void k2_load_block(f32x16 &t, const float *img, int li, int h) {
+    const float *row = img + li * K2_PS + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 8 * q);
+        t[4 * q] = v.x, t[4 * q + 1] = v.y, t[4 * q + 2] = v.z, t[4 * q + 3] = v.w;
+    }
+}
+
+// The in-wave substitution along a block's columns, lane = block row (both lane halves run the same rows): x_j = (a_j -
+// sum_{k < j} x_k L[j][k]) / L[j][j] for j = 0 .. 31, row j of L read from LDS at one address (broadcast).
+//   factor == false: L = the finished diagonal block (`ld`, 1 / l_jj in `dinv`): X L^T = A, the panel solve;
+//   factor == true : A IS the diagonal block: the same recurrence is its Cholesky factorisation row by row - x_j of lane j is the
+//                    pivot (broadcast with v_readlane), every lane's x_j / sqrt(pivot) is L[i][j], published to `ld` at once so
+//                    that row j + 1 can be read back in the next step.  Returns whether a pivot fell below `drop_below`.
+// `img` = the block's row-major image in LDS (input and output).
+__device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv, bool factor, int li, int lane, int rows_real,
+                                          float drop_below, float ridge) {
+    float x[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(img + li * K2_PS + 4 * q);
+        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+    }
+    bool low_any = false;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        float v0 = x[j], v1 = 0.f;  // two partial sums: half the dependent chain
+#pragma unroll
+        for (int k8 = 0; k8 < j; k8 += 8) {  // row j of L eight entries at a time: the loads must not pile up in registers (64 of
+                                              // the 128 hold the wave's blocks, 32 hold x: a spill here is a memory round trip)
+            const float4 l0 = *reinterpret_cast<const float4 *>(ld + j * K2_PS + k8);  // (the same address in every lane)
+            float4 l1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k8 + 4 < j) l1 = *reinterpret_cast<const float4 *>(ld + j * K2_PS + k8 + 4);
+            v0 = fmaf(-x[k8], l0.x, v0);
+            if (k8 + 1 < j) v1 = fmaf(-x[k8 + 1], l0.y, v1);
+            if (k8 + 2 < j) v0 = fmaf(-x[k8 + 2], l0.z, v0);
+            if (k8 + 3 < j) v1 = fmaf(-x[k8 + 3], l0.w, v1);
+            if (k8 + 4 < j) v0 = fmaf(-x[k8 + 4], l1.x, v0);
+            if (k8 + 5 < j) v1 = fmaf(-x[k8 + 5], l1.y, v1);
+            if (k8 + 6 < j) v0 = fmaf(-x[k8 + 6], l1.z, v0);
+            if (k8 + 7 < j) v1 = fmaf(-x[k8 + 7], l1.w, v1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float v = v0 + v1;
+        float inv;
+        if (factor) {  // (uniform)
+            float piv = k2_bcast(v, j);
+            const bool low = !(piv > drop_below) && j < rows_real;  // (uniform; also catches NaN)
+            low_any |= low;
+            piv = low ? fmaxf(ridge, drop_below) : piv;
+            inv = __builtin_amdgcn_rsqf(piv);
+            inv = inv * fmaf(-0.5f * piv * inv, inv, 1.5f);  // one Newton step: 1 / sqrt(piv) to within an ulp
+            const float lij = li == j ? piv * inv : (li > j ? v * inv : 0.f);
+            x[j] = lij;
+            ld[li * K2_PS + j] = lij;  // column j of L_kk (0 above the diagonal); both halves write the same value
+            if (lane == 0) dinv[j] = inv;
+        } else {
+            x[j] = v * dinv[j];
+        }
+    }
+    if (!factor && lane < 32) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(img + li * K2_PS + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    }
+    return low_any;
+}
+
+#ifdef K2_PROFILE  // diagnostic build (make EXTRA=-DK2_PROFILE): thread 0 of workgroup 0 sums the shader clocks spent per phase
+#define K2_T(k)                                                                   \
+    do {                                                                          \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+            k2_prof[k] += now_ - k2_last;                                         \
+            k2_last = now_;                                                       \
+        }                                                                         \
+    } while (0)
+#else
+#define K2_T(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_kr_job *__restrict__ jobs) {
+    __shared__ float P[(K2_NB - 1) * 32 * K2_PS];      // the step's panel L[a, kb], a > kb: [a - kb - 1][row][k], stride 36
+    __shared__ float LD[K2_NB * 32 * K2_PS];           // the diagonal blocks L_kk, row-major (kept: the back substitution reads them)
+    __shared__ float Dinv[K2_NB * 32];                 // 1 / l_kk
+    __shared__ float zs[K2_NB * 32 * KR_MAX_C];        // right-hand sides: one-hot labels -> z = L^-1 Y (block by block)
+    __shared__ float al[K2_NB * 32 * KR_MAX_C];        // alpha
+    __shared__ float part[K2_WAVES][32][KR_MAX_C];     // per-wave partial sums (back substitution)
+    __shared__ int tr_idx[K2_NB * 32];
+    __shared__ signed char blk_a[K2_WAVES * K2_SLOTS], blk_b[K2_WAVES * K2_SLOTS];
+    __shared__ int deficient, correct;
+    __shared__ float red[K2_WAVES];
+
+    const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + blockIdx.x);
+    const global_ptr<const float> K = to_global(job->K);
+    const global_ptr<const int32_t> train = to_global(job->train), val = to_global(job->val), labels = to_global(job->labels);
+    const int64_t ldk = job->ldk;
+    const int nt = job->n_train, nv = job->n_val, C = job->n_classes;
+    const int ablate = job->reserved;  // timing-only diagnostics (scripts/dev/time_kr_batch.py): 1 no gather, 2 no factorisation,
+                                       // 4 no back substitution, 8 no predictions; 0 on every product path
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li_ = lane & 31, h_ = lane >> 5;
+    if (nt <= 0 || nt > K2_NB * 32 || C <= 0 || C > KR_MAX_C) {
+        if (tid == 0 && job->correct_out) *to_global(job->correct_out) = -1;
+        if (tid == 0 && job->flags_out) *to_global(job->flags_out) = 0;
+        return;
+    }
+#ifdef K2_PROFILE
+    unsigned long long k2_prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, k2_last = __builtin_amdgcn_s_memtime();
+#endif
+    const int nb = (nt + 31) >> 5;
+    const int n_blocks = nb * (nb + 1) / 2;
+    for (int i = tid; i < K2_NB * 32; i += K2_THREADS) tr_idx[i] = i < nt ? train[i] : -1;
+    if (tid < K2_WAVES * K2_SLOTS) {  // block `tid` of the enumeration: columns nb-1 .. 0, rows b .. nb-1 inside a column
+        int idx = tid, b = nb - 1;
+        while (b >= 0 && idx >= nb - b) {
+            idx -= nb - b;
+            --b;
+        }
+        blk_a[tid] = static_cast<signed char>(b >= 0 ? b + idx : -1);
+        blk_b[tid] = static_cast<signed char>(b);
+    }
+    if (tid == 0) correct = 0;
+    __syncthreads();
+    // max K_ii of the train rows (the scale of the pivot test)
+    float dmax = 0.f;
+    for (int t = tid; t < nt; t += K2_THREADS) dmax = fmaxf(dmax, K[static_cast<int64_t>(tr_idx[t]) * ldk + tr_idx[t]]);
+    for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+    if (lane == 0) red[wave] = dmax;
+    __syncthreads();
+    dmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < K2_WAVES; ++w) dmax = fmaxf(dmax, red[w]);
+    const float drop_below = static_cast<float>(nt) * 1.1920929e-7f * dmax * (1.f / 64.f);
+    int sa[K2_SLOTS], sb[K2_SLOTS];  // this wave's blocks (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < K2_SLOTS; ++s) {
+        const int idx = wave + K2_WAVES * s;
+        sa[s] = __builtin_amdgcn_readfirstlane(idx < n_blocks ? blk_a[idx] : -1);
+        sb[s] = __builtin_amdgcn_readfirstlane(idx < n_blocks ? blk_b[idx] : -1);
+    }
+
+    f32x16 acc[K2_SLOTS];
+    float ridge = 0.f;
+    K2_T(0);  // setup
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // ---- right-hand sides and the gather
+        for (int i = tid; i < K2_NB * 32 * KR_MAX_C; i += K2_THREADS) {
+            const int row = i / KR_MAX_C, c = i % KR_MAX_C;
+            zs[i] = (row < nt && labels[tr_idx[row]] == c) ? 1.f : 0.f;
+            al[i] = 0.f;
+        }
+        if (tid == 0) deficient = 0;
+#pragma unroll
+        for (int s = 0; s < K2_SLOTS; ++s) {
+            if (sa[s] < 0) continue;
+            int li = li_, h = h_;
+            asm volatile("" : "+v"(li), "+v"(h));
+            const int gi = tr_idx[32 * sa[s] + li];  // the lane's row of the block = the COLUMN it reads (K is symmetric)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = k2_jmap(h, r), gj = tr_idx[32 * sb[s] + j];
+                const bool diag = sa[s] == sb[s] && li == j;
+                float v = (gi >= 0 && gj >= 0 && !(ablate & 1)) ? K[static_cast<int64_t>(gj) * ldk + gi] : (diag ? 1.f : 0.f);
+                if (diag && gi >= 0) v += ridge;
+                acc[s][r] = v;
+                if (r == 7) __builtin_amdgcn_sched_barrier(0);  // (eight gathers and their addresses in flight at a time)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        K2_T(1);  // right-hand sides + gather
+
+        // ---- the factorisation
+        for (int kb = 0; kb < ((ablate & 2) ? 0 : nb); ++kb) {
+            // (lane coordinates made opaque per iteration: otherwise the compiler hoists every LDS address of the loop body -
+            // dozens of loop-invariant lane-dependent offsets - out of the loop, spills them next to the 64 accumulator registers
+            // and reloads each one from scratch memory, a global-memory round trip, in front of the LDS access that needs it)
+            int li = li_, h = h_;
+            asm volatile("" : "+v"(li), "+v"(h));
+            // the column's blocks -> LDS, row-major: the diagonal block into its slot of LD, block (a, kb) into P[a - kb - 1]
+            int role = -1;  // this wave's block of column kb: 0 = the diagonal block, a - kb for block (a, kb), -1 = none
+#pragma unroll
+            for (int s = 0; s < K2_SLOTS; ++s) {
+                if (sb[s] != kb) continue;  // (wave-uniform; a column's blocks sit on distinct waves)
+                role = sa[s] - kb;
+                k2_store_block(acc[s], role == 0 ? &LD[kb * 32 * K2_PS] : &P[(role - 1) * 32 * K2_PS], li, h);
+            }
+            // (1) the diagonal block's wave factors it alone; (2) the column's other blocks: X L_kk^T = A, while the diagonal
+            //     block's wave solves z_kb = L_kk^-1 y_kb.  One copy of the substitution in the code: two passes of a rolled loop.
+            bool restart = false;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                if ((pass == 0 && role == 0) || (pass == 1 && role > 0)) {  // (wave-uniform)
+                    float *img = pass == 0 ? &LD[kb * 32 * K2_PS] : &P[(role - 1) * 32 * K2_PS];
+                    if (k2_substitute(img, &LD[kb * 32 * K2_PS], &Dinv[kb * 32], pass == 0, li, lane, nt - 32 * kb, drop_below, ridge) && lane == 0)
+                        deficient = 1;
+                }
+                if (pass == 0) {
+                    K2_T(2);
+                    __syncthreads();
+                    K2_T(3);
+                    restart = deficient && attempt == 0;
+                    if (restart) break;  // (uniform)
+                }
+            }
+            if (restart) break;  // restart on K + ridge I
+            if (role == 0) {  // z_kb, column form, lane = row: z_k = y_k / l_kk, y_i -= L[i][k] z_k
+                float y[KR_MAX_C];
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) y[c] = zs[(32 * kb + li) * KR_MAX_C + c];
+                const float *lrow = &LD[(kb * 32 + li) * K2_PS];
+                float inv_n = Dinv[kb * 32], lik_n = lrow[0];
+#pragma unroll 1
+                for (int k = 0; k < 32; ++k) {  // (rolled: the loop body is the code; the next step's two LDS values are in flight)
+                    const float inv = inv_n, lik = li > k ? lik_n : 0.f;
+                    inv_n = Dinv[kb * 32 + min(k + 1, 31)], lik_n = lrow[min(k + 1, 31)];
+                    float zk[KR_MAX_C];
+#pragma unroll
+                    for (int c = 0; c < KR_MAX_C; ++c) {
+                        zk[c] = k2_bcast(y[c], k) * inv;
+                        y[c] = fmaf(-lik, zk[c], y[c]);
+                    }
+                    if (lane == 0) {
+                        *reinterpret_cast<float4 *>(&zs[(32 * kb + k) * KR_MAX_C]) = make_float4(zk[0], zk[1], zk[2], zk[3]);
+                        *reinterpret_cast<float4 *>(&zs[(32 * kb + k) * KR_MAX_C + 4]) = make_float4(zk[4], zk[5], zk[6], zk[7]);
+                    }
+                }
+            }
+            K2_T(4);
+            __syncthreads();
+            K2_T(5);
+            // (3) the panel's blocks come back into their registers; the trailing update T(a, b) -= L_b L_a^T on the matrix pipe;
+            //     the panel's waves subtract L_a z_kb from the right-hand sides
+#pragma unroll
+            for (int s = 0; s < K2_SLOTS; ++s) {
+                if (sb[s] > kb) {
+                    const float *pa = &P[((sa[s] - kb - 1) * 32 + li) * K2_PS + 4 * h];
+                    const float *pb = &P[((sb[s] - kb - 1) * 32 + li) * K2_PS + 4 * h];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 va = *reinterpret_cast<const float4 *>(pa + 8 * q), vb = *reinterpret_cast<const float4 *>(pb + 8 * q);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(-vb.x, va.x, acc[s], 0, 0, 0);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(-vb.y, va.y, acc[s], 0, 0, 0);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(-vb.z, va.z, acc[s], 0, 0, 0);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(-vb.w, va.w, acc[s], 0, 0, 0);
+                    }
+                } else if (sb[s] == kb && sa[s] > kb) {
+                    k2_load_block(acc[s], &P[(sa[s] - kb - 1) * 32 * K2_PS], li, h);  // L[a, kb], final
+                    float sum[KR_MAX_C];
+#pragma unroll
+                    for (int c = 0; c < KR_MAX_C; ++c) sum[c] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float *z = &zs[(32 * kb + k2_jmap(h, r)) * KR_MAX_C];
+                        const float4 z0 = *reinterpret_cast<const float4 *>(z), z1 = *reinterpret_cast<const float4 *>(z + 4);
+                        const float l = acc[s][r];
+                        sum[0] = fmaf(l, z0.x, sum[0]), sum[1] = fmaf(l, z0.y, sum[1]), sum[2] = fmaf(l, z0.z, sum[2]), sum[3] = fmaf(l, z0.w, sum[3]);
+                        sum[4] = fmaf(l, z1.x, sum[4]), sum[5] = fmaf(l, z1.y, sum[5]), sum[6] = fmaf(l, z1.z, sum[6]), sum[7] = fmaf(l, z1.w, sum[7]);
+                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int c = 0; c < KR_MAX_C; ++c) sum[c] += __shfl_xor(sum[c], 32);
+                    if (h == 0) {
+                        float *y = &zs[(32 * sa[s] + li) * KR_MAX_C];
+#pragma unroll
+                        for (int c = 0; c < KR_MAX_C; ++c) y[c] -= sum[c];
+                    }
+                }
+            }
+            K2_T(6);
+            __syncthreads();
+            K2_T(7);
+        }
+        __syncthreads();
+        if (!deficient || attempt == 1) break;  // (uniform)
+        ridge = 8.f * drop_below;                // = n eps max K_ii / 8
+        __syncthreads();
+    }
+
+    // ---- back substitution L^T alpha = z, block column by block column from the last (L_kk: still in LD)
+    for (int kb = (ablate & 4) ? -1 : nb - 1; kb >= 0; --kb) {
+        int li = li_, h = h_;  // (opaque per iteration: see the factorisation loop)
+        asm volatile("" : "+v"(li), "+v"(h));
+#pragma unroll
+        for (int s = 0; s < K2_SLOTS; ++s)  // the column's blocks below the diagonal -> LDS, row-major
+            if (sb[s] == kb && sa[s] > kb) k2_store_block(acc[s], &P[(sa[s] - kb - 1) * 32 * K2_PS], li, h);
+        __syncthreads();
+        K2_T(10);
+        // wave w takes block a = kb + 1 + w: lane (j, h) sums L[i][j] alpha_a[i][.] over the 16 rows i of its half
+        if (wave < nb - kb - 1) {
+            const int a = kb + 1 + wave;
+            float sum[KR_MAX_C];
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) sum[c] = 0.f;
+#pragma unroll 4
+            for (int ii = 0; ii < 16; ++ii) {
+                const int i = 16 * h + ii;
+                const float l = P[(wave * 32 + i) * K2_PS + li];
+                const float *av = &al[(32 * a + i) * KR_MAX_C];
+                const float4 a0 = *reinterpret_cast<const float4 *>(av), a1 = *reinterpret_cast<const float4 *>(av + 4);
+                sum[0] = fmaf(l, a0.x, sum[0]), sum[1] = fmaf(l, a0.y, sum[1]), sum[2] = fmaf(l, a0.z, sum[2]), sum[3] = fmaf(l, a0.w, sum[3]);
+                sum[4] = fmaf(l, a1.x, sum[4]), sum[5] = fmaf(l, a1.y, sum[5]), sum[6] = fmaf(l, a1.z, sum[6]), sum[7] = fmaf(l, a1.w, sum[7]);
+            }
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) sum[c] += __shfl_xor(sum[c], 32);
+            if (h == 0) {
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) part[wave][li][c] = sum[c];
+            }
+        }
+        K2_T(11);
+        __syncthreads();
+        K2_T(12);
+        if (wave == 0) {  // alpha_kb = L_kk^-T (z_kb - the blocks' sums): lane = column j, rows k from the last
+            float v[KR_MAX_C];
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) {
+                float r = zs[(32 * kb + li) * KR_MAX_C + c];
+                for (int w = 0; w < nb - kb - 1; ++w) r -= part[w][li][c];  // (fixed order)
+                v[c] = r;
+            }
+            K2_T(13);
+            float inv_n = Dinv[kb * 32 + 31], lkj_n = LD[(kb * 32 + 31) * K2_PS + li];
+#pragma unroll 1
+            for (int k = 31; k >= 0; --k) {  // (rolled; the next step's two LDS values are in flight)
+                const float inv = inv_n, lkj = li < k ? lkj_n : 0.f;
+                inv_n = Dinv[kb * 32 + max(k - 1, 0)], lkj_n = LD[(kb * 32 + max(k - 1, 0)) * K2_PS + li];
+                float ak[KR_MAX_C];
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) {
+                    ak[c] = k2_bcast(v[c], k) * inv;
+                    v[c] = fmaf(-lkj, ak[c], v[c]);
+                }
+                if (lane == 0) {
+                    const bool real = 32 * kb + k < nt;
+                    *reinterpret_cast<float4 *>(&al[(32 * kb + k) * KR_MAX_C]) = real ? make_float4(ak[0], ak[1], ak[2], ak[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4 *>(&al[(32 * kb + k) * KR_MAX_C + 4]) = real ? make_float4(ak[4], ak[5], ak[6], ak[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        K2_T(8);
+    }
+
+    // ---- predictions: a wave takes four validation rows at a time (twenty gathers in flight), the lanes split the train rows
+    //      (ascending columns of one row of K); sums in a fixed order
+    int hits = 0;
+    for (int v0 = 4 * wave; v0 < ((ablate & 8) ? 0 : nv); v0 += 4 * K2_WAVES) {
+        float p[4][KR_MAX_C];
+        int gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gv[u] = val[min(v0 + u, nv - 1)];
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) p[u][c] = 0.f;
+        }
+        for (int t = lane; t < nt; t += 64) {
+            const int col = tr_idx[t];
+            float kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kv[u] = K[static_cast<int64_t>(gv[u]) * ldk + col];
+            const float4 a0 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C]), a1 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C + 4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p[u][0] = fmaf(kv[u], a0.x, p[u][0]), p[u][1] = fmaf(kv[u], a0.y, p[u][1]), p[u][2] = fmaf(kv[u], a0.z, p[u][2]), p[u][3] = fmaf(kv[u], a0.w, p[u][3]);
+                p[u][4] = fmaf(kv[u], a1.x, p[u][4]), p[u][5] = fmaf(kv[u], a1.y, p[u][5]), p[u][6] = fmaf(kv[u], a1.z, p[u][6]), p[u][7] = fmaf(kv[u], a1.w, p[u][7]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c)
+                for (int o = 32; o > 0; o >>= 1) p[u][c] += __shfl_xor(p[u][c], o);  // (butterfly: every lane ends with the same sum)
+            int best = 0;
+            float bv = -3.4e38f;
+            for (int c = 0; c < C; ++c)
+                if (p[u][c] > bv) {  // first maximum, like torch.argmax
+                    bv = p[u][c];
+                    best = c;
+                }
+            hits += (v0 + u < nv) && best == labels[gv[u]];
+        }
+    }
+    if (lane == 0 && hits) atomicAdd(&correct, hits);
+    __syncthreads();
+    if (tid == 0 && job->correct_out) *to_global(job->correct_out) = correct;
+    if (tid == 0 && job->flags_out) *to_global(job->flags_out) = ridge > 0.f ? 1 : 0;
+#ifdef K2_PROFILE
+    K2_T(9);
+    if (blockIdx.x == 0 && tid == 0)
+        printf("k2 cycles: setup %llu gather %llu diag %llu b1 %llu panel %llu b2 %llu update %llu b3 %llu bwd-solve %llu pred %llu | bwd: store+bar %llu "
+               "contrib %llu bar %llu sums %llu\n", k2_prof[0], k2_prof[1], k2_prof[2], k2_prof[3], k2_prof[4], k2_prof[5], k2_prof[6], k2_prof[7],
+               k2_prof[8], k2_prof[9], k2_prof[10], k2_prof[11], k2_prof[12], k2_prof[13]);
+#endif
+}
+
 }  // namespace
 
 extern "C" {
@@ -579,7 +1015,13 @@ int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, w
     WDG_REQUIRE(n_jobs >= 0, "kernel_regress_batched: negative size");
     if (n_jobs == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev != nullptr, "kernel_regress_batched: null job table");
-    hipLaunchKernelGGL(kr_solve_kernel, dim3(n_jobs), dim3(KR_THREADS), 0, wdg::as_stream(stream), jobs_dev);
+    // WDG_KR_KERNEL=rank1: round 2's solver (one barrier per eliminated column); default: the blocked solver on the matrix pipe
+    static const bool rank1 = [] {
+        const char *e = getenv("WDG_KR_KERNEL");
+        return e && e[0] == 'r';
+    }();
+    if (rank1) hipLaunchKernelGGL(kr_solve_kernel, dim3(n_jobs), dim3(KR_THREADS), 0, wdg::as_stream(stream), jobs_dev);
+    else hipLaunchKernelGGL(kr_solve_blocked_kernel, dim3(n_jobs), dim3(K2_THREADS), 0, wdg::as_stream(stream), jobs_dev);
     return wdg::check_launch("kr_solve_kernel");
 }
 

@@ -1238,6 +1238,7 @@ class KrBatch:
         tab["correct_out"] = self.correct.data_ptr() + 4 * np.arange(n, dtype=np.int64)
         tab["flags_out"] = self.flags.data_ptr() + 4 * np.arange(n, dtype=np.int64)
         tab["ldk"], tab["n_train"], tab["n_val"], tab["n_classes"] = ldk, n_train, n_val, int(n_classes)
+        tab["reserved"] = int(os.environ.get("WDG_KR_ABLATE", "0"))  # timing-only diagnostics of the blocked solver; 0 = none
         self.table = torch.from_numpy(tab.view(np.uint8)).to(dev) if n else torch.empty(0, dtype=torch.uint8)
 
     def launch(self):
