@@ -83,7 +83,9 @@ def test_no_shipped_kernel_spills_vector_registers():
     # known and bounded: the two 64-column B-resident MFMA kernels sit at the 128-register cap of a
     # 1024-thread workgroup and spill a handful of registers outside their K loop's MFMA chain
     # ... and the kernel-regression solver parks a few registers around (not inside) the factorisation steps of a block
-    allowed = {"gemm_bres_kernelILi2E": 13, "mlp2_bres_kernelILi2E": 9, "kr_solve_kernel": 16}
+    # ... and the blocked solver (48 accumulator registers + the in-wave substitution) parks 9 outside its steps: the gather, the
+    # update's operand addresses and the predictions (tests read the per-phase count with scripts in DESIGN.md 4.8)
+    allowed = {"gemm_bres_kernelILi2E": 13, "mlp2_bres_kernelILi2E": 9, "kr_solve_kernel": 16, "kr_solve_blocked_kernel": 12}
     seen = 0
     for path in reports:
         name = None

@@ -587,8 +587,8 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
 //   then     back substitution block column by block column (the column's blocks go through LDS once more: the product with
 //            L^T sums over the lane index), predictions one wave per four validation rows.
 // Rank-deficient blocks: as in kr_solve_kernel (pivot test at n eps max K_ii / 64, one restart on K + n eps max K_ii / 8 I).
-constexpr int K2_THREADS = 1024, K2_WAVES = 16, K2_NB = 10, K2_SLOTS = 4, K2_PS = 36;
-static_assert(K2_NB * (K2_NB + 1) / 2 <= K2_WAVES * K2_SLOTS, "every block needs a register slot");
+constexpr int K2_THREADS = 1024, K2_WAVES = 16, K2_NB = 10, K2_SLOTS = 3, K2_PS = 36;
+static_assert(K2_NB * (K2_NB - 1) / 2 <= K2_WAVES * K2_SLOTS, "every block below the diagonal needs a register slot");
 
 __device__ __forceinline__ int k2_jmap(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ float k2_bcast(float v, int lane) {
@@ -609,61 +609,90 @@ __device__ __forceinline__ void k2_load_block(f32x16 &t, const float *img, int l
     }
 }
 
-// The in-wave substitution along a block's columns, lane = block row (both lane halves run the same rows): x_j = (a_j -
-// sum_{k < j} x_k L[j][k]) / L[j][j] for j = 0 .. 31, row j of L read from LDS at one address (broadcast).
+// The in-wave substitution along a block's columns: x_j = (a_j - sum_{k < j} x_k L[j][k]) / L[j][j], j = 0 .. 31, for the 32 rows of
+// a block at once.  Lane (i, h) works on row i and holds the entries k = 8 q + 4 h + e of x (the block's own register layout): the
+// two lane halves split every row's sum, each reads its half of row j of L from LDS (one address per half: broadcast) a whole
+// row AHEAD of the fmas that use it, and one v_permlane32_swap adds the halves.
 //   factor == false: L = the finished diagonal block (`ld`, 1 / l_jj in `dinv`): X L^T = A, the panel solve;
-//   factor == true : A IS the diagonal block: the same recurrence is its Cholesky factorisation row by row - x_j of lane j is the
-//                    pivot (broadcast with v_readlane), every lane's x_j / sqrt(pivot) is L[i][j], published to `ld` at once so
-//                    that row j + 1 can be read back in the next step.  Returns whether a pivot fell below `drop_below`.
-// `img` = the block's row-major image in LDS (input and output).
-__device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv, bool factor, int li, int lane, int rows_real,
-                                          float drop_below, float ridge) {
-    float x[32];
+//   factor == true : A IS the diagonal block (img == ld): the same recurrence is its Cholesky factorisation row by row - x_j of
+//                    lane j is the pivot (v_readlane), every lane's x_j / sqrt(pivot) is L[i][j], written to `ld` at once.  The
+//                    one entry of row j that the step before has only just produced, L[j][j - 1], comes from lane j's register
+//                    (v_readlane) instead of the prefetched row.  Returns whether a pivot fell below `drop_below`.
+__device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv, bool factor, int li, int h, int lane, int rows_real,
+                                              float drop_below, float ridge) {
+    float x[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(img + li * K2_PS + 4 * q);
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(img + li * K2_PS + 4 * h + 8 * q);
         x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
     }
+    const float *lh = ld + 4 * h;  // this half's entries of row j: lh[j * K2_PS + 8 q .. + 3]
+    const bool hi = h != 0;
     bool low_any = false;
+    // Two rows in flight: while row j is finished (add the halves, scale: a chain of dependent operations), the sums of row
+    // j + 1 over the entries k < j - independent of that chain - are issued between its links; only the term k = j waits for x_j.
+    float4 row_a[4], row_b[4];  // this half's entries of row j + 1 (in use) and of row j + 2 (arriving)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row_a[q] = row_b[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    row_a[0] = *reinterpret_cast<const float4 *>(lh + 1 * K2_PS);  // row 1: entry 0
+    float p0 = 0.f, p1 = 0.f;  // - sum_{k < j} x_k L[j][k] over this half's entries, for the row being finished
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        float v0 = x[j], v1 = 0.f;  // two partial sums: half the dependent chain
-#pragma unroll
-        for (int k8 = 0; k8 < j; k8 += 8) {  // row j of L eight entries at a time: the loads must not pile up in registers (64 of
-                                              // the 128 hold the wave's blocks, 32 hold x: a spill here is a memory round trip)
-            const float4 l0 = *reinterpret_cast<const float4 *>(ld + j * K2_PS + k8);  // (the same address in every lane)
-            float4 l1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k8 + 4 < j) l1 = *reinterpret_cast<const float4 *>(ld + j * K2_PS + k8 + 4);
-            v0 = fmaf(-x[k8], l0.x, v0);
-            if (k8 + 1 < j) v1 = fmaf(-x[k8 + 1], l0.y, v1);
-            if (k8 + 2 < j) v0 = fmaf(-x[k8 + 2], l0.z, v0);
-            if (k8 + 3 < j) v1 = fmaf(-x[k8 + 3], l0.w, v1);
-            if (k8 + 4 < j) v0 = fmaf(-x[k8 + 4], l1.x, v0);
-            if (k8 + 5 < j) v1 = fmaf(-x[k8 + 5], l1.y, v1);
-            if (k8 + 6 < j) v0 = fmaf(-x[k8 + 6], l1.z, v0);
-            if (k8 + 7 < j) v1 = fmaf(-x[k8 + 7], l1.w, v1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float v = v0 + v1;
-        float inv;
+        const int hj = (j >> 2) & 1, mj = 4 * (j >> 3) + (j & 3);  // the half and the register that hold entry j
+        // ---- finish row j
+        const float own = (hi == (hj != 0)) ? x[mj] : 0.f;
+        const float partial = own + (p0 + p1);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(partial), __float_as_uint(partial), false, false);
+        const float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // lower + upper half's partial, in both halves
+        float res;
         if (factor) {  // (uniform)
             float piv = k2_bcast(v, j);
             const bool low = !(piv > drop_below) && j < rows_real;  // (uniform; also catches NaN)
             low_any |= low;
             piv = low ? fmaxf(ridge, drop_below) : piv;
-            inv = __builtin_amdgcn_rsqf(piv);
+            float inv = __builtin_amdgcn_rsqf(piv);
             inv = inv * fmaf(-0.5f * piv * inv, inv, 1.5f);  // one Newton step: 1 / sqrt(piv) to within an ulp
-            const float lij = li == j ? piv * inv : (li > j ? v * inv : 0.f);
-            x[j] = lij;
-            ld[li * K2_PS + j] = lij;  // column j of L_kk (0 above the diagonal); both halves write the same value
+            res = li == j ? piv * inv : (li > j ? v * inv : 0.f);
+            if (!hi) ld[li * K2_PS + j] = res;  // column j of L_kk (0 above the diagonal)
             if (lane == 0) dinv[j] = inv;
         } else {
-            x[j] = v * dinv[j];
+            res = v * dinv[j];
         }
-    }
-    if (!factor && lane < 32) {
+        x[mj] = (hi == (hj != 0)) ? res : x[mj];
+        if (j + 1 == 32) break;
+        // ---- row j + 2 of L for the step after the next (behind this step's write of column j: fresh up to entry j)
+        if (j + 2 < 32) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(img + li * K2_PS + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+            for (int q = 0; q < 4; ++q)
+                if (8 * q < j + 2) row_b[q] = *reinterpret_cast<const float4 *>(lh + (j + 2) * K2_PS + 8 * q);
+        }
+        // ---- the sums of row j + 1 over the entries k <= j (row_a: read before column j existed - entry j of it is stale when
+        //      factoring and comes from lane j + 1's register instead)
+        p0 = p1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k0 = 8 * q + e, k1 = k0 + 4;  // the entry this register is in the lower / upper lane half
+                if (k0 > j) continue;                   // (compile-time: neither half has a term)
+                float l = e == 0 ? row_a[q].x : e == 1 ? row_a[q].y : e == 2 ? row_a[q].z : row_a[q].w;
+                if (k1 > j) l = hi ? 0.f : l;           // only the lower half's entry is <= j
+                if (k0 == j || k1 == j) {               // the entry that was written a moment ago
+                    const float fresh = factor ? k2_bcast(res, j + 1) : l;
+                    l = (hi == (k1 == j)) ? fresh : l;
+                }
+                if (e & 1) p1 = fmaf(-x[4 * q + e], l, p1);
+                else p0 = fmaf(-x[4 * q + e], l, p0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row_a[q] = row_b[q];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!factor) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(img + li * K2_PS + 4 * h + 8 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     }
     return low_any;
 }
@@ -710,15 +739,15 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     unsigned long long k2_prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, k2_last = __builtin_amdgcn_s_memtime();
 #endif
     const int nb = (nt + 31) >> 5;
-    const int n_blocks = nb * (nb + 1) / 2;
+    const int n_blocks = nb * (nb - 1) / 2;  // the blocks BELOW the diagonal live in registers; the diagonal blocks in LDS (LD)
     for (int i = tid; i < K2_NB * 32; i += K2_THREADS) tr_idx[i] = i < nt ? train[i] : -1;
-    if (tid < K2_WAVES * K2_SLOTS) {  // block `tid` of the enumeration: columns nb-1 .. 0, rows b .. nb-1 inside a column
-        int idx = tid, b = nb - 1;
-        while (b >= 0 && idx >= nb - b) {
-            idx -= nb - b;
+    if (tid < K2_WAVES * K2_SLOTS) {  // block `tid` of the enumeration: columns nb-2 .. 0, rows b+1 .. nb-1 inside a column
+        int idx = tid, b = nb - 2;
+        while (b >= 0 && idx >= nb - 1 - b) {
+            idx -= nb - 1 - b;
             --b;
         }
-        blk_a[tid] = static_cast<signed char>(b >= 0 ? b + idx : -1);
+        blk_a[tid] = static_cast<signed char>(b >= 0 ? b + 1 + idx : -1);
         blk_b[tid] = static_cast<signed char>(b);
     }
     if (tid == 0) correct = 0;
@@ -752,22 +781,28 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             al[i] = 0.f;
         }
         if (tid == 0) deficient = 0;
-#pragma unroll
-        for (int s = 0; s < K2_SLOTS; ++s) {
-            if (sa[s] < 0) continue;
+        auto gather_block = [&](int a, int b, f32x16 &t) {  // lane (i, h): A[32 a + i][32 b + jmap(h, r)] = K[tr[32 b + j]][tr[32 a + i]]
             int li = li_, h = h_;
             asm volatile("" : "+v"(li), "+v"(h));
-            const int gi = tr_idx[32 * sa[s] + li];  // the lane's row of the block = the COLUMN it reads (K is symmetric)
+            const int gi = tr_idx[32 * a + li];  // the lane's row of the block = the COLUMN it reads (K is symmetric)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = k2_jmap(h, r), gj = tr_idx[32 * sb[s] + j];
-                const bool diag = sa[s] == sb[s] && li == j;
+                const int j = k2_jmap(h, r), gj = tr_idx[32 * b + j];
+                const bool diag = a == b && li == j;
                 float v = (gi >= 0 && gj >= 0 && !(ablate & 1)) ? K[static_cast<int64_t>(gj) * ldk + gi] : (diag ? 1.f : 0.f);
                 if (diag && gi >= 0) v += ridge;
-                acc[s][r] = v;
+                t[r] = v;
                 if (r == 7) __builtin_amdgcn_sched_barrier(0);  // (eight gathers and their addresses in flight at a time)
             }
             __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int s = 0; s < K2_SLOTS; ++s)
+            if (sa[s] >= 0) gather_block(sa[s], sb[s], acc[s]);
+        if (wave < nb) {  // the diagonal blocks: straight into their LDS images
+            f32x16 t;
+            gather_block(wave, wave, t);
+            k2_store_block(t, &LD[wave * 32 * K2_PS], li_, h_);
         }
         __syncthreads();
         K2_T(1);  // right-hand sides + gather
@@ -779,22 +814,30 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             // and reloads each one from scratch memory, a global-memory round trip, in front of the LDS access that needs it)
             int li = li_, h = h_;
             asm volatile("" : "+v"(li), "+v"(h));
-            // the column's blocks -> LDS, row-major: the diagonal block into its slot of LD, block (a, kb) into P[a - kb - 1]
-            int role = -1;  // this wave's block of column kb: 0 = the diagonal block, a - kb for block (a, kb), -1 = none
+            // the column's blocks below the diagonal -> LDS, row-major: block (a, kb) into P[a - kb - 1]; the diagonal block is in
+            // LD already.  role: 0 = this wave factors the diagonal block (the wave BEFORE the column's first block in the deal:
+            // it holds none of the column's blocks), a - kb = it holds block (a, kb), -1 = neither
+            int role = -1;
 #pragma unroll
             for (int s = 0; s < K2_SLOTS; ++s) {
                 if (sb[s] != kb) continue;  // (wave-uniform; a column's blocks sit on distinct waves)
                 role = sa[s] - kb;
-                k2_store_block(acc[s], role == 0 ? &LD[kb * 32 * K2_PS] : &P[(role - 1) * 32 * K2_PS], li, h);
+                k2_store_block(acc[s], &P[(role - 1) * 32 * K2_PS], li, h);
+            }
+            {
+                // first block of column kb in the enumeration: sum over the columns after it
+                const int first = (nb - 1 - kb) * (nb - 2 - kb) / 2;
+                if (wave == ((first + K2_WAVES - 1) & (K2_WAVES - 1))) role = 0;
             }
             // (1) the diagonal block's wave factors it alone; (2) the column's other blocks: X L_kk^T = A, while the diagonal
             //     block's wave solves z_kb = L_kk^-1 y_kb.  One copy of the substitution in the code: two passes of a rolled loop.
             bool restart = false;
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
+                for (int rep = 0; rep < ((ablate & 16) ? 3 : 1); ++rep)  // (timing diagnostics: the routine three times over)
                 if ((pass == 0 && role == 0) || (pass == 1 && role > 0)) {  // (wave-uniform)
                     float *img = pass == 0 ? &LD[kb * 32 * K2_PS] : &P[(role - 1) * 32 * K2_PS];
-                    if (k2_substitute(img, &LD[kb * 32 * K2_PS], &Dinv[kb * 32], pass == 0, li, lane, nt - 32 * kb, drop_below, ridge) && lane == 0)
+                    if (k2_substitute(img, &LD[kb * 32 * K2_PS], &Dinv[kb * 32], pass == 0, li, h, lane, nt - 32 * kb, drop_below, ridge) && lane == 0)
                         deficient = 1;
                 }
                 if (pass == 0) {
@@ -867,6 +910,24 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
 #pragma unroll
                         for (int c = 0; c < KR_MAX_C; ++c) y[c] -= sum[c];
                     }
+                }
+            }
+            {  // the diagonal blocks (a, a), a > kb, live in LDS: LD[a] -= L[a, kb] L[a, kb]^T, dealt to the waves from the top (the
+               // deal of the register blocks fills the waves from the bottom)
+                const int da = kb + 1 + (K2_WAVES - 1 - wave);
+                if (da < nb) {  // (wave-uniform)
+                    f32x16 t;
+                    k2_load_block(t, &LD[da * 32 * K2_PS], li, h);
+                    const float *pa = &P[((da - kb - 1) * 32 + li) * K2_PS + 4 * h];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 va = *reinterpret_cast<const float4 *>(pa + 8 * q);
+                        t = __builtin_amdgcn_mfma_f32_32x32x2f32(-va.x, va.x, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x2f32(-va.y, va.y, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x2f32(-va.z, va.z, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x2f32(-va.w, va.w, t, 0, 0, 0);
+                    }
+                    k2_store_block(t, &LD[da * 32 * K2_PS], li, h);
                 }
             }
             K2_T(6);
