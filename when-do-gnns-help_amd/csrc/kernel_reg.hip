@@ -855,20 +855,25 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 for (int c = 0; c < KR_MAX_C; ++c) y[c] = zs[(32 * kb + li) * KR_MAX_C + c];
                 const float *lrow = &LD[(kb * 32 + li) * K2_PS];
                 float inv_n = Dinv[kb * 32], lik_n = lrow[0];
+                float mine[KR_MAX_C];  // z of this lane's row (caught when its step comes: no LDS store inside the loop, whose
+                                       // wait would also cover the loop's own prefetches)
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) mine[c] = 0.f;
 #pragma unroll 1
                 for (int k = 0; k < 32; ++k) {  // (rolled: the loop body is the code; the next step's two LDS values are in flight)
                     const float inv = inv_n, lik = li > k ? lik_n : 0.f;
                     inv_n = Dinv[kb * 32 + min(k + 1, 31)], lik_n = lrow[min(k + 1, 31)];
-                    float zk[KR_MAX_C];
+                    const bool me = li == k;
 #pragma unroll
                     for (int c = 0; c < KR_MAX_C; ++c) {
-                        zk[c] = k2_bcast(y[c], k) * inv;
-                        y[c] = fmaf(-lik, zk[c], y[c]);
+                        const float zk = k2_bcast(y[c], k) * inv;
+                        y[c] = fmaf(-lik, zk, y[c]);
+                        mine[c] = me ? zk : mine[c];
                     }
-                    if (lane == 0) {
-                        *reinterpret_cast<float4 *>(&zs[(32 * kb + k) * KR_MAX_C]) = make_float4(zk[0], zk[1], zk[2], zk[3]);
-                        *reinterpret_cast<float4 *>(&zs[(32 * kb + k) * KR_MAX_C + 4]) = make_float4(zk[4], zk[5], zk[6], zk[7]);
-                    }
+                }
+                if (h == 0) {
+                    *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C]) = make_float4(mine[0], mine[1], mine[2], mine[3]);
+                    *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C + 4]) = make_float4(mine[4], mine[5], mine[6], mine[7]);
                 }
             }
             K2_T(4);
@@ -984,65 +989,62 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             }
             K2_T(13);
             float inv_n = Dinv[kb * 32 + 31], lkj_n = LD[(kb * 32 + 31) * K2_PS + li];
+            float mine[KR_MAX_C];  // alpha of this lane's row (caught when its step comes; one store after the loop)
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) mine[c] = 0.f;
 #pragma unroll 1
             for (int k = 31; k >= 0; --k) {  // (rolled; the next step's two LDS values are in flight)
                 const float inv = inv_n, lkj = li < k ? lkj_n : 0.f;
                 inv_n = Dinv[kb * 32 + max(k - 1, 0)], lkj_n = LD[(kb * 32 + max(k - 1, 0)) * K2_PS + li];
-                float ak[KR_MAX_C];
+                const bool me = li == k;
 #pragma unroll
                 for (int c = 0; c < KR_MAX_C; ++c) {
-                    ak[c] = k2_bcast(v[c], k) * inv;
-                    v[c] = fmaf(-lkj, ak[c], v[c]);
+                    const float ak = k2_bcast(v[c], k) * inv;
+                    v[c] = fmaf(-lkj, ak, v[c]);
+                    mine[c] = me ? ak : mine[c];
                 }
-                if (lane == 0) {
-                    const bool real = 32 * kb + k < nt;
-                    *reinterpret_cast<float4 *>(&al[(32 * kb + k) * KR_MAX_C]) = real ? make_float4(ak[0], ak[1], ak[2], ak[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4 *>(&al[(32 * kb + k) * KR_MAX_C + 4]) = real ? make_float4(ak[4], ak[5], ak[6], ak[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            }
+            if (h == 0) {
+                const bool real = 32 * kb + li < nt;
+                *reinterpret_cast<float4 *>(&al[(32 * kb + li) * KR_MAX_C]) = real ? make_float4(mine[0], mine[1], mine[2], mine[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(&al[(32 * kb + li) * KR_MAX_C + 4]) = real ? make_float4(mine[4], mine[5], mine[6], mine[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         __syncthreads();
         K2_T(8);
     }
 
-    // ---- predictions: a wave takes four validation rows at a time (twenty gathers in flight), the lanes split the train rows
-    //      (ascending columns of one row of K); sums in a fixed order
+    // ---- predictions: sixteen lanes per validation row (four rows per wave at a time), the lanes of a row split the train rows
+    //      (ascending columns of one row of K); a row's sum: its lanes' partial sums added by a four-step butterfly - fixed order
     int hits = 0;
-    for (int v0 = 4 * wave; v0 < ((ablate & 8) ? 0 : nv); v0 += 4 * K2_WAVES) {
-        float p[4][KR_MAX_C];
-        int gv[4];
+    {
+        const int g = lane >> 4, gl = lane & 15;
+        for (int v0 = 4 * wave; v0 < ((ablate & 8) ? 0 : nv); v0 += 4 * K2_WAVES) {
+            const int v = v0 + g, gv = val[min(v, nv - 1)];
+            const global_ptr<const float> krow = K + static_cast<int64_t>(gv) * ldk;
+            float p[KR_MAX_C];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            gv[u] = val[min(v0 + u, nv - 1)];
-#pragma unroll
-            for (int c = 0; c < KR_MAX_C; ++c) p[u][c] = 0.f;
-        }
-        for (int t = lane; t < nt; t += 64) {
-            const int col = tr_idx[t];
-            float kv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) kv[u] = K[static_cast<int64_t>(gv[u]) * ldk + col];
-            const float4 a0 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C]), a1 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C + 4]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                p[u][0] = fmaf(kv[u], a0.x, p[u][0]), p[u][1] = fmaf(kv[u], a0.y, p[u][1]), p[u][2] = fmaf(kv[u], a0.z, p[u][2]), p[u][3] = fmaf(kv[u], a0.w, p[u][3]);
-                p[u][4] = fmaf(kv[u], a1.x, p[u][4]), p[u][5] = fmaf(kv[u], a1.y, p[u][5]), p[u][6] = fmaf(kv[u], a1.z, p[u][6]), p[u][7] = fmaf(kv[u], a1.w, p[u][7]);
+            for (int c = 0; c < KR_MAX_C; ++c) p[c] = 0.f;
+#pragma unroll 4
+            for (int t = gl; t < nt; t += 16) {
+                const float kv = krow[tr_idx[t]];
+                const float4 a0 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C]), a1 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C + 4]);
+                p[0] = fmaf(kv, a0.x, p[0]), p[1] = fmaf(kv, a0.y, p[1]), p[2] = fmaf(kv, a0.z, p[2]), p[3] = fmaf(kv, a0.w, p[3]);
+                p[4] = fmaf(kv, a1.x, p[4]), p[5] = fmaf(kv, a1.y, p[5]), p[6] = fmaf(kv, a1.z, p[6]), p[7] = fmaf(kv, a1.w, p[7]);
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int c = 0; c < KR_MAX_C; ++c)
-                for (int o = 32; o > 0; o >>= 1) p[u][c] += __shfl_xor(p[u][c], o);  // (butterfly: every lane ends with the same sum)
+                for (int o = 8; o > 0; o >>= 1) p[c] += __shfl_xor(p[c], o);  // (inside the row's 16 lanes: every lane ends with the sum)
             int best = 0;
             float bv = -3.4e38f;
             for (int c = 0; c < C; ++c)
-                if (p[u][c] > bv) {  // first maximum, like torch.argmax
-                    bv = p[u][c];
+                if (p[c] > bv) {  // first maximum, like torch.argmax
+                    bv = p[c];
                     best = c;
                 }
-            hits += (v0 + u < nv) && best == labels[gv[u]];
+            hits += (gl == 0 && v < nv && best == labels[gv]) ? 1 : 0;
         }
+        for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
     }
     if (lane == 0 && hits) atomicAdd(&correct, hits);
     __syncthreads();
