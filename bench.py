@@ -294,13 +294,15 @@ def roofline_of(args, m):
 
 def workload_text(args, m, world):
     batch = m["batch"]
-    n_launches = 4 + (batch.spmm_las is not None) + (1 if batch.gcn["mlp"] is not None else 2)
+    n_launches = 3 + (not batch.derive_counts) + (batch.spmm_las is not None) + (1 if batch.gcn["mlp"] is not None else 2)
     return (f"synthetic homophily sweep (data_synthesis/{m['k'] * 400}-equivalent): "
             + (f"{len(m['h_levels'])} h-levels x {m['seeds']} seeds = {len(m['h_levels']) * m['seeds']} graphs/step sharded by job over "
                f"{world} GPU(s) ({len(m['mine'])} on rank 0), " if args.scaling == "strong" else
                f"{len(m['h_levels'])} h-levels x {m['seeds']} seeds = {len(m['mine'])} graphs/GPU/step, ") +
             f"N={args.nodes} nodes, k={m['k']}, F={args.feat} fp32, C=5; step = batched "
-            f"D^-1(A+I)X aggregation + edge/label statistics + label aggregation & LAS + "
+            f"D^-1(A+I)X aggregation + edge/label statistics ("
+            + ("derived from the label columns inside the LAS launch" if batch.derive_counts else "integer pass over the edges")
+            + ") + label aggregation & LAS + "
             f"GCN-2 forward (hidden 64, per-graph weights), {n_launches} launches"
             + (f"; the C one-hot label columns of the LAS metric ride in the feature aggregation "
                f"(F_agg={batch.agg_feat})" if batch.spmm_las is None else ""))

@@ -423,7 +423,18 @@ typedef struct wdg_las_job {
     void *workspace;      /* wdg_las_workspace_bytes(n, F, C) bytes, private to this job */
     int64_t ldh;
     int32_t n, F, C, reserved;
+    /* Optional: the integer counters of wdg_edge_label_stats for the SAME graph, derived from H instead of a second pass over
+     * the edges.  Valid when H = diag(row_scale) P onehot(labels) (F == C, rows == NULL) for the 0/1 pattern P the counters
+     * describe, P holds exactly one diagonal entry per row (A + I), every label lies in [0, C) and the launch takes the fused
+     * one-workgroup path (wdg_las_fused_eligible): then P onehot = H / row_scale holds every node's neighbour-class counts -
+     * exact integers after rounding (< 2^22 per entry) - and totals / compat / classdeg / the row arrays follow from an
+     * O(n C) pass over them.  counts->rowptr supplies |P_u|; counts->col is not read; the outputs are
+     * written, not accumulated (no zeroing needed).  NULL: nothing extra. */
+    const struct wdg_stats_job *counts;
+    const float *row_scale;
 } wdg_las_job;
+/* 1 when wdg_las_batched_f32 / wdg_las_f32 take the fused one-workgroup-per-problem kernel for these sizes (needed by `counts`) */
+int wdg_las_fused_eligible(int32_t max_n, int32_t max_F, int32_t max_C);
 int wdg_las_batched_f32(const wdg_las_job *jobs_dev, int32_t n_jobs, int32_t max_n, int32_t max_F, int32_t max_C,
                         wdg_stream_t stream);
 

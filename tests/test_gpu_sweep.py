@@ -340,3 +340,27 @@ def test_empty_shard_steps_and_gathers():
     assert tuple(sb.full_metrics().shape) == (0, len(sweep.METRIC_NAMES))
     assert [tuple(t.shape) for t in sweep.gather_results(rows, rows.device)] == [(0, sweep.STEP_METRICS)]
     assert sb.spmm_algorithmic_bytes() == 0 and sb.spmm_unique_bytes() == 0
+
+
+@pytest.mark.parametrize("k,seeds", [(2, 10), (10, 5)])
+def test_counters_derived_from_the_label_columns_equal_the_edge_pass(k, seeds, monkeypatch):
+    """The C2 / C3 shards at full size: every integer counter of the step (totals, compatibility histogram, class degrees,
+    the three per-row arrays) derived from H = D^-1 (A + I) onehot inside the LAS launch is bit for bit what
+    wdg_edge_label_stats_batched counts over the edges; the step then has one launch fewer."""
+    from wdg_amd import sweep, synth
+    jobs = sweep.make_jobs(synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10, range(seeds), k=k)
+    out = {}
+    for derive in ("1", "0"):
+        monkeypatch.setenv("WDG_SWEEP_DERIVE_COUNTS", derive)
+        sb = sweep.SweepBatch(jobs, n_feat=64, gcn_hidden=0)
+        assert sb.derive_counts == (derive == "1")
+        sb.stats.counters.fill_(-7)  # (the derived path writes, it does not accumulate: stale values must not survive)
+        sb.stats.rows.fill_(-7)
+        sb.step()
+        sb.step()
+        torch.cuda.synchronize()
+        out[derive] = (sb.stats.totals.clone(), sb.stats.compat.clone(), sb.stats.classdeg.clone(), sb.stats.rows.clone(), sb.results().clone(),
+                       sb.las.counts.clone())
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b)
+    assert int(out["1"][0][:, 0].sum()) == sum(j.nnz for j in jobs)

@@ -115,6 +115,7 @@ SIGNATURES = {
     "wdg_gemm_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
     "wdg_mlp2_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_las_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_las_fused_eligible": (c_int, [c_int32, c_int32, c_int32]),
     "wdg_gram_map_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "wdg_kernel_regress_max_train": (c_int32, []),
     "wdg_edge_gram_workspace_bytes": (c_size_t, [c_int32, c_int32]),
@@ -160,7 +161,7 @@ class LasJob(ctypes.Structure):
     """mirror of `wdg_las_job` (include/wdg.h)"""
     _fields_ = [("H", c_void_p), ("labels", c_void_p), ("rows", c_void_p), ("W_out", c_void_p), ("count_out", c_void_p),
                 ("workspace", c_void_p), ("ldh", c_int64), ("n", c_int32), ("F", c_int32), ("C", c_int32),
-                ("reserved", c_int32)]
+                ("reserved", c_int32), ("counts", c_void_p), ("row_scale", c_void_p)]
 
 
 class GemmJob(ctypes.Structure):

@@ -50,6 +50,8 @@ struct LasView {
     void *workspace;
     int64_t ldh;
     int32_t n, F, C;
+    const wdg_stats_job *counts;
+    global_ptr<const float> row_scale;
 };
 __device__ __forceinline__ LasView las_view(const wdg_las_job *jobs, const wdg_las_job &inline_job, int id) {
     const desc_ptr<wdg_las_job> d = descriptor(jobs, inline_job, id);
@@ -57,6 +59,7 @@ __device__ __forceinline__ LasView las_view(const wdg_las_job *jobs, const wdg_l
     v.H = to_global(d->H); v.labels = to_global(d->labels); v.rows = to_global(d->rows);
     v.W_out = to_global(d->W_out); v.count_out = to_global(d->count_out);
     v.workspace = d->workspace; v.ldh = d->ldh; v.n = d->n; v.F = d->F; v.C = d->C;
+    v.counts = d->counts; v.row_scale = to_global(d->row_scale);
     return v;
 }
 struct LasWsView {
@@ -249,6 +252,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
     __shared__ int cnt_partial[(FUSED_LDS_DOUBLES / SMALL_F) + 64];  // [n_tiles][C]
     __shared__ long long cls_cnt[SMALL_F];
     __shared__ int counts[2];
+    __shared__ int st_hist[SMALL_F * SMALL_F];      // derived counters (job.counts): compat, class degrees, totals
+    __shared__ long long st_cdeg[SMALL_F];
+    __shared__ int st_tot[6];
     const LasView job = las_view(jobs, inline_job, blockIdx.x);
     const int n = job.n, F = job.F, C = job.C;
     if (n <= 0 || C <= 0) return;
@@ -256,6 +262,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *M = partial + static_cast<size_t>(n_tiles) * C * F;
     if (threadIdx.x < 2) counts[threadIdx.x] = 0;
+    const bool derive = job.counts != nullptr && F == C && !job.rows && job.row_scale;
+    if (derive) {
+        for (int i = threadIdx.x; i < C * C; i += FUSED_THREADS) st_hist[i] = 0;
+        if (threadIdx.x < C) st_cdeg[threadIdx.x] = 0;
+        if (threadIdx.x < 6) st_tot[threadIdx.x] = 0;
+    }
     // step 1 (las_middle_partial_small): partial[t][c][f], cnt_partial[t][c]; wave w takes tiles w, w + 16, ...
     for (int tile = wave; tile < n_tiles; tile += FUSED_THREADS / 64) {
         float h[TILE_ROWS / 64][SMALL_F];
@@ -332,6 +344,34 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
             const double ratio = (own / ny) / ((tot - own) / (static_cast<double>(n) - ny));
             soft = !(ratio != ratio) && ratio >= 1.0;
             hard = best_c == y;
+            if (derive && y >= 0 && y < C) {
+                // h = row_scale_u * (this node's neighbour-class counts over the pattern, its own loop included): exact integers
+                // after rounding.  The counters of wdg_edge_label_stats from them: |P_u| from rowptr, the
+                // loop taken out of the non-loop counts, row y of the compatibility histogram.
+                const desc_ptr<wdg_stats_job> sj = (desc_ptr<wdg_stats_job>)job.counts;
+                const global_ptr<const int32_t> rp = to_global(sj->rowptr);
+                const int nn = rp[r + 1] - rp[r];
+                const float scale = 1.f / job.row_scale[r];
+                int lab = 0, own_cnt = 0;
+                for (int c = 0; c < C; ++c) {
+                    const int cnt = static_cast<int>(rintf(h[c] * scale));
+                    lab += cnt;
+                    if (c == y) own_cnt = cnt;
+                    const int off_loop = cnt - (c == y ? 1 : 0);
+                    if (off_loop) atomicAdd(&st_hist[y * C + c], off_loop);
+                }
+                const global_ptr<int32_t> rn = to_global(sj->row_nnz), rs = to_global(sj->row_nnz_noself), rm = to_global(sj->row_match_noself);
+                if (rn) rn[r] = nn;
+                if (rs) rs[r] = nn - 1;
+                if (rm) rm[r] = own_cnt - 1;
+                atomicAdd(&st_tot[0], nn);
+                atomicAdd(&st_tot[1], own_cnt);
+                atomicAdd(&st_tot[2], lab);
+                atomicAdd(&st_tot[3], own_cnt);
+                atomicAdd(&st_tot[4], nn - 1);
+                atomicAdd(&st_tot[5], own_cnt - 1);
+                atomicAdd(reinterpret_cast<u64 *>(&st_cdeg[y]), static_cast<u64>(static_cast<long long>(nn) - 1));
+            }
         }
         const unsigned long long ms = __ballot(soft), mh = __ballot(hard);
         if (lane == 0) {
@@ -341,6 +381,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
     }
     __syncthreads();
     if (threadIdx.x < 2) job.count_out[threadIdx.x] = counts[threadIdx.x];
+    if (derive) {  // one workgroup per graph: plain stores, nothing to zero beforehand
+        const desc_ptr<wdg_stats_job> sj = (desc_ptr<wdg_stats_job>)job.counts;
+        const global_ptr<int64_t> totals = to_global(sj->totals), compat = to_global(sj->compat), classdeg = to_global(sj->classdeg);
+        if (threadIdx.x < 6) totals[threadIdx.x] = st_tot[threadIdx.x];
+        for (int i = threadIdx.x; i < C * C; i += FUSED_THREADS) compat[i] = st_hist[i];
+        if (threadIdx.x < C) classdeg[threadIdx.x] = st_cdeg[threadIdx.x];
+    }
+}
+
+bool las_fused(int max_n, int max_F, int max_C) {
+    const int n_tiles = static_cast<int>(ceil_div(max_n, TILE_ROWS));
+    return max_F <= SMALL_F && max_C <= SMALL_F && max_F > 0 &&
+           (static_cast<int64_t>(n_tiles) + 1) * max_C * max_F <= FUSED_LDS_DOUBLES && n_tiles * max_C <= FUSED_LDS_DOUBLES / SMALL_F;
 }
 
 int launch_las(const wdg_las_job *jobs, const wdg_las_job &inl, int n_jobs, int max_n, int max_F, int max_C, hipStream_t st) {
@@ -348,8 +401,7 @@ int launch_las(const wdg_las_job *jobs, const wdg_las_job &inl, int n_jobs, int 
     const int fchunks = static_cast<int>(ceil_div(max_F > 0 ? max_F : 1, 64));
     const int cf = max_C * (max_F > 0 ? max_F : 1);
     const bool small = max_F <= SMALL_F;
-    if (small && max_C <= SMALL_F && max_F > 0 &&
-        (static_cast<int64_t>(n_tiles) + 1) * max_C * max_F <= FUSED_LDS_DOUBLES && n_tiles * max_C <= FUSED_LDS_DOUBLES / SMALL_F) {
+    if (las_fused(max_n, max_F, max_C)) {
         hipLaunchKernelGGL(las_small_fused, dim3(n_jobs), dim3(FUSED_THREADS), 0, st, jobs, inl);
         return check_launch("las_small_fused");
     }
@@ -365,6 +417,8 @@ int launch_las(const wdg_las_job *jobs, const wdg_las_job &inl, int n_jobs, int 
 }  // namespace
 
 extern "C" {
+
+int wdg_las_fused_eligible(int32_t max_n, int32_t max_F, int32_t max_C) { return las_fused(max_n, max_F, max_C) ? 1 : 0; }
 
 size_t wdg_las_workspace_bytes(int32_t n, int32_t F, int32_t C) {
     return las_layout(static_cast<int>(wdg::ceil_div(n > 0 ? n : 1, TILE_ROWS)), F, C, nullptr, nullptr) + 512;

@@ -977,10 +977,14 @@ class StatsBatch:
 class LasBatch:
     """Job table for wdg_las_batched_f32: soft / hard LAS counts of many graphs in one launch (3 kernels)."""
 
-    def __init__(self, entries, n_classes):
-        """entries: list of (H [n,F] fp32 device, labels int32 device [n])."""
+    def __init__(self, entries, n_classes, counts=None, row_scales=None):
+        """entries: list of (H [n,F] fp32 device, labels int32 device [n]).
+        counts (a StatsBatch over the same graphs) + row_scales (each graph's D^-1 coefficients): the launch also derives that
+        batch's integer counters from H = D^-1 (A + I) onehot(labels) - every node's neighbour-class counts ride in H already -
+        instead of a second pass over the edges (include/wdg.h, wdg_las_job.counts; needs the fused one-workgroup path:
+        self.derives_counts tells whether it applies)."""
         dev = require_gpu()
-        self.keep = entries
+        self.keep = (entries, counts, row_scales)
         self.n_jobs, self.c = len(entries), int(n_classes)
         self.counts = torch.zeros((self.n_jobs, 2), dtype=torch.int64, device=dev)
         self.n = torch.tensor([h.shape[0] for h, _ in entries], dtype=torch.float32, device=dev)
@@ -994,6 +998,14 @@ class LasBatch:
             job.count_out, job.workspace = self.counts[i].data_ptr(), self.ws.data_ptr() + int(offs[i])
             job.ldh, job.n, job.F, job.C = _ld(h), h.shape[0], h.shape[1], self.c
             self.max_n, self.max_f = max(self.max_n, h.shape[0]), max(self.max_f, h.shape[1])
+        self.derives_counts = bool(counts is not None and row_scales is not None and self.n_jobs and counts.n_jobs == self.n_jobs
+                                   and all(h.shape[1] == self.c for h, _ in entries)
+                                   and lib.wdg_las_fused_eligible(self.max_n, self.max_f, self.c))
+        if self.derives_counts:
+            sj = ctypes.sizeof(StatsJob)
+            for i, job in enumerate(arr):
+                job.counts = counts.table.data_ptr() + i * sj
+                job.row_scale = row_scales[i].data_ptr()
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
         self.table = host.to(dev)
 

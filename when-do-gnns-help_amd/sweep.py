@@ -255,7 +255,14 @@ class SweepBatch:
                 self.h_las.append(torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev))
                 las_entries.append((self.graphs[len(las_entries)], onehot, self.h_las[-1]))
             self.spmm_las = ops.SpmmBatch([(g, z, h, d, scale(d), False) for (g, z, h), d in zip(las_entries, self.dinv)])
-        self.las = ops.LasBatch(list(zip(self.h_las, self.labels)), n_classes)
+        # the integer counters of the step (edge / node / class homophily, ...) ride in the label columns as well: H = D^-1 (A + I)
+        # onehot holds every node's neighbour-class counts, so the LAS launch derives them in its per-row pass and the separate
+        # pass over the edges (wdg_edge_label_stats_batched, 62 us beside nothing when there is no GCN chain) leaves the step.
+        # Random-walk normalisation only (a column scale would mix the counts); WDG_SWEEP_DERIVE_COUNTS=0 keeps the edge pass.
+        derive = ride and not symmetric and os.environ.get("WDG_SWEEP_DERIVE_COUNTS", "1") != "0"
+        self.las = ops.LasBatch(list(zip(self.h_las, self.labels)), n_classes, counts=self.stats if derive else None,
+                                row_scales=self.dinv if derive else None)
+        self.derive_counts = self.las.derives_counts
 
         # GCN-2 forward (build-defined model, models.py): logits = A_hat relu((A_hat X) W0) W1, every job its own weights
         self.gcn = None
@@ -358,7 +365,8 @@ class SweepBatch:
             if self.side2 is not None:
                 self.side2.wait_event(self._fork)
                 with torch.cuda.stream(self.side):
-                    self.stats.launch()
+                    if not self.derive_counts:
+                        self.stats.launch()
                 with torch.cuda.stream(self.side2):
                     if self.spmm_las is not None:
                         self.spmm_las.launch()
@@ -388,6 +396,9 @@ class SweepBatch:
         return graph.replay
 
     def _metric_chain(self):
+        if self.derive_counts:
+            self.las.launch()       # soft / hard LAS counts + the integer counters, derived from the label columns of Y
+            return
         # LAS first: its 100 workgroups of 1024 threads + 51 KiB of LDS need whole free CUs, which the 1 600 small
         # workgroups of the statistics kernel would otherwise occupy for as long as that kernel crawls beside the GEMM
         self.stats.zero()           # (the counters' memset, ahead of LAS instead of between the two kernels)
