@@ -449,6 +449,14 @@ int wdg_las_batched_f32(const wdg_las_job *jobs_dev, int32_t n_jobs, int32_t max
  */
 int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, int act,
                  float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, wdg_stream_t stream);
+/*
+ * The same product for a classifier-sized N <= 8 and any K (the SGC-1 head X W: Cora 2708 x 1433 x 7): bound by the read of A,
+ * so the rows are spread over the whole chip (8 rows per workgroup, 16 lanes per row splitting K, B in LDS) instead of 128-row
+ * MFMA tiles.  Summation order: per lane k = l, l + 16, ... ascending, then a fixed butterfly over the row's 16 lanes - bitwise
+ * reproducible, within fp32 rounding of wdg_gemm_f32's k-ordered chain (not bit-identical to it).  B is [K, N] (no transb).
+ */
+int wdg_gemm_skinny_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int act, float *C,
+                        int64_t ldc, int32_t M, int32_t N, int32_t K, wdg_stream_t stream);
 
 /* Many independent products in one launch (every graph of a sweep batch with its own weights); B is [K,N]. */
 typedef struct wdg_gemm_job {

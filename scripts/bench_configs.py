@@ -2,7 +2,10 @@
 """One JSON line per BASELINE.json config (C1..C5): the aggregation launch of that config timed with HIP events on the
 stream it runs on, priced by SURVEY 8(d)'s algorithmic bytes (rowptr + col + dinv + X read once + Y written once).
 
-    python3 scripts/bench_configs.py [--out profiles/r02_configs.jsonl] [--reps 30]
+    python3 scripts/bench_configs.py [--out profiles/r03_configs.jsonl] [--reps 30] [--only C1,C1m,...]
+Lines tagged C1m / C4m / C5m time the config's STATED workload (BASELINE.json configs[0], [3], [4]): SGC-1 forward in both
+association orders, GCN-2 forward, the aggregation-homophily metric - leg by leg, each leg against its own roofline (the
+transform X W0 against the fp32 matrix peak, everything else against HBM).  C2-literal / C3-literal: N = 800 / 4000 nodes.
 
 C1  Cora (real topology + real features, tests/golden/real_cora.npz), SGC-1 forward: D^-1/2 (A+I) D^-1/2 X, then X W
 C2  synthetic N=2000 k=2, 10 h-levels x 10 seeds as one batched launch (the `800` set; bench.py --k 2 --seeds 10)
@@ -117,6 +120,157 @@ def c4(name, f, reps):
                         f"F={f} synthetic fp32 features, D^-1/2 (A+I) D^-1/2 X", g, x, reps)
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = the fp32 vector rate
+
+
+def leg(name, us, bound, work, peak, unit, **extra):
+    """one leg of a config's forward pass: `work` = algorithmic bytes (hbm) or flops (mfma) of the launch"""
+    achieved = work / (us * 1e-6) / (1e9 if bound == "hbm" else 1e12)
+    return {"leg": name, "us": us, "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                                                 "traffic": None}, **extra}
+
+
+def sgc1_lines(config, what, g, x, n_classes, symmetric, reps):
+    """SGC-1 forward in both association orders (models.SGC1): (A_hat X) W - what training caches - and A_hat (X W), what a
+    one-shot inference takes; each leg timed on its own and priced against its own roofline"""
+    import torch
+    from wdg_amd import models, ops
+    adj = models.NormAdj(g, symmetric=symmetric, add_self_loops=False)
+    n, f, e = g.n_rows, x.shape[1], g.nnz
+    sgc = models.SGC1(f, n_classes).cuda().eval()
+    w = sgc.weight.detach()
+    rs, cs = adj.row_scale, adj.col_scale
+    out = []
+    with torch.no_grad():
+        y = ops.spmm(g, x, row_scale=rs, col_scale=cs)
+        us_agg, _ = timed(lambda: ops.spmm(g, x, row_scale=rs, col_scale=cs, out=y), reps)
+        us_head, _ = timed(lambda: ops.gemm_skinny(y, w), reps)
+        us_head_mfma, _ = timed(lambda: ops.gemm(y, w), reps)
+        us_all, _ = timed(lambda: sgc(adj, x, order="agg_first"), reps)
+        agg_bytes = 4 * (n + 1) + 4 * e + 4 * n + x.element_size() * n * f + 4 * n * f
+        gemm_bytes = 4 * (n * f + f * n_classes + n * n_classes)
+        out.append({"config": config, "workload": f"{what}: SGC-1 forward (A_hat X) W, F={f} -> C={n_classes}", "forward_us": us_all,
+                    "legs": [leg("aggregation F=%d" % f, us_agg, "hbm", agg_bytes, HBM_PEAK_GBS, "GB/s"),
+                             leg("head (skinny product)", us_head, "hbm", gemm_bytes, HBM_PEAK_GBS, "GB/s", mfma_tile_kernel_us=us_head_mfma)]})
+        sgc._cache = None
+        z = ops.gemm_skinny(x, w)
+        us_head2, _ = timed(lambda: ops.gemm_skinny(x, w), reps)
+        yz = ops.spmm(g, z, row_scale=rs, col_scale=cs)
+        us_agg2, _ = timed(lambda: ops.spmm(g, z, row_scale=rs, col_scale=cs, out=yz), reps)
+
+        def head_first():
+            sgc._cache = None
+            return sgc(adj, x)
+        us_all2, _ = timed(head_first, reps)
+        agg2_bytes = 4 * (n + 1) + 4 * e + 4 * n + 4 * n * n_classes * 2
+        out.append({"config": config, "workload": f"{what}: SGC-1 forward A_hat (X W) (inference order), F={f} -> C={n_classes}",
+                    "forward_us": us_all2,
+                    "legs": [leg("head (skinny product)", us_head2, "hbm", gemm_bytes, HBM_PEAK_GBS, "GB/s"),
+                             leg("aggregation F=%d" % n_classes, us_agg2, "hbm", agg2_bytes, HBM_PEAK_GBS, "GB/s")]})
+    return out
+
+
+def gcn2_line(config, what, g, x, n_classes, symmetric, reps, hidden=64):
+    """GCN-2 forward A_hat relu(A_hat (X W0)) W1 (transform-then-aggregate, models.GCN2), leg by leg"""
+    import torch
+    from wdg_amd import models, ops
+    adj = models.NormAdj(g, symmetric=symmetric, add_self_loops=False)
+    n, f, e = g.n_rows, x.shape[1], g.nnz
+    gcn = models.GCN2(f, n_classes, nhid=hidden, dropout=0.0).cuda().eval()
+    rs, cs = adj.row_scale, adj.col_scale
+    with torch.no_grad():
+        w0, w1 = gcn.w0.detach(), gcn.w1.detach()
+        p = ops.gemm(x, w0)
+        us_g0, _ = timed(lambda: ops.gemm(x, w0), reps)
+        hcur = ops.spmm(g, p, row_scale=rs, col_scale=cs)
+        us_a0, _ = timed(lambda: ops.spmm(g, p, row_scale=rs, col_scale=cs, out=hcur), reps)
+        hr = torch.relu(hcur)
+        us_g1, _ = timed(lambda: ops.gemm_skinny(hr, w1), reps)
+        z = ops.gemm(hr, w1)
+        lo = ops.spmm(g, z, row_scale=rs, col_scale=cs)
+        us_a1, _ = timed(lambda: ops.spmm(g, z, row_scale=rs, col_scale=cs, out=lo), reps)
+        us_all, _ = timed(lambda: gcn(adj, x), reps)
+    idx = 4 * (n + 1) + 4 * e + 4 * n
+    return {"config": config, "workload": f"{what}: GCN-2 forward A_hat relu(A_hat (X W0)) W1, F={f} -> {hidden} -> C={n_classes}",
+            "forward_us": us_all,
+            "legs": [leg(f"transform X W0 (K={f}, N={hidden})", us_g0, "mfma", 2.0 * n * f * hidden, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                         hbm_frac=4 * (n * f + f * hidden + n * hidden) / (us_g0 * 1e-6) / 1e9 / HBM_PEAK_GBS),
+                     leg(f"aggregation F={hidden}", us_a0, "hbm", idx + 8 * n * hidden, HBM_PEAK_GBS, "GB/s"),
+                     leg("head W1 (skinny product)", us_g1, "hbm", 4 * (n * hidden + hidden * n_classes + n * n_classes), HBM_PEAK_GBS, "GB/s"),
+                     leg(f"aggregation F={n_classes}", us_a1, "hbm", idx + 8 * n * n_classes, HBM_PEAK_GBS, "GB/s")]}
+
+
+def c1_models(reps):
+    import scipy.sparse as sp
+    import torch
+    from _golden import load
+    from wdg_amd import ops
+    d = load("real_cora")
+    n, f = int(d["n_nodes"]), int(d["n_feat"])
+    g = ops.CsrGraph.from_coo(d["adj_row"], d["adj_col"], n, None, ops.COO_ADD_SELF_LOOPS)
+    x = torch.from_numpy(sp.csr_matrix((d["featn_data"], d["feat_indices"], d["feat_indptr"]), (n, f)).toarray().astype(np.float32)).cuda()
+    return sgc1_lines("C1", f"Cora (N={n}, {g.nnz} stored entries of A+I)", g, x, 7, 1, reps)
+
+
+def c4_models(name, f, reps):
+    import torch
+    from _golden import load
+    from wdg_amd import ops
+    g0 = load("topo_" + name)
+    n = int(g0["n_nodes"])
+    g = ops.CsrGraph.from_coo(g0["adj_row"], g0["adj_col"], n, None, ops.COO_ADD_SELF_LOOPS)
+    rng = np.random.default_rng(17)
+    x = torch.from_numpy(((rng.random((n, f), dtype=np.float32) < 0.02) * rng.random((n, f), dtype=np.float32))).cuda()
+    what = f"{name} real topology (N={n}, {g.nnz} stored entries of A+I), synthetic features"
+    return [gcn2_line("C4", what, g, x, 5, 1, reps)] + sgc1_lines("C4", what, g, x, 5, 1, reps)
+
+
+def c5_models(reps):
+    """configs[4] as stated: the aggregation-homophily metric (10 class-balanced 10 000-node samples, homophily_tests.py:124-131)
+    + SGC-1 on the twitch-scale graph, bf16 features"""
+    import time
+    import torch
+    from wdg_amd import models, ops, synth
+    from wdg_amd.utils import homophily_metrics as hm
+    from wdg_amd.utils.util_funcs import random_disassortative_splits
+    n, e_und, f = 168114, 6797557, 7
+    rng = np.random.default_rng(6)
+    src, dst = synth.random_graph(n, e_und, seed=5)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_ADD_SELF_LOOPS)
+    raw = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE)
+    labels = torch.from_numpy(rng.integers(0, 2, n))
+    onehot = torch.eye(2)[labels].cuda()
+    torch.manual_seed(3)
+    masks = [random_disassortative_splits(labels, labels.max() + 1, 10000 / n)[0] for _ in range(10)]
+    hm.similarity(onehot, raw, onehot, hard=None, LP=1, idx_train=masks[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vals = [float(hm.similarity(onehot, raw, onehot, hard=None, LP=1, idx_train=m)) for m in masks]
+    torch.cuda.synchronize()
+    us_metric = (time.perf_counter() - t0) * 1e6
+    e = raw.nnz
+    rec = {"config": "C5", "workload": f"twitch-gamers scale (N={n}, {e} stored entries): aggregation homophily = 10 x similarity() on a "
+           "class-balanced 10 000-node sample (label aggregation A onehot on the whole graph + LAS on the sample), host wall time",
+           "metric_us_10_samples": us_metric, "agg_homo_soft": 2 * float(np.mean(vals)) - 1,
+           "legs": [leg("10 x (label aggregation F=2 + LAS)", us_metric, "hbm", 10 * (4 * (n + 1) + 4 * e + 16 * n), HBM_PEAK_GBS, "GB/s")]}
+    x = torch.from_numpy(rng.standard_normal((n, f), dtype=np.float32)).cuda()
+    return [rec] + sgc1_lines("C5", f"twitch-gamers scale (N={n}, {g.nnz} stored entries of A+I), fp32 head on the F=7 features", g, x, 2, 1, reps)
+
+
+def literal(config, n_nodes, k, seeds, reps):
+    """the LITERAL reading of configs[1] / configs[2]: N = 800 / 4000 NODES (the reference's `800` / `4000` are edge
+    counts per class, every reference graph has 2000 nodes) - same generator rule, same sweep shard"""
+    from wdg_amd import sweep as sw, synth
+    h_levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
+    jobs = sw.make_jobs(h_levels, range(seeds), k=k, n_nodes=n_nodes)
+    sb = sw.SweepBatch(jobs, n_feat=500, gcn_hidden=64)
+    us, med = timed(sb.spmm.launch, reps)
+    us_step, _ = timed(sb.step, reps)
+    return line(config, f"literal variant: 10 h-levels x {seeds} seeds = {len(jobs)} graphs in ONE launch, N={n_nodes} nodes, k={k}, "
+                f"F=500 (+5 one-hot label columns), fp32", sb.spmm.kernel_name(), sb.spmm_algorithmic_bytes(),
+                sum(g.nnz for g in sb.graphs), us, med, whole_step_us=us_step, graphs_per_s_step=len(jobs) / (us_step * 1e-6))
+
+
 def c5(reps):
     import torch
     from wdg_amd import ops
@@ -138,18 +292,23 @@ def main():
     args = ap.parse_args()
     import torch
     import wdg_amd  # noqa: F401  (fails loudly without the HIP library)
-    todo = [("C1", lambda: c1(args.reps)), ("C2", lambda: sweep("C2", 2, 10, args.reps)), ("C3", lambda: sweep("C3", 10, 5, args.reps)),
-            ("C4", lambda: c4("squirrel", 2089, args.reps)), ("C4", lambda: c4("chameleon", 2325, args.reps)), ("C5", lambda: c5(args.reps))]
+    todo = [("C1", lambda: c1(args.reps)), ("C1m", lambda: c1_models(args.reps)),
+            ("C2", lambda: sweep("C2", 2, 10, args.reps)), ("C2-literal", lambda: literal("C2-literal", 800, 2, 10, args.reps)),
+            ("C3", lambda: sweep("C3", 10, 5, args.reps)), ("C3-literal", lambda: literal("C3-literal", 4000, 10, 5, args.reps)),
+            ("C4", lambda: c4("squirrel", 2089, args.reps)), ("C4", lambda: c4("chameleon", 2325, args.reps)),
+            ("C4m", lambda: c4_models("squirrel", 2089, args.reps)), ("C4m", lambda: c4_models("chameleon", 2325, args.reps)),
+            ("C5", lambda: c5(args.reps)), ("C5m", lambda: c5_models(args.reps))]
     out = open(args.out, "w") if args.out else None
     for tag, fn in todo:
         if args.only and tag not in args.only.split(","):
             continue
-        rec = fn()
-        rec["device"] = torch.cuda.get_device_name(0)
-        s = json.dumps(rec)
-        print(s, flush=True)
-        if out:
-            out.write(s + "\n")
+        recs = fn()
+        for rec in (recs if isinstance(recs, list) else [recs]):
+            rec["device"] = torch.cuda.get_device_name(0)
+            s = json.dumps(rec)
+            print(s, flush=True)
+            if out:
+                out.write(s + "\n")
         torch.cuda.empty_cache()
 
 

@@ -108,3 +108,64 @@ def test_c5_twitch_scale(oracle):
         got = float(hm.similarity(onehot, adj_raw, onehot, hard=hard, LP=1, idx_train=mask))
         want = oracle.similarity(_np(onehot), r2, c2, v2, _np(onehot), hard=hard, idx_train=_np(mask), f64=True)
         assert abs(got - want) <= 1.01 / int(mask.sum())
+
+
+@pytest.mark.parametrize("m,n,k,pad", [(2708, 7, 1433, 0), (5201, 5, 2089, 3), (1, 1, 1, 0), (9, 8, 4100, 0), (1000, 2, 7, 1), (17, 3, 2048, 0)])
+def test_skinny_gemm_against_the_oracle(oracle, m, n, k, pad):
+    """wdg_gemm_skinny_f32 (N <= 8: the SGC-1 head): any K (chunks of 2048 through LDS), unaligned rows (lda = K + pad), bias +
+    relu, ragged last row group; fp32 within 1e-5 of the oracle's k-ordered product, bitwise reproducible"""
+    from wdg_amd import ops
+    rng = np.random.default_rng(m + 3 * n + k)
+    store = rng.standard_normal((m, k + pad)).astype(np.float32)
+    a, b, bias = store[:, :k], rng.standard_normal((k, n)).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    at = torch.from_numpy(store).cuda()[:, :k]
+    bt, biast = torch.from_numpy(b).cuda(), torch.from_numpy(bias).cuda()
+    got = ops.gemm_skinny(at, bt)
+    want = oracle.gemm(np.ascontiguousarray(a), b)
+    np.testing.assert_allclose(_np(got), want, rtol=1e-5, atol=1e-5 * max(np.abs(want).max(), 1e-30))
+    want = oracle.gemm(np.ascontiguousarray(a), b, bias, relu=True)
+    np.testing.assert_allclose(_np(ops.gemm_skinny(at, bt, bias=biast, relu=True)), want, rtol=1e-5, atol=1e-5 * max(np.abs(want).max(), 1e-30))
+    assert torch.equal(ops.gemm_skinny(at, bt), got)
+    with pytest.raises(ValueError):
+        from wdg_amd._lib import check, lib
+        from wdg_amd.ops import _ptr, stream_handle
+        c = torch.empty((m, 9), device="cuda")
+        check(lib.wdg_gemm_skinny_f32(_ptr(at), k + pad, _ptr(torch.zeros((k, 9), device="cuda")), 9, None, 0, _ptr(c), 9, m, 9, k, stream_handle()), "x")
+
+
+@pytest.mark.parametrize("name", ["cora", "squirrel"])
+def test_sgc1_forward_in_both_orders(oracle, name):
+    """SGC-1 inference: (A_hat X) W and A_hat (X W) (head first: skinny product, then an aggregation of C columns instead of F)
+    give the oracle's logits within 1e-5 - BASELINE configs[0] (Cora) and [3] (squirrel topology)"""
+    from wdg_amd import models, ops
+    rng = np.random.default_rng(5)
+    if name == "cora":
+        g0 = load("real_cora")
+        n, f, c = int(g0["n_nodes"]), int(g0["n_feat"]), 7
+        x = np.zeros((n, f), np.float32)
+        x[np.repeat(np.arange(n), np.diff(g0["feat_indptr"])), g0["feat_indices"]] = g0["featn_data"]
+        src, dst = g0["adj_row"], g0["adj_col"]
+    else:
+        g0 = load("topo_squirrel")
+        n, f, c = int(g0["n_nodes"]), 2089, 5
+        x = ((rng.random((n, f), dtype=np.float32) < 0.02) * rng.random((n, f), dtype=np.float32)).astype(np.float32)
+        src, dst = g0["adj_row"], g0["adj_col"]
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+    rowptr, col, val = oracle.coo_to_csr(src, dst, n, None, oracle.ADD_SELF_LOOPS)
+    xt = torch.from_numpy(x).cuda()
+    for symmetric in (0, 1):
+        adj = models.NormAdj(g, symmetric=symmetric, add_self_loops=False)
+        torch.manual_seed(1)
+        sgc = models.SGC1(f, c).cuda().eval()
+        with torch.no_grad():
+            head_first = sgc(adj, xt)                      # eval mode, nothing cached: A_hat (X W)
+            agg_first = sgc(adj, xt, order="agg_first")    # (A_hat X) W
+            cached = sgc(adj, xt)                          # A_hat X is cached now: the default takes it
+        vhat = oracle.normalised_csr(rowptr, col, val, symmetric, oracle.PREC_F32)
+        w = _np(sgc.weight)
+        want = oracle.gemm(oracle.spmm_csr(rowptr, col, vhat, x), w)
+        tol = dict(rtol=1e-5, atol=1e-5 * np.abs(want).max())
+        np.testing.assert_allclose(_np(agg_first), want, **tol)
+        np.testing.assert_allclose(_np(head_first), want, **tol)
+        np.testing.assert_allclose(_np(head_first), oracle.spmm_csr(rowptr, col, vhat, oracle.gemm(x, w)), **tol)
+        assert torch.equal(cached, agg_first)

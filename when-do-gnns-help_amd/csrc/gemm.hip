@@ -428,6 +428,56 @@ int launch_bres(const wdg_gemm_job *jobs, const wdg_gemm_job &inl, int n_jobs, i
     return check_launch("gemm_bres_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------ skinny products (N <= 8)
+// C[M, N] = act(A[M, K] B[K, N] + bias) for a classifier-sized N (the SGC-1 head X W: Cora 2708 x 1433 x 7).  The product is a
+// read of A: 4 M K bytes against 2 M K N flops - nothing for the matrix pipe, and the 128 x 32 tiles of the MFMA kernels put
+// 22 workgroups on 256 CUs for Cora (57 us for 15.5 MB).  Here B sits in LDS ([K][8] floats, staged per workgroup in chunks
+// of <= 2048 rows), sixteen lanes own a row of A and split its K (every load instruction reads 64 contiguous bytes of each of
+// the wave's four rows), each lane keeps the N running sums of its k's, and a four-step butterfly adds the sixteen lanes.
+// Summation order: per lane k ascending (k = lane16 + 16 t), then the butterfly - fixed, so results are bitwise reproducible;
+// NOT the k-ordered chain of wdg_gemm_f32 (a separate entry point: callers that need that chain keep wdg_gemm_f32).
+constexpr int SK_THREADS = 128, SK_ROWS = SK_THREADS / 16, SK_KCHUNK = 2048, SK_N = 8;
+
+__global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                                                                 int64_t ldb, const float *__restrict__ bias, int act,
+                                                                 float *__restrict__ C, int64_t ldc, int M, int N, int K) {
+    __shared__ float Bs[SK_KCHUNK * SK_N];
+    const int tid = threadIdx.x, gl = tid & 15;
+    const int row = blockIdx.x * SK_ROWS + (tid >> 4);
+    const float *a = A + static_cast<int64_t>(min(row, M - 1)) * lda;
+    float acc[SK_N];
+#pragma unroll
+    for (int c = 0; c < SK_N; ++c) acc[c] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += SK_KCHUNK) {
+        const int kc = min(SK_KCHUNK, K - k0);
+        if (k0) __syncthreads();
+        for (int i = tid; i < kc * SK_N; i += SK_THREADS) {
+            const int k = i >> 3, c = i & 7;
+            Bs[i] = c < N ? B[static_cast<int64_t>(k0 + k) * ldb + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = gl; k < kc; k += 16) {
+            const float av = a[k0 + k];
+            const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[k * SK_N]), b1 = *reinterpret_cast<const float4 *>(&Bs[k * SK_N + 4]);
+            acc[0] = fmaf(av, b0.x, acc[0]), acc[1] = fmaf(av, b0.y, acc[1]), acc[2] = fmaf(av, b0.z, acc[2]), acc[3] = fmaf(av, b0.w, acc[3]);
+            acc[4] = fmaf(av, b1.x, acc[4]), acc[5] = fmaf(av, b1.y, acc[5]), acc[6] = fmaf(av, b1.z, acc[6]), acc[7] = fmaf(av, b1.w, acc[7]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < SK_N; ++c)
+        for (int o = 8; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+    if (gl == 0 && row < M) {
+        float *out = C + static_cast<int64_t>(row) * ldc;
+#pragma unroll
+        for (int c = 0; c < SK_N; ++c) {
+            if (c >= N) break;
+            const float v = acc[c] + (bias ? bias[c] : 0.f);
+            out[c] = act == WDG_ACT_RELU ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -462,6 +512,19 @@ int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int t
         else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), grid, dim3(THREADS), 0, st, none, j);
     }
     return wdg::check_launch("gemm_f32_kernel");
+}
+
+int wdg_gemm_skinny_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int act, float *C, int64_t ldc,
+                        int32_t M, int32_t N, int32_t K, wdg_stream_t stream) {
+    WDG_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_skinny: negative size");
+    WDG_REQUIRE(N <= SK_N, "gemm_skinny: more than 8 columns (wdg_gemm_f32 takes those)");
+    if (M == 0 || N == 0) return WDG_OK;
+    WDG_REQUIRE(A && B && C, "gemm_skinny: null matrix");
+    WDG_REQUIRE(lda >= K && ldc >= N && ldb >= N, "gemm_skinny: leading dimension too small");
+    WDG_REQUIRE(act == WDG_ACT_NONE || act == WDG_ACT_RELU, "gemm_skinny: bad activation");
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(static_cast<unsigned>(wdg::ceil_div(M, SK_ROWS))), dim3(SK_THREADS), 0,
+                       wdg::as_stream(stream), A, lda, B, ldb, bias, act, C, ldc, M, N, K);
+    return wdg::check_launch("gemm_skinny_kernel");
 }
 
 int wdg_gemm_batched_flags_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N, int32_t max_K,

@@ -64,17 +64,36 @@ class _Linear(torch.autograd.Function):
 
 
 class SGC1(torch.nn.Module):
+    """logits = (A_hat X) W.  Training caches A_hat X (loop invariant: one wide aggregation for the whole run) and learns W on it;
+    a forward pass WITHOUT that cache in eval mode (one-shot inference on a graph: BASELINE configs[0], [3], [4]) takes the
+    other association, A_hat (X W): the head first - N x F x C on wdg_gemm_skinny_f32, a read of X - and then an aggregation
+    of C <= 8 columns instead of F (Cora: 1433 -> 7, squirrel: 2089 -> 5); same logits within fp32 rounding
+    (tests/test_gpu_configs.py)."""
+
     def __init__(self, nfeat, nclass):
         super().__init__()
         self.weight = torch.nn.Parameter(torch.empty(nfeat, nclass))
         torch.nn.init.xavier_uniform_(self.weight)
         self._cache = None
 
-    def forward(self, adj, x):
+    def aggregate_once(self, adj, x):
+        """A_hat X, computed on first use and kept (keyed on the feature tensor)"""
         if self._cache is None or self._cache[0] is not x:
             with torch.no_grad():
                 self._cache = (x, ops.spmm(adj.graph, x, row_scale=adj.row_scale, col_scale=adj.col_scale))
-        return _Linear.apply(self._cache[1], self.weight, False)
+        return self._cache[1]
+
+    def forward(self, adj, x, order=None):
+        """order: "agg_first" (A_hat X) W | "head_first" A_hat (X W) | None: agg_first when training or when A_hat X is cached
+        for this x, else head_first (no gradient path: inference)"""
+        cached = self._cache is not None and self._cache[0] is x
+        if order is None:
+            order = "agg_first" if (self.training or cached) else "head_first"
+        if order == "head_first":
+            with torch.no_grad():
+                z = ops.gemm_skinny(x, self.weight.detach()) if self.weight.shape[1] <= 8 else ops.gemm(x, self.weight.detach())
+                return ops.spmm(adj.graph, z, row_scale=adj.row_scale, col_scale=adj.col_scale)
+        return _Linear.apply(self.aggregate_once(adj, x), self.weight, False)
 
 
 class GCN2(torch.nn.Module):

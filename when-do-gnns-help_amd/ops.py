@@ -1313,3 +1313,21 @@ def gemm(a, b, bias=None, relu=False, transb=False, out=None):
                            ACT_RELU if relu else ACT_NONE, _ptr(c), _ld(c), m, n, k, stream_handle()),
           "wdg_gemm_f32")
     return c
+
+
+def gemm_skinny(a, b, bias=None, relu=False, out=None):
+    """act(A @ B + bias) for B of <= 8 columns (a classifier head) on wdg_gemm_skinny_f32: the rows of A spread over the whole
+    chip, K split over 16 lanes per row.  Within fp32 rounding of gemm() (whose k-ordered chain it does not reproduce bit for
+    bit); wider B: gemm()."""
+    dev = require_gpu()
+    a, b, bias = _dev(a, torch.float32, dev), _dev(b, torch.float32, dev), _dev(bias, torch.float32, dev)
+    m, k = a.shape
+    n = b.shape[1]
+    if b.shape[0] != k:
+        raise ValueError("gemm_skinny: inner dimensions differ")
+    if n > 8:
+        return gemm(a, b, bias=bias, relu=relu, out=out)
+    c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
+    check(lib.wdg_gemm_skinny_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(bias), ACT_RELU if relu else ACT_NONE, _ptr(c), _ld(c),
+                                  m, n, k, stream_handle()), "wdg_gemm_skinny_f32")
+    return c
