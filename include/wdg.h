@@ -451,8 +451,9 @@ int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int t
                  float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, wdg_stream_t stream);
 /*
  * The same product for a classifier-sized N <= 8 and any K (the SGC-1 head X W: Cora 2708 x 1433 x 7): bound by the read of A,
- * so the rows are spread over the whole chip (8 rows per workgroup, 16 lanes per row splitting K, B in LDS) instead of 128-row
- * MFMA tiles.  Summation order: per lane k = l, l + 16, ... ascending, then a fixed butterfly over the row's 16 lanes - bitwise
+ * so the rows are spread over the whole chip (a wave per row for K > 512, B read through the caches; 16 / 4 / 1 lanes per row and
+ * B in LDS for shorter rows) instead of 128-row MFMA tiles.  Summation order: per lane k = l, l + L, ... ascending (L lanes per
+ * row), then a fixed butterfly over the row's lanes - bitwise
  * reproducible, within fp32 rounding of wdg_gemm_f32's k-ordered chain (not bit-identical to it).  B is [K, N] (no transb).
  */
 int wdg_gemm_skinny_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int act, float *C,

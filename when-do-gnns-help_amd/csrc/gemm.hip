@@ -434,16 +434,52 @@ int launch_bres(const wdg_gemm_job *jobs, const wdg_gemm_job &inl, int n_jobs, i
 // 22 workgroups on 256 CUs for Cora (57 us for 15.5 MB).  Here B sits in LDS ([K][8] floats, staged per workgroup in chunks
 // of <= 2048 rows), sixteen lanes own a row of A and split its K (every load instruction reads 64 contiguous bytes of each of
 // the wave's four rows), each lane keeps the N running sums of its k's, and a four-step butterfly adds the sixteen lanes.
-// Summation order: per lane k ascending (k = lane16 + 16 t), then the butterfly - fixed, so results are bitwise reproducible;
+// Summation order: per lane k ascending (k = l + LPR t), then the butterfly - fixed, so results are bitwise reproducible;
 // NOT the k-ordered chain of wdg_gemm_f32 (a separate entry point: callers that need that chain keep wdg_gemm_f32).
-constexpr int SK_THREADS = 128, SK_ROWS = SK_THREADS / 16, SK_KCHUNK = 2048, SK_N = 8;
+constexpr int SK_THREADS = 256, SK_KCHUNK = 2048, SK_N = 8;
 
+// A wave per row for long rows (K > 512): B is read straight from L2 / L1 (coalesced: 64 consecutive rows of B per load
+// instruction) - staging 46 KB of B in LDS per workgroup cost more than Cora's whole product (18.7 us against 15.5 MB of A).
+template <int NCOLS>
+__global__ __launch_bounds__(256) void gemm_skinny_wave_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                                                                 int64_t ldb, const float *__restrict__ bias, int act,
+                                                                 float *__restrict__ C, int64_t ldc, int M, int K) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;  // (whole waves)
+    const float *a = A + static_cast<int64_t>(row) * lda;
+    float acc[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) acc[c] = 0.f;
+#pragma unroll 4
+    for (int k = lane; k < K; k += 64) {
+        const float av = a[k];
+        const float *b = B + static_cast<int64_t>(k) * ldb;
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) acc[c] = fmaf(av, b[c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c)
+        for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+    if (lane == 0) {
+        float *out = C + static_cast<int64_t>(row) * ldc;
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            const float v = acc[c] + (bias ? bias[c] : 0.f);
+            out[c] = act == WDG_ACT_RELU ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// LPR lanes per row: 16 for rows of up to 512 entries, 4 / 1 for short ones (K <= 128 / K <= 16: the C5 head has K = 7 - with 16 lanes per row
+// nine of them would idle and a workgroup would cover 8 rows)
+template <int LPR>
 __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                                                                  int64_t ldb, const float *__restrict__ bias, int act,
                                                                  float *__restrict__ C, int64_t ldc, int M, int N, int K) {
     __shared__ float Bs[SK_KCHUNK * SK_N];
-    const int tid = threadIdx.x, gl = tid & 15;
-    const int row = blockIdx.x * SK_ROWS + (tid >> 4);
+    constexpr int ROWS = SK_THREADS / LPR;
+    const int tid = threadIdx.x, gl = tid % LPR;
+    const int row = blockIdx.x * ROWS + tid / LPR;
     const float *a = A + static_cast<int64_t>(min(row, M - 1)) * lda;
     float acc[SK_N];
 #pragma unroll
@@ -451,13 +487,15 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const float *__
     for (int k0 = 0; k0 < K; k0 += SK_KCHUNK) {
         const int kc = min(SK_KCHUNK, K - k0);
         if (k0) __syncthreads();
+        // B[k0 .. k0 + kc) -> LDS as [k][8] (columns >= N zero); eight loads in flight per thread
+#pragma unroll 8
         for (int i = tid; i < kc * SK_N; i += SK_THREADS) {
             const int k = i >> 3, c = i & 7;
             Bs[i] = c < N ? B[static_cast<int64_t>(k0 + k) * ldb + c] : 0.f;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k = gl; k < kc; k += 16) {
+#pragma unroll 8
+        for (int k = gl; k < kc; k += LPR) {  // (eight loads of A in flight per lane: the product is a read of A)
             const float av = a[k0 + k];
             const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[k * SK_N]), b1 = *reinterpret_cast<const float4 *>(&Bs[k * SK_N + 4]);
             acc[0] = fmaf(av, b0.x, acc[0]), acc[1] = fmaf(av, b0.y, acc[1]), acc[2] = fmaf(av, b0.z, acc[2]), acc[3] = fmaf(av, b0.w, acc[3]);
@@ -466,7 +504,7 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const float *__
     }
 #pragma unroll
     for (int c = 0; c < SK_N; ++c)
-        for (int o = 8; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+        for (int o = LPR / 2; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
     if (gl == 0 && row < M) {
         float *out = C + static_cast<int64_t>(row) * ldc;
 #pragma unroll
@@ -522,8 +560,31 @@ int wdg_gemm_skinny_f32(const float *A, int64_t lda, const float *B, int64_t ldb
     WDG_REQUIRE(A && B && C, "gemm_skinny: null matrix");
     WDG_REQUIRE(lda >= K && ldc >= N && ldb >= N, "gemm_skinny: leading dimension too small");
     WDG_REQUIRE(act == WDG_ACT_NONE || act == WDG_ACT_RELU, "gemm_skinny: bad activation");
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(static_cast<unsigned>(wdg::ceil_div(M, SK_ROWS))), dim3(SK_THREADS), 0,
-                       wdg::as_stream(stream), A, lda, B, ldb, bias, act, C, ldc, M, N, K);
+    hipStream_t st = wdg::as_stream(stream);
+    if (K <= 16)
+        hipLaunchKernelGGL(gemm_skinny_kernel<1>, dim3(static_cast<unsigned>(wdg::ceil_div(M, SK_THREADS))), dim3(SK_THREADS), 0, st, A, lda,
+                           B, ldb, bias, act, C, ldc, M, N, K);
+    else if (K <= 128)
+        hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(static_cast<unsigned>(wdg::ceil_div(M, SK_THREADS / 4))), dim3(SK_THREADS), 0, st, A,
+                           lda, B, ldb, bias, act, C, ldc, M, N, K);
+    else if (K <= 512)
+        hipLaunchKernelGGL(gemm_skinny_kernel<16>, dim3(static_cast<unsigned>(wdg::ceil_div(M, SK_THREADS / 16))), dim3(SK_THREADS), 0, st, A,
+                           lda, B, ldb, bias, act, C, ldc, M, N, K);
+    else {  // a wave per row: enough lanes that every lane's handful of loads is in flight at once (Cora: 23 per lane)
+        const dim3 grid(static_cast<unsigned>(wdg::ceil_div(M, 4)));
+#define WDG_SKINNY_WAVE(NC) hipLaunchKernelGGL(gemm_skinny_wave_kernel<NC>, grid, dim3(256), 0, st, A, lda, B, ldb, bias, act, C, ldc, M, K)
+        switch (N) {
+            case 1: WDG_SKINNY_WAVE(1); break;
+            case 2: WDG_SKINNY_WAVE(2); break;
+            case 3: WDG_SKINNY_WAVE(3); break;
+            case 4: WDG_SKINNY_WAVE(4); break;
+            case 5: WDG_SKINNY_WAVE(5); break;
+            case 6: WDG_SKINNY_WAVE(6); break;
+            case 7: WDG_SKINNY_WAVE(7); break;
+            default: WDG_SKINNY_WAVE(8); break;
+        }
+#undef WDG_SKINNY_WAVE
+    }
     return wdg::check_launch("gemm_skinny_kernel");
 }
 

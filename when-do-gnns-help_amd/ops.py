@@ -477,7 +477,8 @@ def unpack_bits(words, n_feat, row_normalise=False):
 
 
 # ------------------------------------------------------------------------------------------- aggregation
-NARROW_MIN_ENTRIES = 1 << 18  # below that a launch is latency-bound whatever the kernel: keep the general families
+NARROW_MIN_ENTRIES = int(os.environ.get("WDG_NARROW_MIN_ENTRIES", 1 << 15))  # below: the general families (round 2: 2^18 - chameleon's
+# 65 019 entries then took the gather kernel for its C = 5 logits aggregation: 85 us against the narrow kernel's 20)
 
 
 def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
