@@ -51,7 +51,10 @@ constexpr int Q_SU = 4;                // slices per super-unit (64 rows): the g
 constexpr int Q_SU_ROWS = Q_SU * Q_ROWS;
 constexpr int Q_MAX_BLOCK_COLS = 2528; // rows of a slab block: (2528 + 1 zero row) x 64 B = 158.1 KiB of the 160 KiB
 constexpr int Q_MAX_BLOCKS = 4;        // column blocks (graphs of up to 10 112 columns); more: the CSR kernels
-constexpr int Q_MAXU = 8;              // units per wave and phase when a graph has several column blocks
+constexpr int Q_MAXU = 16;             // units (slices) per wave and phase when a graph has several column blocks: 4 super-units
+                                       // x 16 waves = 64 super-units = 4096 rows per item - a whole N = 4000 graph, so that a
+                                       // (graph, feature group) item stages each column block of X once (round 2: 8 -> two
+                                       // items per such graph, every block staged twice: 728 us for the 50-graph shard)
 
 // columns per slab block: the columns cut into the fewest blocks of <= 2528, evenly, a multiple of 4 (column class mod 4 =
 // local class mod 4: what the bank-aware order of sell16_fill keys on)
@@ -905,9 +908,13 @@ __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const w
     else q_units_simple<HAS_VAL>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, no_store, wave, lane);
 }
 
-// ---- a phase whose graphs have SEVERAL column blocks (more than 2528 columns): the blocks of the slab are staged one
-//      after the other, every wave keeps the accumulators of its <= 2 super-units (8 slices) across the blocks (barriers
-//      between blocks).  Plain loads: the sweeps of a block are short and the barriers dominate anyway.
+// ---- a phase whose graphs have SEVERAL column blocks (more than 2528 columns; N = 4000: two blocks of 2000): the blocks of
+//      the slab are staged one after the other, every wave keeps the accumulators of its <= 4 super-units (16 slices) across the
+//      blocks (barriers between blocks), so an item of <= 64 super-units - a whole N = 4000 graph - stages each block once.
+//      The item lies inside ONE job (the caller cuts the items of such tables at job boundaries).  Per block a wave fetches
+//      the extents of all its slices with one load (lane s < 16: slice s) and keeps the first two index chunks of the NEXT
+//      slice in flight while it sweeps the current one (round 2: extent, then chunk, then sweep, one dependent load after the
+//      other - 90 us per item where staging plus sweep need 25).
 template <typename TIN, bool HAS_VAL>
 __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                               int unit_begin, int unit_end, int stride, int f0, float4 *xs, bool first_phase,
@@ -926,6 +933,17 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
     const int ustep = Q_WAVES * stride;
     constexpr int MAX_SU = Q_MAXU / Q_SU;
 
+    // the job that holds the item, and the item's range inside it
+    int j = first_job, base = 0;
+    QJob j0 = q_load_job(jobs, inl, j);
+    while (unit_begin >= base + j0.n_su && j < first_job + n_jobs - 1) {
+        base += j0.n_su;
+        ++j;
+        j0 = q_load_job(jobs, inl, j);
+    }
+    const int su_first = unit_begin - base + wave * stride, su_end = min(unit_end - base, j0.n_su);
+    const int n_entries = j0.n_su * Q_SU;
+
     f32x2 acc0[Q_MAXU], acc1[Q_MAXU];
 #pragma unroll
     for (int k = 0; k < Q_MAXU; ++k) acc0[k] = acc1[k] = f32x2{0.f, 0.f};
@@ -934,32 +952,36 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
         if (blk > 0 || !first_phase) q_barrier_lds();  // the previous block's readers are done
         const int begin = blk * head.block_cols, rows = min(head.block_cols, head.n_cols - begin);
         q_stage<TIN>(head, begin, rows, head.block_cols, f0, xs, wave, lane, tid);
+        // lane s < 16: {first chunk, width | flags} of this wave's slice s = (super-unit su_first + (s / 4) ustep, slice s % 4);
+        // slices past the item's end: ghosts (nothing to sweep, nothing to store)
+        i32x2 ext = {0, Q_CONT};
+        {
+            const int my_su = su_first + ((lane >> 2) & 3) * ustep;
+            if (lane < Q_MAXU && my_su < su_end)
+                ext = *(global_ptr<const i32x2>)(j0.ext + 2 * (blk * n_entries + my_su * Q_SU + (lane & 3)));
+        }
         q_barrier_lds();
-        int j = first_job, base = 0;
-        QJob j0 = q_load_job(jobs, inl, j);
-        int u = unit_begin + wave * stride;
+        const int64_t lane4 = lane * 4;
+        auto chunk_ptr = [&](int chunk) { return (global_ptr<const i32x4>)(j0.col + static_cast<int64_t>(chunk) * Q_CHUNK_INTS + lane4); };
+        int chunk_cur = __builtin_amdgcn_readlane(ext.x, 0);
+        i32x4 c0 = *chunk_ptr(chunk_cur), c1 = *chunk_ptr(chunk_cur + 1);  // (the index arrays carry two chunks of slack)
+        const bool last = blk + 1 == head.n_blocks;
 #pragma unroll
-        for (int k = 0; k < MAX_SU; ++k, u += ustep) {
-            if (u >= unit_end) break;  // wave-uniform
-            while (u >= base + j0.n_su && j < first_job + n_jobs - 1) {
-                base += j0.n_su;
-                ++j;
-                j0 = q_load_job(jobs, inl, j);
+        for (int s = 0; s < Q_MAXU; ++s) {
+            const int wf = __builtin_amdgcn_readlane(ext.y, s);
+            const int chunk0 = chunk_cur;
+            i32x4 n0 = c0, n1 = c1;
+            if (s + 1 < Q_MAXU) {  // the next slice's first two chunks: in flight during this slice's sweep
+                chunk_cur = __builtin_amdgcn_readlane(ext.x, s + 1);
+                n0 = *chunk_ptr(chunk_cur);
+                n1 = *chunk_ptr(chunk_cur + 1);
             }
-            const int su = u - base;
-#pragma unroll
-            for (int i = 0; i < Q_SU; ++i) {
-                const int slice = su * Q_SU + i;  // (graphs of several column blocks: one entry per slice)
-                const int task = blk * (j0.n_su * Q_SU) + slice;
-                const i32x2 ext = *(global_ptr<const i32x2>)(j0.ext + 2 * task);
-                const int chunk0 = __builtin_amdgcn_readfirstlane(ext.x);
-                const int wf = __builtin_amdgcn_readfirstlane(ext.y);
-                if (wf & Q_CONT) continue;  // a ghost entry (it pads the last super-unit): wave-uniform
+            if (!(wf & Q_CONT)) {  // (wave-uniform; ghosts: skipped)
                 const int width0 = no_sweep ? 0 : wf;
                 const f32x4_t ones = {1.f, 1.f, 1.f, 1.f};
-                f32x2 a0 = acc0[k * Q_SU + i], a1 = acc1[k * Q_SU + i];
+                f32x2 a0 = acc0[s], a1 = acc1[s];
                 for (int ch = 0; ch * Q_CHUNK < width0; ++ch) {
-                    const i32x4 cc = *(global_ptr<const i32x4>)(j0.col + static_cast<int64_t>(chunk0 + ch) * Q_CHUNK_INTS + lane * 4);
+                    const i32x4 cc = ch == 0 ? c0 : (ch == 1 ? c1 : *chunk_ptr(chunk0 + ch));
                     [[maybe_unused]] f32x4_t wc = ones;
                     if (HAS_VAL && j0.val) wc = *(global_ptr<const f32x4_t>)(j0.val + static_cast<int64_t>(chunk0 + ch) * Q_CHUNK_INTS + lane * 4);
                     const int left = width0 - ch * Q_CHUNK;
@@ -968,27 +990,30 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
                     if (left > 8) { WDG_Q_QUAD(2) }
                     if (left > 12) { WDG_Q_QUAD(3) }
                 }
-                acc0[k * Q_SU + i] = a0;
-                acc1[k * Q_SU + i] = a1;
-                if (blk + 1 == head.n_blocks) {
+                acc0[s] = a0;
+                acc1[s] = a1;
+                if (last && !no_store) {
+                    // (the rows and their scales: two dependent loads per slice.  Requesting them slices ahead was measured:
+                    // with 16 slices of accumulators the extra live registers spill - 627 us against 513 for the C3-literal shard)
+                    const int slice = (su_first + (s >> 2) * ustep) * Q_SU + (s & 3);
                     const int row = j0.perm[slice * Q_ROWS + r];  // (padding slots / slices repeat rows: always a row)
-                    if (!no_store) {
-                        const float sc = j0.row_scale ? j0.row_scale[row] : 1.f;
-                        const int f = f0 + p * 4;
-                        const global_ptr<float> dst = j0.Y + static_cast<int64_t>(row) * j0.ldy + f;
-                        const float4 o = make_float4(a0.x * sc, a0.y * sc, a1.x * sc, a1.y * sc);
-                        const bool y_vec = (F % 4 == 0) && (j0.ldy % 4 == 0) && (((uintptr_t)j0.Y & 15) == 0);
-                        if (y_vec) {
-                            if (f < F) store_f32x4(dst, o);
-                        } else {
-                            if (f + 0 < F) dst[0] = o.x;
-                            if (f + 1 < F) dst[1] = o.y;
-                            if (f + 2 < F) dst[2] = o.z;
-                            if (f + 3 < F) dst[3] = o.w;
-                        }
+                    const float sc = j0.row_scale ? j0.row_scale[row] : 1.f;
+                    const int f = f0 + p * 4;
+                    const global_ptr<float> dst = j0.Y + static_cast<int64_t>(row) * j0.ldy + f;
+                    const float4 o = make_float4(a0.x * sc, a0.y * sc, a1.x * sc, a1.y * sc);
+                    const bool y_vec = (F % 4 == 0) && (j0.ldy % 4 == 0) && (((uintptr_t)j0.Y & 15) == 0);
+                    if (y_vec) {
+                        if (f < F) store_f32x4(dst, o);
+                    } else {
+                        if (f + 0 < F) dst[0] = o.x;
+                        if (f + 1 < F) dst[1] = o.y;
+                        if (f + 2 < F) dst[2] = o.z;
+                        if (f + 3 < F) dst[3] = o.w;
                     }
                 }
             }
+            c0 = n0;
+            c1 = n1;
         }
     }
 }

@@ -674,6 +674,9 @@ def _quad_cut(cum, g_off, n_seg, phase, shares=None):
     return np.maximum.accumulate(np.asarray(cuts, np.int64))
 
 
+QUAD_MULTI_ITEM_SU = 64  # super-units per item of a table whose graphs have several column blocks (csrc/spmm_quad.hip: Q_MAXU / 4 x 16 waves)
+
+
 def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
     """Cut the tape of super-units (64 rows) of the jobs (in table order `order`) into 8 x S segments of equal modelled cost
     and split every segment into items; -> (items [(first_job, n_jobs, unit_begin, unit_end)], seg_ptr, n_segments).
@@ -710,8 +713,8 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
     if forced:
         subs = int(forced)
     subs = max(1, min(subs, max(1, n_units // (8 * 8))))
-    if multi:  # a wave keeps at most 2 super-units across the column blocks: items of <= 32 super-units
-        subs = max(subs, -(-n_units // (8 * 32)))
+    if multi:  # a wave keeps at most 4 super-units (Q_MAXU = 16 slices) across the column blocks: items of <= 64 super-units
+        subs = max(subs, -(-n_units // (8 * QUAD_MULTI_ITEM_SU)))
     n_seg = 8 * subs
     g_off = np.concatenate([[0], np.cumsum([g[2] for g in groups])]).astype(np.int64)
     if phase_ns is None:
@@ -727,8 +730,10 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
         while a < b:
             gi = int(np.searchsorted(g_off, a, side="right") - 1)
             end = min(b, int(g_off[gi + 1]))
-            if multi:
-                end = min(end, a + 32)
+            if multi:  # an item of a several-block table lies inside one job (the kernel's wave keeps that job's slices)
+                first_pos, nj_, _n = groups[gi]
+                jb = np.concatenate([[0], np.cumsum([entries[order[first_pos + t]][0].quad["n_su"] for t in range(nj_)])]) + int(g_off[gi])
+                end = min(end, a + QUAD_MULTI_ITEM_SU, int(jb[np.searchsorted(jb, a, side="right")]))
             first, nj, _n = groups[gi]
             items.append((first, nj, a - int(g_off[gi]), end - int(g_off[gi])))
             seg_items.append((float(cum[end] - cum[a]), len(items) - 1))
