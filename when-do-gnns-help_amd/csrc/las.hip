@@ -160,9 +160,37 @@ __global__ __launch_bounds__(256) void las_weights_kernel(const wdg_las_job *__r
 // ---- narrow-feature path (F <= 16: label propagation, F = C): rows on lanes instead of features on lanes.
 constexpr int SMALL_F = 16;
 
+// Wave sums without the LDS crossbar: four DPP steps leave every row of 16 lanes holding its row's sum (lane ^ 1, lane ^ 2 by
+// quad permutes; the other quad of the half row and the other half row by the two mirrors - after a step the lanes of a
+// group hold one value, so the mirror pairs the same two groups an xor would); the four row sums are read with v_readlane
+// and added as (r0 + r1) + (r2 + r3).  A fixed tree: the result does not depend on scheduling, and every caller (the
+// three-kernel path and the fused one) goes through it, so the two stay bit-identical.  All 64 lanes must be active.
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+template <int CTRL>
+__device__ __forceinline__ int dpp_move(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    return __hiloint2double(dpp_move<CTRL>(__double2hiint(v)), dpp_move<CTRL>(__double2loint(v)));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);  // fixed butterfly -> scheduling-independent
-    return v;
+    v += dpp_move<DPP_XOR1>(v);
+    v += dpp_move<DPP_XOR2>(v);
+    v += dpp_move<DPP_HALF_MIRROR>(v);
+    v += dpp_move<DPP_MIRROR>(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k), __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    v += dpp_move<DPP_XOR1>(v);
+    v += dpp_move<DPP_XOR2>(v);
+    v += dpp_move<DPP_HALF_MIRROR>(v);
+    v += dpp_move<DPP_MIRROR>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
 __global__ __launch_bounds__(64) void las_middle_partial_small(const wdg_las_job *__restrict__ jobs,
@@ -189,7 +217,7 @@ __global__ __launch_bounds__(64) void las_middle_partial_small(const wdg_las_job
         int cnt = 0;
 #pragma unroll
         for (int s = 0; s < TILE_ROWS / 64; ++s) cnt += (lab[s] == c);
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        cnt = wave_sum(cnt);
         if (lane == 0) ws.cnt_partial[tile * C + c] = cnt;
 #pragma unroll
         for (int f = 0; f < SMALL_F; ++f) {
@@ -268,6 +296,23 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
         if (threadIdx.x < C) st_cdeg[threadIdx.x] = 0;
         if (threadIdx.x < 6) st_tot[threadIdx.x] = 0;
     }
+    // The derived counters need two per-row inputs that are not on the LAS path - the row's length and its scale.  Those of
+    // the first two rounds of step 3 are fetched here, so the trip to HBM hides under step 1.
+    const desc_ptr<wdg_stats_job> sj = (desc_ptr<wdg_stats_job>)job.counts;
+    global_ptr<const int32_t> st_rowptr = nullptr;
+    int pre_nn[2] = {0, 0};
+    float pre_scale[2] = {1.f, 1.f};
+    if (derive) {
+        st_rowptr = to_global(sj->rowptr);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = k * FUSED_THREADS + static_cast<int>(threadIdx.x);
+            if (i < n) {
+                pre_nn[k] = st_rowptr[i + 1] - st_rowptr[i];
+                pre_scale[k] = job.row_scale[i];
+            }
+        }
+    }
     // step 1 (las_middle_partial_small): partial[t][c][f], cnt_partial[t][c]; wave w takes tiles w, w + 16, ...
     for (int tile = wave; tile < n_tiles; tile += FUSED_THREADS / 64) {
         float h[TILE_ROWS / 64][SMALL_F];
@@ -288,7 +333,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
             int cnt = 0;
 #pragma unroll
             for (int s = 0; s < TILE_ROWS / 64; ++s) cnt += (lab[s] == c);
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            cnt = wave_sum(cnt);
             if (lane == 0) cnt_partial[tile * C + c] = cnt;
 #pragma unroll
             for (int f = 0; f < SMALL_F; ++f) {
@@ -318,13 +363,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
     for (int i0 = 0; i0 < n; i0 += FUSED_THREADS) {
         const int i = i0 + threadIdx.x;
         bool soft = false, hard = false;
+        int y = -1, nn = 0, own_cnt = 0, lab = 0, cnt[SMALL_F];  // derived counters: this row's share
+        bool ok = false;
         if (i < n) {
             const int r = job.rows ? job.rows[i] : i;
             const global_ptr<const float> hp = job.H + static_cast<int64_t>(r) * job.ldh;
             float h[SMALL_F];
 #pragma unroll
             for (int f = 0; f < SMALL_F; ++f) h[f] = (f < F) ? hp[f] : 0.f;
-            const int y = job.labels[r];
+            y = job.labels[r];
             double own = 0.0, tot = 0.0, best = 0.0;
             int best_c = -1;
             for (int c = 0; c < C; ++c) {
@@ -344,33 +391,60 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
             const double ratio = (own / ny) / ((tot - own) / (static_cast<double>(n) - ny));
             soft = !(ratio != ratio) && ratio >= 1.0;
             hard = best_c == y;
-            if (derive && y >= 0 && y < C) {
-                // h = row_scale_u * (this node's neighbour-class counts over the pattern, its own loop included): exact integers
-                // after rounding.  The counters of wdg_edge_label_stats from them: |P_u| from rowptr, the
-                // loop taken out of the non-loop counts, row y of the compatibility histogram.
-                const desc_ptr<wdg_stats_job> sj = (desc_ptr<wdg_stats_job>)job.counts;
-                const global_ptr<const int32_t> rp = to_global(sj->rowptr);
-                const int nn = rp[r + 1] - rp[r];
-                const float scale = 1.f / job.row_scale[r];
-                int lab = 0, own_cnt = 0;
-                for (int c = 0; c < C; ++c) {
-                    const int cnt = static_cast<int>(rintf(h[c] * scale));
-                    lab += cnt;
-                    if (c == y) own_cnt = cnt;
-                    const int off_loop = cnt - (c == y ? 1 : 0);
-                    if (off_loop) atomicAdd(&st_hist[y * C + c], off_loop);
+            ok = derive && y >= 0 && y < C;
+            if (ok) {
+                // h = row_scale_u * (this node's neighbour-class counts over the pattern, its own loop included): exact
+                // integers after rounding.  The counters of wdg_edge_label_stats from them: |P_u| from
+                // rowptr, the loop taken out of the non-loop counts, row y of the compatibility histogram.  (derive: r == i)
+                const int round = i0 / FUSED_THREADS;
+                nn = round == 0 ? pre_nn[0] : round == 1 ? pre_nn[1] : st_rowptr[i + 1] - st_rowptr[i];
+                const float scale = 1.f / (round == 0 ? pre_scale[0] : round == 1 ? pre_scale[1] : job.row_scale[i]);
+#pragma unroll
+                for (int c = 0; c < SMALL_F; ++c) {
+                    cnt[c] = (c < C) ? static_cast<int>(rintf(h[c] * scale)) : 0;
+                    lab += cnt[c];
+                    if (c == y) own_cnt = cnt[c];
                 }
                 const global_ptr<int32_t> rn = to_global(sj->row_nnz), rs = to_global(sj->row_nnz_noself), rm = to_global(sj->row_match_noself);
-                if (rn) rn[r] = nn;
-                if (rs) rs[r] = nn - 1;
-                if (rm) rm[r] = own_cnt - 1;
-                atomicAdd(&st_tot[0], nn);
-                atomicAdd(&st_tot[1], own_cnt);
-                atomicAdd(&st_tot[2], lab);
-                atomicAdd(&st_tot[3], own_cnt);
-                atomicAdd(&st_tot[4], nn - 1);
-                atomicAdd(&st_tot[5], own_cnt - 1);
-                atomicAdd(reinterpret_cast<u64 *>(&st_cdeg[y]), static_cast<u64>(static_cast<long long>(nn) - 1));
+                if (rn) rn[i] = nn;
+                if (rs) rs[i] = nn - 1;
+                if (rm) rm[i] = own_cnt - 1;
+            }
+        }
+        if (derive) {  // (workgroup-uniform) - every lane takes part in the wave sums
+            // Sums go through the wave first - one LDS atomic per wave and counter (1024 threads adding to the same six
+            // words serialise: the first version of this pass doubled the kernel's time).
+            if (!ok) {
+#pragma unroll
+                for (int c = 0; c < SMALL_F; ++c) cnt[c] = 0;
+            }
+            const unsigned long long okm = __ballot(ok);
+            const int rows_ok = __popcll(okm), s_nn = wave_sum(nn), s_own = wave_sum(own_cnt), s_lab = wave_sum(lab);
+            if (lane == 0 && rows_ok) {
+                atomicAdd(&st_tot[0], s_nn);
+                atomicAdd(&st_tot[1], s_own);
+                atomicAdd(&st_tot[2], s_lab);
+                atomicAdd(&st_tot[3], s_own);
+                atomicAdd(&st_tot[4], s_nn - rows_ok);
+                atomicAdd(&st_tot[5], s_own - rows_ok);
+            }
+            // the histogram row and the class degree, one label of the wave at a time (labels come in blocks: one label per
+            // wave is the common case, two at a block boundary)
+            unsigned long long left = okm;
+            while (left) {
+                const int y0 = __builtin_amdgcn_readlane(y, __ffsll(static_cast<long long>(left)) - 1);
+                const bool mine = ok && y == y0;
+                const unsigned long long members = __ballot(mine);
+                const int rows_y = __popcll(members);
+                const int deg = (members == okm ? s_nn : wave_sum(mine ? nn : 0)) - rows_y;
+#pragma unroll
+                for (int c = 0; c < SMALL_F; ++c) {
+                    if (c >= C) break;
+                    const int sc = wave_sum(mine ? cnt[c] : 0) - (c == y0 ? rows_y : 0);
+                    if (lane == 0 && sc) atomicAdd(&st_hist[y0 * C + c], sc);
+                }
+                if (lane == 0) atomicAdd(reinterpret_cast<u64 *>(&st_cdeg[y0]), static_cast<u64>(static_cast<long long>(deg)));
+                left &= ~members;
             }
         }
         const unsigned long long ms = __ballot(soft), mh = __ballot(hard);
@@ -382,7 +456,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void las_small_fused(const wdg_las_j
     __syncthreads();
     if (threadIdx.x < 2) job.count_out[threadIdx.x] = counts[threadIdx.x];
     if (derive) {  // one workgroup per graph: plain stores, nothing to zero beforehand
-        const desc_ptr<wdg_stats_job> sj = (desc_ptr<wdg_stats_job>)job.counts;
         const global_ptr<int64_t> totals = to_global(sj->totals), compat = to_global(sj->compat), classdeg = to_global(sj->classdeg);
         if (threadIdx.x < 6) totals[threadIdx.x] = st_tot[threadIdx.x];
         for (int i = threadIdx.x; i < C * C; i += FUSED_THREADS) compat[i] = st_hist[i];
