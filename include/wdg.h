@@ -303,17 +303,20 @@ int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int3
 /*
  * The aggregation for ONE graph with at most 8 features (csrc/spmm_narrow.hip; config C5: twitch-gamers scale with 7 bf16
  * features): the job carries a band plan; `workspace` (wdg_spmm_narrow_workspace_bytes(n_rows, n_cols) bytes) receives the
- * packed sources cs[c] X[c, 0..7] as fp32 - column scale, conversion and padding once per column - and every stored entry
- * then costs one 32-byte gather.  When the packed table exceeds what an XCD's L2 holds (wdg_spmm_narrow_parts(n_cols) =
- * 2, 4 or 8 > 1) the columns are cut into that many ranges, each swept by its own XCDs, and the partial rows are summed in
- * range order: the call then needs `part_ptr` = the split positions of every row ([n_rows x (parts - 1)] ints, filled once
- * per graph by wdg_spmm_narrow_plan; NULL when parts is 1).  Sums in a fixed order (lanes split a row's entries, fixed
- * butterfly, parts ascending).
+ * packed sources - column scale, conversion and padding once per column - and every stored entry then costs one gather of
+ * wdg_spmm_narrow_col_bytes(n_feat, x_is_bf16, has_col_scale) bytes: 16 when the job has at most four features (four fp32,
+ * cs[c] X[c, 0..3]) or bf16 sources and no column scale (the row's eight bf16 as they are: exact), else 32 (eight fp32,
+ * cs[c] X[c, 0..7]).  When the packed table exceeds what an XCD's L2 holds (wdg_spmm_narrow_parts(n_cols, col_bytes) = 2, 4
+ * or 8 > 1) the columns are cut into that many ranges, each swept by its own XCDs, and the partial rows are summed in range
+ * order: the call then needs `part_ptr` = the split positions of every row ([n_rows x (parts - 1)] ints, filled once per
+ * graph and `parts` by wdg_spmm_narrow_plan; NULL when parts is 1).  Sums in a fixed order (lanes split a row's entries,
+ * fixed butterfly, parts ascending).
  * Replaces `torch.spmm(adj, label_onehot)` utils/homophily_metrics.py:199 and the SGC-1 aggregation on large graphs.
  */
-int32_t wdg_spmm_narrow_parts(int32_t n_cols);
+int32_t wdg_spmm_narrow_col_bytes(int32_t n_feat, int32_t x_is_bf16, int32_t has_col_scale);
+int32_t wdg_spmm_narrow_parts(int32_t n_cols, int32_t col_bytes);
 size_t wdg_spmm_narrow_workspace_bytes(int32_t n_rows, int32_t n_cols);
-int wdg_spmm_narrow_plan(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *part_ptr,
+int wdg_spmm_narrow_plan(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t parts, int32_t *part_ptr,
                          wdg_stream_t stream);
 int wdg_spmm_narrow_f32(const wdg_spmm_job *job_host, const int32_t *part_ptr, void *workspace, size_t workspace_bytes,
                         wdg_stream_t stream);

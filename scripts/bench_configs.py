@@ -51,12 +51,13 @@ def line(config, workload, kernel, alg_bytes, edges, us_mean, us_med, **extra):
     return rec
 
 
-def single_graph(config, workload, g, x, reps, elem=4, **extra):
+def single_graph(config, workload, g, x, reps, elem=4, norm=1, **extra):
     import torch
     from wdg_amd import ops
-    d = ops.degree_norm(g, 1, ops.PREC_F32)["dinv"]
-    y = ops.spmm(g, x, row_scale=d, col_scale=d)
-    us, med = timed(lambda: ops.spmm(g, x, row_scale=d, col_scale=d, out=y), reps)
+    d = ops.degree_norm(g, norm, ops.PREC_F32)["dinv"]
+    cs = d if norm == 1 else None  # symmetric: D^-1/2 on both sides; random walk: rows only
+    y = ops.spmm(g, x, row_scale=d, col_scale=cs)
+    us, med = timed(lambda: ops.spmm(g, x, row_scale=d, col_scale=cs, out=y), reps)
     n, f, e = g.n_rows, x.shape[1], g.nnz
     alg = 4 * (n + 1) + 4 * e + 4 * n + elem * n * f + y.element_size() * n * f
     quad = getattr(g, "quad", None)
@@ -236,7 +237,7 @@ def c5_models(reps):
     n, e_und, f = 168114, 6797557, 7
     rng = np.random.default_rng(6)
     src, dst = synth.random_graph(n, e_und, seed=5)
-    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_ADD_SELF_LOOPS)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_DROP_SELF_LOOPS | ops.COO_ADD_SELF_LOOPS)  # (twitch-gamers has no self loops: A + I is binary)
     raw = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE)
     labels = torch.from_numpy(rng.integers(0, 2, n))
     onehot = torch.eye(2)[labels].cuda()
@@ -278,10 +279,35 @@ def c5(reps):
     from wdg_amd import synth
     rng = np.random.default_rng(6)
     src, dst = synth.random_graph(n, e_und, seed=5)
-    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_ADD_SELF_LOOPS)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_DROP_SELF_LOOPS | ops.COO_ADD_SELF_LOOPS)  # (twitch-gamers has no self loops: A + I is binary)
     x = torch.from_numpy(rng.standard_normal((n, f), dtype=np.float32)).cuda().to(torch.bfloat16)
-    return single_graph("C5", f"twitch-gamers scale: N={n}, {g.nnz} stored entries (A+I, duplicates merged), F={f} bf16 features, "
-                        "fp32 accumulation, D^-1/2 (A+I) D^-1/2 X", g, x, reps, elem=2)
+    sym = single_graph("C5", f"twitch-gamers scale: N={n}, {g.nnz} stored entries (A+I, duplicates merged), F={f} bf16 features, "
+                       "fp32 accumulation, D^-1/2 (A+I) D^-1/2 X", g, x, reps, elem=2)
+    rw = single_graph("C5", f"twitch-gamers scale: N={n}, {g.nnz} stored entries (A+I, duplicates merged), F={f} bf16 features, "
+                      "fp32 accumulation, random-walk D^-1 (A+I) X (no column scale: the bf16 rows gathered as they are, 16 B per entry)",
+                      g, x, reps, elem=2, norm=0)
+    return [sym, rw]
+
+
+def c5_calibration(reps):
+    """FETCH_SIZE calibration for the narrow kernel's access pattern (guide: widths other than 16-B-per-lane streams are
+    uncalibrated): the C5 graph's rows and entry count with every column folded into 0..4095, so the gathered table is 64 KB
+    (always an L2 hit) and what reaches the fabric is the known streams - 4 B per entry of indices, rowptr, the length order."""
+    import torch
+    from wdg_amd import ops, synth
+    n, e_und, f = 168114, 6797557, 7
+    rng = np.random.default_rng(6)
+    src, dst = synth.random_graph(n, e_und, seed=5)
+    g0 = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_SYMMETRISE | ops.COO_BINARISE | ops.COO_DROP_SELF_LOOPS | ops.COO_ADD_SELF_LOOPS)
+    g = ops.CsrGraph(g0.rowptr, g0.col % 4096, None, n, 4096)
+    x = torch.from_numpy(rng.standard_normal((4096, f), dtype=np.float32)).cuda().to(torch.bfloat16)
+    d = ops.degree_norm(g0, 0, ops.PREC_F32)["dinv"]
+    y = ops.spmm(g, x, row_scale=d)
+    us, med = timed(lambda: ops.spmm(g, x, row_scale=d, out=y), reps)
+    known = 4 * g.nnz + 4 * (n + 1) + 4 * n + 4 * n + 4 * n * f  # indices, rowptr, length order, row scale; + the stores
+    return line("C5cal", f"FETCH_SIZE calibration: the C5 rows ({g.nnz} entries) with columns folded into 4096 (64-KB table, L2-resident), "
+                "random-walk, bf16 F=7: fabric traffic = the index / rowptr / order / scale streams", "narrow_pack + spmm_narrow_kernel",
+                known, g.nnz, us, med, known_read_bytes=4 * g.nnz + 4 * (n + 1) + 8 * n, known_write_bytes=4 * n * f)
 
 
 def main():
@@ -297,10 +323,10 @@ def main():
             ("C3", lambda: sweep("C3", 10, 5, args.reps)), ("C3-literal", lambda: literal("C3-literal", 4000, 10, 5, args.reps)),
             ("C4", lambda: c4("squirrel", 2089, args.reps)), ("C4", lambda: c4("chameleon", 2325, args.reps)),
             ("C4m", lambda: c4_models("squirrel", 2089, args.reps)), ("C4m", lambda: c4_models("chameleon", 2325, args.reps)),
-            ("C5", lambda: c5(args.reps)), ("C5m", lambda: c5_models(args.reps))]
+            ("C5", lambda: c5(args.reps)), ("C5m", lambda: c5_models(args.reps)), ("C5cal", lambda: c5_calibration(args.reps))]
     out = open(args.out, "w") if args.out else None
     for tag, fn in todo:
-        if args.only and tag not in args.only.split(","):
+        if (args.only and tag not in args.only.split(",")) or (not args.only and tag == "C5cal"):
             continue
         recs = fn()
         for rec in (recs if isinstance(recs, list) else [recs]):

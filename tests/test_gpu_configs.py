@@ -86,7 +86,7 @@ def test_c5_twitch_scale(oracle):
     xb = torch.from_numpy(x).cuda().to(torch.bfloat16)
     d = ops.degree_norm(g, ops.NORM_SYM, ops.PREC_F32)["dinv"]
     y = ops.spmm(g, xb, row_scale=d, col_scale=d)
-    assert g.narrow_ws is not None and g.narrow_parts is not None and g.narrow_parts[0] == 2  # narrow kernel, two column ranges
+    assert g.narrow_ws is not None and list(g.narrow_parts) == [2]  # narrow kernel, 32-byte fp32 table in two column ranges
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
@@ -97,6 +97,25 @@ def test_c5_twitch_scale(oracle):
     vhat = oracle.normalised_csr(rowptr, col, val, 1, oracle.PREC_F32)
     want = oracle.spmm_csr(rowptr, col, vhat, _np(xb.float()))
     np.testing.assert_allclose(_np(y), want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+    # random-walk A_hat = D^-1 (A+I): no column scale, so the bf16 rows are gathered as they are (16 bytes per column: the
+    # whole table in one L2, one column range); and a two-column product with a column scale (four fp32 per column)
+    drw = ops.degree_norm(g, ops.NORM_RW, ops.PREC_F32)["dinv"]
+    y_rw = ops.spmm(g, xb, row_scale=drw)
+    assert list(g.narrow_parts) == [2]  # (no second plan: one range)
+    vrw = oracle.normalised_csr(rowptr, col, val, 0, oracle.PREC_F32)
+    want = oracle.spmm_csr(rowptr, col, vrw, _np(xb.float()))
+    np.testing.assert_allclose(_np(y_rw), want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+    assert not g.unit_values  # (the random pairs hold a few self loops: A + I stores 2 there, the value stream is read)
+    g1 = ops.CsrGraph.from_coo(src, dst, n, None, flags | ops.COO_DROP_SELF_LOOPS)  # binary A + I: the value stream is skipped
+    assert g1.unit_values
+    r1, c1, v1 = oracle.coo_to_csr(src, dst, n, None, oracle.SYMMETRISE | oracle.BINARISE | oracle.ADD_SELF_LOOPS | oracle.DROP_SELF_LOOPS)
+    d1 = ops.degree_norm(g1, ops.NORM_RW, ops.PREC_F32)["dinv"]
+    want = oracle.spmm_csr(r1, c1, oracle.normalised_csr(r1, c1, v1, 0, oracle.PREC_F32), _np(xb.float()))
+    np.testing.assert_allclose(_np(ops.spmm(g1, xb, row_scale=d1)), want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+    x2 = torch.from_numpy(x[:, :2].copy()).cuda()
+    y2 = ops.spmm(g, x2, row_scale=d, col_scale=d)
+    want = oracle.spmm_csr(rowptr, col, vhat, x[:, :2].copy())
+    np.testing.assert_allclose(_np(y2), want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
     # aggregation homophily with the 10 000-node class-balanced sample (homophily_tests.py:124-131)
     lab_t = torch.from_numpy(labels)
     onehot = torch.eye(2)[lab_t]

@@ -45,6 +45,30 @@ __global__ __launch_bounds__(256) void narrow_pack(const TIN *__restrict__ X, in
     T[i] = v;
 }
 
+// The 16-byte tables (168 114 columns x 16 B = 2.7 MB: an XCD's L2 keeps all of it, one request per entry, no column
+// ranges and no combine pass).  Four features or fewer: T[c] = cs[c] * X[c, 0..3] as four fp32 (label aggregation with
+// C <= 4 classes, the inference order A_hat (X W) of a two-class head).  bf16 sources without a column scale (random-walk
+// A_hat): the row's eight bf16 values as they are - exact, converted per entry by one shift / mask.
+template <typename TIN>
+__global__ __launch_bounds__(256) void narrow_pack4(const TIN *__restrict__ X, int64_t ldx, const float *__restrict__ cs, int n_cols,
+                                                    int F, float *__restrict__ T) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= static_cast<int64_t>(n_cols) * 4) return;
+    const int c = static_cast<int>(i >> 2), f = static_cast<int>(i & 3);
+    float v = 0.f;
+    if (f < F) v = n_f32<TIN>(X[static_cast<int64_t>(c) * ldx + f]) * (cs ? cs[c] : 1.f);
+    T[i] = v;
+}
+__global__ __launch_bounds__(256) void narrow_pack_bf16x8(const bf16_t *__restrict__ X, int64_t ldx, int n_cols, int F,
+                                                          bf16_t *__restrict__ T) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= static_cast<int64_t>(n_cols) * 8) return;
+    const int c = static_cast<int>(i >> 3), f = static_cast<int>(i & 7);
+    T[i] = f < F ? X[static_cast<int64_t>(c) * ldx + f] : static_cast<bf16_t>(0);
+}
+
+enum { TABLE_F32X8 = 0, TABLE_F32X4 = 1, TABLE_BF16X8 = 2 };
+
 struct Acc8 {
     float v[8];
 };
@@ -52,7 +76,16 @@ struct Acc8 {
 // partial sums of the entries b + sub, b + sub + G, ... < e of one row; four gathers in flight per lane.  A source row is
 // `ldq` float4s apart (2 for the packed table); WIDE: eight features (two 16-byte loads), else four (one);
 // HAS_W: explicit values and / or a column scale gathered per entry (either pointer may be null)
-template <int G, bool HAS_W, bool WIDE = true>
+// the 16 bytes of a TABLE_BF16X8 row: feature f in half f % 2 (low first) of word f / 2
+__device__ __forceinline__ void narrow_unpack_bf16(const f32x4_t raw, f32x4_t &lo, f32x4_t &hi) {
+    const unsigned w0 = __float_as_uint(raw[0]), w1 = __float_as_uint(raw[1]), w2 = __float_as_uint(raw[2]), w3 = __float_as_uint(raw[3]);
+    lo[0] = __uint_as_float(w0 << 16); lo[1] = __uint_as_float(w0 & 0xffff0000u);
+    lo[2] = __uint_as_float(w1 << 16); lo[3] = __uint_as_float(w1 & 0xffff0000u);
+    hi[0] = __uint_as_float(w2 << 16); hi[1] = __uint_as_float(w2 & 0xffff0000u);
+    hi[2] = __uint_as_float(w3 << 16); hi[3] = __uint_as_float(w3 & 0xffff0000u);
+}
+
+template <int G, bool HAS_W, bool WIDE = true, bool BF16 = false>
 __device__ __forceinline__ Acc8 narrow_sweep(global_ptr<const int32_t> col, global_ptr<const float> val,
                                              global_ptr<const f32x4_t> T, int b, int e, int sub, int64_t ldq = 2,
                                              global_ptr<const float> cs = nullptr) {
@@ -70,12 +103,13 @@ __device__ __forceinline__ Acc8 narrow_sweep(global_ptr<const int32_t> col, glob
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             lo[u] = T[ldq * static_cast<int64_t>(idx[u])];
-            hi[u] = WIDE ? T[ldq * static_cast<int64_t>(idx[u]) + 1] : zero;
+            hi[u] = (WIDE && !BF16) ? T[ldq * static_cast<int64_t>(idx[u]) + 1] : zero;
             w[u] = 1.f;
             if (HAS_W) w[u] = (val ? val[k + u * G] : 1.f) * (cs ? cs[idx[u]] : 1.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (BF16) narrow_unpack_bf16(lo[u], lo[u], hi[u]);
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 a.v[f] = HAS_W ? __builtin_fmaf(w[u], lo[u][f], a.v[f]) : a.v[f] + lo[u][f];
@@ -85,7 +119,8 @@ __device__ __forceinline__ Acc8 narrow_sweep(global_ptr<const int32_t> col, glob
     }
     for (; k < e; k += G) {
         const int idx = col[k];
-        const f32x4_t lo = T[ldq * static_cast<int64_t>(idx)], hi = WIDE ? T[ldq * static_cast<int64_t>(idx) + 1] : zero;
+        f32x4_t lo = T[ldq * static_cast<int64_t>(idx)], hi = (WIDE && !BF16) ? T[ldq * static_cast<int64_t>(idx) + 1] : zero;
+        if (BF16) narrow_unpack_bf16(lo, lo, hi);
         float w = 1.f;
         if (HAS_W) w = (val ? val[k] : 1.f) * (cs ? cs[idx] : 1.f);
 #pragma unroll
@@ -131,11 +166,13 @@ __device__ __forceinline__ float narrow_reduce64(Acc8 a, int lane) {
 // entries of part x PARTS / 8 (a row's entries are sorted by column: part_ptr holds the PARTS - 1 split positions of every
 // row), so each L2 holds the 1 / PARTS of the table its CUs gather from; the partial rows P[part][row][8] are summed in part
 // order by narrow_combine.
-template <bool HAS_VAL>
+template <bool HAS_VAL, int TABLE = TABLE_F32X8>
 __global__ __launch_bounds__(N_THREADS) void spmm_narrow_kernel(const wdg_spmm_job job, const float *__restrict__ Tf,
                                                                 const int32_t *__restrict__ part_ptr, int parts,
                                                                 float *__restrict__ P) {
     __shared__ float part_sums[N_WAVES][8];
+    constexpr bool WIDE = TABLE != TABLE_F32X4, BF16 = TABLE == TABLE_BF16X8;
+    constexpr int64_t LDQ = TABLE == TABLE_F32X8 ? 2 : 1;
     const global_ptr<const int32_t> rowptr = to_global(job.rowptr), col = to_global(job.col), perm = to_global(job.band_perm);
     const global_ptr<const int32_t> pptr = to_global(part_ptr);
     const global_ptr<const float> val = to_global(job.val), rs = to_global(job.row_scale);
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(N_THREADS) void spmm_narrow_kernel(const wdg_spmm_j
         const int row = perm[i];
         int b, e;
         bounds(row, b, e);
-        const float total = narrow_reduce64(narrow_sweep<N_THREADS, HAS_VAL>(col, val, T, b, e, tid), lane);
+        const float total = narrow_reduce64(narrow_sweep<N_THREADS, HAS_VAL, WIDE, BF16>(col, val, T, b, e, tid, LDQ), lane);
         if (lane < 16 && !(lane & 1)) part_sums[wave][feat] = total;
         __syncthreads();
         if (tid < n_out) {
@@ -184,7 +221,7 @@ __global__ __launch_bounds__(N_THREADS) void spmm_narrow_kernel(const wdg_spmm_j
         const int row = perm[i];
         int b, e;
         bounds(row, b, e);
-        const float total = narrow_reduce64(narrow_sweep<kWave, HAS_VAL>(col, val, T, b, e, lane), lane);
+        const float total = narrow_reduce64(narrow_sweep<kWave, HAS_VAL, WIDE, BF16>(col, val, T, b, e, lane, LDQ), lane);
         if (lane < 16 && !(lane & 1) && feat < n_out) out[static_cast<int64_t>(row) * ldo + feat] = total * scale_of(row);
     }
     // ---- the other rows: 16 lanes per row, four rows per wave (neighbours in the length order)
@@ -195,7 +232,7 @@ __global__ __launch_bounds__(N_THREADS) void spmm_narrow_kernel(const wdg_spmm_j
         const int row = live ? perm[n_wave_rows + slot] : 0;
         int b = 0, e = 0;
         if (live) bounds(row, b, e);
-        const float total = narrow_reduce16(narrow_sweep<16, HAS_VAL>(col, val, T, b, e, lane & 15), lane);
+        const float total = narrow_reduce16(narrow_sweep<16, HAS_VAL, WIDE, BF16>(col, val, T, b, e, lane & 15, LDQ), lane);
         if (live && !(lane & 1) && feat < n_out) out[static_cast<int64_t>(row) * ldo + feat] = total * scale_of(row);
     }
 }
@@ -256,25 +293,32 @@ constexpr int64_t N_PART_BYTES = 3 << 20;  // 3 MiB of packed sources per part: 
 
 extern "C" {
 
-int32_t wdg_spmm_narrow_parts(int32_t n_cols) {
+int32_t wdg_spmm_narrow_col_bytes(int32_t n_feat, int32_t x_is_bf16, int32_t has_col_scale) {
+    if (const char *s = getenv("WDG_NARROW_TABLE32")) {  // experiments / tests: always the 32-byte fp32 table
+        if (atoi(s) != 0) return 32;
+    }
+    return (n_feat <= 4 || (x_is_bf16 && !has_col_scale)) ? 16 : 32;
+}
+
+int32_t wdg_spmm_narrow_parts(int32_t n_cols, int32_t col_bytes) {
     if (const char *s = getenv("WDG_NARROW_PARTS")) {
         const int v = atoi(s);
         if (v == 1 || v == 2 || v == 4 || v == 8) return v;
     }
     int parts = 1;
-    while (parts < 8 && static_cast<int64_t>(n_cols) * 32 > N_PART_BYTES * parts) parts <<= 1;
+    while (parts < 8 && static_cast<int64_t>(n_cols) * col_bytes > N_PART_BYTES * parts) parts <<= 1;
     return parts;
 }
 
-size_t wdg_spmm_narrow_workspace_bytes(int32_t n_rows, int32_t n_cols) {
-    const int parts = wdg_spmm_narrow_parts(n_cols);
+size_t wdg_spmm_narrow_workspace_bytes(int32_t n_rows, int32_t n_cols) {  // (sized for the 32-byte table: any call fits)
+    const int parts = wdg_spmm_narrow_parts(n_cols, 32);
     return static_cast<size_t>(n_cols > 0 ? n_cols : 0) * 32 + (parts > 1 ? static_cast<size_t>(parts) * (n_rows > 0 ? n_rows : 0) * 32 : 0) + 512;
 }
 
-int wdg_spmm_narrow_plan(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *part_ptr,
+int wdg_spmm_narrow_plan(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t parts, int32_t *part_ptr,
                          wdg_stream_t stream) {
     WDG_REQUIRE(N >= 0 && n_cols >= 0, "spmm_narrow_plan: negative size");
-    const int parts = wdg_spmm_narrow_parts(n_cols);
+    WDG_REQUIRE(parts == 1 || parts == 2 || parts == 4 || parts == 8, "spmm_narrow_plan: parts must be 1, 2, 4 or 8");
     if (parts == 1 || N == 0) return WDG_OK;
     WDG_REQUIRE(rowptr && col && part_ptr, "spmm_narrow_plan: null array");
     const int part_cols = static_cast<int>(wdg::ceil_div(n_cols, parts));
@@ -293,7 +337,9 @@ static int narrow_launch(const wdg_spmm_job *j, bool bf16, const int32_t *part_p
     WDG_REQUIRE(j->rowptr && j->Y && (j->n_cols == 0 || j->X), "spmm_narrow: null rowptr / X / Y");
     WDG_REQUIRE(j->band_perm && j->band_cuts, "spmm_narrow: the job carries no band plan (wdg_csr_band_plan)");
     WDG_REQUIRE(j->ldx >= j->n_feat && j->ldy >= j->n_feat, "spmm_narrow: leading dimension smaller than n_feat");
-    const int parts = wdg_spmm_narrow_parts(j->n_cols);
+    const int col_bytes = wdg_spmm_narrow_col_bytes(j->n_feat, bf16 ? 1 : 0, j->col_scale ? 1 : 0);
+    const int table = col_bytes == 32 ? TABLE_F32X8 : (j->n_feat <= 4 ? TABLE_F32X4 : TABLE_BF16X8);
+    const int parts = wdg_spmm_narrow_parts(j->n_cols, col_bytes);
     WDG_REQUIRE(parts == 1 || part_ptr, "spmm_narrow: this column count needs the split positions of wdg_spmm_narrow_plan");
     if (!workspace || workspace_bytes < wdg_spmm_narrow_workspace_bytes(j->n_rows, j->n_cols))
         return wdg::fail(WDG_ERR_WORKSPACE, "spmm_narrow: workspace too small");
@@ -301,16 +347,34 @@ static int narrow_launch(const wdg_spmm_job *j, bool bf16, const int32_t *part_p
     float *T = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
     float *P = T + static_cast<size_t>(j->n_cols) * 8;
     if (j->n_cols > 0) {
-        const unsigned blocks = static_cast<unsigned>(wdg::ceil_div(static_cast<int64_t>(j->n_cols) * 8, 256));
-        if (bf16) hipLaunchKernelGGL(narrow_pack<bf16_t>, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t *>(j->X), j->ldx, j->col_scale, j->n_cols, j->n_feat, T);
-        else hipLaunchKernelGGL(narrow_pack<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float *>(j->X), j->ldx, j->col_scale, j->n_cols, j->n_feat, T);
+        const int per_col = table == TABLE_F32X4 ? 4 : 8;
+        const unsigned blocks = static_cast<unsigned>(wdg::ceil_div(static_cast<int64_t>(j->n_cols) * per_col, 256));
+        if (table == TABLE_BF16X8)
+            hipLaunchKernelGGL(narrow_pack_bf16x8, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t *>(j->X), j->ldx, j->n_cols, j->n_feat, reinterpret_cast<bf16_t *>(T));
+        else if (table == TABLE_F32X4 && bf16)
+            hipLaunchKernelGGL(narrow_pack4<bf16_t>, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t *>(j->X), j->ldx, j->col_scale, j->n_cols, j->n_feat, T);
+        else if (table == TABLE_F32X4)
+            hipLaunchKernelGGL(narrow_pack4<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float *>(j->X), j->ldx, j->col_scale, j->n_cols, j->n_feat, T);
+        else if (bf16)
+            hipLaunchKernelGGL(narrow_pack<bf16_t>, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t *>(j->X), j->ldx, j->col_scale, j->n_cols, j->n_feat, T);
+        else
+            hipLaunchKernelGGL(narrow_pack<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float *>(j->X), j->ldx, j->col_scale, j->n_cols, j->n_feat, T);
     }
     const int cus = std::max(wdg_device_cus(), 8);
     int per_cu = 8;
     if (const char *s = getenv("WDG_NARROW_WGS")) per_cu = std::max(1, std::min(8, atoi(s)));
     const dim3 grid(static_cast<unsigned>(cus / kXcds * kXcds * per_cu));
-    if (j->val) hipLaunchKernelGGL(spmm_narrow_kernel<true>, grid, dim3(N_THREADS), 0, st, *j, T, part_ptr, parts, P);
-    else hipLaunchKernelGGL(spmm_narrow_kernel<false>, grid, dim3(N_THREADS), 0, st, *j, T, part_ptr, parts, P);
+#define WDG_NARROW_LAUNCH(V, TB) hipLaunchKernelGGL((spmm_narrow_kernel<V, TB>), grid, dim3(N_THREADS), 0, st, *j, T, part_ptr, parts, P)
+    if (j->val) {
+        if (table == TABLE_F32X8) WDG_NARROW_LAUNCH(true, TABLE_F32X8);
+        else if (table == TABLE_F32X4) WDG_NARROW_LAUNCH(true, TABLE_F32X4);
+        else WDG_NARROW_LAUNCH(true, TABLE_BF16X8);
+    } else {
+        if (table == TABLE_F32X8) WDG_NARROW_LAUNCH(false, TABLE_F32X8);
+        else if (table == TABLE_F32X4) WDG_NARROW_LAUNCH(false, TABLE_F32X4);
+        else WDG_NARROW_LAUNCH(false, TABLE_BF16X8);
+    }
+#undef WDG_NARROW_LAUNCH
     if (parts > 1) {
         const unsigned blocks = static_cast<unsigned>(wdg::ceil_div(static_cast<int64_t>(j->n_rows) * 8, 256));
         hipLaunchKernelGGL(narrow_combine, dim3(blocks), dim3(256), 0, st, P, j->n_rows, parts, j->n_feat, j->row_scale, j->Y, j->ldy);

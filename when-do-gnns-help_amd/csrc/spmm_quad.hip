@@ -42,7 +42,14 @@ namespace {
 
 using namespace wdg;
 
-constexpr int Q_THREADS = 1024;
+#ifndef WDG_Q_THREADS  // (experiments: scripts/dev/try_two_wg.py builds 512-thread workgroups, two per CU)
+#define WDG_Q_THREADS 1024
+#define WDG_Q_WGS_PER_CU 1
+#define WDG_Q_OCCUPANCY
+#else
+#define WDG_Q_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+constexpr int Q_THREADS = WDG_Q_THREADS;
 constexpr int Q_WAVES = Q_THREADS / 64;
 constexpr int Q_ROWS = 16;             // rows per unit (SELL-16 slice)
 constexpr int Q_CHUNK = 16;            // entries per row and index chunk (one 16-byte load per lane)
@@ -1023,7 +1030,7 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
 // items != NULL: segment `seg` = the phases items[seg_ptr[seg] .. seg_ptr[seg + 1]); items == NULL: one job (the by-value
 // descriptor), segment `seg` = its units seg, seg + n_segments, ...
 template <typename TIN, bool HAS_VAL, bool MULTI>
-__global__ __launch_bounds__(Q_THREADS) void spmm_quad_kernel(const wdg_spmm_job *__restrict__ jobs,
+__global__ __launch_bounds__(Q_THREADS) WDG_Q_OCCUPANCY void spmm_quad_kernel(const wdg_spmm_job *__restrict__ jobs,
                                                               const wdg_spmm_job inline_job,
                                                               const wdg_spmm_item *__restrict__ items,
                                                               const int32_t *__restrict__ seg_ptr, int subs, int n_groups,
@@ -1092,7 +1099,7 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
         configured_dev = dev;
     }
     const int cus = std::max(wdg_device_cus(), 8);
-    const int wgs_per_xcd = std::max(1, std::min(cus / kXcds, subs * n_groups));
+    const int wgs_per_xcd = std::max(1, std::min(cus * WDG_Q_WGS_PER_CU / kXcds, subs * n_groups));
     const dim3 grid(static_cast<unsigned>(wgs_per_xcd * kXcds));
 #define WDG_Q_LAUNCH(V, M)                                                                                             \
     hipLaunchKernelGGL((spmm_quad_kernel<TIN, V, M>), grid, dim3(Q_THREADS), lds, st, jobs, inl, items, seg_ptr, subs, \
@@ -1292,7 +1299,7 @@ int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, cons
 int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat) {  // the grid of the batched launch (sizes wg_clock)
     const int n_groups = static_cast<int>(wdg::ceil_div(max_feat, 16));
     const int cus = std::max(wdg_device_cus(), 8);
-    return std::max(1, std::min(cus / wdg::kXcds, (n_segments / wdg::kXcds) * n_groups)) * wdg::kXcds;
+    return std::max(1, std::min(cus * WDG_Q_WGS_PER_CU / wdg::kXcds, (n_segments / wdg::kXcds) * n_groups)) * wdg::kXcds;
 }
 
 }  // extern "C"

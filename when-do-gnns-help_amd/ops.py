@@ -60,7 +60,17 @@ class CsrGraph:
         self.quad = None  # SELL-16 copy (dict) for the quad-row kernel, built on demand; False = decided against
         self.band = None  # band plan (dict) for the band kernel, built on demand; False = not applicable
         self.narrow_ws = None  # packed-source workspace of the narrow kernel (one per graph: calls on one stream)
-        self.narrow_parts = None  # (parts, split positions of every row) when the packed sources exceed an XCD's L2
+        self.narrow_parts = None  # {parts: split positions of every row} when the packed sources exceed an XCD's L2
+        self._unit_values = None if val is not None else True  # every stored value == 1 (checked once, on first use)
+
+    @property
+    def unit_values(self):
+        """True when every stored value is exactly 1 (a binary adjacency, what the reference's loaders build): products then
+        skip the value stream - a + 1 * x and a + x are the same bits, and the entries are 4 bytes instead of 8.  One
+        reduction + host read-back per graph, on first use (like the other one-time plans: not inside a stream capture)."""
+        if self._unit_values is None:
+            self._unit_values = bool((self.val == 1).all().item()) if self.val.numel() else True
+        return self._unit_values
 
     def ensure_sell(self, max_padding=3.0):
         """Build the SELL-64 copy (wdg_csr_to_sell_*) that the row-lane SpMM consumes.  One-time per graph.
@@ -483,7 +493,7 @@ NARROW_MIN_ENTRIES = int(os.environ.get("WDG_NARROW_MIN_ENTRIES", 1 << 15))  # b
 
 def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
     job.rowptr, job.col = g.rowptr.data_ptr(), g.col.data_ptr()
-    job.val = g.val.data_ptr() if (use_values and g.val is not None) else 0
+    job.val = g.val.data_ptr() if (use_values and g.val is not None and not g.unit_values) else 0
     job.row_scale = 0 if row_scale is None else row_scale.data_ptr()
     job.col_scale = 0 if col_scale is None else col_scale.data_ptr()
     job.X, job.Y = x.data_ptr(), y.data_ptr()
@@ -591,12 +601,16 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
         ws_bytes = lib.wdg_spmm_narrow_workspace_bytes(g.n_rows, g.n_cols)
         if g.narrow_ws is None or g.narrow_ws.numel() < ws_bytes:
             g.narrow_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        parts = int(lib.wdg_spmm_narrow_parts(g.n_cols))
-        if parts > 1 and (g.narrow_parts is None or g.narrow_parts[0] != parts):  # one-time: every row's split positions
+        # 16-byte source rows (<= 4 features, or bf16 sources without a column scale) halve the table: fewer column ranges
+        col_bytes = int(lib.wdg_spmm_narrow_col_bytes(x.shape[1], int(x.dtype == torch.bfloat16), int(col_scale is not None)))
+        parts = int(lib.wdg_spmm_narrow_parts(g.n_cols, col_bytes))
+        if g.narrow_parts is None:
+            g.narrow_parts = {}
+        if parts > 1 and parts not in g.narrow_parts:  # one-time per graph and range count: every row's split positions
             pp = torch.empty(g.n_rows * (parts - 1), dtype=torch.int32, device=dev)
-            check(lib.wdg_spmm_narrow_plan(_ptr(g.rowptr), _ptr(g.col), g.n_rows, g.n_cols, _ptr(pp), stream_handle()), "wdg_spmm_narrow_plan")
-            g.narrow_parts = (parts, pp)
-        part_ptr = g.narrow_parts[1] if parts > 1 else None
+            check(lib.wdg_spmm_narrow_plan(_ptr(g.rowptr), _ptr(g.col), g.n_rows, g.n_cols, parts, _ptr(pp), stream_handle()), "wdg_spmm_narrow_plan")
+            g.narrow_parts[parts] = pp
+        part_ptr = g.narrow_parts[parts] if parts > 1 else None
         fn = lib.wdg_spmm_narrow_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_narrow_f32
         check(fn(ctypes.byref(job), _ptr(part_ptr), _ptr(g.narrow_ws), ws_bytes, stream_handle()), "wdg_spmm_narrow")
         return y
