@@ -4,6 +4,9 @@ CSRC     := $(PKG)/csrc
 HIPCC    ?= /opt/rocm/bin/hipcc
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-unused-value $(if $(STAMPS),-DWDG_STAMPS,) $(if $(DEPTH),-DWDG_PREFETCH_DEPTH=$(DEPTH),) $(EXTRA)
 SRCS     := $(wildcard $(CSRC)/*.hip)
+# per-file flags: the 32 steps of kernel_reg.hip's in-wave substitution must unroll completely (their register indices and
+# branch conditions are compile-time only then) - with the default budget the compiler peels 11 steps and rolls the rest
+FLAGS_kernel_reg := -mllvm -pragma-unroll-threshold=200000
 OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 LIB      := $(PKG)/lib/libwdg_hip.so
 
@@ -17,7 +20,7 @@ $(LIB): $(OBJS)
 # checks that no shipped kernel spills vector registers)
 build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/wdg.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> build/$*.rsrc || (cat build/$*.rsrc; exit 1)
+	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> build/$*.rsrc || (cat build/$*.rsrc; exit 1)
 	@grep -E "warning:|error:" build/$*.rsrc || true
 
 oracle: oracle/_build/libwdg_oracle.so

@@ -612,20 +612,55 @@ __device__ __forceinline__ void k2_load_block(f32x16 &t, const float *img, int l
 // The in-wave substitution along a block's columns: x_j = (a_j - sum_{k < j} x_k L[j][k]) / L[j][j], j = 0 .. 31, for the 32 rows of
 // a block at once.  Lane (i, h) works on row i and holds the entries k = 8 q + 4 h + e of x (the block's own register layout): the
 // two lane halves split every row's sum, each reads its half of row j of L from LDS (one address per half: broadcast) a whole
-// row AHEAD of the fmas that use it, and one v_permlane32_swap adds the halves.
-//   factor == false: L = the finished diagonal block (`ld`, 1 / l_jj in `dinv`): X L^T = A, the panel solve;
-//   factor == true : A IS the diagonal block (img == ld): the same recurrence is its Cholesky factorisation row by row - x_j of
-//                    lane j is the pivot (v_readlane), every lane's x_j / sqrt(pivot) is L[i][j], written to `ld` at once.  The
+// row AHEAD of the fmas that use it, and one v_permlane32_swap adds the halves.  Two waves run it per block column:
+//   factor == true : the LEADER.  A is the diagonal block itself (in `ld`): the recurrence is its Cholesky factorisation row by row -
+//                    x_j of lane j is the pivot (v_readlane), every lane's x_j / sqrt(pivot) is L[i][j], written to `ld` at once.  The
 //                    one entry of row j that the step before has only just produced, L[j][j - 1], comes from lane j's register
-//                    (v_readlane) instead of the prefetched row.  Returns whether a pivot fell below `drop_below`.
-__device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv, bool factor, int li, int h, int lane, int rows_real,
-                                              float drop_below, float ridge) {
+//                    (v_readlane) instead of the prefetched row.  After step j it publishes `step_base + j` in *progress.
+//                    Returns whether a pivot fell below `drop_below`.
+//   factor == false: the FOLLOWER inverts L_kk while it is being made: A = I, so X = L_kk^-T, i.e. lane i ends with COLUMN i of
+//                    M = L_kk^-1.  Step j needs row j + 2 of L (the prefetch), so it runs two rows behind the leader, waiting on
+//                    *progress (both waves are resident: the leader never waits for the follower).  Its last act overwrites the
+//                    image of L_kk in `ld` with M, row-major - from here on every solve against L_kk is a product with M on the
+//                    matrix pipe or a 32-term dot product, not a 32-step recurrence (panel solve, z, back substitution).
+__device__ __forceinline__ bool k2_substitute(float *ld, float *dinv, bool factor, int li, int h, int lane, int rows_real,
+                                              float drop_below, float ridge, int *progress, int step_base, bool nowait = false) {
     float x[16];
+    if (factor) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(img + li * K2_PS + 4 * h + 8 * q);
-        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(ld + li * K2_PS + 4 * h + 8 * q);
+            x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (8 * (r >> 2) + 4 * h + (r & 3)) == li ? 1.f : 0.f;
     }
+    // (follower) until the leader has finished row `row` of L_kk.  The poll is one opaque asm statement: a C loop inside the body
+    // keeps the compiler from unrolling the 32 steps, and x[] then lives in scratch memory (measured: 3.5 x the time).
+    typedef __attribute__((address_space(3))) int lds_int;
+    const unsigned progress_at = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_int *)progress));
+    // (the leader passes -1 and falls through on a scalar compare: the statement sits in the middle of the step's straight-line
+    // code in both modes - a C-level `if` around it would cut the step into basic blocks and stop the scheduler from filling the
+    // row's dependent chain with the next row's sums: 2.2 x the time of a step)
+    const int wait_base = __builtin_amdgcn_readfirstlane((factor || nowait) ? -64 : step_base);  // (wave-uniform: a scalar)
+    auto wait_for = [&](int row) {
+        int seen;
+        const int need = wait_base + row;  // < 0: no wait
+        asm volatile("s_cmp_lt_i32 %2, 0\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "1:\n\t"
+                     "ds_read_b32 %0, %1\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_cmp_gt_i32 vcc, %2, %0\n\t"
+                     "s_cbranch_vccz 2f\n\t"
+                     "s_sleep 1\n\t"
+                     "s_branch 1b\n\t"
+                     "2:"
+                     : "=&v"(seen)
+                     : "v"(progress_at), "s"(need)
+                     : "vcc", "scc", "memory");
+    };
     const float *lh = ld + 4 * h;  // this half's entries of row j: lh[j * K2_PS + 8 q .. + 3]
     const bool hi = h != 0;
     bool low_any = false;
@@ -634,6 +669,7 @@ __device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv
     float4 row_a[4], row_b[4];  // this half's entries of row j + 1 (in use) and of row j + 2 (arriving)
 #pragma unroll
     for (int q = 0; q < 4; ++q) row_a[q] = row_b[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wait_for(1);
     row_a[0] = *reinterpret_cast<const float4 *>(lh + 1 * K2_PS);  // row 1: entry 0
     float p0 = 0.f, p1 = 0.f;  // - sum_{k < j} x_k L[j][k] over this half's entries, for the row being finished
 #pragma unroll
@@ -655,6 +691,10 @@ __device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv
             res = li == j ? piv * inv : (li > j ? v * inv : 0.f);
             if (!hi) ld[li * K2_PS + j] = res;  // column j of L_kk (0 above the diagonal)
             if (lane == 0) dinv[j] = inv;
+            // (LDS operations of one wave are carried out in issue order: whoever reads the step number sees the column)
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(progress, step_base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
         } else {
             res = v * dinv[j];
         }
@@ -662,6 +702,7 @@ __device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv
         if (j + 1 == 32) break;
         // ---- row j + 2 of L for the step after the next (behind this step's write of column j: fresh up to entry j)
         if (j + 2 < 32) {
+            wait_for(j + 2);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (8 * q < j + 2) row_b[q] = *reinterpret_cast<const float4 *>(lh + (j + 2) * K2_PS + 8 * q);
@@ -689,10 +730,9 @@ __device__ __forceinline__ bool k2_substitute(float *img, float *ld, float *dinv
         for (int q = 0; q < 4; ++q) row_a[q] = row_b[q];
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (!factor) {
+    if (!factor) {  // x = row li of L_kk^-T = column li of M: M[k][li], k = 8 q + 4 h + e, over the image of L_kk (the leader is done)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4 *>(img + li * K2_PS + 4 * h + 8 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        for (int r = 0; r < 16; ++r) ld[(8 * (r >> 2) + 4 * h + (r & 3)) * K2_PS + li] = x[r];
     }
     return low_any;
 }
@@ -720,6 +760,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     __shared__ int tr_idx[K2_NB * 32];
     __shared__ signed char blk_a[K2_WAVES * K2_SLOTS], blk_b[K2_WAVES * K2_SLOTS];
     __shared__ int deficient, correct;
+    __shared__ int progress;  // 32 kb + j: the leader has finished row j of L_kk of block column kb (k2_substitute)
     __shared__ float red[K2_WAVES];
 
     const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + blockIdx.x);
@@ -780,7 +821,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             zs[i] = (row < nt && labels[tr_idx[row]] == c) ? 1.f : 0.f;
             al[i] = 0.f;
         }
-        if (tid == 0) deficient = 0;
+        if (tid == 0) deficient = 0, progress = -1;
         auto gather_block = [&](int a, int b, f32x16 &t) {  // lane (i, h): A[32 a + i][32 b + jmap(h, r)] = K[tr[32 b + j]][tr[32 a + i]]
             int li = li_, h = h_;
             asm volatile("" : "+v"(li), "+v"(h));
@@ -815,8 +856,9 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             int li = li_, h = h_;
             asm volatile("" : "+v"(li), "+v"(h));
             // the column's blocks below the diagonal -> LDS, row-major: block (a, kb) into P[a - kb - 1]; the diagonal block is in
-            // LD already.  role: 0 = this wave factors the diagonal block (the wave BEFORE the column's first block in the deal:
-            // it holds none of the column's blocks), a - kb = it holds block (a, kb), -1 = neither
+            // LD already.  role: 0 = this wave factors the diagonal block (the LEADER: the wave BEFORE the column's first block in
+            // the deal - it holds none of the column's blocks), -2 = the wave before that inverts it (the FOLLOWER),
+            // a - kb = it holds block (a, kb), -1 = none of these
             int role = -1;
 #pragma unroll
             for (int s = 0; s < K2_SLOTS; ++s) {
@@ -825,55 +867,63 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 k2_store_block(acc[s], &P[(role - 1) * 32 * K2_PS], li, h);
             }
             {
-                // first block of column kb in the enumeration: sum over the columns after it
+                // first block of column kb in the enumeration: sum over the columns after it (<= 9 blocks + these two < 16 waves)
                 const int first = (nb - 1 - kb) * (nb - 2 - kb) / 2;
                 if (wave == ((first + K2_WAVES - 1) & (K2_WAVES - 1))) role = 0;
+                if (wave == ((first + K2_WAVES - 2) & (K2_WAVES - 1))) role = -2;
             }
-            // (1) the diagonal block's wave factors it alone; (2) the column's other blocks: X L_kk^T = A, while the diagonal
-            //     block's wave solves z_kb = L_kk^-1 y_kb.  One copy of the substitution in the code: two passes of a rolled loop.
-            bool restart = false;
-#pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {
-                for (int rep = 0; rep < ((ablate & 16) ? 3 : 1); ++rep)  // (timing diagnostics: the routine three times over)
-                if ((pass == 0 && role == 0) || (pass == 1 && role > 0)) {  // (wave-uniform)
-                    float *img = pass == 0 ? &LD[kb * 32 * K2_PS] : &P[(role - 1) * 32 * K2_PS];
-                    if (k2_substitute(img, &LD[kb * 32 * K2_PS], &Dinv[kb * 32], pass == 0, li, h, lane, nt - 32 * kb, drop_below, ridge) && lane == 0)
-                        deficient = 1;
-                }
-                if (pass == 0) {
-                    K2_T(2);
-                    __syncthreads();
-                    K2_T(3);
-                    restart = deficient && attempt == 0;
-                    if (restart) break;  // (uniform)
-                }
+            // (1) the leader factors the diagonal block, the follower turns it into M = L_kk^-1 two rows behind (one copy of the
+            //     routine: the mode is a wave-uniform flag); LD[kb] holds M afterwards
+            if (role == 0 || (role == -2 && !(ablate & 64))) {  // (wave-uniform)
+                if (k2_substitute(&LD[kb * 32 * K2_PS], &Dinv[kb * 32], role == 0, li, h, lane, nt - 32 * kb, drop_below, ridge, &progress, 32 * kb, (ablate & 32) != 0) &&
+                    lane == 0)
+                    deficient = 1;
             }
-            if (restart) break;  // restart on K + ridge I
-            if (role == 0) {  // z_kb, column form, lane = row: z_k = y_k / l_kk, y_i -= L[i][k] z_k
-                float y[KR_MAX_C];
+            K2_T(2);
+            __syncthreads();
+            K2_T(3);
+            if (deficient && attempt == 0) break;  // (uniform) restart on K + ridge I
+            // (2) the column's other blocks: X L_kk^T = A  <=>  X = A M^T, 16 MFMAs per block (lane (i, h): row i of A from P, row i
+            //     of M from LD, the k index dealt like the accumulator's columns - the layout of the trailing update); the leader's
+            //     wave meanwhile: z_kb = M y_kb
+            if (role > 0) {
+                f32x16 t;
 #pragma unroll
-                for (int c = 0; c < KR_MAX_C; ++c) y[c] = zs[(32 * kb + li) * KR_MAX_C + c];
-                const float *lrow = &LD[(kb * 32 + li) * K2_PS];
-                float inv_n = Dinv[kb * 32], lik_n = lrow[0];
-                float mine[KR_MAX_C];  // z of this lane's row (caught when its step comes: no LDS store inside the loop, whose
-                                       // wait would also cover the loop's own prefetches)
+                for (int r = 0; r < 16; ++r) t[r] = 0.f;
+                const float *pa = &P[((role - 1) * 32 + li) * K2_PS + 4 * h];
+                const float *pm = &LD[(kb * 32 + li) * K2_PS + 4 * h];
 #pragma unroll
-                for (int c = 0; c < KR_MAX_C; ++c) mine[c] = 0.f;
-#pragma unroll 1
-                for (int k = 0; k < 32; ++k) {  // (rolled: the loop body is the code; the next step's two LDS values are in flight)
-                    const float inv = inv_n, lik = li > k ? lik_n : 0.f;
-                    inv_n = Dinv[kb * 32 + min(k + 1, 31)], lik_n = lrow[min(k + 1, 31)];
-                    const bool me = li == k;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 va = *reinterpret_cast<const float4 *>(pa + 8 * q), vm = *reinterpret_cast<const float4 *>(pm + 8 * q);
+                    t = __builtin_amdgcn_mfma_f32_32x32x2f32(vm.x, va.x, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x2f32(vm.y, va.y, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x2f32(vm.z, va.z, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x2f32(vm.w, va.w, t, 0, 0, 0);
+                }
+                k2_store_block(t, &P[(role - 1) * 32 * K2_PS], li, h);  // L[a, kb], final (only this wave touches the image)
+            } else if (role == 0) {  // z_kb[i] = sum_k M[i][k] y[k]: the lane halves split k, one cross-half add
+                float sum[KR_MAX_C];
 #pragma unroll
-                    for (int c = 0; c < KR_MAX_C; ++c) {
-                        const float zk = k2_bcast(y[c], k) * inv;
-                        y[c] = fmaf(-lik, zk, y[c]);
-                        mine[c] = me ? zk : mine[c];
+                for (int c = 0; c < KR_MAX_C; ++c) sum[c] = 0.f;
+                const float *mrow = &LD[(kb * 32 + li) * K2_PS + 4 * h];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 m = *reinterpret_cast<const float4 *>(mrow + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float *y = &zs[(32 * kb + 8 * q + 4 * h + e) * KR_MAX_C];
+                        const float4 y0 = *reinterpret_cast<const float4 *>(y), y1 = *reinterpret_cast<const float4 *>(y + 4);
+                        const float l = e == 0 ? m.x : e == 1 ? m.y : e == 2 ? m.z : m.w;
+                        sum[0] = fmaf(l, y0.x, sum[0]), sum[1] = fmaf(l, y0.y, sum[1]), sum[2] = fmaf(l, y0.z, sum[2]), sum[3] = fmaf(l, y0.w, sum[3]);
+                        sum[4] = fmaf(l, y1.x, sum[4]), sum[5] = fmaf(l, y1.y, sum[5]), sum[6] = fmaf(l, y1.z, sum[6]), sum[7] = fmaf(l, y1.w, sum[7]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (h == 0) {
-                    *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C]) = make_float4(mine[0], mine[1], mine[2], mine[3]);
-                    *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C + 4]) = make_float4(mine[4], mine[5], mine[6], mine[7]);
+#pragma unroll
+                for (int c = 0; c < KR_MAX_C; ++c) sum[c] += __shfl_xor(sum[c], 32);
+                if (h == 0) {  // (every read of y above precedes these writes: they depend on all of them)
+                    *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C]) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+                    *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C + 4]) = make_float4(sum[4], sum[5], sum[6], sum[7]);
                 }
             }
             K2_T(4);
@@ -988,26 +1038,30 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 v[c] = r;
             }
             K2_T(13);
-            float inv_n = Dinv[kb * 32 + 31], lkj_n = LD[(kb * 32 + 31) * K2_PS + li];
-            float mine[KR_MAX_C];  // alpha of this lane's row (caught when its step comes; one store after the loop)
-#pragma unroll
-            for (int c = 0; c < KR_MAX_C; ++c) mine[c] = 0.f;
-#pragma unroll 1
-            for (int k = 31; k >= 0; --k) {  // (rolled; the next step's two LDS values are in flight)
-                const float inv = inv_n, lkj = li < k ? lkj_n : 0.f;
-                inv_n = Dinv[kb * 32 + max(k - 1, 0)], lkj_n = LD[(kb * 32 + max(k - 1, 0)) * K2_PS + li];
-                const bool me = li == k;
-#pragma unroll
-                for (int c = 0; c < KR_MAX_C; ++c) {
-                    const float ak = k2_bcast(v[c], k) * inv;
-                    v[c] = fmaf(-lkj, ak, v[c]);
-                    mine[c] = me ? ak : mine[c];
-                }
+            // alpha_kb[i] = sum_j M[j][i] v[j] (M = L_kk^-1 sits in LD[kb]): v goes through the block's z slot so that every lane can
+            // read every row of it (one wave: its LDS operations are carried out in issue order); the lane halves split j
+            if (h == 0) {
+                *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C]) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(&zs[(32 * kb + li) * KR_MAX_C + 4]) = make_float4(v[4], v[5], v[6], v[7]);
             }
+            float sum[KR_MAX_C];
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) sum[c] = 0.f;
+#pragma unroll 4
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = 16 * h + jj;
+                const float m = LD[(kb * 32 + j) * K2_PS + li];
+                const float *vj = &zs[(32 * kb + j) * KR_MAX_C];
+                const float4 v0 = *reinterpret_cast<const float4 *>(vj), v1 = *reinterpret_cast<const float4 *>(vj + 4);
+                sum[0] = fmaf(m, v0.x, sum[0]), sum[1] = fmaf(m, v0.y, sum[1]), sum[2] = fmaf(m, v0.z, sum[2]), sum[3] = fmaf(m, v0.w, sum[3]);
+                sum[4] = fmaf(m, v1.x, sum[4]), sum[5] = fmaf(m, v1.y, sum[5]), sum[6] = fmaf(m, v1.z, sum[6]), sum[7] = fmaf(m, v1.w, sum[7]);
+            }
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) sum[c] += __shfl_xor(sum[c], 32);
             if (h == 0) {
                 const bool real = 32 * kb + li < nt;
-                *reinterpret_cast<float4 *>(&al[(32 * kb + li) * KR_MAX_C]) = real ? make_float4(mine[0], mine[1], mine[2], mine[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4 *>(&al[(32 * kb + li) * KR_MAX_C + 4]) = real ? make_float4(mine[4], mine[5], mine[6], mine[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(&al[(32 * kb + li) * KR_MAX_C]) = real ? make_float4(sum[0], sum[1], sum[2], sum[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(&al[(32 * kb + li) * KR_MAX_C + 4]) = real ? make_float4(sum[4], sum[5], sum[6], sum[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         __syncthreads();
