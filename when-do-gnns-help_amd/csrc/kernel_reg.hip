@@ -833,16 +833,25 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 float v = (gi >= 0 && gj >= 0 && !(ablate & 1)) ? K[static_cast<int64_t>(gj) * ldk + gi] : (diag ? 1.f : 0.f);
                 if (diag && gi >= 0) v += ridge;
                 t[r] = v;
-                if (r == 7) __builtin_amdgcn_sched_barrier(0);  // (eight gathers and their addresses in flight at a time)
             }
             __builtin_amdgcn_sched_barrier(0);
         };
+        // Only what the first step needs is gathered up front: block columns 0 and 1 and diagonal block 0.  Every other block starts
+        // at zero, collects its updates, and has its K entries ADDED while the leader and the follower work on the diagonal block
+        // two steps (the diagonal blocks: one step) before it turns into a panel block - the gather of 55 blocks per regression
+        // comes from beyond the L2 (a 16-MB Gram per graph and kernel) and was a sixth of the kernel's time in front of step 0.
 #pragma unroll
-        for (int s = 0; s < K2_SLOTS; ++s)
-            if (sa[s] >= 0) gather_block(sa[s], sb[s], acc[s]);
+        for (int s = 0; s < K2_SLOTS; ++s) {
+            if (sa[s] >= 0 && sb[s] <= 1) gather_block(sa[s], sb[s], acc[s]);
+            else
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+        }
         if (wave < nb) {  // the diagonal blocks: straight into their LDS images
             f32x16 t;
-            gather_block(wave, wave, t);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = 0.f;
+            if (wave == 0) gather_block(0, 0, t);
             k2_store_block(t, &LD[wave * 32 * K2_PS], li_, h_);
         }
         __syncthreads();
@@ -878,6 +887,22 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 if (k2_substitute(&LD[kb * 32 * K2_PS], &Dinv[kb * 32], role == 0, li, h, lane, nt - 32 * kb, drop_below, ridge, &progress, 32 * kb, (ablate & 32) != 0) &&
                     lane == 0)
                     deficient = 1;
+            } else {  // (the other 14 waves would wait at the barrier: the deferred gathers run here, hidden behind the recurrence)
+                const int first = (nb - 1 - kb) * (nb - 2 - kb) / 2;
+#pragma unroll
+                for (int s = 0; s < K2_SLOTS; ++s) {
+                    if (sa[s] < 0 || sb[s] != kb + 2) continue;  // (wave-uniform; never a wave that leads or follows at this step)
+                    f32x16 t;
+                    gather_block(sa[s], sb[s], t);
+                    acc[s] += t;
+                }
+                if (kb + 1 < nb && wave == ((first + K2_WAVES - 3) & (K2_WAVES - 1))) {  // diagonal block kb + 1 (nobody else touches it now)
+                    f32x16 t, d;
+                    gather_block(kb + 1, kb + 1, t);
+                    k2_load_block(d, &LD[(kb + 1) * 32 * K2_PS], li, h);
+                    d += t;
+                    k2_store_block(d, &LD[(kb + 1) * 32 * K2_PS], li, h);
+                }
             }
             K2_T(2);
             __syncthreads();
@@ -1031,11 +1056,14 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         K2_T(12);
         if (wave == 0) {  // alpha_kb = L_kk^-T (z_kb - the blocks' sums): lane = column j, rows k from the last
             float v[KR_MAX_C];
-#pragma unroll
-            for (int c = 0; c < KR_MAX_C; ++c) {
-                float r = zs[(32 * kb + li) * KR_MAX_C + c];
-                for (int w = 0; w < nb - kb - 1; ++w) r -= part[w][li][c];  // (fixed order)
-                v[c] = r;
+            {
+                const float4 r0 = *reinterpret_cast<const float4 *>(&zs[(32 * kb + li) * KR_MAX_C]), r1 = *reinterpret_cast<const float4 *>(&zs[(32 * kb + li) * KR_MAX_C + 4]);
+                v[0] = r0.x, v[1] = r0.y, v[2] = r0.z, v[3] = r0.w, v[4] = r1.x, v[5] = r1.y, v[6] = r1.z, v[7] = r1.w;
+            }
+#pragma unroll 3
+            for (int w = 0; w < nb - kb - 1; ++w) {  // (fixed order)
+                const float4 p0 = *reinterpret_cast<const float4 *>(&part[w][li][0]), p1 = *reinterpret_cast<const float4 *>(&part[w][li][4]);
+                v[0] -= p0.x, v[1] -= p0.y, v[2] -= p0.z, v[3] -= p0.w, v[4] -= p1.x, v[5] -= p1.y, v[6] -= p1.z, v[7] -= p1.w;
             }
             K2_T(13);
             // alpha_kb[i] = sum_j M[j][i] v[j] (M = L_kk^-1 sits in LD[kb]): v goes through the block's z slot so that every lane can
@@ -1079,10 +1107,14 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             float p[KR_MAX_C];
 #pragma unroll
             for (int c = 0; c < KR_MAX_C; ++c) p[c] = 0.f;
-#pragma unroll 4
-            for (int t = gl; t < nt; t += 16) {
-                const float kv = krow[tr_idx[t]];
-                const float4 a0 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C]), a1 = *reinterpret_cast<const float4 *>(&al[t * KR_MAX_C + 4]);
+            // (a fixed trip count, predicated: two batches of ten gathers per lane - the K rows come from beyond the L2, and a
+            // remainder loop would pay that latency once per leftover step)
+#pragma unroll 10
+            for (int k = 0; k < K2_NB * 2; ++k) {
+                const int t = gl + 16 * k;
+                const bool ok = t < nt;
+                const float kv = ok ? krow[tr_idx[ok ? t : 0]] : 0.f;
+                const float4 a0 = *reinterpret_cast<const float4 *>(&al[(ok ? t : 0) * KR_MAX_C]), a1 = *reinterpret_cast<const float4 *>(&al[(ok ? t : 0) * KR_MAX_C + 4]);
                 p[0] = fmaf(kv, a0.x, p[0]), p[1] = fmaf(kv, a0.y, p[1]), p[2] = fmaf(kv, a0.z, p[2]), p[3] = fmaf(kv, a0.w, p[3]);
                 p[4] = fmaf(kv, a1.x, p[4]), p[5] = fmaf(kv, a1.y, p[5]), p[6] = fmaf(kv, a1.z, p[6]), p[7] = fmaf(kv, a1.w, p[7]);
             }
