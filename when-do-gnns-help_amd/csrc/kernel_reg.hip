@@ -565,8 +565,9 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
 // ------------------------------------------------------------------------------------------------ blocked solver (round 3)
 // The same problem as kr_solve_kernel - one workgroup of 16 waves per (kernel, train rows, validation rows) regression - as a
 // right-looking BLOCKED Cholesky with 32 x 32 blocks: the trailing update, > 90 % of the flops, runs on the fp32 matrix pipe
-// (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain, fixed order -> bitwise reproducible), and a regression takes ~60
-// workgroup barriers instead of ~330 (kr_solve_kernel: one per eliminated column).
+// (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain, fixed order -> bitwise reproducible), every solve against a diagonal block is
+// a product with that block's inverse, and a regression takes ~60 workgroup barriers instead of ~330 (kr_solve_kernel: one per
+// eliminated column).
 //
 //   layout   block (a, b), b <= a, of the train block lives in ONE wave's registers, TRANSPOSED in the MFMA accumulator layout:
 //            lane (i, h) = (lane & 31, lane >> 5) holds A[32 a + i][32 b + j] for the 16 columns j = jmap(h, r) = (r & 3) +
@@ -576,16 +577,19 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
 //   blocks   enumerated by column (last first), dealt round-robin to the 16 waves: at every step the still-active blocks are a
 //            prefix of that order, so the update is balanced to one block; a column's blocks sit on distinct waves.
 //   gather   K is symmetric: lane (i, h) reads K[tr[32 b + j]][tr[32 a + i]] - per register a wave-uniform ROW (one per lane
-//            half) and 32 ascending columns inside a ~200-column window - instead of 32 different rows per instruction.
-//   step kb  the column's blocks go to LDS (row-major); (1) the diagonal block's wave factors it: lane = row, row j of L_kk is
-//            read back from LDS (broadcast) as soon as it is complete - the same substitution loop that (2) the other blocks of
-//            the column run against the finished L_kk (X L_kk^T = A), while the diagonal wave solves z_kb = L_kk^-1 y_kb; (3)
-//            every wave updates its active blocks with 16 MFMAs each, the panel's waves subtract L_a z_kb from the right-hand
-//            sides.  The in-wave routines exist ONCE in the code (a wave's block reaches them through LDS, whatever register
-//            slot it lives in) and their solves are rolled loops: the first version unrolled them per slot, 200 KB of straight-
-//            line code that ran at the speed of instruction-cache misses (450 us per regression; this one: see DESIGN.md).
+//            half) and 32 ascending columns inside a ~200-column window - instead of 32 different rows per instruction.  Only
+//            block columns 0, 1 and diagonal block 0 are fetched up front; the others are ADDED to the collected updates while
+//            the diagonal block two steps before them is being factored (the Gram is 16 MB: these reads come from beyond the L2).
+//   step kb  the column's blocks go to LDS (row-major); (1) two waves work on the diagonal block - the leader factors it column by
+//            column (k2_factor), the follower turns the columns into M = L_kk^-1 as they appear (k2_invert) - while the other
+//            waves run the deferred gathers; (2) the column's blocks: X = A M^T on the matrix pipe, and z_kb = M y_kb; (3) every
+//            wave updates its active blocks with 16 MFMAs each, the panel's waves subtract L_a z_kb from the right-hand sides.
+//            (History: the first version unrolled the in-wave routines per register slot, 200 KB of straight-line code that ran at
+//            the speed of instruction-cache misses; the second solved the panel and the right-hand sides by 32-step recurrences
+//            against L_kk - a dependent chain on one wave per block, ~14 000 cycles each)
 //   then     back substitution block column by block column (the column's blocks go through LDS once more: the product with
-//            L^T sums over the lane index), predictions one wave per four validation rows.
+//            L^T sums over the lane index; alpha_kb = M^T v is a 32-term dot product per lane), predictions one wave per four
+//            validation rows.
 // Rank-deficient blocks: as in kr_solve_kernel (pivot test at n eps max K_ii / 64, one restart on K + n eps max K_ii / 8 I).
 constexpr int K2_THREADS = 1024, K2_WAVES = 16, K2_NB = 10, K2_SLOTS = 3, K2_PS = 36;
 static_assert(K2_NB * (K2_NB - 1) / 2 <= K2_WAVES * K2_SLOTS, "every block below the diagonal needs a register slot");
@@ -609,44 +613,93 @@ __device__ __forceinline__ void k2_load_block(f32x16 &t, const float *img, int l
     }
 }
 
-// The in-wave substitution along a block's columns: x_j = (a_j - sum_{k < j} x_k L[j][k]) / L[j][j], j = 0 .. 31, for the 32 rows of
-// a block at once.  Lane (i, h) works on row i and holds the entries k = 8 q + 4 h + e of x (the block's own register layout): the
-// two lane halves split every row's sum, each reads its half of row j of L from LDS (one address per half: broadcast) a whole
-// row AHEAD of the fmas that use it, and one v_permlane32_swap adds the halves.  Two waves run it per block column:
-//   factor == true : the LEADER.  A is the diagonal block itself (in `ld`): the recurrence is its Cholesky factorisation row by row -
-//                    x_j of lane j is the pivot (v_readlane), every lane's x_j / sqrt(pivot) is L[i][j], written to `ld` at once.  The
-//                    one entry of row j that the step before has only just produced, L[j][j - 1], comes from lane j's register
-//                    (v_readlane) instead of the prefetched row.  After step j it publishes `step_base + j` in *progress.
-//                    Returns whether a pivot fell below `drop_below`.
-//   factor == false: the FOLLOWER inverts L_kk while it is being made: A = I, so X = L_kk^-T, i.e. lane i ends with COLUMN i of
-//                    M = L_kk^-1.  Step j needs row j + 2 of L (the prefetch), so it runs two rows behind the leader, waiting on
-//                    *progress (both waves are resident: the leader never waits for the follower).  Its last act overwrites the
-//                    image of L_kk in `ld` with M, row-major - from here on every solve against L_kk is a product with M on the
-//                    matrix pipe or a 32-term dot product, not a 32-step recurrence (panel solve, z, back substitution).
-__device__ __forceinline__ bool k2_substitute(float *ld, float *dinv, bool factor, int li, int h, int lane, int rows_real,
-                                              float drop_below, float ridge, int *progress, int step_base, bool nowait = false) {
+// The diagonal block, RIGHT-LOOKING, by two waves.  Lane (i, h) works on row i of the 32 x 32 block and holds the 16 entries of
+// columns c(r) = 8 (r >> 2) + 4 h + (r & 3) (the block's own register layout).
+//   k2_factor (the LEADER): step j takes a[i][j] (one permlane32 swap brings it to both lane halves), the pivot from lane j
+//            (v_readlane), l[i][j] = a[i][j] / sqrt(pivot); column j goes to LDS TRANSPOSED (`lt[j][i]`: the lanes' values are one
+//            contiguous row) together with 1 / l_jj, and the step number is published in *progress; every lane then reads the
+//            column back as broadcast float4s and takes l[i][j] l[c][j] off its entries c > j.  The one product the NEXT pivot
+//            waits for - entry j + 1 - takes l[j + 1][j] from lane j + 1's register (v_readlane), so the LDS round trip is not in
+//            the step's dependent chain: pivot -> rsq -> scale -> readlane -> fma -> swap -> pivot.
+//   k2_invert (the FOLLOWER): X L^T = I by columns as they appear: x_j = x[.][j] / l_jj, then x[.][c] -= x_j l[c][j] for c > j -
+//            the same column reads, no pivot, no square root; it waits on *progress (every other step: two columns at a time) and
+//            ends with row i of L^-T = column i of M = L_kk^-1, which it writes row-major over the image of the block in `ld`.
+// (The left-looking recurrence of the first versions - every step a 16-term dot product per lane half in front of the pivot -
+// was ~100 instructions and ~480 cycles per step for either wave; this form is ~40 and has no LDS access in the chain.)
+// LDS operations of one wave are carried out in issue order: whoever reads the step number sees the column and 1 / l_jj.
+__device__ __forceinline__ int k2_col(int h, int r) { return 8 * (r >> 2) + 4 * h + (r & 3); }
+
+__device__ __forceinline__ bool k2_factor(const float *ld, float *lt, float *dinv, int li, int h, int lane, int rows_real, float drop_below,
+                                          float ridge, int *progress, int step_base) {
     float x[16];
-    if (factor) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(ld + li * K2_PS + 4 * h + 8 * q);
+        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+    }
+    const bool hi = h != 0;
+    bool low_any = false;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int hj = (j >> 2) & 1, mj = 4 * (j >> 3) + (j & 3);  // the half and the register that hold column j
+        const float own = (hi == (hj != 0)) ? x[mj] : 0.f;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
+        const float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // a[i][j], in both halves (the other half's `own` is 0)
+        float piv = k2_bcast(v, j);
+        const bool low = !(piv > drop_below) && j < rows_real;  // (uniform; also catches NaN)
+        low_any |= low;
+        piv = low ? fmaxf(ridge, drop_below) : piv;
+        float inv = __builtin_amdgcn_rsqf(piv);
+        inv = inv * fmaf(-0.5f * piv * inv, inv, 1.5f);  // one Newton step: 1 / sqrt(piv) to within an ulp
+        const float res = li == j ? piv * inv : (li > j ? v * inv : 0.f);  // l[i][j] (0 above the diagonal)
+        if (!hi) lt[j * K2_PS + li] = res;
+        if (lane == 0) dinv[j] = inv;
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(progress, step_base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (j + 1 == 32) break;
+        // the entry the next pivot waits for: column j + 1 of this row, with l[j + 1][j] from lane j + 1's register
+        {
+            const int hn = ((j + 1) >> 2) & 1, mn = 4 * ((j + 1) >> 3) + ((j + 1) & 3);
+            const float ln = k2_bcast(res, j + 1);
+            x[mn] = (hi == (hn != 0)) ? fmaf(-res, ln, x[mn]) : x[mn];
+        }
+        // every other entry c > j + 1: column j read back from LDS (this half's c = 8 q + 4 h + e)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(ld + li * K2_PS + 4 * h + 8 * q);
-            x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
-        }
-    } else {
+            if (8 * q + 7 <= j + 1) continue;  // (compile-time: neither half has an entry beyond j + 1 in this quadruple)
+            const float4 c4 = *reinterpret_cast<const float4 *>(lt + j * K2_PS + 8 * q + 4 * h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = (8 * (r >> 2) + 4 * h + (r & 3)) == li ? 1.f : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const int c_lo = 8 * q + e, c_hi = c_lo + 4;  // the column this register is in the lower / upper half
+                if (c_hi <= j + 1) continue;              // (compile-time)
+                const float l = e == 0 ? c4.x : e == 1 ? c4.y : e == 2 ? c4.z : c4.w;
+                const bool live = hi ? c_hi > j + 1 : c_lo > j + 1;
+                x[4 * q + e] = (c_lo > j + 1 || live) ? fmaf(-res, live ? l : 0.f, x[4 * q + e]) : x[4 * q + e];
+                // (pinned: left alone, the compiler sinks these products down to the step that reads the entry - a left-looking
+                // factorisation again, with every earlier column held in registers: 430 spilled registers)
+                asm volatile("" : "+v"(x[4 * q + e]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // (follower) until the leader has finished row `row` of L_kk.  The poll is one opaque asm statement: a C loop inside the body
-    // keeps the compiler from unrolling the 32 steps, and x[] then lives in scratch memory (measured: 3.5 x the time).
+    return low_any;
+}
+
+__device__ __forceinline__ void k2_invert(float *ld, const float *lt, const float *dinv, int li, int h, int lane, int *progress,
+                                          int step_base, bool nowait) {
+    float x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = k2_col(h, r) == li ? 1.f : 0.f;
+    const bool hi = h != 0;
+    // until the leader has finished column `col` of L_kk.  One opaque asm statement: a C loop inside the body keeps the compiler
+    // from unrolling the 32 steps (x[] then lives in scratch memory: 3.5 x the time).
     typedef __attribute__((address_space(3))) int lds_int;
     const unsigned progress_at = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_int *)progress));
-    // (the leader passes -1 and falls through on a scalar compare: the statement sits in the middle of the step's straight-line
-    // code in both modes - a C-level `if` around it would cut the step into basic blocks and stop the scheduler from filling the
-    // row's dependent chain with the next row's sums: 2.2 x the time of a step)
-    const int wait_base = __builtin_amdgcn_readfirstlane((factor || nowait) ? -64 : step_base);  // (wave-uniform: a scalar)
-    auto wait_for = [&](int row) {
+    const int wait_base = __builtin_amdgcn_readfirstlane(nowait ? -64 : step_base);
+    auto wait_for = [&](int col) {
         int seen;
-        const int need = wait_base + row;  // < 0: no wait
+        const int need = wait_base + col;  // < 0: no wait (timing diagnostics)
         asm volatile("s_cmp_lt_i32 %2, 0\n\t"
                      "s_cbranch_scc1 2f\n\t"
                      "1:\n\t"
@@ -661,80 +714,34 @@ __device__ __forceinline__ bool k2_substitute(float *ld, float *dinv, bool facto
                      : "v"(progress_at), "s"(need)
                      : "vcc", "scc", "memory");
     };
-    const float *lh = ld + 4 * h;  // this half's entries of row j: lh[j * K2_PS + 8 q .. + 3]
-    const bool hi = h != 0;
-    bool low_any = false;
-    // Two rows in flight: while row j is finished (add the halves, scale: a chain of dependent operations), the sums of row
-    // j + 1 over the entries k < j - independent of that chain - are issued between its links; only the term k = j waits for x_j.
-    float4 row_a[4], row_b[4];  // this half's entries of row j + 1 (in use) and of row j + 2 (arriving)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) row_a[q] = row_b[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    wait_for(1);
-    row_a[0] = *reinterpret_cast<const float4 *>(lh + 1 * K2_PS);  // row 1: entry 0
-    float p0 = 0.f, p1 = 0.f;  // - sum_{k < j} x_k L[j][k] over this half's entries, for the row being finished
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        const int hj = (j >> 2) & 1, mj = 4 * (j >> 3) + (j & 3);  // the half and the register that hold entry j
-        // ---- finish row j
+        if ((j & 1) == 0) wait_for(j + 1);  // columns j and j + 1
+        const int hj = (j >> 2) & 1, mj = 4 * (j >> 3) + (j & 3);
         const float own = (hi == (hj != 0)) ? x[mj] : 0.f;
-        const float partial = own + (p0 + p1);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(partial), __float_as_uint(partial), false, false);
-        const float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // lower + upper half's partial, in both halves
-        float res;
-        if (factor) {  // (uniform)
-            float piv = k2_bcast(v, j);
-            const bool low = !(piv > drop_below) && j < rows_real;  // (uniform; also catches NaN)
-            low_any |= low;
-            piv = low ? fmaxf(ridge, drop_below) : piv;
-            float inv = __builtin_amdgcn_rsqf(piv);
-            inv = inv * fmaf(-0.5f * piv * inv, inv, 1.5f);  // one Newton step: 1 / sqrt(piv) to within an ulp
-            res = li == j ? piv * inv : (li > j ? v * inv : 0.f);
-            if (!hi) ld[li * K2_PS + j] = res;  // column j of L_kk (0 above the diagonal)
-            if (lane == 0) dinv[j] = inv;
-            // (LDS operations of one wave are carried out in issue order: whoever reads the step number sees the column)
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_store(progress, step_base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
-        } else {
-            res = v * dinv[j];
-        }
-        x[mj] = (hi == (hj != 0)) ? res : x[mj];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
+        const float xj = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * dinv[j];  // X[i][j], in both halves
+        x[mj] = (hi == (hj != 0)) ? xj : x[mj];
         if (j + 1 == 32) break;
-        // ---- row j + 2 of L for the step after the next (behind this step's write of column j: fresh up to entry j)
-        if (j + 2 < 32) {
-            wait_for(j + 2);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (8 * q < j + 2) row_b[q] = *reinterpret_cast<const float4 *>(lh + (j + 2) * K2_PS + 8 * q);
-        }
-        // ---- the sums of row j + 1 over the entries k <= j (row_a: read before column j existed - entry j of it is stale when
-        //      factoring and comes from lane j + 1's register instead)
-        p0 = p1 = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (8 * q + 7 <= j) continue;  // (compile-time)
+            const float4 c4 = *reinterpret_cast<const float4 *>(lt + j * K2_PS + 8 * q + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int k0 = 8 * q + e, k1 = k0 + 4;  // the entry this register is in the lower / upper lane half
-                if (k0 > j) continue;                   // (compile-time: neither half has a term)
-                float l = e == 0 ? row_a[q].x : e == 1 ? row_a[q].y : e == 2 ? row_a[q].z : row_a[q].w;
-                if (k1 > j) l = hi ? 0.f : l;           // only the lower half's entry is <= j
-                if (k0 == j || k1 == j) {               // the entry that was written a moment ago
-                    const float fresh = factor ? k2_bcast(res, j + 1) : l;
-                    l = (hi == (k1 == j)) ? fresh : l;
-                }
-                if (e & 1) p1 = fmaf(-x[4 * q + e], l, p1);
-                else p0 = fmaf(-x[4 * q + e], l, p0);
+                const int c_lo = 8 * q + e, c_hi = c_lo + 4;
+                if (c_hi <= j) continue;  // (compile-time)
+                const float l = e == 0 ? c4.x : e == 1 ? c4.y : e == 2 ? c4.z : c4.w;
+                const bool live = hi ? c_hi > j : c_lo > j;
+                x[4 * q + e] = fmaf(-xj, live ? l : 0.f, x[4 * q + e]);
+                asm volatile("" : "+v"(x[4 * q + e]));  // (pinned: see k2_factor)
             }
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) row_a[q] = row_b[q];
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (!factor) {  // x = row li of L_kk^-T = column li of M: M[k][li], k = 8 q + 4 h + e, over the image of L_kk (the leader is done)
+    // x = row li of L_kk^-T = column li of M: M[c][li] over the image of the block (the leader read it long ago)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ld[(8 * (r >> 2) + 4 * h + (r & 3)) * K2_PS + li] = x[r];
-    }
-    return low_any;
+    for (int r = 0; r < 16; ++r) ld[k2_col(h, r) * K2_PS + li] = x[r];
 }
 
 #ifdef K2_PROFILE  // diagnostic build (make EXTRA=-DK2_PROFILE): thread 0 of workgroup 0 sums the shader clocks spent per phase
@@ -754,13 +761,14 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     __shared__ float P[(K2_NB - 1) * 32 * K2_PS];      // the step's panel L[a, kb], a > kb: [a - kb - 1][row][k], stride 36
     __shared__ float LD[K2_NB * 32 * K2_PS];           // the diagonal blocks L_kk, row-major (kept: the back substitution reads them)
     __shared__ float Dinv[K2_NB * 32];                 // 1 / l_kk
+    __shared__ float LT[32 * K2_PS];                   // the diagonal block being factored, transposed: LT[j][i] = l[i][j] (k2_factor)
     __shared__ float zs[K2_NB * 32 * KR_MAX_C];        // right-hand sides: one-hot labels -> z = L^-1 Y (block by block)
     __shared__ float al[K2_NB * 32 * KR_MAX_C];        // alpha
     __shared__ float part[K2_WAVES][32][KR_MAX_C];     // per-wave partial sums (back substitution)
     __shared__ int tr_idx[K2_NB * 32];
     __shared__ signed char blk_a[K2_WAVES * K2_SLOTS], blk_b[K2_WAVES * K2_SLOTS];
     __shared__ int deficient, correct;
-    __shared__ int progress;  // 32 kb + j: the leader has finished row j of L_kk of block column kb (k2_substitute)
+    __shared__ int progress;  // 32 kb + j: the leader has finished column j of L_kk of block column kb (k2_factor)
     __shared__ float red[K2_WAVES];
 
     const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + blockIdx.x);
@@ -881,12 +889,13 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 if (wave == ((first + K2_WAVES - 1) & (K2_WAVES - 1))) role = 0;
                 if (wave == ((first + K2_WAVES - 2) & (K2_WAVES - 1))) role = -2;
             }
-            // (1) the leader factors the diagonal block, the follower turns it into M = L_kk^-1 two rows behind (one copy of the
-            //     routine: the mode is a wave-uniform flag); LD[kb] holds M afterwards
-            if (role == 0 || (role == -2 && !(ablate & 64))) {  // (wave-uniform)
-                if (k2_substitute(&LD[kb * 32 * K2_PS], &Dinv[kb * 32], role == 0, li, h, lane, nt - 32 * kb, drop_below, ridge, &progress, 32 * kb, (ablate & 32) != 0) &&
-                    lane == 0)
+            // (1) the leader factors the diagonal block, the follower turns it into M = L_kk^-1 a column or two behind; LD[kb] holds M
+            //     afterwards
+            if (role == 0) {  // (wave-uniform)
+                if (k2_factor(&LD[kb * 32 * K2_PS], LT, &Dinv[kb * 32], li, h, lane, nt - 32 * kb, drop_below, ridge, &progress, 32 * kb) && lane == 0)
                     deficient = 1;
+            } else if (role == -2) {
+                if (!(ablate & 64)) k2_invert(&LD[kb * 32 * K2_PS], LT, &Dinv[kb * 32], li, h, lane, &progress, 32 * kb, (ablate & 32) != 0);
             } else {  // (the other 14 waves would wait at the barrier: the deferred gathers run here, hidden behind the recurrence)
                 const int first = (nb - 1 - kb) * (nb - 2 - kb) / 2;
 #pragma unroll
