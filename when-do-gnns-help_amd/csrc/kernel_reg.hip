@@ -613,135 +613,75 @@ __device__ __forceinline__ void k2_load_block(f32x16 &t, const float *img, int l
     }
 }
 
-// The diagonal block, RIGHT-LOOKING, by two waves.  Lane (i, h) works on row i of the 32 x 32 block and holds the 16 entries of
-// columns c(r) = 8 (r >> 2) + 4 h + (r & 3) (the block's own register layout).
-//   k2_factor (the LEADER): step j takes a[i][j] (one permlane32 swap brings it to both lane halves), the pivot from lane j
-//            (v_readlane), l[i][j] = a[i][j] / sqrt(pivot); column j goes to LDS TRANSPOSED (`lt[j][i]`: the lanes' values are one
-//            contiguous row) together with 1 / l_jj, and the step number is published in *progress; every lane then reads the
-//            column back as broadcast float4s and takes l[i][j] l[c][j] off its entries c > j.  The one product the NEXT pivot
-//            waits for - entry j + 1 - takes l[j + 1][j] from lane j + 1's register (v_readlane), so the LDS round trip is not in
-//            the step's dependent chain: pivot -> rsq -> scale -> readlane -> fma -> swap -> pivot.
-//   k2_invert (the FOLLOWER): X L^T = I by columns as they appear: x_j = x[.][j] / l_jj, then x[.][c] -= x_j l[c][j] for c > j -
-//            the same column reads, no pivot, no square root; it waits on *progress (every other step: two columns at a time) and
-//            ends with row i of L^-T = column i of M = L_kk^-1, which it writes row-major over the image of the block in `ld`.
-// (The left-looking recurrence of the first versions - every step a 16-term dot product per lane half in front of the pivot -
-// was ~100 instructions and ~480 cycles per step for either wave; this form is ~40 and has no LDS access in the chain.)
-// LDS operations of one wave are carried out in issue order: whoever reads the step number sees the column and 1 / l_jj.
-__device__ __forceinline__ int k2_col(int h, int r) { return 8 * (r >> 2) + 4 * h + (r & 3); }
-
-__device__ __forceinline__ bool k2_factor(const float *ld, float *lt, float *dinv, int li, int h, int lane, int rows_real, float drop_below,
-                                          float ridge, int *progress, int step_base) {
-    float x[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(ld + li * K2_PS + 4 * h + 8 * q);
-        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
-    }
+// The diagonal block: factored AND inverted by one wave, right-looking, in one instruction stream.  Lane i of the LOWER half
+// holds row i of the 32 x 32 block A, lane i of the UPPER half row i of the identity - 32 registers each.  Step j:
+//     pivot = a[j][j] (v_readlane from lane j), inv = 1 / sqrt(pivot), res = x[j] inv, x[c] -= res l[c][j] for c > j,
+// which for the lower half is column j of the Cholesky factor (res = l[i][j]) and the right-looking update of the trailing
+// rows, and for the upper half - the SAME instructions - the substitution X L^T = I by columns (res = X[i][j], the entries c > j
+// of the right-hand side reduced by it): the upper half ends with row i of L^-T, i.e. column i of M = L_kk^-1, and writes it
+// row-major over the image of the block in `ld`.  Column j of L reaches all lanes through LDS (`lt[j][.]`, written by the lower
+// half, read back as broadcast float4s); the ONE product the next pivot waits for - entry j + 1 - takes l[j + 1][j] from lane
+// j + 1's register (v_readlane), so the step's dependent chain is pivot -> rsq -> scale -> readlane -> fma, no LDS access in it.
+// History: a left-looking recurrence (a 16-term dot product per lane half in front of every pivot, ~100
+// instructions and ~480 cycles per step) for the factor, the same code run by a second wave two rows behind for the inverse
+// (polling a step counter in LDS); then both right-looking on two waves (~460 cycles per step: the chain still carried the
+// half-select / permlane swap of the split-row layout and the follower's polls).
+__device__ __forceinline__ bool k2_factor_invert(float *ld, float *lt, int li, int h, int rows_real, float drop_below, float ridge) {
+    float x[32];
     const bool hi = h != 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(ld + li * K2_PS + 4 * q);
+        x[4 * q] = hi ? (4 * q == li ? 1.f : 0.f) : v.x, x[4 * q + 1] = hi ? (4 * q + 1 == li ? 1.f : 0.f) : v.y;
+        x[4 * q + 2] = hi ? (4 * q + 2 == li ? 1.f : 0.f) : v.z, x[4 * q + 3] = hi ? (4 * q + 3 == li ? 1.f : 0.f) : v.w;
+    }
+    // Software-pipelined by one step: the column read back from LDS in step j - 1 is applied (to the entries c > j) in step j,
+    // in the shadow of step j's own chain; the entry that chain needs, x[j], got column j - 1 through the v_readlane shortcut.
     bool low_any = false;
+    float4 cp[8];  // column j - 1 of L, as read back (cp[q] = l[4 q .. 4 q + 3][j - 1])
+    float res_p = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        const int hj = (j >> 2) & 1, mj = 4 * (j >> 3) + (j & 3);  // the half and the register that hold column j
-        const float own = (hi == (hj != 0)) ? x[mj] : 0.f;
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
-        const float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // a[i][j], in both halves (the other half's `own` is 0)
-        float piv = k2_bcast(v, j);
+        float piv = k2_bcast(x[j], j);
         const bool low = !(piv > drop_below) && j < rows_real;  // (uniform; also catches NaN)
         low_any |= low;
         piv = low ? fmaxf(ridge, drop_below) : piv;
+        const float xj = (!hi && li == j) ? piv : x[j];  // (the diagonal entry follows a replaced pivot)
         float inv = __builtin_amdgcn_rsqf(piv);
         inv = inv * fmaf(-0.5f * piv * inv, inv, 1.5f);  // one Newton step: 1 / sqrt(piv) to within an ulp
-        const float res = li == j ? piv * inv : (li > j ? v * inv : 0.f);  // l[i][j] (0 above the diagonal)
-        if (!hi) lt[j * K2_PS + li] = res;
-        if (lane == 0) dinv[j] = inv;
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_store(progress, step_base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("" ::: "memory");
-        if (j + 1 == 32) break;
-        // the entry the next pivot waits for: column j + 1 of this row, with l[j + 1][j] from lane j + 1's register
-        {
-            const int hn = ((j + 1) >> 2) & 1, mn = 4 * ((j + 1) >> 3) + ((j + 1) & 3);
-            const float ln = k2_bcast(res, j + 1);
-            x[mn] = (hi == (hn != 0)) ? fmaf(-res, ln, x[mn]) : x[mn];
-        }
-        // every other entry c > j + 1: column j read back from LDS (this half's c = 8 q + 4 h + e)
+        const float res = xj * inv;
+        x[j] = res;
+        // column j - 1 on the entries c > j (independent of the chain above: the scheduler runs them in its bubbles)
+        if (j > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (8 * q + 7 <= j + 1) continue;  // (compile-time: neither half has an entry beyond j + 1 in this quadruple)
-            const float4 c4 = *reinterpret_cast<const float4 *>(lt + j * K2_PS + 8 * q + 4 * h);
+            for (int q = 0; q < 8; ++q) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c_lo = 8 * q + e, c_hi = c_lo + 4;  // the column this register is in the lower / upper half
-                if (c_hi <= j + 1) continue;              // (compile-time)
-                const float l = e == 0 ? c4.x : e == 1 ? c4.y : e == 2 ? c4.z : c4.w;
-                const bool live = hi ? c_hi > j + 1 : c_lo > j + 1;
-                x[4 * q + e] = (c_lo > j + 1 || live) ? fmaf(-res, live ? l : 0.f, x[4 * q + e]) : x[4 * q + e];
-                // (pinned: left alone, the compiler sinks these products down to the step that reads the entry - a left-looking
-                // factorisation again, with every earlier column held in registers: 430 spilled registers)
-                asm volatile("" : "+v"(x[4 * q + e]));
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * q + e;
+                    if (c <= j) continue;  // (compile-time)
+                    x[c] = fmaf(-res_p, e == 0 ? cp[q].x : e == 1 ? cp[q].y : e == 2 ? cp[q].z : cp[q].w, x[c]);
+                    // (pinned: left alone, the compiler sinks these products down to the step that reads the entry - a left-
+                    // looking factorisation again, with every earlier column held in registers: 430 spilled registers)
+                    asm volatile("" : "+v"(x[c]));
+                }
             }
         }
+        if (j + 1 == 32) break;
+        if (!hi) lt[j * K2_PS + li] = res;  // column j of L (rows < j: never read)
+        x[j + 1] = fmaf(-res, k2_bcast(res, j + 1), x[j + 1]);  // the entry the next pivot waits for
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (4 * q + 3 > j + 1) cp[q] = *reinterpret_cast<const float4 *>(lt + j * K2_PS + 4 * q);  // (for the next step)
+        res_p = res;
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (hi) {  // x = row li of L_kk^-T = column li of M
+#pragma unroll
+        for (int c = 0; c < 32; ++c) ld[c * K2_PS + li] = x[c];
     }
     return low_any;
-}
-
-__device__ __forceinline__ void k2_invert(float *ld, const float *lt, const float *dinv, int li, int h, int lane, int *progress,
-                                          int step_base, bool nowait) {
-    float x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = k2_col(h, r) == li ? 1.f : 0.f;
-    const bool hi = h != 0;
-    // until the leader has finished column `col` of L_kk.  One opaque asm statement: a C loop inside the body keeps the compiler
-    // from unrolling the 32 steps (x[] then lives in scratch memory: 3.5 x the time).
-    typedef __attribute__((address_space(3))) int lds_int;
-    const unsigned progress_at = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_int *)progress));
-    const int wait_base = __builtin_amdgcn_readfirstlane(nowait ? -64 : step_base);
-    auto wait_for = [&](int col) {
-        int seen;
-        const int need = wait_base + col;  // < 0: no wait (timing diagnostics)
-        asm volatile("s_cmp_lt_i32 %2, 0\n\t"
-                     "s_cbranch_scc1 2f\n\t"
-                     "1:\n\t"
-                     "ds_read_b32 %0, %1\n\t"
-                     "s_waitcnt lgkmcnt(0)\n\t"
-                     "v_cmp_gt_i32 vcc, %2, %0\n\t"
-                     "s_cbranch_vccz 2f\n\t"
-                     "s_sleep 1\n\t"
-                     "s_branch 1b\n\t"
-                     "2:"
-                     : "=&v"(seen)
-                     : "v"(progress_at), "s"(need)
-                     : "vcc", "scc", "memory");
-    };
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        if ((j & 1) == 0) wait_for(j + 1);  // columns j and j + 1
-        const int hj = (j >> 2) & 1, mj = 4 * (j >> 3) + (j & 3);
-        const float own = (hi == (hj != 0)) ? x[mj] : 0.f;
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
-        const float xj = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * dinv[j];  // X[i][j], in both halves
-        x[mj] = (hi == (hj != 0)) ? xj : x[mj];
-        if (j + 1 == 32) break;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (8 * q + 7 <= j) continue;  // (compile-time)
-            const float4 c4 = *reinterpret_cast<const float4 *>(lt + j * K2_PS + 8 * q + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c_lo = 8 * q + e, c_hi = c_lo + 4;
-                if (c_hi <= j) continue;  // (compile-time)
-                const float l = e == 0 ? c4.x : e == 1 ? c4.y : e == 2 ? c4.z : c4.w;
-                const bool live = hi ? c_hi > j : c_lo > j;
-                x[4 * q + e] = fmaf(-xj, live ? l : 0.f, x[4 * q + e]);
-                asm volatile("" : "+v"(x[4 * q + e]));  // (pinned: see k2_factor)
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // x = row li of L_kk^-T = column li of M: M[c][li] over the image of the block (the leader read it long ago)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ld[k2_col(h, r) * K2_PS + li] = x[r];
 }
 
 #ifdef K2_PROFILE  // diagnostic build (make EXTRA=-DK2_PROFILE): thread 0 of workgroup 0 sums the shader clocks spent per phase
@@ -760,15 +700,13 @@ __device__ __forceinline__ void k2_invert(float *ld, const float *lt, const floa
 __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_kr_job *__restrict__ jobs) {
     __shared__ float P[(K2_NB - 1) * 32 * K2_PS];      // the step's panel L[a, kb], a > kb: [a - kb - 1][row][k], stride 36
     __shared__ float LD[K2_NB * 32 * K2_PS];           // the diagonal blocks L_kk, row-major (kept: the back substitution reads them)
-    __shared__ float Dinv[K2_NB * 32];                 // 1 / l_kk
-    __shared__ float LT[32 * K2_PS];                   // the diagonal block being factored, transposed: LT[j][i] = l[i][j] (k2_factor)
+    __shared__ float LT[32 * K2_PS];                   // the diagonal block being factored, by columns: LT[j][i] = l[i][j] (k2_factor_invert)
     __shared__ float zs[K2_NB * 32 * KR_MAX_C];        // right-hand sides: one-hot labels -> z = L^-1 Y (block by block)
     __shared__ float al[K2_NB * 32 * KR_MAX_C];        // alpha
     __shared__ float part[K2_WAVES][32][KR_MAX_C];     // per-wave partial sums (back substitution)
     __shared__ int tr_idx[K2_NB * 32];
     __shared__ signed char blk_a[K2_WAVES * K2_SLOTS], blk_b[K2_WAVES * K2_SLOTS];
     __shared__ int deficient, correct;
-    __shared__ int progress;  // 32 kb + j: the leader has finished column j of L_kk of block column kb (k2_factor)
     __shared__ float red[K2_WAVES];
 
     const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + blockIdx.x);
@@ -829,7 +767,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             zs[i] = (row < nt && labels[tr_idx[row]] == c) ? 1.f : 0.f;
             al[i] = 0.f;
         }
-        if (tid == 0) deficient = 0, progress = -1;
+        if (tid == 0) deficient = 0;
         auto gather_block = [&](int a, int b, f32x16 &t) {  // lane (i, h): A[32 a + i][32 b + jmap(h, r)] = K[tr[32 b + j]][tr[32 a + i]]
             int li = li_, h = h_;
             asm volatile("" : "+v"(li), "+v"(h));
@@ -873,9 +811,9 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             int li = li_, h = h_;
             asm volatile("" : "+v"(li), "+v"(h));
             // the column's blocks below the diagonal -> LDS, row-major: block (a, kb) into P[a - kb - 1]; the diagonal block is in
-            // LD already.  role: 0 = this wave factors the diagonal block (the LEADER: the wave BEFORE the column's first block in
-            // the deal - it holds none of the column's blocks), -2 = the wave before that inverts it (the FOLLOWER),
-            // a - kb = it holds block (a, kb), -1 = none of these
+            // LD already.  role: 0 = this wave factors and inverts the diagonal block (the wave BEFORE the column's first block in
+            // the deal: it holds none of the column's blocks and none of the blocks fetched in this step),
+            // a - kb = it holds block (a, kb), -1 = neither
             int role = -1;
 #pragma unroll
             for (int s = 0; s < K2_SLOTS; ++s) {
@@ -884,28 +822,23 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 k2_store_block(acc[s], &P[(role - 1) * 32 * K2_PS], li, h);
             }
             {
-                // first block of column kb in the enumeration: sum over the columns after it (<= 9 blocks + these two < 16 waves)
+                // first block of column kb in the enumeration: sum over the columns after it
                 const int first = (nb - 1 - kb) * (nb - 2 - kb) / 2;
                 if (wave == ((first + K2_WAVES - 1) & (K2_WAVES - 1))) role = 0;
-                if (wave == ((first + K2_WAVES - 2) & (K2_WAVES - 1))) role = -2;
             }
-            // (1) the leader factors the diagonal block, the follower turns it into M = L_kk^-1 a column or two behind; LD[kb] holds M
-            //     afterwards
+            // (1) one wave factors the diagonal block and inverts it in the same pass: LD[kb] holds M = L_kk^-1 afterwards
             if (role == 0) {  // (wave-uniform)
-                if (k2_factor(&LD[kb * 32 * K2_PS], LT, &Dinv[kb * 32], li, h, lane, nt - 32 * kb, drop_below, ridge, &progress, 32 * kb) && lane == 0)
-                    deficient = 1;
-            } else if (role == -2) {
-                if (!(ablate & 64)) k2_invert(&LD[kb * 32 * K2_PS], LT, &Dinv[kb * 32], li, h, lane, &progress, 32 * kb, (ablate & 32) != 0);
-            } else {  // (the other 14 waves would wait at the barrier: the deferred gathers run here, hidden behind the recurrence)
+                if (k2_factor_invert(&LD[kb * 32 * K2_PS], LT, li, h, nt - 32 * kb, drop_below, ridge) && lane == 0) deficient = 1;
+            } else {  // (the other 15 waves would wait at the barrier: the deferred gathers run here, hidden behind the recurrence)
                 const int first = (nb - 1 - kb) * (nb - 2 - kb) / 2;
 #pragma unroll
                 for (int s = 0; s < K2_SLOTS; ++s) {
-                    if (sa[s] < 0 || sb[s] != kb + 2) continue;  // (wave-uniform; never a wave that leads or follows at this step)
+                    if (sa[s] < 0 || sb[s] != kb + 2) continue;  // (wave-uniform; never the wave that factors at this step)
                     f32x16 t;
                     gather_block(sa[s], sb[s], t);
                     acc[s] += t;
                 }
-                if (kb + 1 < nb && wave == ((first + K2_WAVES - 3) & (K2_WAVES - 1))) {  // diagonal block kb + 1 (nobody else touches it now)
+                if (kb + 1 < nb && wave == ((first + K2_WAVES - 2) & (K2_WAVES - 1))) {  // diagonal block kb + 1 (nobody else touches it now)
                     f32x16 t, d;
                     gather_block(kb + 1, kb + 1, t);
                     k2_load_block(d, &LD[(kb + 1) * 32 * K2_PS], li, h);
