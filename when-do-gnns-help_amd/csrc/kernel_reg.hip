@@ -644,33 +644,45 @@ __device__ __forceinline__ bool k2_factor_invert(float *ld, float *lt, int li, i
     for (int q = 0; q < 8; ++q) cp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
+        // column j - 1 on the entries c > j, dealt into six slots that are placed BETWEEN the later links of the step's dependent chain
+        // (the column was requested from LDS at the end of the step before: the first links run while it arrives)
+        // (a scheduling barrier after every link pins the order: left to itself the scheduler issues the chain first and the
+        // products after it - a wave issues in order, so the chain's latencies then stay empty)
+        auto bulk = [&](int slot) {
+            if (j == 0) return;
+#pragma unroll
+            for (int c = j + 1; c < 32; ++c) {
+                if ((c - j - 1) % 6 != slot) continue;  // (compile-time)
+                const float4 &cq = cp[c >> 2];
+                x[c] = fmaf(-res_p, (c & 3) == 0 ? cq.x : (c & 3) == 1 ? cq.y : (c & 3) == 2 ? cq.z : cq.w, x[c]);
+                // (pinned: left alone, the compiler sinks these products down to the step that reads the entry - a left-looking
+                // factorisation again, with every earlier column held in registers: 430 spilled registers)
+                asm volatile("" : "+v"(x[c]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
         float piv = k2_bcast(x[j], j);
         const bool low = !(piv > drop_below) && j < rows_real;  // (uniform; also catches NaN)
         low_any |= low;
         piv = low ? fmaxf(ridge, drop_below) : piv;
         const float xj = (!hi && li == j) ? piv : x[j];  // (the diagonal entry follows a replaced pivot)
         float inv = __builtin_amdgcn_rsqf(piv);
-        inv = inv * fmaf(-0.5f * piv * inv, inv, 1.5f);  // one Newton step: 1 / sqrt(piv) to within an ulp
+        float nt_ = -0.5f * piv * inv;
+        __builtin_amdgcn_sched_barrier(0);
+        bulk(0);
+        nt_ = fmaf(nt_, inv, 1.5f);  // one Newton step: 1 / sqrt(piv) to within an ulp
+        bulk(1);
+        inv = inv * nt_;
+        bulk(2);
         const float res = xj * inv;
         x[j] = res;
-        // column j - 1 on the entries c > j (independent of the chain above: the scheduler runs them in its bubbles)
-        if (j > 0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 4 * q + e;
-                    if (c <= j) continue;  // (compile-time)
-                    x[c] = fmaf(-res_p, e == 0 ? cp[q].x : e == 1 ? cp[q].y : e == 2 ? cp[q].z : cp[q].w, x[c]);
-                    // (pinned: left alone, the compiler sinks these products down to the step that reads the entry - a left-
-                    // looking factorisation again, with every earlier column held in registers: 430 spilled registers)
-                    asm volatile("" : "+v"(x[c]));
-                }
-            }
-        }
+        bulk(3);
         if (j + 1 == 32) break;
         if (!hi) lt[j * K2_PS + li] = res;  // column j of L (rows < j: never read)
-        x[j + 1] = fmaf(-res, k2_bcast(res, j + 1), x[j + 1]);  // the entry the next pivot waits for
+        const float ln = k2_bcast(res, j + 1);
+        bulk(4);
+        x[j + 1] = fmaf(-res, ln, x[j + 1]);  // the entry the next pivot waits for
+        bulk(5);
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (4 * q + 3 > j + 1) cp[q] = *reinterpret_cast<const float4 *>(lt + j * K2_PS + 4 * q);  // (for the next step)
@@ -700,6 +712,7 @@ __device__ __forceinline__ bool k2_factor_invert(float *ld, float *lt, int li, i
 __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_kr_job *__restrict__ jobs) {
     __shared__ float P[(K2_NB - 1) * 32 * K2_PS];      // the step's panel L[a, kb], a > kb: [a - kb - 1][row][k], stride 36
     __shared__ float LD[K2_NB * 32 * K2_PS];           // the diagonal blocks L_kk, row-major (kept: the back substitution reads them)
+    __shared__ float stash[K2_SLOTS * 32 * K2_PS];     // the factoring wave's own register blocks, while it factors
     __shared__ float LT[32 * K2_PS];                   // the diagonal block being factored, by columns: LT[j][i] = l[i][j] (k2_factor_invert)
     __shared__ float zs[K2_NB * 32 * KR_MAX_C];        // right-hand sides: one-hot labels -> z = L^-1 Y (block by block)
     __shared__ float al[K2_NB * 32 * KR_MAX_C];        // alpha
@@ -828,7 +841,12 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             }
             // (1) one wave factors the diagonal block and inverts it in the same pass: LD[kb] holds M = L_kk^-1 afterwards
             if (role == 0) {  // (wave-uniform)
+                // (its own register blocks wait in LDS meanwhile: the routine wants 32 + 32 registers beside its chain)
+#pragma unroll
+                for (int s = 0; s < K2_SLOTS; ++s) k2_store_block(acc[s], &stash[s * 32 * K2_PS], li, h);
                 if (k2_factor_invert(&LD[kb * 32 * K2_PS], LT, li, h, nt - 32 * kb, drop_below, ridge) && lane == 0) deficient = 1;
+#pragma unroll
+                for (int s = 0; s < K2_SLOTS; ++s) k2_load_block(acc[s], &stash[s * 32 * K2_PS], li, h);
             } else {  // (the other 15 waves would wait at the barrier: the deferred gathers run here, hidden behind the recurrence)
                 const int first = (nb - 1 - kb) * (nb - 2 - kb) / 2;
 #pragma unroll
