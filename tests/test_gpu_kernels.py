@@ -1150,7 +1150,7 @@ def test_gram_map_fused_epilogue(ops, oracle):
     """wdg_gram_map_batched_f32: K = map(A A^T) for all rows, linear and arc-cosine in one launch: the Gram part is the
     k-ordered fp32 chain (bitwise = wdg_gemm_f32 with transb), the map within 2e-6 of the largest entry of numpy's fp32."""
     rng = np.random.default_rng(12)
-    mats = [rng.random((n, f), dtype=np.float32) * (rng.random((n, f)) < 0.3) for n, f in ((300, 50), (1, 7), (130, 500), (257, 64))]
+    mats = [rng.random((n, f), dtype=np.float32) * (rng.random((n, f)) < 0.3) for n, f in ((300, 50), (1, 7), (130, 500), (257, 64), (700, 33))]
     mats[0][5] = 0.0  # a zero row: nu clamps to 1e-8, acos(0 / 1e-8) = pi / 2
     dev = [torch.from_numpy(a.astype(np.float32)).cuda() for a in mats]
     gb = ops.GramBatch(dev)
@@ -1159,6 +1159,7 @@ def test_gram_map_fused_epilogue(ops, oracle):
     for a, t, kl, ka in zip(mats, dev, gb.k_linear, gb.k_arccos):
         g = _np(ops.gemm(t, t, transb=True))
         assert np.array_equal(_np(kl), g / 2)
+        assert torch.equal(kl, kl.T) and torch.equal(ka, ka.T)  # (tiles above the diagonal are written mirrored, not computed)
         want = _arccos_map(g, 1)
         np.testing.assert_allclose(_np(ka), want, rtol=2e-5, atol=2e-6 * max(float(np.abs(want).max()), 1e-30))
     only = ops.GramBatch(dev[:1], linear=False)

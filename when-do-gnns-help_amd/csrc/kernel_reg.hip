@@ -59,33 +59,56 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
     if (m0 >= n || n0 >= n) return;
+    // The Gram and both maps are symmetric, bit for bit (the products of a k-ordered chain commute, and so do the two norms under
+    // the map): tiles that lie entirely above the diagonal are not computed - the tile below writes their entries mirrored.
+    if (n0 >= m0 + GBM) return;
 
-    constexpr int A_PER = GBM * GBK / GTHREADS, B_PER = GBN * GBK / GTHREADS;
-    float ra[A_PER], rb[B_PER];
+    // A thread fetches quadruples of consecutive k: one 16-byte load each when the rows allow it (16-byte aligned base, lda a
+    // multiple of 4 - every contiguous fp32 matrix with F % 4 == 0), else four scalar loads (the first version loaded scalars
+    // only: 12 load instructions per thread and K step with their address arithmetic - ten VALU instructions per MFMA)
+    constexpr int A_PER = GBM * GBK / GTHREADS / 4, B_PER = GBN * GBK / GTHREADS / 4;  // quadruples per thread: 2, 1
+    const bool vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(job->A) & 15) == 0;
+    float4 ra[A_PER], rb[B_PER];
+    auto load_quad = [&](int row, int gk) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n) {
+            const global_ptr<const float> p = A + static_cast<int64_t>(row) * lda + gk;
+            if (vec && gk + 3 < K) {
+                const f32x4_t q = *(global_ptr<const f32x4_t>)p;
+                v = make_float4(q[0], q[1], q[2], q[3]);
+            } else {
+                if (gk < K) v.x = p[0];
+                if (gk + 1 < K) v.y = p[1];
+                if (gk + 2 < K) v.z = p[2];
+                if (gk + 3 < K) v.w = p[3];
+            }
+        }
+        return v;
+    };
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int e = tid + i * GTHREADS, k = e % GBK, m = e / GBK;
-            const int gm = m0 + m, gk = k0 + k;
-            ra[i] = (gm < n && gk < K) ? A[static_cast<int64_t>(gm) * lda + gk] : 0.f;
+            const int e = tid + i * GTHREADS;  // quadruple e: row e / 4 of the tile, k = 4 (e % 4)
+            ra[i] = load_quad(m0 + e / 4, k0 + 4 * (e & 3));
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            const int e = tid + i * GTHREADS, k = e % GBK, c = e / GBK;
-            const int gn = n0 + c, gk = k0 + k;
-            rb[i] = (gn < n && gk < K) ? A[static_cast<int64_t>(gn) * lda + gk] : 0.f;
+            const int e = tid + i * GTHREADS;
+            rb[i] = load_quad(n0 + e / 4, k0 + 4 * (e & 3));
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            As[(e / GBK) * GLD + e % GBK] = ra[i];
+            float *d = &As[(e / 4) * GLD + 4 * (e & 3)];
+            d[0] = ra[i].x, d[1] = ra[i].y, d[2] = ra[i].z, d[3] = ra[i].w;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            Bs[(e / GBK) * GLD + e % GBK] = rb[i];
+            float *d = &Bs[(e / 4) * GLD + 4 * (e & 3)];
+            d[0] = rb[i].x, d[1] = rb[i].y, d[2] = rb[i].z, d[3] = rb[i].w;
         }
     };
     f32x16 acc[2];
@@ -113,6 +136,7 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
     // ---- epilogue: C/D map of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const float pi = 3.14159265358979323846f;
     const int row0 = m0 + wave * 32;
+
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int gn = n0 + t * 32 + li;
@@ -123,7 +147,12 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
             const int gm = row0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (gm >= n) continue;
             const float g = acc[t][r];
-            if (Klin) Klin[static_cast<int64_t>(gm) * ldk + gn] = g * 0.5f;
+            // (gn, gm) lies in a tile that was skipped: rows 128 floor(gn / 128) .., columns 64 floor(gm / 64) ..
+            const bool mirror = (gm / GBN) * GBN >= (gn / GBM) * GBM + GBM;
+            if (Klin) {
+                Klin[static_cast<int64_t>(gm) * ldk + gn] = g * 0.5f;
+                if (mirror) Klin[static_cast<int64_t>(gn) * ldk + gm] = g * 0.5f;
+            }
             if (Karc) {
                 float nu = sqrtf(norm2[gm]) * dn;
                 nu = nu > 1e-8f ? nu : 1e-8f;
@@ -131,7 +160,9 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
                 float sq = sqrtf(nu * nu - g * g);
                 ac = ac != ac ? 0.f : ac;
                 sq = sq != sq ? 0.f : sq;
-                Karc[static_cast<int64_t>(gm) * ldk + gn] = (1.f / pi) * (g * (pi - ac) + sq) * 0.5f;
+                const float kv = (1.f / pi) * (g * (pi - ac) + sq) * 0.5f;
+                Karc[static_cast<int64_t>(gm) * ldk + gn] = kv;
+                if (mirror) Karc[static_cast<int64_t>(gn) * ldk + gm] = kv;
             }
         }
     }
