@@ -45,8 +45,12 @@ __global__ __launch_bounds__(256) void row_norm2_kernel(const wdg_gram_job *__re
 }
 
 // ------------------------------------------------------------------------------------------------ Gram + map
-constexpr int GBM = 128, GBN = 64, GBK = 16, GTHREADS = 256;
-constexpr int GLD = GBK + 1;
+#ifndef WDG_GBK
+#define WDG_GBK 16
+#define WDG_GPAD 1
+#endif
+constexpr int GBM = 128, GBN = 64, GBK = WDG_GBK, GTHREADS = 256;
+constexpr int GLD = GBK + WDG_GPAD, GQ = GBK / 4;  // (GQ: quadruples of k per tile row)
 
 __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *__restrict__ jobs) {
     __shared__ float As[GBM * GLD];
@@ -88,26 +92,26 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int e = tid + i * GTHREADS;  // quadruple e: row e / 4 of the tile, k = 4 (e % 4)
-            ra[i] = load_quad(m0 + e / 4, k0 + 4 * (e & 3));
+            const int e = tid + i * GTHREADS;  // quadruple e: row e / GQ of the tile, k = 4 (e % GQ)
+            ra[i] = load_quad(m0 + e / GQ, k0 + 4 * (e % GQ));
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            rb[i] = load_quad(n0 + e / 4, k0 + 4 * (e & 3));
+            rb[i] = load_quad(n0 + e / GQ, k0 + 4 * (e % GQ));
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            float *d = &As[(e / 4) * GLD + 4 * (e & 3)];
+            float *d = &As[(e / GQ) * GLD + 4 * (e % GQ)];
             d[0] = ra[i].x, d[1] = ra[i].y, d[2] = ra[i].z, d[3] = ra[i].w;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            float *d = &Bs[(e / 4) * GLD + 4 * (e & 3)];
+            float *d = &Bs[(e / GQ) * GLD + 4 * (e % GQ)];
             d[0] = rb[i].x, d[1] = rb[i].y, d[2] = rb[i].z, d[3] = rb[i].w;
         }
     };
