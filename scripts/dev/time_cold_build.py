@@ -37,4 +37,11 @@ pr.enable()
 sb = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0, inputs=inputs)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+pr = cProfile.Profile()
+pr.enable()
+coos = [(i[0], i[1], 2000) for i in inputs]
+gb = ops.GraphBatch(coos, ops.COO_ADD_SELF_LOOPS, quad=True)
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
