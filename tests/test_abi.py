@@ -108,6 +108,50 @@ def test_no_shipped_kernel_spills_vector_registers():
     assert seen >= 20
 
 
+def test_quad_row_fast_loop_keeps_its_memory_operations_to_itself(tmp_path):
+    """csrc/spmm_quad.hip issues the loads and stores of its pipelined loop from inline asm and waits for them with hand-counted
+    `s_waitcnt vmcnt(n)`: that is only right while the COMPILER puts no memory operation of its own between them (its wait
+    insertion does not see the asm ones, and a spill reload or a conditional global access would shift the counts).  The device
+    code of the shipped flags is generated here and every basic block that holds asm memory operations is checked: no
+    compiler-emitted global / buffer / flat / scratch instruction in it, and no scratch use in the kernel at all."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    import subprocess
+    out = tmp_path / "quad.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/when-do-gnns-help_amd/csrc", "-S",
+                    "--cuda-device-only", "-o", str(out), f"{ROOT}/when-do-gnns-help_amd/csrc/spmm_quad.hip"], check=True, capture_output=True)
+    text = out.read_text()
+    checked = 0
+    for variant in ("IfLb0ELb0E", "ItLb0ELb0E"):  # fp32 / bf16 sources, pattern only, one column block: the pipelined loop
+        m = re.search(r"^(_ZN\S*spmm_quad_kernel%s[^:\s]*):[^\n]*\n(.*?)s_endpgm" % variant, text, re.M | re.S)
+        assert m, f"spmm_quad_kernel<{variant}> not found in the generated code"
+        body = m.group(2)
+        assert "scratch_" not in body, f"{variant}: scratch memory in the quad-row kernel"
+        blocks, in_asm, asm_ops, own_ops = [], False, 0, []
+        for line in body.split("\n"):
+            t = line.strip()
+            if re.match(r"^\.LBB\d+_\d+:", t):
+                blocks.append((asm_ops, own_ops))
+                asm_ops, own_ops = 0, []
+            elif t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif re.match(r"^(global|buffer|flat|scratch)_", t):
+                if in_asm:
+                    asm_ops += 1
+                else:
+                    own_ops.append(t)
+        blocks.append((asm_ops, own_ops))
+        with_asm = [b for b in blocks if b[0]]
+        assert len(with_asm) >= 10 and sum(b[0] for b in with_asm) >= 40, f"{variant}: the asm loop was not found"
+        for n_asm, own in with_asm:
+            assert not own, f"{variant}: compiler-emitted memory operations beside {n_asm} asm ones: {own[:3]}"
+        checked += 1
+    assert checked == 2
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
 def test_product_path_fails_loudly_without_gpu():
     from wdg_amd import ops

@@ -370,3 +370,22 @@ def test_counters_derived_from_the_label_columns_equal_the_edge_pass(k, seeds, m
     for a, b in zip(out["1"], out["0"]):
         assert torch.equal(a, b)
     assert int(out["1"][0][:, 0].sum()) == sum(j.nnz for j in jobs)
+
+
+def test_quad_verify_mode_checks_the_table_against_the_csr_kernel(monkeypatch):
+    """WDG_QUAD_VERIFY=1: every quad-row table is launched once at construction and compared with the CSR gather kernel; a
+    corrupted SELL-16 copy is reported"""
+    from wdg_amd import ops, sweep
+    jobs = sweep.make_jobs([0.2, 0.7], [0], k=10, n_nodes=2000)
+    monkeypatch.setenv("WDG_QUAD_VERIFY", "1")
+    sb = sweep.SweepBatch(jobs, n_feat=64, gcn_hidden=0)  # (verifies inside SpmmBatch.__init__)
+    assert sb.spmm.quad
+    sb.spmm.verify()
+    monkeypatch.delenv("WDG_QUAD_VERIFY")
+    q = sb.graphs[0].quad
+    saved = q["col"][:4096].clone()
+    q["col"][:4096] = 0  # the first index chunks now point every entry at column 0
+    with pytest.raises(RuntimeError, match="WDG_QUAD_VERIFY"):
+        sb.spmm.verify()
+    q["col"][:4096] = saved
+    sb.spmm.verify()

@@ -827,6 +827,34 @@ class SpmmBatch:
                 self.flags |= SPMM_SMALL_OFFSETS
             self.order = order
             self._set_segments(None)
+            if os.environ.get("WDG_QUAD_VERIFY", "0") not in ("", "0"):
+                self.verify()
+
+    def verify(self, tol=1e-5):
+        """WDG_QUAD_VERIFY=1 (or called directly): launch the table once and check every job against the CSR gather kernel.
+        The quad-row kernel's fast loop issues its loads and stores from inline asm with hand-counted `s_waitcnt vmcnt`
+        (csrc/spmm_quad.hip: q_units_fast) - invisible to the compiler's own bookkeeping; tests/test_abi.py checks the
+        generated code of the shipped build, this checks the results on the machine and data at hand.  The two kernels
+        sum a row's entries in different orders: agreement to `tol` of the largest entry, not bitwise.  Overwrites Y."""
+        if not self.quad:
+            return
+        self.launch()
+        torch.cuda.synchronize()
+        for i, (g, x, y, rs, cs, uv) in enumerate(self.keep):
+            got = y.clone()
+            ref = torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=y.device)
+            job = _fill_job(SpmmJob(), g, x, ref, rs, cs, uv)
+            job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0  # no SELL copies: the CSR families
+            job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
+            job.sell_ptr = job.sell_col = job.sell_val = job.sell_perm = 0
+            job.sell_block_cols = job.sell_n_blocks = 0
+            check(lib.wdg_spmm_csr_f32(ctypes.byref(job), stream_handle()), "wdg_spmm_csr_f32")
+            torch.cuda.synchronize()
+            err = float((got[:, :x.shape[1]] - ref).abs().max()) if ref.numel() else 0.0
+            scale = max(float(ref.abs().max()) if ref.numel() else 0.0, 1e-30)
+            if not err <= tol * scale:
+                raise RuntimeError(f"WDG_QUAD_VERIFY: job {i} of the quad-row table differs from the CSR kernel by {err:.3e} "
+                                   f"(largest entry {scale:.3e})")
 
     def _set_segments(self, phase_ns, shares=None):
         """cut the tape (ops._quad_segments; phase_ns: what a phase switch is priced at, None = the default; shares: the
