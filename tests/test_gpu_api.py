@@ -172,6 +172,13 @@ def test_classifier_metric_seeded(mods, name, clf):
     assert np.abs(acc[:, 0] - rec["g_results"][:6]).max() * n_val <= rows + 0.01
     assert np.abs(acc[:, 1] - rec["x_results"][:6]).max() * n_val <= rows + 0.01
     assert abs(p - want) <= p_tolerance(rec["g_results"][:6], rec["x_results"][:6], n_val, rows)
+    # the rank-deficient blocks are counted and announced (cora's 1433-feature linear kernel of 120 train rows is full rank;
+    # texas's raw-adjacency graph-aware kernel is not)
+    assert 0 <= hm.LAST_KR_RIDGED <= 12
+    if hm.LAST_KR_RIDGED:
+        with pytest.warns(UserWarning, match="rank-deficient"):
+            torch.manual_seed(11)
+            hm.classifier_based_performance_metric(features, adj_raw, labels, 200.0, base_classifier=clf, epochs=6)  # (the same call)
 
 
 @pytest.mark.parametrize("clf", ["kernel_reg1", "kernel_reg0"])

@@ -230,6 +230,7 @@ def gntk_homophily_(features, adj, sample, n_layers):
 
 FULL_KERNEL_MAX_NODES = 16384  # n x n fp32 kernels of all nodes: 1 GiB each at this size
 LAST_KR_ACCURACIES = None
+LAST_KR_RIDGED = 0
 
 
 def _kernel_regression_on_device(features, adj, labels, sample_max, base_classifier, epochs):
@@ -269,8 +270,17 @@ def _kernel_regression_on_device(features, adj, labels, sample_max, base_classif
     kb = ops.KrBatch(problems, n_cls)
     kb.launch()
     acc = kb.accuracy().cpu().reshape(epochs, 2)
-    global LAST_KR_ACCURACIES
+    global LAST_KR_ACCURACIES, LAST_KR_RIDGED
     LAST_KR_ACCURACIES = acc.clone()  # [epoch, (graph-aware, features only)]: diagnostics / tests
+    # Rank-deficient train blocks (duplicate nodes, a linear kernel of fewer features than train rows) are refactored once on
+    # K + ridge I (csrc/kernel_reg.hip): the reference's pinv inverts such a block's rounding-level singular values instead, so
+    # the two agree to within a few validation rows per epoch there, not exactly - said once per call
+    LAST_KR_RIDGED = int(kb.ridged().sum())
+    if LAST_KR_RIDGED and os.environ.get("WDG_KR_QUIET", "0") in ("", "0"):
+        import warnings
+        warnings.warn(f"kernel regression: {LAST_KR_RIDGED} of {len(problems)} train blocks were rank-deficient at fp32 rounding level and "
+                      "solved with a ridge; their accuracies can differ from the reference's pseudo-inverse by a few validation rows "
+                      "(WDG_KR_SOLVER=host runs the reference's host path)", stacklevel=3)
     G_results, X_results = acc[:, 0], acc[:, 1]
     _, p = ttest_ind(X_results, G_results, axis=0, equal_var=False, nan_policy='propagate')
     p = p / 2 if torch.mean((G_results > X_results).float()) <= 0.5 else 1 - p / 2
