@@ -76,6 +76,31 @@ def _worker(rank, world, port, out_dir, h_levels=(0.1, 0.5, 0.9), seeds=4):
     dist.destroy_process_group()
 
 
+def test_welch_p_values_equal_scipys_ttest():
+    """sweep.welch_p_values (the host tail of a shard: the reference's ttest_ind + the side rule of utils/homophily_metrics.py:335-347
+    for every (job, classifier) at once) against scipy on the reference's fp32 lists: random accuracies, a tie in every epoch,
+    two constant samples (NaN propagates), one-sided wins"""
+    import warnings
+    import numpy as np
+    from _golden import welch_p
+    from wdg_amd.sweep import welch_p_values
+    rng = np.random.default_rng(3)
+    g = (rng.integers(100, 200, (40, 2, 100)) / 200).astype(np.float32)
+    x = (rng.integers(90, 190, (40, 2, 100)) / 200).astype(np.float32)
+    x[3, 0] = g[3, 0]
+    g[4, 1], x[4, 1] = 0.5, 0.5
+    x[5, 0] = g[5, 0] - 0.2  # the graph-aware regression wins every epoch
+    x[6, 1] = g[6, 1] + 0.2
+    got = welch_p_values(g, x)
+    assert got.shape == (40, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = np.array([[welch_p(g[j, c], x[j, c]) for c in range(2)] for j in range(40)])
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).sum() == 1
+    assert np.nanmax(np.abs(got - want)) < 1e-6
+    assert got[5, 0] > 1 - 1e-6 and got[6, 1] < 1e-6  # (the reference's side rule: 1 - p / 2 when the graph-aware side wins)
+
+
 def test_two_rank_sweep_gloo(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
