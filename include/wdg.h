@@ -473,6 +473,18 @@ typedef struct wdg_gemm_job {
 } wdg_gemm_job;
 int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_N,
                          wdg_stream_t stream);
+/*
+ * Split-K for one product with few output tiles and a long K (the first layer of a GCN on a single wide-feature graph:
+ * squirrel's X W0 is 5201 x 2089 x 64, 41 tiles on 256 CUs): K is cut into `splits` ranges (wdg_gemm_splitk_plan: 1 = the shape
+ * does not need it), every range a workgroup of its own per tile writing a partial product into `workspace`
+ * (wdg_gemm_splitk_workspace_bytes), and a second launch adds the partials in split order, then bias and activation.  Each
+ * partial is the k-ordered fma chain of its range and the ranges are added in order: bitwise reproducible, but NOT the single
+ * chain of wdg_gemm_f32 - the two agree to fp32 rounding.  Replaces the same `x @ W` as wdg_gemm_f32.
+ */
+int32_t wdg_gemm_splitk_plan(int32_t M, int32_t N, int32_t K);
+size_t wdg_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splits);
+int wdg_gemm_splitk_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int act, float *C, int64_t ldc,
+                        int32_t M, int32_t N, int32_t K, int32_t splits, void *workspace, size_t workspace_bytes, wdg_stream_t stream);
 /* Same, with what the host knows about the table: max_K = the largest K, flags = WDG_GEMM_*.  With WDG_GEMM_A_VEC4 the
  * caller promises that in EVERY job A is 16-byte aligned, lda % 4 == 0 and K % 4 == 0 (any contiguous fp32 row-major
  * activation matrix with K % 4 == 0); tall-skinny tables (max_N <= 64, max_K <= 512, max_M >= 256) then run on the

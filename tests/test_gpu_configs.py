@@ -188,3 +188,26 @@ def test_sgc1_forward_in_both_orders(oracle, name):
         np.testing.assert_allclose(_np(head_first), want, **tol)
         np.testing.assert_allclose(_np(head_first), oracle.spmm_csr(rowptr, col, vhat, oracle.gemm(x, w)), **tol)
         assert torch.equal(cached, agg_first)
+
+
+@pytest.mark.parametrize("m,n,k,splits", [(5201, 64, 2089, 0), (2277, 64, 2325, 0), (300, 16, 1500, 4), (129, 33, 1024, 16), (5, 3, 4096, 7)])
+def test_split_k_gemm_against_the_oracle(oracle, monkeypatch, m, n, k, splits):
+    """wdg_gemm_splitk_f32 (few output tiles, K >= 1024: the first layer of a GCN on squirrel / chameleon): partial products over
+    ranges of K added in order - within 1e-5 of the oracle's k-ordered product, bitwise reproducible, bias + relu applied after
+    the reduction, ragged last range; splits = 0: what ops.gemm picks by itself"""
+    from wdg_amd import ops
+    from wdg_amd._lib import lib
+    rng = np.random.default_rng(m + n + k)
+    a, b, bias = (rng.standard_normal(s_).astype(np.float32) for s_ in ((m, k), (k, n), (n,)))
+    at, bt, biast = (torch.from_numpy(v).cuda() for v in (a, b, bias))
+    if splits:
+        monkeypatch.setenv("WDG_GEMM_SPLITK", str(splits))
+    assert int(lib.wdg_gemm_splitk_plan(m, n, k)) == (splits if splits else int(lib.wdg_gemm_splitk_plan(m, n, k)))
+    assert int(lib.wdg_gemm_splitk_plan(m, n, k)) > 1
+    got = ops.gemm(at, bt, bias=biast, relu=True)
+    want = np.maximum(oracle.gemm(a, b) + bias, 0)
+    np.testing.assert_allclose(_np(got), want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+    assert torch.equal(got, ops.gemm(at, bt, bias=biast, relu=True))
+    monkeypatch.setenv("WDG_GEMM_SPLITK", "1")  # never: the single chain
+    one = ops.gemm(at, bt, bias=biast, relu=True)
+    np.testing.assert_allclose(_np(got), _np(one), rtol=1e-5, atol=1e-5 * np.abs(want).max())

@@ -114,6 +114,10 @@ SIGNATURES = {
                              c_int32, c_int32, c_int32, c_void_p]),
     "wdg_gemm_skinny_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                     c_void_p]),
+    "wdg_gemm_splitk_plan": (c_int32, [c_int32, c_int32, c_int32]),
+    "wdg_gemm_splitk_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "wdg_gemm_splitk_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p, c_size_t, c_void_p]),
     "wdg_gemm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_gemm_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
     "wdg_mlp2_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

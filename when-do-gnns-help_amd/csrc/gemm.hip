@@ -79,6 +79,16 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     if (m0 >= M || n0 >= N) return;  // table entries smaller than the launch bounds
+    // split-K (wdg_gemm_splitk_f32: one by-value job, gridDim.z = splits): this workgroup sums k in [kb, ke) into partial number
+    // blockIdx.z, stored behind one another at C (M rows of ldc each); bias and activation wait for the reduction
+    const bool split = jobs == nullptr && gridDim.z > 1;
+    int kb = 0, ke = K;
+    global_ptr<float> Cw = C;
+    if (split) {
+        const int kc = (((K + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z)) + BK - 1) / BK * BK;
+        kb = min(K, static_cast<int>(blockIdx.z) * kc), ke = min(K, kb + kc);
+        Cw = C + static_cast<int64_t>(blockIdx.z) * M * ldc;
+    }
 
     constexpr int A_PER = BM * BK / THREADS;  // 8
     constexpr int B_PER = BN * BK / THREADS;  // 2 or 4
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
         for (int i = 0; i < A_PER; ++i) {  // k fastest: 16 consecutive threads read 64 contiguous bytes
             const int e = tid + i * THREADS, k = e % BK, m = e / BK;
             const int gm = m0 + m, gk = k0 + k;
-            ra[i] = (gm < M && gk < K) ? A[static_cast<int64_t>(gm) * lda + gk] : 0.f;
+            ra[i] = (gm < M && gk < ke) ? A[static_cast<int64_t>(gm) * lda + gk] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
@@ -97,11 +107,11 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
             if constexpr (TRANSB) {
                 const int k = e % BK, n = e / BK;
                 const int gn = n0 + n, gk = k0 + k;
-                rb[i] = (gn < N && gk < K) ? B[static_cast<int64_t>(gn) * ldb + gk] : 0.f;
+                rb[i] = (gn < N && gk < ke) ? B[static_cast<int64_t>(gn) * ldb + gk] : 0.f;
             } else {
                 const int n = e % BN, k = e / BN;
                 const int gn = n0 + n, gk = k0 + k;
-                rb[i] = (gn < N && gk < K) ? B[static_cast<int64_t>(gk) * ldb + gn] : 0.f;
+                rb[i] = (gn < N && gk < ke) ? B[static_cast<int64_t>(gk) * ldb + gn] : 0.f;
             }
         }
     };
@@ -133,12 +143,12 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
     const int li = lane & 31, lk = lane >> 5;
     float bv[NT];
     tile_bias<NT>(bias, n0, li, N, bv);
-    load_tiles(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    load_tiles(kb);
+    for (int k0 = kb; k0 < ke; k0 += BK) {
         __syncthreads();  // previous step's operand reads are done
         store_tiles();
         __syncthreads();
-        if (k0 + BK < K) load_tiles(k0 + BK);  // in flight while the MFMAs below run
+        if (k0 + BK < ke) load_tiles(k0 + BK);  // in flight while the MFMAs below run
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a = As[(wave * 32 + li) * LDA_S + kk + lk];
@@ -152,7 +162,20 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(const wdg_gemm_job *_
         }
     }
 
-    tile_store<NT>(acc, bv, C, ldc, m0 + wave * 32, n0, li, lk, M, N, act);
+    tile_store<NT>(acc, bv, Cw, ldc, m0 + wave * 32, n0, li, lk, M, N, act);
+}
+
+// C = act(P[0] + P[1] + ... + bias), partials in split order (fixed: bitwise reproducible)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const float *__restrict__ P, int splits, int M, int N, int64_t ldp,
+                                                          const float *__restrict__ bias, int act, float *__restrict__ C, int64_t ldc) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= static_cast<int64_t>(M) * N) return;
+    const int m = static_cast<int>(i / N), n = static_cast<int>(i % N);
+    float v = P[static_cast<int64_t>(m) * ldp + n];
+    for (int z = 1; z < splits; ++z) v += P[(static_cast<int64_t>(z) * M + m) * ldp + n];
+    if (bias) v += bias[n];
+    if (act == WDG_ACT_RELU) v = fmaxf(v, 0.f);
+    C[static_cast<int64_t>(m) * ldc + n] = v;
 }
 
 // ------------------------------------------------------------------------------------------------ B-resident kernel
@@ -550,6 +573,54 @@ int wdg_gemm_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int t
         else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), grid, dim3(THREADS), 0, st, none, j);
     }
     return wdg::check_launch("gemm_f32_kernel");
+}
+
+// ---- split-K: few output tiles, a long K (squirrel's X W0: 5201 x 2089 x 64 = 41 tiles of the tile kernel on 256 CUs, 125 us
+//      for a 43-MB read of X).  K is cut into `splits` ranges, each a workgroup of its own per tile (blockIdx.z) writing a partial
+//      product; a second launch adds the partials in split order, then bias and activation.  Every partial is the k-ordered
+//      fma chain of its range, the ranges are added in order: bitwise reproducible, NOT the single chain of wdg_gemm_f32
+//      (agreement to fp32 rounding).
+int32_t wdg_gemm_splitk_plan(int32_t M, int32_t N, int32_t K) {
+    if (const char *e = getenv("WDG_GEMM_SPLITK")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 16) return std::max(v, 1);  // 0 / 1: never; 2 .. 16: that many where the shape allows it at all
+    }
+    const int cus = std::max(wdg_device_cus(), 8);
+    const int64_t tiles = wdg::ceil_div(M, BM) * wdg::ceil_div(N, N > 32 ? 64 : 32);
+    if (M <= 0 || N <= 0 || tiles * 2 > cus || K < 1024) return 1;
+    return static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>({cus / tiles, K / 256, 16})));
+}
+
+size_t wdg_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t splits) {
+    return static_cast<size_t>(std::max(splits, 1)) * std::max(M, 0) * ((std::max(N, 0) + 3) / 4 * 4) * sizeof(float) + 256;
+}
+
+int wdg_gemm_splitk_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int act, float *C, int64_t ldc,
+                        int32_t M, int32_t N, int32_t K, int32_t splits, void *workspace, size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_splitk: negative size");
+    WDG_REQUIRE(splits >= 1 && splits <= 16, "gemm_splitk: 1 .. 16 splits");
+    if (M == 0 || N == 0) return WDG_OK;
+    if (splits == 1 || K < splits * BK) return wdg_gemm_f32(A, lda, B, ldb, 0, bias, act, C, ldc, M, N, K, stream);
+    WDG_REQUIRE(A && B && C, "gemm_splitk: null matrix");
+    WDG_REQUIRE(lda >= K && ldc >= N && ldb >= N, "gemm_splitk: leading dimension too small");
+    WDG_REQUIRE(act == WDG_ACT_NONE || act == WDG_ACT_RELU, "gemm_splitk: bad activation");
+    if (!workspace || workspace_bytes < wdg_gemm_splitk_workspace_bytes(M, N, splits))
+        return wdg::fail(WDG_ERR_WORKSPACE, "gemm_splitk: workspace too small");
+    hipStream_t st = wdg::as_stream(stream);
+    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+    const int64_t ldp = (N + 3) / 4 * 4;
+    const bool wide = N > 32;
+    const dim3 grid(static_cast<unsigned>(wdg::ceil_div(M, BM)), static_cast<unsigned>(wdg::ceil_div(N, wide ? 64 : 32)), static_cast<unsigned>(splits));
+    wdg_gemm_job j{};
+    j.A = A; j.B = B; j.bias = nullptr; j.C = P;
+    j.lda = lda; j.ldb = ldb; j.ldc = ldp;
+    j.M = M; j.N = N; j.K = K; j.act = WDG_ACT_NONE;
+    const wdg_gemm_job *none = nullptr;
+    if (wide) hipLaunchKernelGGL((gemm_f32_kernel<2, false>), grid, dim3(THREADS), 0, st, none, j);
+    else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), grid, dim3(THREADS), 0, st, none, j);
+    hipLaunchKernelGGL(gemm_splitk_reduce, dim3(static_cast<unsigned>(wdg::ceil_div(static_cast<int64_t>(M) * N, 256))), dim3(256), 0, st, P, splits,
+                       M, N, ldp, bias, act, C, ldc);
+    return wdg::check_launch("gemm_splitk");
 }
 
 int wdg_gemm_skinny_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, int act, float *C, int64_t ldc,

@@ -1349,7 +1349,8 @@ def las(h, labels, n_classes, rows=None, want_weights=False):
 
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, bias=None, relu=False, transb=False, out=None):
-    """act(A @ B + bias) (or A @ B^T with transb) in exact fp32 on the MFMA pipe (wdg_gemm_f32)."""
+    """act(A @ B + bias) (or A @ B^T with transb) in exact fp32 on the MFMA pipe (wdg_gemm_f32; products with few output tiles
+    and K >= 1024 as partial products over ranges of K, wdg_gemm_splitk_f32: same arithmetic per range, ranges added in order)."""
     dev = require_gpu()
     a, b, bias = _dev(a, torch.float32, dev), _dev(b, torch.float32, dev), _dev(bias, torch.float32, dev)
     m, k = a.shape
@@ -1357,6 +1358,13 @@ def gemm(a, b, bias=None, relu=False, transb=False, out=None):
     if (b.shape[1] if transb else b.shape[0]) != k:
         raise ValueError("gemm: inner dimensions differ")
     c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=dev)
+    splits = 1 if transb else int(lib.wdg_gemm_splitk_plan(m, n, k))
+    if splits > 1:  # few output tiles, a long K (a GCN's first layer on one wide-feature graph): partial products over ranges of K
+        ws_bytes = lib.wdg_gemm_splitk_workspace_bytes(m, n, splits)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.wdg_gemm_splitk_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(bias), ACT_RELU if relu else ACT_NONE, _ptr(c), _ld(c),
+                                      m, n, k, splits, _ptr(ws), ws_bytes, stream_handle()), "wdg_gemm_splitk_f32")
+        return c
     check(lib.wdg_gemm_f32(_ptr(a), _ld(a), _ptr(b), _ld(b), int(transb), _ptr(bias),
                            ACT_RELU if relu else ACT_NONE, _ptr(c), _ld(c), m, n, k, stream_handle()),
           "wdg_gemm_f32")
