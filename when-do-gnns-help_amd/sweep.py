@@ -528,10 +528,24 @@ class SweepBatch:
 
     def launch_full(self):
         """the launches of the three extra scalars (after the aggregation: they read Y): Gram + maps, edge cosines, regressions"""
+        side = None
         if self.kr_sets is not None:
-            self.kr_sets.launch()   # the epochs' node sets (device sampler; a host-sampled batch uploaded them in prepare_full)
+            # the epochs' node sets (device sampler; a host-sampled batch uploaded them in prepare_full) depend on nothing the
+            # step produces: drawn on a second stream beside the Grams (0.8 ms of LDS sorting beside 2.7 ms of MFMA tiles)
+            cur = torch.cuda.current_stream()
+            if os.environ.get("WDG_SWEEP_SIDE_STREAM", "1") != "0":
+                if getattr(self, "_side_stream", None) is None:
+                    self._side_stream = torch.cuda.Stream()
+                side = self._side_stream
+                side.wait_stream(cur)  # (the previous batch's regressions have read the old sets)
+                with torch.cuda.stream(side):
+                    self.kr_sets.launch()
+            else:
+                self.kr_sets.launch()
         self.gram.launch()
         self.ge.launch()
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         self.kr.launch()
 
     def full_metrics(self):
