@@ -37,7 +37,7 @@ pr.enable()
 sb = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0, inputs=inputs)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
 pr = cProfile.Profile()
 pr.enable()
 coos = [(i[0], i[1], 2000) for i in inputs]
