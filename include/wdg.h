@@ -391,6 +391,19 @@ typedef struct wdg_stats_job {
 int wdg_edge_label_stats_batched(const wdg_stats_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_classes,
                                  wdg_stream_t stream);
 
+/*
+ * The six scalars of a sweep step for every job of a shard, from the pooled counters of wdg_edge_label_stats_batched (totals
+ * [n_jobs, 6], rows [n_jobs, 3, max_rows] = row_nnz / row_nnz_noself / row_match_noself padded with zeros, compat [n_jobs, C, C],
+ * classdeg [n_jobs, C]), the LAS counts ([n_jobs, 2]) and node counts ([n_jobs] fp32) and the class proportions ([n_jobs, C]):
+ * out[j] = {edge homophily, node homophily, class homophily, adjusted homophily, label informativeness, soft LAS} in fp32.
+ * replaces: the tails of edge_homophily / node_homophily / our_measure / adjusted_homo / label_informativeness / similarity as
+ *           synthetic_plot.py:94-106 calls them (utils/homophily_plot.py:43-160): fp32 arithmetic on integer counters, NaN class
+ *           terms skipped, zeros -> 1e-8.  Deterministic (fixed summation order).  1 <= C <= 32.
+ */
+int wdg_sweep_scalars_f32(const int64_t *totals, const int32_t *rows, const int64_t *compat, const int64_t *classdeg,
+                          const int64_t *las_counts, const float *las_n, const float *class_prop, int32_t n_jobs, int32_t max_rows,
+                          int32_t n_classes, float *out, wdg_stream_t stream);
+
 /* ------------------------------------------------------------------ per-edge cosine (SDDMM) */
 /*
  * out[i] = cos(x_u, x_v) for stored entry e_i = (u, v) (e_i = entries[i], or i when entries == NULL); NaN -> 0;

@@ -389,3 +389,19 @@ def test_quad_verify_mode_checks_the_table_against_the_csr_kernel(monkeypatch):
         sb.spmm.verify()
     q["col"][:4096] = saved
     sb.spmm.verify()
+
+
+def test_step_scalars_kernel_equals_the_torch_formulas():
+    """SweepBatch.results() (wdg_sweep_scalars_f32: one launch per shard) against results_torch() (the reference's formulas as
+    torch operations) on a shard of graphs of different sizes and densities - fp32 both, sums in different orders: 2e-6 relative,
+    1e-6 absolute (label informativeness is 2 - a ratio near 2)"""
+    from wdg_amd import sweep
+    jobs = (sweep.make_jobs([0.05, 0.3, 0.9], [0, 1], k=10, n_nodes=2000) + sweep.make_jobs([0.1, 0.6], [2], k=2, n_nodes=1000)
+            + sweep.make_jobs([0.5], [3], k=4, n_nodes=300))
+    sb = sweep.SweepBatch(jobs, n_feat=64, gcn_hidden=0)
+    sb.step()
+    torch.cuda.synchronize()
+    got, want = sb.results().cpu().numpy(), sb.results_torch().cpu().numpy()
+    assert got.shape == want.shape == (len(jobs), 6) and np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+    assert torch.equal(sb.results(), sb.results())

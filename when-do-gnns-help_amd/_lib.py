@@ -105,6 +105,8 @@ SIGNATURES = {
     "wdg_edge_label_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "wdg_edge_label_stats_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_sweep_scalars_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                      c_void_p, c_void_p]),
     "wdg_edge_cosine_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int,
                                     c_void_p, c_void_p]),
     "wdg_las_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

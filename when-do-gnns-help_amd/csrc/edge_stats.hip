@@ -134,6 +134,69 @@ int launch(const wdg_stats_job *jobs, const wdg_stats_job &inl, int n_jobs, int 
     return fail(WDG_ERR_UNSUPPORTED, "edge_label_stats: bad group width");
 }
 
+// ---- the sweep step's six scalars from the counters, one launch for a whole shard (sweep.SweepBatch.results).  The formulas of
+// the reference's dense flavour (utils/homophily_plot.py:43-53 edge, 69-78 node, 81-120 class, 123-160 adjusted homophily and
+// label informativeness; soft LAS = count / n) on the counters of wdg_edge_label_stats: a workgroup per job, the per-row term of
+// node homophily summed in a fixed order (per thread by stride, a wave butterfly, the waves in order), the C x C tails by one
+// thread.  Round 2 ran this as ~50 tiny torch launches per call: 0.4 ms at the end of every timed region, 1 ms of every cold shard.
+constexpr int SC_THREADS = 256, SC_MAX_C = 32;
+
+__global__ __launch_bounds__(SC_THREADS) void sweep_scalars_kernel(const int64_t *__restrict__ totals, const int32_t *__restrict__ rows,
+                                                                   const int64_t *__restrict__ compat, const int64_t *__restrict__ classdeg,
+                                                                   const int64_t *__restrict__ las_counts, const float *__restrict__ las_n,
+                                                                   const float *__restrict__ class_prop, int max_rows, int C,
+                                                                   float *__restrict__ out) {
+    __shared__ float wsum[SC_THREADS / 64];
+    __shared__ int wcnt[SC_THREADS / 64];
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *nnz = rows + static_cast<int64_t>(j) * 3 * max_rows, *noself = nnz + max_rows, *match = noself + max_rows;
+    float sum = 0.f;
+    int cnt = 0;
+    for (int i = tid; i < max_rows; i += SC_THREADS) {
+        const float d = static_cast<float>(nnz[i]);
+        if (nnz[i] != 0) {
+            sum += (static_cast<float>(match[i]) + (d - static_cast<float>(noself[i]))) / d;
+            ++cnt;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o), cnt += __shfl_xor(cnt, o);
+    if (lane == 0) wsum[wave] = sum, wcnt[wave] = cnt;
+    __syncthreads();
+    if (tid != 0) return;
+    float node_sum = 0.f;
+    int node_cnt = 0;
+    for (int w = 0; w < SC_THREADS / 64; ++w) node_sum += wsum[w], node_cnt += wcnt[w];
+    const int64_t *tot = totals + static_cast<int64_t>(j) * 6, *k = compat + static_cast<int64_t>(j) * C * C, *cd = classdeg + static_cast<int64_t>(j) * C;
+    const float edge = static_cast<float>(tot[5]) / static_cast<float>(tot[4]);
+    const float node = node_sum / static_cast<float>(node_cnt);
+    int64_t degsum_i = 0;
+    for (int c = 0; c < C; ++c) degsum_i += cd[c];
+    const float degsum = static_cast<float>(degsum_i);
+    float cls = 0.f, s2 = 0.f, hp = 0.f, hpc = 0.f;
+    for (int a = 0; a < C; ++a) {
+        float rowsum = 0.f;
+        for (int b = 0; b < C; ++b) rowsum += static_cast<float>(k[a * C + b]);
+        const float term = fmaxf(static_cast<float>(k[a * C + a]) / rowsum - class_prop[static_cast<int64_t>(j) * C + a], 0.f);
+        cls += term != term ? 0.f : term;  // (NaN terms - a class without edges - are skipped, utils/homophily_metrics.py:119)
+        float pb = static_cast<float>(cd[a]) / degsum;
+        pb = pb == 0.f ? 1e-8f : pb;
+        s2 += pb * pb;
+        hp += pb * logf(pb);
+        for (int b = 0; b < C; ++b) {
+            float pc = static_cast<float>(k[a * C + b]) / degsum;
+            pc = pc == 0.f ? 1e-8f : pc;
+            hpc += pc * logf(pc);
+        }
+    }
+    float *o = out + static_cast<int64_t>(j) * 6;
+    o[0] = edge;
+    o[1] = node;
+    o[2] = cls / static_cast<float>(C - 1);
+    o[3] = (edge - s2) / (1.f - s2);
+    o[4] = 2.f - hpc / hp;
+    o[5] = static_cast<float>(las_counts[2 * j]) / las_n[j];
+}
+
 }  // namespace
 
 extern "C" {
@@ -166,6 +229,18 @@ int wdg_edge_label_stats_batched(const wdg_stats_job *jobs_dev, int32_t n_jobs, 
     WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_classes >= 0, "edge_label_stats_batched: negative size");
     WDG_REQUIRE(n_jobs == 0 || jobs_dev, "edge_label_stats_batched: null job table");
     return launch(jobs_dev, wdg_stats_job{}, n_jobs, max_rows, max_classes, 16, as_stream(stream));
+}
+
+int wdg_sweep_scalars_f32(const int64_t *totals, const int32_t *rows, const int64_t *compat, const int64_t *classdeg,
+                          const int64_t *las_counts, const float *las_n, const float *class_prop, int32_t n_jobs, int32_t max_rows,
+                          int32_t n_classes, float *out, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0, "sweep_scalars: negative size");
+    WDG_REQUIRE(n_classes >= 1 && n_classes <= SC_MAX_C, "sweep_scalars: 1 .. 32 classes");
+    if (n_jobs == 0) return WDG_OK;
+    WDG_REQUIRE(totals && rows && compat && classdeg && las_counts && las_n && class_prop && out, "sweep_scalars: null array");
+    hipLaunchKernelGGL(sweep_scalars_kernel, dim3(static_cast<unsigned>(n_jobs)), dim3(SC_THREADS), 0, as_stream(stream), totals, rows, compat,
+                       classdeg, las_counts, las_n, class_prop, max_rows, n_classes, out);
+    return check_launch("sweep_scalars_kernel");
 }
 
 }  // extern "C"

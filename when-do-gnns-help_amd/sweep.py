@@ -415,11 +415,41 @@ class SweepBatch:
             self.gcn["gemm2"].launch()  # (.) W1
         self.gcn["spmm"].launch()   # logits = A_hat (.)           (F = C)
 
+    def _class_proportions(self):
+        """[jobs, C] fp32: every job's class proportions (fixed per batch; counted where the labels already are)"""
+        if getattr(self, "_class_prop", None) is None:
+            st, c = self.stats, self.stats.c
+            host = getattr(self, "labels_host", None)
+            if host is not None and len(host) == st.n_jobs:
+                cnt = np.stack([np.bincount(np.asarray(l)[(np.asarray(l) >= 0) & (np.asarray(l) < c)], minlength=c)[:c] for l in host])
+                counts = torch.from_numpy(cnt.astype(np.float32)).to(st.counters.device)
+            else:
+                n = st.max_rows
+                lab = torch.stack([torch.nn.functional.pad(l, (0, n - l.shape[0]), value=-1) for l in st.labels]) if st.n_jobs else torch.zeros((0, n))
+                counts = torch.stack([(lab == i).sum(1) for i in range(c)], 1).to(torch.float32)
+            self._class_prop = (counts / counts.sum(1, keepdim=True)).contiguous()
+        return self._class_prop
+
     def results(self):
-        """[jobs, STEP_METRICS] fp32: dense-flavour metric scalars (utils/homophily_plot.py) from the counters."""
+        """[jobs, STEP_METRICS] fp32: dense-flavour metric scalars (utils/homophily_plot.py) from the counters - one launch for the
+        shard (wdg_sweep_scalars_f32); results_torch() is the same arithmetic as ~50 torch launches (round 2's path, kept as
+        the yardstick of tests/test_gpu_sweep.py and for more than 32 classes)."""
         st = self.stats
         if not self.jobs:  # an empty shard (more ranks than jobs): no rows, same columns
             return torch.zeros((0, STEP_METRICS), dtype=torch.float32, device=st.counters.device)
+        if not 1 <= st.c <= 32 or os.environ.get("WDG_SWEEP_SCALARS", "kernel") == "torch":
+            return self.results_torch()
+        ops = self.ops
+        out = torch.empty((st.n_jobs, STEP_METRICS), dtype=torch.float32, device=st.counters.device)
+        prop = self._class_proportions()
+        ops.check(ops.lib.wdg_sweep_scalars_f32(st.totals.data_ptr(), st.rows.data_ptr(), st.compat.data_ptr(), st.classdeg.data_ptr(),
+                                                self.las.counts.data_ptr(), self.las.n.data_ptr(), prop.data_ptr(), st.n_jobs,
+                                                st.rows.shape[2], st.c, out.data_ptr(), ops.stream_handle()), "wdg_sweep_scalars_f32")
+        return out
+
+    def results_torch(self):
+        """results() in torch operations (the reference's formulas line by line)"""
+        st = self.stats
         tot = st.totals.to(torch.float32)
         edge = tot[:, 5] / tot[:, 4]
         n = st.max_rows
@@ -430,16 +460,7 @@ class SweepBatch:
         k = st.compat.to(torch.float32)
         c = k.shape[1]
         hmat = k / k.sum(2, keepdim=True)
-        if getattr(self, "_class_prop", None) is None:  # the class proportions: fixed per batch (60 tiny launches per call otherwise)
-            host = getattr(self, "labels_host", None)
-            if host is not None and len(host) == st.n_jobs:  # (counted where the labels already are: one upload)
-                cnt = np.stack([np.bincount(np.asarray(l)[(np.asarray(l) >= 0) & (np.asarray(l) < c)], minlength=c)[:c] for l in host])
-                counts = torch.from_numpy(cnt.astype(np.float32)).to(k.device)
-            else:
-                lab = torch.stack([torch.nn.functional.pad(l, (0, n - l.shape[0]), value=-1) for l in st.labels]) if st.n_jobs else torch.zeros((0, n))
-                counts = torch.stack([(lab == i).sum(1) for i in range(c)], 1).to(torch.float32)
-            self._class_prop = counts / counts.sum(1, keepdim=True)
-        prop = self._class_prop
+        prop = self._class_proportions()
         terms = torch.clamp(torch.diagonal(hmat, dim1=1, dim2=2) - prop, min=0)
         cls = torch.where(torch.isnan(terms), torch.zeros_like(terms), terms).sum(1) / (c - 1)
         degsum = st.classdeg.sum(1, keepdim=True).to(torch.float32)
