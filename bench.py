@@ -132,8 +132,10 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     # HIP events around the aggregation launch of every `stride`-th step (about 50 samples over the timed region): an
     # event pair costs ~20 us of queue markers per step (scripts/dev/time_gaps.py: 0.443 -> 0.423 ms without them), so the
     # roofline figure is sampled instead of taxing every step; all steps run the same launches either way
-    stride = max(1, steps // 50)
-    ev = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in range(0, steps, stride)}
+    # (never more than every fourth step, starting at the third: a run of 20 steps is not taxed on every step, and the launch
+    # right behind the synchronisation - 20-25 us of wake-up on top of the kernel - is not one of five samples)
+    stride = max(4, steps // 50)
+    ev = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in range(min(2, steps - 1), steps, stride)}
     sync_all()
     t0 = time.perf_counter()
     for s in range(steps):
@@ -158,6 +160,8 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
         total_edges = int(e.item())
     else:
         total_edges = batch.edges
+    if os.environ.get("WDG_BENCH_DUMP_LAUNCHES"):
+        print("launch us by step:", " ".join(f"{s_}:{a.elapsed_time(b) * 1e3:.0f}" for s_, (a, b) in sorted(ev.items())), file=sys.stderr)
     spmm_ms = sorted(a.elapsed_time(b) for a, b in ev.values())
     return dict(batch=batch, mine=mine, h_levels=h_levels, elapsed=elapsed, enqueue_s=enqueue_s, total_edges=total_edges,
                 n_graphs=sum(g.shape[0] for g in gathered), spmm_ms=spmm_ms, k=k, seeds=seeds, steps=steps)
