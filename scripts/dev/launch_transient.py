@@ -46,3 +46,29 @@ for trial in range(2):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     print("bench-like loop:", " ".join(f"{s}:{a.elapsed_time(c) * 1e3:.0f}" for s, (a, c) in sorted(ev2.items())), f"| {el / n2 * 1e6:.1f} us per step")
+
+# the same loop with every launch clocked: does the workgroups' span follow the event time?
+torch.cuda.synchronize()
+n3 = 60
+clocks3 = [b.spmm.new_clock() for _ in range(n3)]
+ev3 = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in range(2, n3, 4)}
+for _ in range(100):
+    b.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for s in range(n3):
+    if s in ev3:
+        ev3[s][0].record(); b.spmm.launch(clock=clocks3[s]); ev3[s][1].record()
+    else:
+        b.spmm.launch(clock=clocks3[s])
+    b.step_rest()
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+sp3, first3 = [], []
+for c in clocks3:
+    t = c.cpu().numpy().reshape(-1, 2).astype(np.float64) * 10e-3
+    sp3.append(t[:, 1].max() - t[:, 0].min()); first3.append(t[:, 0].min())
+gap = [first3[s + 1] - first3[s] for s in range(n3 - 1)]
+print("clocked bench-like: events", " ".join(f"{s}:{a.elapsed_time(c) * 1e3:.0f}" for s, (a, c) in sorted(ev3.items())), f"| {el / n3 * 1e6:.1f} us per step")
+print("   wg span by step:", " ".join(f"{v:.0f}" for v in sp3))
+print("   start-to-start :", " ".join(f"{v:.0f}" for v in gap))
