@@ -208,6 +208,50 @@ def test_split_k_gemm_against_the_oracle(oracle, monkeypatch, m, n, k, splits):
     want = np.maximum(oracle.gemm(a, b) + bias, 0)
     np.testing.assert_allclose(_np(got), want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
     assert torch.equal(got, ops.gemm(at, bt, bias=biast, relu=True))
+    plain = ops.gemm(at, bt)  # no bias, no activation; into a view with a leading dimension
+    np.testing.assert_allclose(_np(plain), oracle.gemm(a, b), rtol=1e-5, atol=1e-5 * np.abs(want).max())
+    store = torch.full((m, n + 3), -7.0, device="cuda")
+    ops.gemm(at, bt, bias=biast, out=store[:, :n])
+    assert torch.equal(store[:, :n], ops.gemm(at, bt, bias=biast)) and float(store[:, n:].min()) == -7.0 == float(store[:, n:].max())
     monkeypatch.setenv("WDG_GEMM_SPLITK", "1")  # never: the single chain
     one = ops.gemm(at, bt, bias=biast, relu=True)
     np.testing.assert_allclose(_np(got), _np(one), rtol=1e-5, atol=1e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("f,dtype,scaled,ld_pad", [(1, "f32", True, 0), (3, "f32", False, 5), (4, "bf16", True, 0), (5, "bf16", False, 3),
+                                                    (8, "bf16", False, 0), (8, "bf16", True, 0), (7, "f32", True, 1)])
+def test_narrow_kernel_source_tables(oracle, f, dtype, scaled, ld_pad):
+    """every source table of the narrow kernel (csrc/spmm_narrow.hip): four fp32 per column (F <= 4, any dtype, with or without
+    a column scale), the bf16 row as it is (bf16 sources, no column scale), eight fp32 (the rest) - rows of X that are not whole
+    16-byte units (ld = F + pad), explicit values beside unit ones, an empty row, a 3 000-entry hub row"""
+    from wdg_amd import ops
+    from wdg_amd._lib import lib
+    rng = np.random.default_rng(100 * f + ld_pad)
+    n = 40000
+    src = np.concatenate([rng.integers(0, n, 400000), np.full(3000, 7), np.arange(n - 5)])
+    dst = np.concatenate([rng.integers(0, n, 400000), rng.integers(0, n, 3000), np.arange(5, n)])
+    keep = src != 11  # row 11 stays empty
+    src, dst = src[keep], dst[keep]
+    val = rng.random(src.shape[0]).astype(np.float32) + 0.5
+    store = rng.standard_normal((n, f + ld_pad)).astype(np.float32)
+    for use_val in (False, True):
+        g = ops.CsrGraph.from_coo(src, dst, n, val if use_val else None, ops.COO_BINARISE if not use_val else 0)
+        assert g.unit_values == (not use_val)
+        rowptr, col, v = oracle.coo_to_csr(src, dst, n, val if use_val else None, oracle.BINARISE if not use_val else 0)
+        xt = torch.from_numpy(store).cuda()
+        x_np = store[:, :f]
+        if dtype == "bf16":
+            xt = xt.to(torch.bfloat16)
+            x_np = _np(xt.float())[:, :f]
+        xt = xt[:, :f]
+        rs = torch.from_numpy(rng.random(n).astype(np.float32) + 0.5).cuda()
+        cs = torch.from_numpy(rng.random(n).astype(np.float32) + 0.5).cuda() if scaled else None
+        want_bytes = 16 if (f <= 4 or (dtype == "bf16" and not scaled)) else 32
+        assert int(lib.wdg_spmm_narrow_col_bytes(f, int(dtype == "bf16"), int(scaled))) == want_bytes
+        y = ops.spmm(g, xt, row_scale=rs, col_scale=cs)
+        assert g.narrow_ws is not None
+        vv = v * (_np(cs)[col] if scaled else 1.0)
+        want = oracle.spmm_csr(rowptr, col, vv.astype(np.float32), np.ascontiguousarray(x_np)) * _np(rs)[:, None]
+        np.testing.assert_allclose(_np(y), want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+        assert torch.equal(y, ops.spmm(g, xt, row_scale=rs, col_scale=cs))
+        assert float(y[11].abs().max()) == 0.0

@@ -405,3 +405,44 @@ def test_step_scalars_kernel_equals_the_torch_formulas():
     assert got.shape == want.shape == (len(jobs), 6) and np.isfinite(got).all()
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
     assert torch.equal(sb.results(), sb.results())
+
+
+def test_step_scalars_kernel_edge_cases():
+    """wdg_sweep_scalars_f32 called on hand-made counters: a class without edges (its NaN term is skipped), a job whose rows are all
+    empty beyond the first few, two classes; against the torch formulas on the same counters"""
+    from wdg_amd import ops
+    from wdg_amd._lib import lib
+    j, c, n = 3, 4, 50
+    rng = np.random.default_rng(2)
+    compat = rng.integers(1, 50, (j, c, c)).astype(np.int64)
+    compat[1, 2, :] = 0  # class 2 of job 1 has no edges: rowsum 0 -> NaN -> skipped
+    classdeg = compat.sum(2)
+    rows = np.zeros((j, 3, n), np.int32)
+    nnz = rng.integers(0, 9, (j, n)).astype(np.int32)
+    nnz[2, 5:] = 0
+    noself = np.maximum(nnz - 1, 0)
+    match = (noself * rng.random((j, n))).astype(np.int32)
+    rows[:, 0], rows[:, 1], rows[:, 2] = nnz, noself, match
+    totals = rng.integers(10, 1000, (j, 6)).astype(np.int64)
+    las = rng.integers(0, n, (j, 2)).astype(np.int64)
+    las_n = np.full(j, n, np.float32)
+    prop = rng.random((j, c)).astype(np.float32)
+    prop /= prop.sum(1, keepdims=True)
+    dev = [torch.from_numpy(a).cuda() for a in (totals, rows, compat, classdeg, las, las_n, prop)]
+    out = torch.empty((j, 6), dtype=torch.float32, device="cuda")
+    ops.check(lib.wdg_sweep_scalars_f32(*[t.data_ptr() for t in dev], j, n, c, out.data_ptr(), ops.stream_handle()), "wdg_sweep_scalars_f32")
+    tot, k = totals.astype(np.float32), compat.astype(np.float32)
+    edge = tot[:, 5] / tot[:, 4]
+    f = lambda a: a.astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        hs = (f(match) + (f(nnz) - f(noself))) / f(nnz)
+        node = np.where(nnz != 0, hs, 0).sum(1) / (nnz != 0).sum(1)
+        terms = np.maximum(np.diagonal(k / k.sum(2, keepdims=True), axis1=1, axis2=2) - prop, 0)
+    cls = np.where(np.isnan(terms), 0, terms).sum(1) / (c - 1)
+    degsum = f(classdeg.sum(1, keepdims=True))
+    pb, pc = f(classdeg) / degsum, k / degsum[:, :, None]
+    pb, pc = np.where(pb == 0, 1e-8, pb), np.where(pc == 0, 1e-8, pc)
+    s2 = (pb ** 2).sum(1)
+    want = np.stack([edge, node, cls, (edge - s2) / (1 - s2), 2 - (pc * np.log(pc)).sum((1, 2)) / (pb * np.log(pb)).sum(1), f(las[:, 0]) / las_n], 1)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=5e-6, atol=2e-6)
+    assert np.isfinite(out.cpu().numpy()).all()
