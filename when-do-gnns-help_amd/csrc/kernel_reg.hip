@@ -615,8 +615,8 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
 //            half) and 32 ascending columns inside a ~200-column window - instead of 32 different rows per instruction.  Only
 //            block columns 0, 1 and diagonal block 0 are fetched up front; the others are ADDED to the collected updates while
 //            the diagonal block two steps before them is being factored (the Gram is 16 MB: these reads come from beyond the L2).
-//   step kb  the column's blocks go to LDS (row-major); (1) two waves work on the diagonal block - the leader factors it column by
-//            column (k2_factor), the follower turns the columns into M = L_kk^-1 as they appear (k2_invert) - while the other
+//   step kb  the column's blocks go to LDS (row-major); (1) ONE wave factors the diagonal block and inverts it in the same pass
+//            (k2_factor_invert: the lower lane half holds the block's rows, the upper half the identity's) - while the other
 //            waves run the deferred gathers; (2) the column's blocks: X = A M^T on the matrix pipe, and z_kb = M y_kb; (3) every
 //            wave updates its active blocks with 16 MFMAs each, the panel's waves subtract L_a z_kb from the right-hand sides.
 //            (History: the first version unrolled the in-wave routines per register slot, 200 KB of straight-line code that ran at
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             __builtin_amdgcn_sched_barrier(0);
         };
         // Only what the first step needs is gathered up front: block columns 0 and 1 and diagonal block 0.  Every other block starts
-        // at zero, collects its updates, and has its K entries ADDED while the leader and the follower work on the diagonal block
+        // at zero, collects its updates, and has its K entries ADDED while the factoring wave works on the diagonal block
         // two steps (the diagonal blocks: one step) before it turns into a panel block - the gather of 55 blocks per regression
         // comes from beyond the L2 (a 16-MB Gram per graph and kernel) and was a sixth of the kernel's time in front of step 0.
 #pragma unroll
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
             K2_T(3);
             if (deficient && attempt == 0) break;  // (uniform) restart on K + ridge I
             // (2) the column's other blocks: X L_kk^T = A  <=>  X = A M^T, 16 MFMAs per block (lane (i, h): row i of A from P, row i
-            //     of M from LD, the k index dealt like the accumulator's columns - the layout of the trailing update); the leader's
+            //     of M from LD, the k index dealt like the accumulator's columns - the layout of the trailing update); the factoring
             //     wave meanwhile: z_kb = M y_kb
             if (role > 0) {
                 f32x16 t;
