@@ -98,6 +98,32 @@ def test_coo_to_csr_long_and_skewed_rows(ops, oracle):
         _assert_csr_equal(g, oracle.coo_to_csr(src, dst, n, None, flags))
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 258, 1023])
+def test_coo_to_csr_every_row_class_side_by_side(ops, oracle, n):
+    """the row sort's classes (csrc/graph_build.hip): four rows of <= 16 entries share a wave, a wave per row up to 64, a 256-thread
+    workgroup up to 2048, the 1024-thread one beyond - row lengths here walk through all of them in every alignment against the
+    groups of four, with node counts that are not multiples of four, duplicates (summed) and empty rows."""
+    rng = np.random.default_rng(n)
+    lengths = rng.choice([0, 1, 2, 3, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 130, 513, 2047, 2048, 2049, 3000], n)
+    lengths[rng.integers(0, n)] = 16
+    src = np.repeat(np.arange(n), lengths)
+    dst = rng.integers(0, max(n, 4000), src.shape[0])
+    n_nodes = max(n, 4000)
+    perm = rng.permutation(src.shape[0])
+    src, dst = src[perm], dst[perm]
+    val = rng.integers(1, 4, src.shape[0]).astype(np.float32)
+    for flags in (0, 1, 1 | 2 | 4):
+        g = ops.CsrGraph.from_coo(src, dst, n_nodes, val, flags)
+        _assert_csr_equal(g, oracle.coo_to_csr(src, dst, n_nodes, val, flags))
+    # short rows only, the last group of four incomplete
+    m = 4 * 50 + (n % 4)
+    lengths = rng.integers(0, 17, m)
+    src = np.repeat(np.arange(m), lengths)
+    dst = rng.integers(0, m, src.shape[0])
+    g = ops.CsrGraph.from_coo(src, dst, m, None, 0)
+    _assert_csr_equal(g, oracle.coo_to_csr(src, dst, m, None, 0))
+
+
 def test_coo_to_csr_rejects_bad_index(ops):
     with pytest.raises(IndexError):
         ops.CsrGraph.from_coo([0, 5], [1, 0], 4)

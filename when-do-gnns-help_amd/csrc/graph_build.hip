@@ -176,21 +176,13 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
     return (static_cast<u64>(hi) << 32) | lo;
 }
 
-// rows of <= 64 entries: one wave, bitonic network across lanes; longer rows are queued for the block kernel
-__global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict__ rowstart, int32_t N,
-                                                      u64 *__restrict__ bucket, int32_t *__restrict__ long_rows,
-                                                      int32_t *__restrict__ long_count) {
-    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (row >= N) return;
-    const int s = rowstart[row], len = rowstart[row + 1] - s;
-    if (len <= 1) return;
-    if (len > 64) {
-        if (lane == 0) long_rows[atomicAdd(long_count, 1)] = row;
-        return;
-    }
-    u64 k = (lane < len) ? bucket[s + lane] : kInf;
-    for (int size = 2; size <= 64; size <<= 1) {
+// rows of <= 64 entries: bitonic network across lanes, no wider than the row needs (a row of 9..16 entries takes 10 of the 21
+// compare-exchange steps of a 64-wide network); longer rows are queued for the workgroup kernels.  A wave takes four consecutive
+// rows: when none of them has more than 16 entries they are sorted side by side, a row per 16 lanes (the exchanges of a network
+// that narrow never leave the 16), otherwise one after the other on the whole wave.
+// (`lane`: the lane's index inside its network, `width` <= the lanes of one network; entries past a row's end hold +inf)
+__device__ __forceinline__ u64 bitonic_lanes(u64 k, int lane, int width) {
+    for (int size = 2; size <= width; size <<= 1) {
         for (int j = size >> 1; j > 0; j >>= 1) {
             const u64 o = shfl_xor_u64(k, j);
             const bool up = ((lane & size) == 0);
@@ -199,7 +191,59 @@ __global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict_
             k = (lower == up) ? mn : mx;
         }
     }
-    if (lane < len) bucket[s + lane] = k;
+    return k;
+}
+
+__device__ __forceinline__ int pow2_at_least(int len) {
+    int p = 2;
+    while (p < len) p <<= 1;
+    return p;
+}
+
+constexpr int WAVE_SORT_ROWS = 4;    // rows a wave looks at together
+constexpr int WG_SORT_ROWS = 256;    // rows of a workgroup: its long rows reach the queue with ONE atomic on the shared counter
+                                     // (one per long row - 80 000 on a twitch-sized graph, all on one address - took 1.8 ms)
+
+__global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict__ rowstart, int32_t N,
+                                                      u64 *__restrict__ bucket, int32_t *__restrict__ long_rows,
+                                                      int32_t *__restrict__ long_count) {
+    __shared__ int32_t queued[WG_SORT_ROWS];
+    __shared__ int32_t n_queued, queue_base;
+    if (threadIdx.x == 0) n_queued = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, l = lane & 15;
+    const int wg_first = blockIdx.x * WG_SORT_ROWS;
+    for (int r0 = wg_first + wave * WAVE_SORT_ROWS; r0 < min(wg_first + WG_SORT_ROWS, N); r0 += 4 * WAVE_SORT_ROWS) {
+        const int mine = min(r0 + g, N - 1);  // (a row past the end reads the last row's bounds and is given length 0)
+        const int s_q = rowstart[mine];
+        const int len_q = (r0 + g < N) ? rowstart[mine + 1] - s_q : 0;
+        int longest = len_q;
+        longest = max(longest, __shfl_xor(longest, 16));
+        longest = max(longest, __shfl_xor(longest, 32));
+        if (longest <= 1) continue;
+        if (longest <= 16) {
+            u64 k = (l < len_q) ? bucket[s_q + l] : kInf;
+            k = bitonic_lanes(k, l, pow2_at_least(longest));  // (directions from the lane's place in its 16: every group ascending)
+            if (l < len_q) bucket[s_q + l] = k;
+            continue;
+        }
+        for (int q = 0; q < WAVE_SORT_ROWS; ++q) {
+            const int s = __shfl(s_q, q * 16), len = __shfl(len_q, q * 16);
+            if (len <= 1) continue;
+            if (len > 64) {
+                if (lane == 0) queued[atomicAdd(&n_queued, 1)] = r0 + q;
+                continue;
+            }
+            u64 k = (lane < len) ? bucket[s + lane] : kInf;
+            k = bitonic_lanes(k, lane, pow2_at_least(len));
+            if (lane < len) bucket[s + lane] = k;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && n_queued) queue_base = atomicAdd(long_count, n_queued);
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < n_queued) long_rows[queue_base + threadIdx.x] = queued[threadIdx.x];
 }
 
 // longer rows: one workgroup per row, comparator network with all comparators ascending and virtual +inf
@@ -207,12 +251,12 @@ __global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict_
 constexpr int LONG_THREADS = 1024;
 constexpr int LONG_LDS_KEYS = 16384;  // 128 KiB
 
-template <typename Get, typename Put>
+template <int THREADS = LONG_THREADS, typename Get, typename Put>
 __device__ __forceinline__ void network_sort(int len, Get get, Put put) {
     int P = 1;
     while (P < len) P <<= 1;
     for (int k = 2; k <= P; k <<= 1) {
-        for (int i = threadIdx.x; i < len; i += LONG_THREADS) {  // mirror stage
+        for (int i = threadIdx.x; i < len; i += THREADS) {  // mirror stage
             const int l = i ^ (k - 1);
             if (l > i && l < len) {
                 const u64 a = get(i), b = get(l);
@@ -221,7 +265,7 @@ __device__ __forceinline__ void network_sort(int len, Get get, Put put) {
         }
         __syncthreads();
         for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < len; i += LONG_THREADS) {
+            for (int i = threadIdx.x; i < len; i += THREADS) {
                 const int l = i ^ j;
                 if (l > i && l < len) {
                     const u64 a = get(i), b = get(l);
@@ -230,6 +274,28 @@ __device__ __forceinline__ void network_sort(int len, Get get, Put put) {
             }
             __syncthreads();
         }
+    }
+}
+
+// rows of 65 .. 2048 entries: a 256-thread workgroup per row, keys in 16 KB of LDS (a twitch-sized graph has ~80 000 such rows:
+// at one row per 1024-thread workgroup and 256 workgroups the big kernel below took 3.5 ms for them - a barrier of sixteen waves
+// per comparator stage and a quarter of the chip's lanes idle; four waves per barrier and every row its own workgroup here)
+constexpr int MID_THREADS = 256, MID_KEYS = 2048;
+
+__global__ __launch_bounds__(MID_THREADS) void sort_rows_mid(const int32_t *__restrict__ rowstart, u64 *__restrict__ bucket,
+                                                             const int32_t *__restrict__ long_rows, const int32_t *__restrict__ long_count) {
+    __shared__ u64 mkeys[MID_KEYS];
+    const int n_long = *long_count;
+    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const int row = long_rows[li];
+        const int s = rowstart[row], len = rowstart[row + 1] - s;
+        if (len > MID_KEYS) continue;  // (workgroup-uniform: sort_rows_block takes it)
+        u64 *g = bucket + s;
+        for (int i = threadIdx.x; i < len; i += MID_THREADS) mkeys[i] = g[i];
+        __syncthreads();
+        network_sort<MID_THREADS>(len, [&](int i) { return mkeys[i]; }, [&](int i, u64 v) { mkeys[i] = v; });
+        for (int i = threadIdx.x; i < len; i += MID_THREADS) g[i] = mkeys[i];
+        __syncthreads();
     }
 }
 
@@ -242,6 +308,7 @@ __global__ __launch_bounds__(LONG_THREADS) void sort_rows_block(const int32_t *_
     for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
         const int row = long_rows[li];
         const int s = rowstart[row], len = rowstart[row + 1] - s;
+        if (len <= MID_KEYS) continue;  // (workgroup-uniform: sort_rows_mid took it)
         u64 *g = bucket + s;
         if (len <= LONG_LDS_KEYS) {
             for (int i = threadIdx.x; i < len; i += LONG_THREADS) keys[i] = g[i];
@@ -487,6 +554,7 @@ __global__ __launch_bounds__(256) void row_l1_kernel(const float *__restrict__ X
 }
 
 inline unsigned wave_rows_grid(int32_t N) { return static_cast<unsigned>(ceil_div(static_cast<int64_t>(N) * 64, 256)); }
+inline unsigned wave_sort_grid(int32_t N) { return static_cast<unsigned>(ceil_div(N, WG_SORT_ROWS)); }
 
 // Bit-packed binary features -> dense fp32 rows (graph_io.py containers): one workgroup per row; bit j of word w is
 // feature 32 w + j.  With `normalise` the row is scaled by 1 / (number of set bits) - preprocess_features' row-L1
@@ -560,7 +628,7 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
         hipLaunchKernelGGL(coo_scatter, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst,
                            static_cast<long long>(E), cap, flags, N, ws.rowstart, ws.cursor, ws.bucket);
         if (N > 0) {
-            hipLaunchKernelGGL(sort_rows_wave, dim3(wave_rows_grid(N)), dim3(256), 0, st, ws.rowstart, N, ws.bucket,
+            hipLaunchKernelGGL(sort_rows_wave, dim3(wave_sort_grid(N)), dim3(256), 0, st, ws.rowstart, N, ws.bucket,
                                ws.long_rows, ws.long_count);
             static thread_local int configured_dev = -1;
             if (configured_dev != current_device()) {
@@ -570,6 +638,8 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
                     return fail(WDG_ERR_LAUNCH, "coo_to_csr: cannot raise dynamic LDS limit");
                 configured_dev = current_device();
             }
+            hipLaunchKernelGGL(sort_rows_mid, dim3(static_cast<unsigned>(std::min<long long>(std::max<long long>(ceil_div(N, 8), 256), 16384))),
+                               dim3(MID_THREADS), 0, st, ws.rowstart, ws.bucket, ws.long_rows, ws.long_count);
             hipLaunchKernelGGL(sort_rows_block, dim3(256), dim3(LONG_THREADS), LONG_LDS_KEYS * sizeof(u64), st,
                                ws.rowstart, ws.bucket, ws.long_rows, ws.long_count);
         }

@@ -261,78 +261,150 @@ __global__ __launch_bounds__(B_THREADS) void spmm_band_kernel(const wdg_spmm_job
 }
 
 // ---- plan: rows by length (longest first), the hub count, the cost cuts --------------------------------------------------
-__global__ __launch_bounds__(256) void band_hist(const int32_t *__restrict__ rowptr, int32_t N, int32_t *__restrict__ hist) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < N) atomicAdd(&hist[B_BUCKETS - 1 - min(rowptr[i + 1] - rowptr[i], B_BUCKETS - 1)], 1);  // bucket 0 = the longest
-}
-__global__ __launch_bounds__(256) void band_scatter(const int32_t *__restrict__ rowptr, int32_t N, int32_t *__restrict__ cursor,
-                                                    int32_t *__restrict__ perm) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < N) perm[atomicAdd(&cursor[B_BUCKETS - 1 - min(rowptr[i + 1] - rowptr[i], B_BUCKETS - 1)], 1)] = i;
-}
-// one workgroup: n_hub = rows longer than B_HUB_LEN (a prefix of perm), and for both row classes the positions where the
-// accumulated cost (entries + B_ROW_COST per row) passes m / 8 of the class total, m = 0..8
-__global__ __launch_bounds__(1024) void band_cuts_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
-                                                         int32_t N, int32_t hub_len, int32_t *__restrict__ cuts, int32_t *__restrict__ n_hub_out) {
-    __shared__ long long sums[1024];
-    __shared__ long long total_s;
-    __shared__ int hub_s;
-    const int t = threadIdx.x;
-    __shared__ int class_s[2];
-    if (t == 0) hub_s = class_s[0] = class_s[1] = 0;
-    if (t < 24) cuts[t] = 0;
+// (a workgroup counts its rows in LDS first and touches the shared histogram / cursors once per length it met: most rows of a
+// real graph share a few dozen lengths, and one global atomic per row on those few addresses was 0.3 ms per pass at 168 000 rows)
+constexpr int B_SORT_THREADS = 1024, B_SORT_ROWS = 2;  // rows per thread
+
+__global__ __launch_bounds__(B_SORT_THREADS) void band_hist(const int32_t *__restrict__ rowptr, int32_t N, int32_t *__restrict__ hist) {
+    __shared__ int32_t local[B_BUCKETS];
+    for (int b = threadIdx.x; b < B_BUCKETS; b += B_SORT_THREADS) local[b] = 0;
     __syncthreads();
-    int local = 0, wg_rows = 0, wave_rows = 0;
-    for (int i = t; i < N; i += 1024) {
+    const int first = blockIdx.x * (B_SORT_THREADS * B_SORT_ROWS) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < B_SORT_ROWS; ++u) {
+        const int i = first + u * B_SORT_THREADS;
+        if (i < N) atomicAdd(&local[B_BUCKETS - 1 - min(rowptr[i + 1] - rowptr[i], B_BUCKETS - 1)], 1);  // bucket 0 = the longest
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B_BUCKETS; b += B_SORT_THREADS)
+        if (local[b]) atomicAdd(&hist[b], local[b]);
+}
+__global__ __launch_bounds__(B_SORT_THREADS) void band_scatter(const int32_t *__restrict__ rowptr, int32_t N, int32_t *__restrict__ cursor,
+                                                               int32_t *__restrict__ perm) {
+    __shared__ int32_t local[B_BUCKETS];
+    for (int b = threadIdx.x; b < B_BUCKETS; b += B_SORT_THREADS) local[b] = 0;
+    __syncthreads();
+    const int first = blockIdx.x * (B_SORT_THREADS * B_SORT_ROWS) + threadIdx.x;
+    int bucket[B_SORT_ROWS], place[B_SORT_ROWS];
+#pragma unroll
+    for (int u = 0; u < B_SORT_ROWS; ++u) {
+        const int i = first + u * B_SORT_THREADS;
+        bucket[u] = i < N ? B_BUCKETS - 1 - min(rowptr[i + 1] - rowptr[i], B_BUCKETS - 1) : -1;
+        place[u] = i < N ? atomicAdd(&local[bucket[u]], 1) : 0;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B_BUCKETS; b += B_SORT_THREADS)
+        if (local[b]) local[b] = atomicAdd(&cursor[b], local[b]);  // count -> the workgroup's first place in the bucket
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < B_SORT_ROWS; ++u)
+        if (bucket[u] >= 0) perm[local[bucket[u]] + place[u]] = first + u * B_SORT_THREADS;
+}
+// n_hub = rows longer than hub_len (a prefix of perm), and for both row classes the positions where the accumulated cost
+// (entries + B_ROW_COST per row) passes m / 8 of the class total, m = 0..8.  Three small launches: every workgroup sums the cost of
+// its stretch of the order, one workgroup turns the sums into starting values and targets, every workgroup walks its stretch
+// again and marks the places where a target is passed.  (One 1024-thread workgroup doing all of it spent 0.45 ms at 168 000 rows:
+// each row length is two dependent gathers, 64 cache lines per wave instruction, and one CU's address path takes a line a cycle.)
+constexpr int CUT_THREADS = 256, CUT_MAX_WGS = 256;
+struct CutPartial { long long cost[2]; int hub, wg_rows, wave_rows, pad; };   // [0] hub rows, [1] the others
+struct CutTargets { long long start[CUT_MAX_WGS][2]; long long want[2][8]; int n_hub, pad; };
+
+__device__ __forceinline__ int cut_stretch(int32_t N, int n_wgs) { return ((N + n_wgs - 1) / n_wgs + CUT_THREADS - 1) / CUT_THREADS * CUT_THREADS; }
+
+__global__ __launch_bounds__(CUT_THREADS) void band_cost_partials(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
+                                                                  int32_t N, int32_t hub_len, CutPartial *__restrict__ partials) {
+    __shared__ long long cost_s[2];
+    __shared__ int count_s[3];
+    const int t = threadIdx.x;
+    if (t < 2) cost_s[t] = 0;
+    if (t < 3) count_s[t] = 0;
+    __syncthreads();
+    const int stretch = cut_stretch(N, gridDim.x), first = blockIdx.x * stretch, last = min(N, first + stretch);
+    long long cost[2] = {0, 0};
+    int hub = 0, wg_rows = 0, wave_rows = 0;
+    for (int i = first + t; i < last; i += CUT_THREADS) {
         const int row = perm[i];
         const int len = rowptr[row + 1] - rowptr[row];
-        local += len > hub_len;
+        hub += len > hub_len;
         wg_rows += len > 2048;  // the narrow kernel's row classes (csrc/spmm_narrow.hip): a workgroup per row,
         wave_rows += len > 128; // a wave per row, 16 lanes per row
+        cost[len > hub_len ? 0 : 1] += len + B_ROW_COST;
     }
-    atomicAdd(&hub_s, local);
-    atomicAdd(&class_s[0], wg_rows);
-    atomicAdd(&class_s[1], wave_rows);
+    for (int c = 0; c < 2; ++c)
+        if (cost[c]) atomicAdd(reinterpret_cast<unsigned long long *>(&cost_s[c]), static_cast<unsigned long long>(cost[c]));
+    if (hub) atomicAdd(&count_s[0], hub);
+    if (wg_rows) atomicAdd(&count_s[1], wg_rows);
+    if (wave_rows) atomicAdd(&count_s[2], wave_rows);
     __syncthreads();
-    if (t == 0) cuts[18] = class_s[0], cuts[19] = class_s[1];
-    const int R = hub_s;
-    if (t == 0) *n_hub_out = R;
-    for (int cls = 0; cls < 2; ++cls) {
-        const int first = cls ? R : 0, count = cls ? N - R : R;
-        const int per = (count + 1023) / 1024;
-        const int a = min(count, t * per), b = min(count, a + per);
+    if (t == 0) partials[blockIdx.x] = CutPartial{{cost_s[0], cost_s[1]}, count_s[0], count_s[1], count_s[2], 0};
+}
+
+__global__ __launch_bounds__(CUT_MAX_WGS) void band_cut_targets(const CutPartial *__restrict__ partials, int n_wgs, int32_t N,
+                                                                CutTargets *__restrict__ targets, int32_t *__restrict__ cuts,
+                                                                int32_t *__restrict__ n_hub_out) {
+    __shared__ CutPartial part[CUT_MAX_WGS];
+    __shared__ long long start_s[CUT_MAX_WGS][2];
+    const int t = threadIdx.x;
+    if (t < n_wgs) part[t] = partials[t];
+    __syncthreads();
+    long long run[2] = {0, 0};
+    int hub = 0, wg_rows = 0, wave_rows = 0;
+    if (t == 0) {  // (a few hundred additions from LDS once per graph)
+        for (int w = 0; w < n_wgs; ++w) {
+            start_s[w][0] = run[0], start_s[w][1] = run[1];
+            run[0] += part[w].cost[0], run[1] += part[w].cost[1];
+            hub += part[w].hub, wg_rows += part[w].wg_rows, wave_rows += part[w].wave_rows;
+        }
+    }
+    __syncthreads();
+    if (t < n_wgs) targets->start[t][0] = start_s[t][0], targets->start[t][1] = start_s[t][1];
+    if (t != 0) return;
+    for (int c = 0; c < 2; ++c)
+        for (int m = 0; m < 8; ++m) targets->want[c][m] = (run[c] * m + 7) / 8;
+    targets->n_hub = hub;
+    for (int k = 0; k < 24; ++k) cuts[k] = 0;
+    cuts[8] = hub, cuts[17] = N - hub, cuts[18] = wg_rows, cuts[19] = wave_rows;
+    *n_hub_out = hub;
+}
+
+__global__ __launch_bounds__(CUT_THREADS) void band_cut_find(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
+                                                             int32_t N, int32_t hub_len, const CutTargets *__restrict__ targets,
+                                                             int32_t *__restrict__ cuts) {
+    __shared__ long long scan[2][CUT_THREADS];
+    __shared__ long long carry[2];
+    const int t = threadIdx.x;
+    if (t < 2) carry[t] = targets->start[blockIdx.x][t];
+    const int R = targets->n_hub;
+    const int stretch = cut_stretch(N, gridDim.x), first = blockIdx.x * stretch, last = min(N, first + stretch);
+    for (int i0 = first; i0 < last; i0 += CUT_THREADS) {  // (workgroup-uniform bounds)
+        const int i = i0 + t;
+        int cls = 1;
         long long mine = 0;
-        for (int i = a; i < b; ++i) {
-            const int row = perm[first + i];
-            mine += rowptr[row + 1] - rowptr[row] + B_ROW_COST;
+        if (i < last) {
+            const int row = perm[i];
+            const int len = rowptr[row + 1] - rowptr[row];
+            cls = len > hub_len ? 0 : 1;
+            mine = len + B_ROW_COST;
         }
+        __syncthreads();  // (carry of the previous tile / of the start is in place, the previous tile's reads of scan are over)
+        scan[0][t] = cls == 0 ? mine : 0, scan[1][t] = cls == 1 ? mine : 0;
         __syncthreads();
-        sums[t] = mine;
-        __syncthreads();
-        if (t == 0) {  // (1024 additions once per graph)
-            long long run = 0;
-            for (int k = 0; k < 1024; ++k) {
-                const long long v = sums[k];
-                sums[k] = run;
-                run += v;
-            }
-            cuts[cls * 9 + 8] = count;
-            cuts[cls * 9] = 0;
+        for (int d = 1; d < CUT_THREADS; d <<= 1) {  // inclusive prefix sums of both classes
+            const long long a0 = t >= d ? scan[0][t - d] : 0, a1 = t >= d ? scan[1][t - d] : 0;
+            __syncthreads();
+            scan[0][t] += a0, scan[1][t] += a1;
+            __syncthreads();
         }
-        __syncthreads();
-        if (t == 1023) total_s = sums[1023] + mine;
-        __syncthreads();
-        long long run = sums[t];
-        for (int i = a; i < b; ++i) {
-            const int row = perm[first + i];
-            const long long next = run + rowptr[row + 1] - rowptr[row] + B_ROW_COST;
+        if (i < last) {
+            const long long next = carry[cls] + scan[cls][t], run = next - mine;
+            const int place = i - (cls ? R : 0);
             for (int m = 1; m < 8; ++m) {
-                const long long want = (total_s * m + 7) / 8;
-                if (run < want && next >= want) cuts[cls * 9 + m] = i + 1;
+                const long long want = targets->want[cls][m];
+                if (run < want && next >= want) cuts[cls * 9 + m] = place + 1;
             }
-            run = next;
         }
         __syncthreads();
+        if (t < 2) carry[t] += scan[t][CUT_THREADS - 1];
     }
 }
 
@@ -414,13 +486,20 @@ int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int3
         if (int e = wdg::sort_rows_by_length_small(rowptr, N, band_perm, st)) return e;
     } else {  // bucket sort by length (rows of equal length in no particular order: the order only schedules)
         if (hipMemsetAsync(hist, 0, B_BUCKETS * sizeof(int32_t), st) != hipSuccess) return wdg::fail(WDG_ERR_LAUNCH, "csr_band_plan: memset failed");
-        hipLaunchKernelGGL(band_hist, dim3(wdg::ceil_div(N, 256)), dim3(256), 0, st, rowptr, N, hist);
+        hipLaunchKernelGGL(band_hist, dim3(wdg::ceil_div(N, B_SORT_THREADS * B_SORT_ROWS)), dim3(B_SORT_THREADS), 0, st, rowptr, N, hist);
         if (int e = wdg::exclusive_scan_i32(hist, B_BUCKETS, cursor, nullptr, scan_ws, st)) return e;
-        hipLaunchKernelGGL(band_scatter, dim3(wdg::ceil_div(N, 256)), dim3(256), 0, st, rowptr, N, cursor, band_perm);
+        hipLaunchKernelGGL(band_scatter, dim3(wdg::ceil_div(N, B_SORT_THREADS * B_SORT_ROWS)), dim3(B_SORT_THREADS), 0, st, rowptr, N, cursor, band_perm);
     }
     int hub_len = B_HUB_LEN;
     if (const char *h = getenv("WDG_BAND_HUB")) hub_len = std::max(8, atoi(h));
-    hipLaunchKernelGGL(band_cuts_kernel, dim3(1), dim3(1024), 0, st, rowptr, band_perm, N, hub_len, band_cuts, n_hub_dev);
+    const int n_wgs = std::max(1, std::min(CUT_MAX_WGS, static_cast<int>(wdg::ceil_div(N, CUT_THREADS))));
+    CutPartial *partials = reinterpret_cast<CutPartial *>(hist);     // (the bucket sort is done with both arrays by now)
+    CutTargets *targets = reinterpret_cast<CutTargets *>(cursor);
+    static_assert(sizeof(CutPartial) * CUT_MAX_WGS <= sizeof(int32_t) * B_BUCKETS && sizeof(CutTargets) <= sizeof(int32_t) * B_BUCKETS,
+                  "the cut kernels borrow the histogram and cursor arrays");
+    hipLaunchKernelGGL(band_cost_partials, dim3(n_wgs), dim3(CUT_THREADS), 0, st, rowptr, band_perm, N, hub_len, partials);
+    hipLaunchKernelGGL(band_cut_targets, dim3(1), dim3(CUT_MAX_WGS), 0, st, partials, n_wgs, N, targets, band_cuts, n_hub_dev);
+    hipLaunchKernelGGL(band_cut_find, dim3(n_wgs), dim3(CUT_THREADS), 0, st, rowptr, band_perm, N, hub_len, targets, band_cuts);
     if (int e = wdg::check_launch("csr_band_plan")) return e;
     if (hipMemcpyAsync(n_hub_host, n_hub_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return wdg::fail(WDG_ERR_LAUNCH, "csr_band_plan: reading the hub count back failed");
