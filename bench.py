@@ -228,6 +228,7 @@ def measure_cold(args, dev):
         return jobs, inputs
 
     shards = [host_inputs(1000 + args.seeds * b) for b in range(n_shards + 1)]  # (the inputs: like files on disk)
+    extra_shards = [host_inputs(1000 + args.seeds * b) for b in range(n_shards + 1, max(n_shards, 6) + 1)]  # (pipelined run: >= 6 shards)
     out = {}
     for name, nine in (("six_scalars", False), ("nine_scalars", True)):
         phases = {"build_ms": [], "sample_ms": [], "device_ms": [], "host_tail_ms": [], "total_ms": []}
@@ -265,6 +266,16 @@ def measure_cold(args, dev):
         total_s = sum(phases["total_ms"]) * 1e-3
         out[name] = {"graphs_per_s": graphs / total_s, **{k: sum(v) / len(v) for k, v in phases.items()},
                      "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, rows.double().mean(0).tolist())}}
+        # the same shards PIPELINED (sweep.run_shards): shard b + 1's uploads and build on a second stream while shard b's kernels
+        # run; clock = first upload to the last shard's rows on the host
+        piped = shards[1:] + extra_shards
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        piped_rows = list(sweep.run_shards(piped, n_feat=args.feat, nine=nine, epochs=args.kr_epochs, sample_max=500, depth=2, first_seed=1))
+        dt = time.perf_counter() - t0
+        n_graphs = sum(len(j) for j, _ in piped)
+        out[name]["pipelined"] = {"graphs_per_s": n_graphs / dt, "ms_per_shard": dt * 1e3 / len(piped), "shards": len(piped), "streams": 2,
+                                  "rows_equal_sequential": bool(torch.equal(piped_rows[n_shards - 1].double(), rows.double()))}
     out["workload"] = (f"{n_shards} distinct shards of {len(shards[0][0])} graphs (k={args.k}, {args.seeds} seeds each, N={args.nodes}, "
                        f"F={args.feat}), each visited once: host COO -> batched build -> step -> metric rows on the host; nine_scalars adds "
                        f"Gram + maps, {args.kr_epochs} epochs of device-drawn node sets x 2 classifiers x 2 kernels = "

@@ -37,11 +37,19 @@ pr.enable()
 sb = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0, inputs=inputs)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+def show(pr, key, n):
+    st = pstats.Stats(pr)
+    rows = sorted(st.stats.items(), key=lambda kv: -kv[1][3 if key == "cumulative" else 2])[:n]
+    for (fn, line, name), (cc, nc, tt, ct, _) in rows:
+        print(f"{nc:6d} calls  own {tt * 1e6:9.0f} us  cumulative {ct * 1e6:9.0f} us  {os.path.basename(fn)}:{line} {name}")
+
+
+show(pr, "cumulative", 45)
 pr = cProfile.Profile()
 pr.enable()
 coos = [(i[0], i[1], 2000) for i in inputs]
 gb = ops.GraphBatch(coos, ops.COO_ADD_SELF_LOOPS, quad=True)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+print()
+show(pr, "tottime", 14)

@@ -348,6 +348,44 @@ def test_empty_shard_steps_and_gathers():
     assert sb.spmm_algorithmic_bytes() == 0 and sb.spmm_unique_bytes() == 0
 
 
+@pytest.mark.parametrize("nine", [False, True])
+def test_pipelined_shards_compute_the_sequential_rows(nine):
+    """sweep.run_shards: shard b + 1 is uploaded and built on a second HIP stream while shard b's kernels run - the rows of
+    every shard must be the rows of the one-shard-at-a-time loop bit for bit (six scalars) / with the same device-drawn node sets
+    (nine), in order, for uneven shards and an empty one"""
+    from wdg_amd import sweep, synth
+
+    def host_inputs(h_levels, seeds, n_nodes):
+        jobs = sweep.make_jobs(h_levels, seeds, k=10, n_nodes=n_nodes)
+        feats, inputs = {}, []
+        for j in jobs:
+            src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+            feats.setdefault(j.seed, synth.features(j.n_nodes, 100, j.seed))
+            inputs.append((src, dst, lab, feats[j.seed]))
+        return jobs, inputs
+
+    shards = [host_inputs([0.2, 0.5, 0.8], [3, 4], 600), host_inputs([0.3], [5], 1000), ([], []), host_inputs([0.4, 0.6], [6], 800),
+              host_inputs([0.2, 0.9], [7, 8], 600)]
+    kw = dict(n_feat=100, nine=nine, epochs=4, sample_max=200)
+    one = list(sweep.run_shards(shards, depth=1, **kw))
+    for depth in (2, 3):
+        piped = list(sweep.run_shards(shards, depth=depth, **kw))
+        assert len(piped) == len(one) == len(shards)
+        for a, b, (jobs, _) in zip(one, piped, shards):
+            assert tuple(a.shape) == tuple(b.shape) == (len(jobs), 9 if nine else sweep.STEP_METRICS)
+            np.testing.assert_array_equal(a.numpy(), b.numpy())
+    # and a shard's rows are those of its own SweepBatch
+    jobs, inputs = shards[0]
+    sb = sweep.SweepBatch(jobs, n_feat=100, gcn_hidden=0, inputs=inputs)
+    sb.step()
+    if nine:
+        sb.prepare_full(epochs=4, sample_max=200, base_seed=0)
+        sb.launch_full()
+        np.testing.assert_array_equal(sb.full_metrics().numpy(), one[0].numpy())
+    else:
+        np.testing.assert_array_equal(sb.results().cpu().numpy(), one[0].numpy())
+
+
 @pytest.mark.parametrize("k,seeds", [(2, 10), (10, 5)])
 def test_counters_derived_from_the_label_columns_equal_the_edge_pass(k, seeds, monkeypatch):
     """The C2 / C3 shards at full size: every integer counter of the step (totals, compatibility histogram, class degrees,

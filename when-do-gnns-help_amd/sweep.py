@@ -603,6 +603,43 @@ def welch_p_values(g_res, x_res):
     return np.where(better <= 0.5, p / 2, 1 - p / 2)
 
 
+def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symmetric=0, depth=2, first_seed=0):
+    """The one-pass sweep over a sequence of shards (synthetic_plot.py:78-109: every graph visited once), PIPELINED: a generator
+    of the shards' metric rows ([jobs, 6] fp32 / [jobs, 9] fp64 on the host), in order.
+
+    shards: an iterable of (jobs, inputs) as SweepBatch takes them (host COO arrays, labels, features).  Shard b runs on HIP
+    stream b mod `depth`: its uploads, the batched build (and that build's one read-back, which waits for ITS stream only), the
+    step and - nine=True - the Grams, the device-drawn node sets and the regressions are queued, then the host goes on to shard
+    b + 1 and fetches shard b's rows only when `depth` shards are in flight.  The host part of a shard (concatenation, uploads,
+    job tables: 8-11 ms per 50 graphs) thus overlaps the device part of the one before (15.6 ms with the regressions), where the
+    sequential loop of bench.py's `sweep_cold` pays their sum.  depth=1 is that sequential loop.  Every shard computes the same
+    bits either way (tests/test_gpu_sweep.py)."""
+    from collections import deque
+    depth = max(1, int(depth))
+    streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
+    in_flight = deque()
+
+    def fetch():
+        sb, stream = in_flight.popleft()
+        with torch.cuda.stream(stream):
+            return sb.full_metrics() if nine else sb.results().cpu()
+
+    for b, (jobs, inputs) in enumerate(shards):
+        stream = streams[b % depth]
+        with torch.cuda.stream(stream):
+            sb = SweepBatch(jobs, n_feat=n_feat, symmetric=symmetric, gcn_hidden=0, inputs=inputs)
+            if nine and sb.jobs:
+                sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + b)
+            sb.step()
+            if nine and sb.jobs:
+                sb.launch_full()
+        in_flight.append((sb, stream))
+        if len(in_flight) >= depth:
+            yield fetch()
+    while in_flight:
+        yield fetch()
+
+
 class BaseSweep:
     """The feature bases of the reference's sweep (synthetic_plot.py:64-65,78-82: the 300 synthetic adjacencies are paired
     with features sampled from each of six base datasets, 1 800 jobs): one SweepBatch per base over the SAME jobs, all of
