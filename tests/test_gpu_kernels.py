@@ -1042,14 +1042,17 @@ def test_gemm_b_resident_kernel_batched(ops, monkeypatch):
     assert torch.equal(odd.keep[0][2], torch.full((300, 3), 6.0, device="cuda"))
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
 @pytest.mark.parametrize("relu", [True, False])
-def test_mlp2_fused_transform(ops, oracle, relu):
+def test_mlp2_fused_transform(ops, oracle, relu, split, monkeypatch):
     """wdg_mlp2_batched_f32: Z = act(A W0 + b0) W1 + b1 in one pass over A, every job its own shapes (hidden width below /
     across the two column tiles, C = 1..8, K % 32 leftovers, ragged row tiles, padded lda, with / without biases)
     against the oracle's two GEMMs (fp64-accumulated yardstick: 1e-5 of the largest output) and against the unfused
     GPU path (two wdg_gemm calls: same first product bit for bit, second product in another summation order)."""
+    monkeypatch.setenv("WDG_MLP2_SPLIT", split)  # "1": the split-operand kernel on the bf16 matrix pipe (csrc/gemm.hip)
     rng = np.random.default_rng(5 + relu)
-    shapes = [(2000, 500, 64, 5), (700, 500, 64, 5), (33, 64, 32, 1), (1200, 260, 40, 8), (512, 32, 17, 3), (1, 4, 1, 1), (999, 508, 64, 7)]
+    shapes = [(2000, 500, 64, 5), (700, 500, 64, 5), (33, 64, 32, 1), (1200, 260, 40, 8), (512, 32, 17, 3), (1, 4, 1, 1), (999, 508, 64, 7),
+              (600, 256, 64, 5), (40, 288, 33, 2)]
     entries, refs, unfused = [], [], []
     for i, (m, k, h, c) in enumerate(shapes):
         store = torch.from_numpy(rng.standard_normal((m, k + 4 * (i % 2))).astype(np.float32)).cuda()
@@ -1085,6 +1088,34 @@ def test_mlp2_fused_transform(ops, oracle, relu):
     assert not ops.Mlp2Batch.eligible([big])
     with pytest.raises(ValueError):
         ops.Mlp2Batch([big])
+
+
+def test_mlp2_split_operands_are_as_accurate_as_the_fp32_chain(ops, monkeypatch):
+    """WDG_MLP2_SPLIT=1 forms every fp32 product from three bf16 pieces per operand on the bf16 matrix pipe (six piece products,
+    fp32 accumulation).  Its error against an fp64 evaluation must be that of the k-ordered fp32 chain - measured here on data
+    with eight decades of dynamic range inside every row, mixed signs, exact powers of two and values next to bf16 rounding
+    boundaries; hidden layer observed through an identity second layer (H = C = 8)."""
+    rng = np.random.default_rng(77)
+    m, k, h = 4096, 500, 8
+    a = (rng.standard_normal((m, k)) * 10.0 ** rng.uniform(-6, 2, (m, k))).astype(np.float32)
+    a[:, 0] = 2.0 ** rng.integers(-20, 20, m)
+    a[:, 1] = np.float32(1.0) + np.float32(2.0 ** -8) + np.float32(2.0 ** -16) * rng.integers(-3, 4, m).astype(np.float32)  # piece boundaries
+    w0 = (rng.standard_normal((k, h)) * 10.0 ** rng.uniform(-3, 1, (k, h))).astype(np.float32)
+    eye = np.eye(h, dtype=np.float32)
+    ref = a.astype(np.float64) @ w0.astype(np.float64)
+    mag = np.abs(a).astype(np.float64) @ np.abs(w0).astype(np.float64)   # the scale rounding errors of a dot product live on
+    errs = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("WDG_MLP2_SPLIT", split)
+        z = torch.full((m, h), float("nan"), device="cuda")
+        batch = ops.Mlp2Batch([(torch.from_numpy(a).cuda(), torch.from_numpy(w0).cuda(), None, torch.from_numpy(eye).cuda(), None, z)], relu=False)
+        batch.launch()
+        torch.cuda.synchronize()
+        errs[split] = np.abs(_np(z).astype(np.float64) - ref) / mag
+    worst = {s: float(e.max()) for s, e in errs.items()}
+    mean = {s: float(e.mean()) for s, e in errs.items()}
+    assert worst["0"] < 3e-6 and worst["1"] < 3e-6, worst            # a 500-term fp32 chain: well below 500 * 2^-24 = 3e-5
+    assert worst["1"] <= 2.0 * worst["0"] and mean["1"] <= 2.0 * mean["0"], (worst, mean)
 
 
 @pytest.mark.parametrize("seed", range(6))

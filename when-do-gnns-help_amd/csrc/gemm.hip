@@ -409,6 +409,216 @@ __global__ __launch_bounds__(BRES_THREADS) void mlp2_bres_kernel(const wdg_mlp2_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the same transform, split operands
+// fp32 products on the bf16 matrix pipe: x = x_h + x_m + x_l with every piece a bf16 (round to nearest of what the pieces before
+// it left: 8 + 8 + 8 significand bits - the sum is x itself, or x rounded in its 25th bit), likewise w; of the nine piece products
+// the six of weight >= 2^-16 are issued (x_l w_h, x_h w_l, x_m w_m, x_m w_h, x_h w_m, x_h w_h), each exact in the fp32
+// accumulator's input; what is dropped (x_m w_l + x_l w_m + x_l w_l) is below 2^-23 |x w|, the size of the rounding of one fp32
+// fma.  v_mfma_f32_32x32x16_bf16 runs 16 k in the 32 cycles the fp32 instruction takes for 1: six of them per 16 k against
+// sixteen of the other.  The k index of the MFMA is free as long as both operands agree: MFMA m of a 32-k group takes k =
+// 16 (lane / 32) + 8 m + j for element j - exactly the 8 floats the lane loaded as two float4, so the A side needs no lane
+// exchange at all.  W0's pieces sit in LDS as [piece][k / 8][column][8 bf16] (a lane's fragment is one ds_read_b128), 6 bytes per
+// weight, so W0 passes through two 48-KB buffers in quarters of 128 rows while every wave carries its tile's accumulators.
+// Opt-in (WDG_MLP2_SPLIT=1): results differ from the fp32 chain in the last bits (tests/test_gpu_kernels.py measures both against
+// fp64), the default stays the k-ordered fp32 chain above.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int SPLIT_KQ = 128, SPLIT_KB = SPLIT_KQ / 8;            // rows of W0 per LDS buffer, in blocks of 8: one (block, column) per thread
+constexpr int SPLIT_PIECE_WORDS = SPLIT_KB * BRES_COLS * 4;        // 32-bit words of one piece of a buffer (16 KB)
+constexpr int SPLIT_BUF_WORDS = 3 * SPLIT_PIECE_WORDS;             // a buffer: three pieces (48 KB); two buffers
+static_assert(SPLIT_KB * BRES_COLS == BRES_THREADS, "one (k block, column) pair of a buffer per thread");
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // (v_cvt_pk_bf16_f32: round to nearest even, a in the low half)
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// two floats -> their three bf16 pieces, packed pairwise
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    h = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = pack_bf16(s0, s1);
+}
+
+__device__ __forceinline__ bf16x8_t as_frag(const u32x4_t &v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+// the thread's eight rows (k0 + 8 (tid / 64) + 0..7, column tid % 64) of W0: requested / split and written to a buffer
+__device__ __forceinline__ void split_load_w(global_ptr<const float> W0, int64_t ldw0, int K, int H, int k0, float (&w)[8]) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // (opaque per call: the eight row addresses are computed here, not hoisted out of the loops and spilled)
+    const int col = tid % BRES_COLS, kb = tid / BRES_COLS;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // (unconditional loads from clamped addresses, zeroed afterwards: no branch per load)
+        const int k = k0 + 8 * kb + j;
+        const float v = W0[static_cast<int64_t>(min(k, K - 1)) * ldw0 + min(col, H - 1)];
+        w[j] = (k < K && col < H) ? v : 0.f;
+    }
+}
+__device__ __forceinline__ void split_write_w(const float (&w)[8], unsigned *buf) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair(w[2 * j], w[2 * j + 1], h[j], m[j], l[j]);
+    u32x4_t *dst = reinterpret_cast<u32x4_t *>(buf) + threadIdx.x;
+    dst[0] = u32x4_t{h[0], h[1], h[2], h[3]};
+    dst[SPLIT_PIECE_WORDS / 4] = u32x4_t{m[0], m[1], m[2], m[3]};
+    dst[2 * (SPLIT_PIECE_WORDS / 4)] = u32x4_t{l[0], l[1], l[2], l[3]};
+}
+
+// one MFMA's worth of k: the lane's 8 floats (k = 16 lk + 8 m + 0..7 of a 32-k group) against block `kb` (= 4 (group in the buffer)
+// + 2 lk + m) of a buffer.  A piece of W0 is read when its first product needs it and is dead after its last.
+struct SplitChunk { f32x4_t a, b; };
+template <int NT>
+__device__ __forceinline__ void split_compute(const SplitChunk &c, int kb, int li, const unsigned *Ws, f32x16 (&acc)[NT]) {
+    unsigned ph[4], pm[4], pl[4];
+    split_pair(c.a.x, c.a.y, ph[0], pm[0], pl[0]);
+    split_pair(c.a.z, c.a.w, ph[1], pm[1], pl[1]);
+    split_pair(c.b.x, c.b.y, ph[2], pm[2], pl[2]);
+    split_pair(c.b.z, c.b.w, ph[3], pm[3], pl[3]);
+    const u32x4_t xh{ph[0], ph[1], ph[2], ph[3]}, xm{pm[0], pm[1], pm[2], pm[3]}, xl{pl[0], pl[1], pl[2], pl[3]};
+    const u32x4_t *wrow = reinterpret_cast<const u32x4_t *>(Ws) + kb * BRES_COLS + li;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        // operands swapped as in mlp2_bres_kernel (W0^T is the MFMA's A): the accumulators hold the tile transposed
+        const u32x4_t wl = wrow[t * 32 + 2 * (SPLIT_PIECE_WORDS / 4)];
+        const u32x4_t wm = wrow[t * 32 + SPLIT_PIECE_WORDS / 4];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wl), as_frag(xh), acc[t], 0, 0, 0);
+        const u32x4_t wh = wrow[t * 32];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wm), as_frag(xm), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wm), as_frag(xh), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wh), as_frag(xl), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wh), as_frag(xm), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wh), as_frag(xh), acc[t], 0, 0, 0);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(BRES_THREADS) void mlp2_split_kernel(const wdg_mlp2_job *__restrict__ jobs, int n_parts) {
+    extern __shared__ float Bres[];  // two buffers of three pieces of 128 rows of W0, then W1 [64][8] and b0 [64]
+    const int job_id = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
+    const desc_ptr<wdg_mlp2_job> job = (desc_ptr<wdg_mlp2_job>)(jobs + job_id);
+    const global_ptr<const float> A = to_global(job->A), W0 = to_global(job->W0), b0 = to_global(job->b0);
+    const global_ptr<const float> W1 = to_global(job->W1), b1 = to_global(job->b1);
+    const global_ptr<float> Z = to_global(job->Z);
+    const int64_t lda = job->lda, ldw0 = job->ldw0, ldw1 = job->ldw1, ldz = job->ldz;
+    const int M = job->M, K = job->K, H = job->H, C = job->C, act = job->act;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    if (M <= 0 || H <= 0 || C <= 0) return;
+    unsigned *const Ws = reinterpret_cast<unsigned *>(Bres);
+    float *const w1s = Bres + 2 * SPLIT_BUF_WORDS;
+    float *const b0s = w1s + BRES_COLS * MLP2_MAX_C;
+    for (int idx = threadIdx.x; idx < BRES_COLS * MLP2_MAX_C; idx += BRES_THREADS) {
+        const int col = idx / MLP2_MAX_C, c = idx % MLP2_MAX_C;
+        w1s[idx] = (col < H && c < C) ? W1[static_cast<int64_t>(col) * ldw1 + c] : 0.f;
+    }
+    if (threadIdx.x < BRES_COLS) b0s[threadIdx.x] = (b0 && threadIdx.x < H) ? b0[threadIdx.x] : 0.f;
+
+    const int tiles = (M + 31) / 32, per_part = (tiles + n_parts - 1) / n_parts;
+    const int t_first = part * per_part, t_end = min((part + 1) * per_part, tiles);
+    const bool relu = act == WDG_ACT_RELU;
+    const int groups = (K + 31) / 32, quarters = (K + SPLIT_KQ - 1) / SPLIT_KQ;
+    for (int t0 = t_first; t0 < t_end; t0 += BRES_THREADS / 64) {  // (uniform: a round of up to sixteen tiles, one per wave)
+        const int tile = t0 + wave;
+        const bool have = tile < t_end;
+        const int gm = tile * 32 + li;
+        const global_ptr<const float> a_lane = A + static_cast<int64_t>(have && gm < M ? gm : M - 1) * lda + 16 * lk;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const int chunks = 2 * groups;
+        auto load_chunk = [&](int ci, SplitChunk &dst) {  // chunk ci = MFMA (ci & 1) of group ci / 2; float4s past K read as zero
+            ci = min(ci, chunks - 1);
+            const int k = (ci >> 1) * 32 + (ci & 1) * 8, ka = k + 16 * lk;
+            // (unconditional loads; in the last, partial group the addresses are pulled back inside the row and the values zeroed)
+            const f32x4_t va = *(const global_ptr<const f32x4_t>)(a_lane + min(k, K - 4 - 16 * lk));
+            const f32x4_t vb = *(const global_ptr<const f32x4_t>)(a_lane + min(k + 4, K - 4 - 16 * lk));
+            const f32x4_t zero{0.f, 0.f, 0.f, 0.f};
+            dst.a = ka < K ? va : zero;
+            dst.b = ka + 4 < K ? vb : zero;
+        };
+        SplitChunk c0, c1, c2, c3;  // a ring of four: three chunks (96 bytes per lane) in flight beside the one being multiplied -
+        float w[8];                 // one chunk's MFMAs last 0.6 us with four waves on a matrix pipe, a load takes two or three
+        load_chunk(0, c0);
+        load_chunk(1, c1);
+        load_chunk(2, c2);
+        split_load_w(W0, ldw0, K, H, 0, w);     // (the previous round's last barrier: nobody reads buffer 0 any more)
+        split_write_w(w, Ws);
+        __syncthreads();
+        // W0 passes through LDS in quarters of 128 rows, double-buffered: the rows of quarter q + 1 are requested before the MFMAs of
+        // quarter q and split + written after them, one barrier per quarter; the A chunks run ahead straight through
+        for (int q = 0; q < quarters; ++q) {
+            const unsigned *cur = Ws + (q & 1) * SPLIT_BUF_WORDS;
+            if (q + 1 < quarters) split_load_w(W0, ldw0, K, H, (q + 1) * SPLIT_KQ, w);
+            if (have) {
+#pragma unroll
+                for (int c = 0; c < 8; c += 4) {   // chunk 8 q + c + i: group (c + i) / 2 of the buffer, MFMA (c + i) & 1
+                    const int base = 8 * q + c;
+                    if (base >= chunks) break;
+                    load_chunk(base + 3, c3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_compute<NT>(c0, 2 * c + 2 * lk, li, cur, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_chunk(base + 4, c0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_compute<NT>(c1, 2 * c + 2 * lk + 1, li, cur, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_chunk(base + 5, c1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (base + 2 < chunks) split_compute<NT>(c2, 2 * c + 4 + 2 * lk, li, cur, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_chunk(base + 6, c2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (base + 2 < chunks) split_compute<NT>(c3, 2 * c + 4 + 2 * lk + 1, li, cur, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (q + 1 < quarters) split_write_w(w, Ws + ((q + 1) & 1) * SPLIT_BUF_WORDS);
+            __syncthreads();
+        }
+        if (!have) continue;
+
+        float z[MLP2_MAX_C];
+#pragma unroll
+        for (int c = 0; c < MLP2_MAX_C; ++c) z[c] = 0.f;
+        int lds_off = lk * 4;
+        asm volatile("" : "+v"(lds_off));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int col0 = t * 32 + r4 * 8 + lds_off;
+                const float4 bb = *reinterpret_cast<const float4 *>(b0s + col0);
+                float h[4] = {acc[t][4 * r4] + bb.x, acc[t][4 * r4 + 1] + bb.y, acc[t][4 * r4 + 2] + bb.z, acc[t][4 * r4 + 3] + bb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (relu) h[e] = fmaxf(h[e], 0.f);
+                    const float4 wa = *reinterpret_cast<const float4 *>(w1s + (col0 + e) * MLP2_MAX_C);
+                    const float4 wb = *reinterpret_cast<const float4 *>(w1s + (col0 + e) * MLP2_MAX_C + 4);
+                    z[0] = fmaf(h[e], wa.x, z[0]); z[1] = fmaf(h[e], wa.y, z[1]);
+                    z[2] = fmaf(h[e], wa.z, z[2]); z[3] = fmaf(h[e], wa.w, z[3]);
+                    z[4] = fmaf(h[e], wb.x, z[4]); z[5] = fmaf(h[e], wb.y, z[5]);
+                    z[6] = fmaf(h[e], wb.z, z[6]); z[7] = fmaf(h[e], wb.w, z[7]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MLP2_MAX_C; ++c) z[c] += __shfl_xor(z[c], 32);
+        if (lk == 0 && gm < M) {
+            const global_ptr<float> zp = Z + static_cast<int64_t>(gm) * ldz;
+#pragma unroll
+            for (int c = 0; c < MLP2_MAX_C; ++c)
+                if (c < C) zp[c] = z[c] + (b1 ? b1[c] : 0.f);
+        }
+    }
+}
+
 // Shapes the B-resident kernel takes (everything the host can see; the per-job operands of a table must be promised
 // aligned by the caller: 16-byte aligned A, lda % 4 == 0 - every row-major fp32 torch tensor with K % 4 == 0 is), and
 // where it pays: it has a floor of one full K loop per wave (about 70 us at K = 500), so the tile kernel keeps the
@@ -698,9 +908,24 @@ int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t m
         configured_dev = wdg::current_device();
     }
     const int parts = bres_parts(n_jobs, max_M);
-    const size_t lds = (static_cast<size_t>(wdg::ceil_div(max_K, 32) * 32) * BRES_COLS + BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);
     const dim3 grid(static_cast<unsigned>(n_jobs) * parts);
     hipStream_t st = wdg::as_stream(stream);
+    if (const char *e = getenv("WDG_MLP2_SPLIT")) {
+        if (atoi(e)) {  // split-operand products on the bf16 matrix pipe (see mlp2_split_kernel)
+            const size_t lds_split = (2 * SPLIT_BUF_WORDS + BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);
+            static thread_local int split_dev = -1;
+            if (split_dev != wdg::current_device()) {
+                for (const void *k : {reinterpret_cast<const void *>(mlp2_split_kernel<1>), reinterpret_cast<const void *>(mlp2_split_kernel<2>)})
+                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_split)) != hipSuccess)
+                        return wdg::fail(WDG_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+                split_dev = wdg::current_device();
+            }
+            if (max_H > 32) hipLaunchKernelGGL(mlp2_split_kernel<2>, grid, dim3(BRES_THREADS), lds_split, st, jobs_dev, parts);
+            else hipLaunchKernelGGL(mlp2_split_kernel<1>, grid, dim3(BRES_THREADS), lds_split, st, jobs_dev, parts);
+            return wdg::check_launch("mlp2_split_kernel");
+        }
+    }
+    const size_t lds = (static_cast<size_t>(wdg::ceil_div(max_K, 32) * 32) * BRES_COLS + BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);
     if (max_H > 32) hipLaunchKernelGGL(mlp2_bres_kernel<2>, grid, dim3(BRES_THREADS), lds, st, jobs_dev, parts);
     else hipLaunchKernelGGL(mlp2_bres_kernel<1>, grid, dim3(BRES_THREADS), lds, st, jobs_dev, parts);
     return wdg::check_launch("mlp2_bres_kernel");
