@@ -383,7 +383,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_text(args, m, world),
                        "graphs_per_step_per_gpu": len(m["mine"]), "edges_per_step_per_gpu": batch.edges,
-                       "parallelism": f"independent sweep shards x{world} (no data-path collective; job-table broadcast + result all_gather)"},
+                       "parallelism": f"independent sweep shards x{world} (no data-path collective; job-table broadcast + result all_gather)",
+                       # what the step's GCN-2 feature transform computes in (the aggregation itself: fp32 sources, fp32 adds)
+                       "feature_transform": ("fp32 chain on v_mfma_f32_32x32x2_f32 (WDG_MLP2_SPLIT=0)" if os.environ.get("WDG_MLP2_SPLIT", "1") == "0" else
+                                             "fp32 products from 3 bf16 pieces per operand (6 piece products on v_mfma_f32_16x16x32_bf16, fp32 accumulation; "
+                                             "measured error against fp64 below the fp32 chain's - DESIGN 4.7; WDG_MLP2_SPLIT=0 for the chain)")},
             "graphs_per_s": m["n_graphs"] * args.steps / m["elapsed"],
             "edge_features_per_s": m["total_edges"] * args.feat * args.steps / m["elapsed"],
             "host_enqueue_ms_per_step": m["enqueue_s"] / args.steps * 1e3,

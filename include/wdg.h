@@ -511,10 +511,13 @@ int wdg_gemm_batched_flags_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int
  * over A (hidden width H <= 64, C <= 8 outputs, K <= 512): the build-defined GCN-2 feature path relu(Y W0) W1 (SURVEY
  * 7.3 / K10; the reference has no model code - gnns_on_syn.py:9-154 is a results table - so the operator is ours).  The
  * hidden activations stay in registers (B-resident kernel with swapped MFMA operands, second product as per-lane fma)
- * and are not stored (a caller that needs them calls wdg_gemm_batched_f32 twice).  Contract as WDG_GEMM_A_VEC4: every A 16-byte aligned, lda % 4 == 0, K % 4 == 0.  The first product
- * is bit-identical to wdg_gemm_f32; the second sums a row's hidden columns in the order (r & 3) + 8 (r >> 2) + 4 j
- * (+ 32 t), j = 0 half first - fp32, not the k-ordered chain of a separate wdg_gemm_f32 call (parity within 1e-5).
- * Returns WDG_ERR_UNSUPPORTED for larger shapes: call wdg_gemm_batched_f32 twice. */
+ * and are not stored (a caller that needs them calls wdg_gemm_batched_f32 twice).  Contract as WDG_GEMM_A_VEC4: every A 16-byte aligned, lda % 4 == 0, K % 4 == 0.
+ * First product: fp32 products formed from three bf16 pieces of each operand (the pieces sum to the fp32 value; the six
+ * piece products of weight >= 2^-16 are issued on the bf16 matrix pipe and accumulated in fp32) - within fp32 rounding of
+ * wdg_gemm_f32's k-ordered chain and closer to an fp64 evaluation than it (csrc/gemm.hip, mlp2_split_kernel);
+ * WDG_MLP2_SPLIT=0 in the environment selects the chain itself (bit-identical to wdg_gemm_f32).  The second product sums a
+ * row's hidden columns per lane in fp32, not in the k order of a separate wdg_gemm_f32 call.  Parity with two calls: 1e-5.
+ * Deterministic.  Returns WDG_ERR_UNSUPPORTED for larger shapes: call wdg_gemm_batched_f32 twice. */
 typedef struct wdg_mlp2_job {
     const float *A;    /* [M,K] */
     const float *W0;   /* [K,H] */
