@@ -537,7 +537,10 @@ int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t m
  * the MFMA launch as its epilogue; either output may be NULL:
  *   K_linear = G / 2                                                           (n_layers = 0)
  *   K_arccos = (G (pi - acos(G / nu)) + sqrt(nu^2 - G^2)) / (2 pi),  nu = max(|a_i| |a_j|, 1e-8), NaN -> 0   (n_layers = 1)
- * with |a_i|^2 = G_ii (computed as the same k-ordered fp32 fma chain; norm2 [n] is scratch the call fills).
+ * with |a_i|^2 = G_ii, the Gram's own diagonal bit for bit (norm2 [n] is scratch the call fills).  G is symmetric bit for bit.
+ * Its fp32 products are formed from three bf16 pieces per operand on the bf16 matrix pipe, fp32 accumulation (no input bit
+ * dropped; against fp64 within a small factor of the k-ordered fp32 chain's error, usually below it); WDG_GRAM_SPLIT=0 in the
+ * environment selects that chain (then G is bit-identical to wdg_gemm_f32 with transb).
  * replaces: gntk_homophily_ utils/homophily_metrics.py:232-257 (utils/homophily_plot.py:238-268).  The reference maps the
  *           Gram of the rows SAMPLED in an epoch; the map is elementwise in (G_ij, |a_i| |a_j|), so that kernel is the
  *           sub-block [sample, sample] of this one - computed once per graph instead of once per epoch.

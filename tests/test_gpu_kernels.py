@@ -1203,9 +1203,13 @@ def _arccos_map(g, n_layers):
     return (np.float32(1 / np.pi) * (g * (np.float32(np.pi) - ac) + sq) / 2).astype(np.float32)
 
 
-def test_gram_map_fused_epilogue(ops, oracle):
-    """wdg_gram_map_batched_f32: K = map(A A^T) for all rows, linear and arc-cosine in one launch: the Gram part is the
-    k-ordered fp32 chain (bitwise = wdg_gemm_f32 with transb), the map within 2e-6 of the largest entry of numpy's fp32."""
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_gram_map_fused_epilogue(ops, oracle, split, monkeypatch):
+    """wdg_gram_map_batched_f32: K = map(A A^T) for all rows, linear and arc-cosine in one launch.  split = 0: the Gram part is the
+    k-ordered fp32 chain (bitwise = wdg_gemm_f32 with transb); split = 1 (gram_split_kernel): fp32 products from bf16 pieces - within
+    fp32 rounding of the chain and no further from an fp64 Gram than the chain is, the stored row norms are the Gram's own diagonal
+    bit for bit.  Either way symmetric bit for bit, the map within 2e-6 of the largest entry of numpy's fp32 map of the same Gram."""
+    monkeypatch.setenv("WDG_GRAM_SPLIT", split)
     rng = np.random.default_rng(12)
     mats = [rng.random((n, f), dtype=np.float32) * (rng.random((n, f)) < 0.3) for n, f in ((300, 50), (1, 7), (130, 500), (257, 64), (700, 33))]
     mats[0][5] = 0.0  # a zero row: nu clamps to 1e-8, acos(0 / 1e-8) = pi / 2
@@ -1213,10 +1217,19 @@ def test_gram_map_fused_epilogue(ops, oracle):
     gb = ops.GramBatch(dev)
     gb.launch()
     torch.cuda.synchronize()
-    for a, t, kl, ka in zip(mats, dev, gb.k_linear, gb.k_arccos):
+    for a, t, kl, ka, n2 in zip(mats, dev, gb.k_linear, gb.k_arccos, gb.norm2):
         g = _np(ops.gemm(t, t, transb=True))
-        assert np.array_equal(_np(kl), g / 2)
-        assert torch.equal(kl, kl.T) and torch.equal(ka, ka.T)  # (tiles above the diagonal are written mirrored, not computed)
+        if split == "0":
+            assert np.array_equal(_np(kl), g / 2)
+        else:
+            a64 = a.astype(np.float64)
+            ref, mag = a64 @ a64.T, np.abs(a64) @ np.abs(a64).T + 1e-300
+            err_split, err_chain = np.abs(2.0 * _np(kl).astype(np.float64) - ref) / mag, np.abs(g.astype(np.float64) - ref) / mag
+            assert err_split.max() <= max(4.0 * err_chain.max(), 2.0 ** -20), (err_split.max(), err_chain.max())
+            assert err_split.mean() <= 2.0 * err_chain.mean() + 1e-9, (err_split.mean(), err_chain.mean())
+            g = 2.0 * _np(kl)  # (exact doubling: the map below is checked on the kernel's own Gram)
+            assert np.array_equal(_np(n2), np.diag(g))  # the norms the map uses = the Gram's diagonal, same bits
+        assert torch.equal(kl, kl.T) and torch.equal(ka, ka.T)  # (entries above the diagonal are written mirrored, not computed)
         want = _arccos_map(g, 1)
         np.testing.assert_allclose(_np(ka), want, rtol=2e-5, atol=2e-6 * max(float(np.abs(want).max()), 1e-30))
     only = ops.GramBatch(dev[:1], linear=False)

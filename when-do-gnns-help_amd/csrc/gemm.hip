@@ -18,6 +18,7 @@
 //   mlp2_split_kernel the default of that fused transform: split bf16 operands on v_mfma_f32_16x16x32_bf16 (below)
 // The first three run the same k-ordered fp32 fma chain per output element of the (first) product: identical bits.
 #include "wdg_common.h"
+#include "split_bf16.h"
 
 namespace {
 
@@ -425,11 +426,6 @@ __global__ __launch_bounds__(BRES_THREADS) void mlp2_bres_kernel(const wdg_mlp2_
 // on rows spanning eight decades, 2.0e-7 against 2.7e-7 on standard normal data; scripts/dev/mlp2_split_error.py,
 // tests/test_gpu_kernels.py::test_mlp2_split_operands_are_as_accurate_as_the_fp32_chain).  Deterministic (fixed order).
 // WDG_MLP2_SPLIT=0 selects mlp2_bres_kernel, whose hidden layer is bit-identical to wdg_gemm_f32's.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
 #ifndef WDG_SPLIT_ABLATE
 #define WDG_SPLIT_ABLATE 0
 #endif
@@ -437,29 +433,6 @@ constexpr int SPLIT_KQ = 128, SPLIT_KB = SPLIT_KQ / 8;            // rows of W0 
 constexpr int SPLIT_PIECE_WORDS = SPLIT_KB * BRES_COLS * 4;        // 32-bit words of one piece of a buffer (16 KB)
 constexpr int SPLIT_BUF_WORDS = 3 * SPLIT_PIECE_WORDS;             // a buffer: three pieces (48 KB); two buffers
 static_assert(SPLIT_KB * BRES_COLS == BRES_THREADS, "one (k block, column) pair of a buffer per thread");
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // (v_cvt_pk_bf16_f32: round to nearest even, a in the low half)
-    const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
-    return __builtin_bit_cast(unsigned, v);
-}
-
-// two floats -> their three bf16 pieces, packed pairwise
-// (the subtractions as single v_sub_f32: left to itself the compiler pairs them into v_pk_add_f32, which costs more than two
-// plain instructions beside MFMAs - MI355X_MICROARCH "packed f32 VALU ... an anti-lever beside MFMAs")
-__device__ __forceinline__ float sub_f32(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    h = pack_bf16(x0, x1);
-    const float r0 = sub_f32(x0, __uint_as_float(h << 16)), r1 = sub_f32(x1, __uint_as_float(h & 0xffff0000u));
-    m = pack_bf16(r0, r1);
-    const float s0 = sub_f32(r0, __uint_as_float(m << 16)), s1 = sub_f32(r1, __uint_as_float(m & 0xffff0000u));
-    l = pack_bf16(s0, s1);
-}
-
-__device__ __forceinline__ bf16x8_t as_frag(const u32x4_t &v) { return __builtin_bit_cast(bf16x8_t, v); }
 
 // the thread's eight rows (k0 + 8 (tid / 64) + 0..7, column tid % 64) of W0: requested / split and written to a buffer
 __device__ __forceinline__ void split_load_w(global_ptr<const float> W0, int64_t ldw0, int K, int H, int k0, float (&w)[8]) {

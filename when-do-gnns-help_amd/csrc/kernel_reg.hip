@@ -13,6 +13,9 @@
 //                       the k-ordered fp32 fma chain) with the map as epilogue - linear (G / 2) and / or arc-cosine
 //                       ((G (pi - acos(G / nu)) + sqrt(nu^2 - G^2)) / (2 pi), nu = max(|h_i| |h_j|, 1e-8), NaN -> 0);
 //   * row_norm2_kernel  |h_i|^2 as the same fma chain (= the Gram's diagonal, bit for bit);
+//   * gram_split_kernel the default since round 3 (WDG_GRAM_SPLIT=0: the two above): the same Gram with every fp32 product formed
+//                       from bf16 pieces of both operands on v_mfma_f32_32x32x16_bf16 (split_bf16.h: no input bit dropped, fp32
+//                       accumulation), gram_diag_split_kernel its diagonal by the same instruction sequence;
 //   * kr_solve_kernel   one workgroup per (graph, classifier, epoch, kernel) problem: gathers the train block K[tr, tr] from
 //                       the graph's kernel into REGISTERS (2-D cyclic over 32 x 32 threads, up to 320 x 320), factors it
 //                       (right-looking Cholesky, one LDS broadcast of the pivot column and one barrier per step), solves
@@ -26,6 +29,7 @@
 #include <type_traits>
 
 #include "wdg_common.h"
+#include "split_bf16.h"
 
 namespace {
 
@@ -168,6 +172,209 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
                 Karc[static_cast<int64_t>(gm) * ldk + gn] = kv;
                 if (mirror) Karc[static_cast<int64_t>(gn) * ldk + gm] = kv;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Gram + map, split operands
+// The same Gram with every fp32 product formed from bf16 pieces on v_mfma_f32_32x32x16_bf16 (split_bf16.h: three pieces per operand,
+// six piece products per 16 k, fp32 accumulation - no input bit dropped, closer to fp64 than the k-ordered chain).  The pieces are
+// made ONCE per tile element on the way into LDS and read back as whole MFMA fragments (one ds_read_b128 = 8 k of a row): against
+// the fp32 tile loop above that is a sixteenth of the operand reads and of the matrix instructions per k, which is what that loop
+// spends its time issuing (ten vector instructions per MFMA).  Same 128 x 64 tiles, same C/D map, same epilogue.
+//   * LDS: [piece][row][32 k as bf16 + 8 pad] - rows 80 bytes apart, so the 16 lanes a ds_read_b128 serves together start in 16
+//     different bank quadruples (5 i mod 16 is a bijection).
+//   * Symmetry: the order of the six piece products is not symmetric in the two operands, so (i, j) and (j, i) computed apart could
+//     differ in the last bit: only entries on or below the diagonal are kept, every entry above it is written as the mirror of one
+//     below (the fp32 kernel mirrors whole skipped tiles only).  Every (i >= j) lies in a computed tile.
+//   * The arc-cosine map wants |h_i|^2 = G_ii with the bits of the Gram's own diagonal: gram_diag_split_kernel runs the SAME
+//     instruction sequence on each 32-row block against itself and stores the diagonal (an output element of an MFMA depends on
+//     its row of A, its column of B and its accumulator only).
+constexpr int SGBK = 32, SG_ROW_WORDS = 20;  // k per step; 32-bit words per LDS row (16 of data + 4 of padding)
+constexpr int SG_A_WORDS = GBM * SG_ROW_WORDS, SG_B_WORDS = GBN * SG_ROW_WORDS;
+
+// four consecutive k of one row -> three pieces, 8 bytes each at [piece][row][k]
+__device__ __forceinline__ void sg_store_quad(unsigned *base, int piece_words, int row, int kq, const float4 &v) {
+    unsigned h[2], m[2], l[2];
+    split_pair(v.x, v.y, h[0], m[0], l[0]);
+    split_pair(v.z, v.w, h[1], m[1], l[1]);
+    u32x2_t *d = reinterpret_cast<u32x2_t *>(base + row * SG_ROW_WORDS + 2 * kq);
+    d[0] = u32x2_t{h[0], h[1]};
+    d[piece_words / 2] = u32x2_t{m[0], m[1]};
+    d[piece_words] = u32x2_t{l[0], l[1]};
+}
+
+// the six piece products of one 16-k half step, in the order split_bf16.h names (A piece, B piece)
+__device__ __forceinline__ f32x16 sg_products(const u32x4_t &ah, const u32x4_t &am, const u32x4_t &al, const u32x4_t &bh,
+                                              const u32x4_t &bm, const u32x4_t &bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(al), as_frag(bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(am), as_frag(bm), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(am), as_frag(bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ah), as_frag(bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ah), as_frag(bm), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ah), as_frag(bh), acc, 0, 0, 0);
+    return acc;
+}
+
+// a tile row's quadruple of k (zero past the matrix); vec: 16-byte aligned rows
+__device__ __forceinline__ float4 sg_load_quad(global_ptr<const float> A, int64_t lda, int n, int K, bool vec, int row, int gk) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n) {
+        const global_ptr<const float> p = A + static_cast<int64_t>(row) * lda + gk;
+        if (vec && gk + 3 < K) {
+            const f32x4_t q = *(global_ptr<const f32x4_t>)p;
+            v = make_float4(q[0], q[1], q[2], q[3]);
+        } else {
+            if (gk < K) v.x = p[0];
+            if (gk + 1 < K) v.y = p[1];
+            if (gk + 2 < K) v.z = p[2];
+            if (gk + 3 < K) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(GTHREADS) void gram_diag_split_kernel(const wdg_gram_job *__restrict__ jobs) {
+    __shared__ unsigned As[3 * SG_A_WORDS];
+    const desc_ptr<wdg_gram_job> job = (desc_ptr<wdg_gram_job>)(jobs + blockIdx.y);
+    const global_ptr<const float> A = to_global(job->A);
+    const int64_t lda = job->lda;
+    const int n = job->n, K = job->F;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
+    const int m0 = blockIdx.x * GBM;
+    if (m0 >= n) return;
+    const bool vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(job->A) & 15) == 0;
+    constexpr int A_PER = GBM * SGBK / GTHREADS / 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += SGBK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int e = tid + i * GTHREADS;
+            sg_store_quad(As, SG_A_WORDS, e / 8, e % 8, sg_load_quad(A, lda, n, K, vec, m0 + e / 8, k0 + 4 * (e % 8)));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const u32x4_t *ap = reinterpret_cast<const u32x4_t *>(As) + (wave * 32 + li) * (SG_ROW_WORDS / 4) + 2 * m + lk;
+            const u32x4_t ah = ap[0], am = ap[SG_A_WORDS / 4], al = ap[2 * (SG_A_WORDS / 4)];
+            acc = sg_products(ah, am, al, ah, am, al, acc);
+        }
+    }
+    // element (li, li) of the block: register (li >> 3) * 4 + (li & 3) of the lane whose half lk = (li >> 2) & 1
+    float d = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d = (r == (li >> 3) * 4 + (li & 3)) ? acc[r] : d;
+    const int row = m0 + wave * 32 + li;
+    if (lk == ((li >> 2) & 1) && row < n) to_global(job->norm2)[row] = d;
+}
+
+__global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job *__restrict__ jobs) {
+    __shared__ unsigned As[3 * SG_A_WORDS];
+    __shared__ unsigned Bs[3 * SG_B_WORDS];
+    const desc_ptr<wdg_gram_job> job = (desc_ptr<wdg_gram_job>)(jobs + blockIdx.z);
+    const global_ptr<const float> A = to_global(job->A), norm2 = to_global(job->norm2);
+    const global_ptr<float> Klin = to_global(job->K_linear), Karc = to_global(job->K_arccos);
+    const int64_t lda = job->lda, ldk = job->ldk;
+    const int n = job->n, K = job->F;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
+    if (m0 >= n || n0 >= n) return;
+    if (n0 >= m0 + GBM) return;  // entirely above the diagonal: written mirrored by the tile below
+    constexpr int A_PER = GBM * SGBK / GTHREADS / 4, B_PER = GBN * SGBK / GTHREADS / 4;  // quadruples per thread: 4, 2
+    const bool vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(job->A) & 15) == 0;
+    float4 ra[A_PER], rb[B_PER];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int e = tid + i * GTHREADS;  // quadruple e: row e / 8 of the tile, k = 4 (e % 8)
+            ra[i] = sg_load_quad(A, lda, n, K, vec, m0 + e / 8, k0 + 4 * (e % 8));
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int e = tid + i * GTHREADS;
+            rb[i] = sg_load_quad(A, lda, n, K, vec, n0 + e / 8, k0 + 4 * (e % 8));
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int li = lane & 31, lk = lane >> 5;
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += SGBK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) sg_store_quad(As, SG_A_WORDS, (tid + i * GTHREADS) / 8, (tid + i * GTHREADS) % 8, ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) sg_store_quad(Bs, SG_B_WORDS, (tid + i * GTHREADS) / 8, (tid + i * GTHREADS) % 8, rb[i]);
+        __syncthreads();
+        if (k0 + SGBK < K) load_tiles(k0 + SGBK);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const u32x4_t *ap = reinterpret_cast<const u32x4_t *>(As) + (wave * 32 + li) * (SG_ROW_WORDS / 4) + 2 * m + lk;
+            const u32x4_t ah = ap[0], am = ap[SG_A_WORDS / 4], al = ap[2 * (SG_A_WORDS / 4)];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4_t *bp = reinterpret_cast<const u32x4_t *>(Bs) + (t * 32 + li) * (SG_ROW_WORDS / 4) + 2 * m + lk;
+                const u32x4_t bh = bp[0], bm = bp[SG_B_WORDS / 4], bl = bp[2 * (SG_B_WORDS / 4)];
+                acc[t] = sg_products(ah, am, al, bh, bm, bl, acc[t]);
+            }
+        }
+    }
+    // ---- epilogue: C/D map of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Entries on or below the
+    // diagonal are stored from the accumulators' layout (a register's 32 lanes = 128 contiguous bytes of a row); their mirrors go
+    // through a wave-private 32 x 33 LDS tile so that they, too, leave as 128-byte row segments (stored straight from the registers
+    // a mirror instruction writes 4 bytes into each of 64 different lines: 0.5 ms of the 2.2 for the two outputs of a sweep shard)
+    const float pi = 3.14159265358979323846f;
+    const int row0 = m0 + wave * 32;
+    __syncthreads();  // every wave is done with the operand tiles: their LDS is the transpose buffers now
+    float *const T = reinterpret_cast<float *>(As) + wave * (32 * 33);
+    static_assert(4 * 32 * 33 <= 3 * SG_A_WORDS, "transpose buffers fit the A tiles");
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gn = n0 + t * 32 + li;
+        const float dn = (Karc && gn < n) ? sqrtf(norm2[gn]) : 0.f;
+        if (n0 + t * 32 >= n || n0 + t * 32 > row0 + 31) continue;  // (uniform: no column of the block exists / all of it above the diagonal)
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const global_ptr<float> Kout = which ? Karc : Klin;
+            if (!Kout) continue;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = row0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float g = acc[t][r];
+                float kv = g * 0.5f;
+                if (which) {
+                    float nu = sqrtf(norm2[gm < n ? gm : n - 1]) * dn;
+                    nu = nu > 1e-8f ? nu : 1e-8f;
+                    float ac = acosf(g / nu);
+                    float sq = sqrtf(nu * nu - g * g);
+                    ac = ac != ac ? 0.f : ac;
+                    sq = sq != sq ? 0.f : sq;
+                    kv = (1.f / pi) * (g * (pi - ac) + sq) * 0.5f;
+                }
+                v[r] = kv;
+                if (gm < n && gn < n && gm >= gn) Kout[static_cast<int64_t>(gm) * ldk + gn] = kv;
+                T[((r & 3) + 8 * (r >> 2) + 4 * lk) * 33 + li] = kv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = 2 * j + lk;  // column c of the block = row n0 + 32 t + c of the mirror, this lane its column row0 + li
+                const float kv = T[li * 33 + c];
+                const int mn = n0 + t * 32 + c, mm = row0 + li;
+                if (mm < n && mn < n && mm > mn) Kout[static_cast<int64_t>(mn) * ldk + mm] = kv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the next output overwrites the tile)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -1149,6 +1356,14 @@ int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32
     if (n_jobs == 0 || max_n == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev != nullptr, "gram_map_batched: null job table");
     hipStream_t st = wdg::as_stream(stream);
+    bool split = true;  // split bf16 operands (gram_split_kernel); WDG_GRAM_SPLIT=0: the k-ordered fp32 chain (gram_map_kernel)
+    if (const char *e = getenv("WDG_GRAM_SPLIT")) split = atoi(e) != 0;
+    if (split) {
+        hipLaunchKernelGGL(gram_diag_split_kernel, dim3(wdg::ceil_div(max_n, GBM), n_jobs), dim3(GTHREADS), 0, st, jobs_dev);
+        hipLaunchKernelGGL(gram_split_kernel, dim3(wdg::ceil_div(max_n, GBM), wdg::ceil_div(max_n, GBN), n_jobs), dim3(GTHREADS), 0, st,
+                           jobs_dev);
+        return wdg::check_launch("gram_split_kernel");
+    }
     hipLaunchKernelGGL(row_norm2_kernel, dim3(wdg::ceil_div(max_n, 256), n_jobs), dim3(256), 0, st, jobs_dev, max_n);
     hipLaunchKernelGGL(gram_map_kernel, dim3(wdg::ceil_div(max_n, GBM), wdg::ceil_div(max_n, GBN), n_jobs), dim3(GTHREADS), 0, st,
                        jobs_dev);
