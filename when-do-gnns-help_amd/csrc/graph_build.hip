@@ -201,10 +201,17 @@ __device__ __forceinline__ int pow2_at_least(int len) {
 }
 
 constexpr int WAVE_SORT_ROWS = 4;    // rows a wave looks at together
-constexpr int WG_SORT_ROWS = 256;    // rows of a workgroup: its long rows reach the queue with ONE atomic on the shared counter
+constexpr int WG_SORT_ROWS = 256;    // most rows of a workgroup: its long rows reach the queue with ONE atomic on the shared counter
                                      // (one per long row - 80 000 on a twitch-sized graph, all on one address - took 1.8 ms)
 
-__global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict__ rowstart, int32_t N,
+// rows per workgroup: 256 on large graphs; a small graph is spread over ~1000 workgroups instead (a 2000-node graph in 8
+// workgroups of 16 dependent iterations each took 20-50 us)
+inline int wave_sort_rows_per_wg(int32_t N) {
+    const int per = static_cast<int>(ceil_div(ceil_div(N, 1024), 16) * 16);
+    return std::max(16, std::min(WG_SORT_ROWS, per));
+}
+
+__global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict__ rowstart, int32_t N, int wg_rows,
                                                       u64 *__restrict__ bucket, int32_t *__restrict__ long_rows,
                                                       int32_t *__restrict__ long_count) {
     __shared__ int32_t queued[WG_SORT_ROWS];
@@ -213,8 +220,8 @@ __global__ __launch_bounds__(256) void sort_rows_wave(const int32_t *__restrict_
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15;
-    const int wg_first = blockIdx.x * WG_SORT_ROWS;
-    for (int r0 = wg_first + wave * WAVE_SORT_ROWS; r0 < min(wg_first + WG_SORT_ROWS, N); r0 += 4 * WAVE_SORT_ROWS) {
+    const int wg_first = blockIdx.x * wg_rows;
+    for (int r0 = wg_first + wave * WAVE_SORT_ROWS; r0 < min(wg_first + wg_rows, N); r0 += 4 * WAVE_SORT_ROWS) {
         const int mine = min(r0 + g, N - 1);  // (a row past the end reads the last row's bounds and is given length 0)
         const int s_q = rowstart[mine];
         const int len_q = (r0 + g < N) ? rowstart[mine + 1] - s_q : 0;
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(256) void row_l1_kernel(const float *__restrict__ X
 }
 
 inline unsigned wave_rows_grid(int32_t N) { return static_cast<unsigned>(ceil_div(static_cast<int64_t>(N) * 64, 256)); }
-inline unsigned wave_sort_grid(int32_t N) { return static_cast<unsigned>(ceil_div(N, WG_SORT_ROWS)); }
+inline unsigned wave_sort_grid(int32_t N) { return static_cast<unsigned>(ceil_div(N, wave_sort_rows_per_wg(N))); }
 
 // Bit-packed binary features -> dense fp32 rows (graph_io.py containers): one workgroup per row; bit j of word w is
 // feature 32 w + j.  With `normalise` the row is scaled by 1 / (number of set bits) - preprocess_features' row-L1
@@ -628,7 +635,7 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
         hipLaunchKernelGGL(coo_scatter, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst,
                            static_cast<long long>(E), cap, flags, N, ws.rowstart, ws.cursor, ws.bucket);
         if (N > 0) {
-            hipLaunchKernelGGL(sort_rows_wave, dim3(wave_sort_grid(N)), dim3(256), 0, st, ws.rowstart, N, ws.bucket,
+            hipLaunchKernelGGL(sort_rows_wave, dim3(wave_sort_grid(N)), dim3(256), 0, st, ws.rowstart, N, wave_sort_rows_per_wg(N), ws.bucket,
                                ws.long_rows, ws.long_count);
             static thread_local int configured_dev = -1;
             if (configured_dev != current_device()) {
