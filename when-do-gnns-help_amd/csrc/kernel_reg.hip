@@ -194,6 +194,9 @@ constexpr int SGBK = 32, SG_ROW_WORDS = 20;  // k per step; 32-bit words per LDS
 #ifndef WDG_SGBN
 #define WDG_SGBN 64
 #endif
+#ifndef WDG_SG_ABLATE
+#define WDG_SG_ABLATE 0
+#endif
 constexpr int SGBM = 128, SGBN = WDG_SGBN, SG_NT = SGBN / 32;  // workgroup tile (a wave: 32 rows x SGBN columns).  128 x 128 tiles
                                                                 // (a third fewer row re-reads, two workgroups per CU instead of
                                                                 // three) measured 2.29 ms against 2.15 for a shard's 55 Grams
@@ -318,7 +321,10 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) sg_store_quad(Bs, SG_B_WORDS, (tid + i * GTHREADS) / 8, (tid + i * GTHREADS) % 8, rb[i]);
         __syncthreads();
+#if WDG_SG_ABLATE != 1  // (timing experiments: 1 = no tile loads after the first, 2 = no products, 3 = no stores, 4 = no map)
         if (k0 + SGBK < K) load_tiles(k0 + SGBK);
+#endif
+#if WDG_SG_ABLATE != 2
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const u32x4_t *ap = reinterpret_cast<const u32x4_t *>(As) + (wave * 32 + li) * (SG_ROW_WORDS / 4) + 2 * m + lk;
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
                 acc[t] = sg_products(ah, am, al, bh, bm, bl, acc[t]);
             }
         }
+#endif
     }
     // ---- epilogue: C/D map of a 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Entries on or below the
     // diagonal are stored from the accumulators' layout (a register's 32 lanes = 128 contiguous bytes of a row); their mirrors go
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
                 const int gm = row0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const float g = acc[t][r];
                 float kv = g * 0.5f;
-                if (which) {
+                if (which && WDG_SG_ABLATE != 4) {
                     float nu = sqrtf(norm2[gm < n ? gm : n - 1]) * dn;
                     nu = nu > 1e-8f ? nu : 1e-8f;
                     float ac = acosf(g / nu);
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
                     kv = (1.f / pi) * (g * (pi - ac) + sq) * 0.5f;
                 }
                 v[r] = kv;
-                if (gm < n && gn < n && gm >= gn) Kout[static_cast<int64_t>(gm) * ldk + gn] = kv;
+                if (gm < n && gn < n && gm >= gn && (WDG_SG_ABLATE != 3 || kv == 123.456f)) Kout[static_cast<int64_t>(gm) * ldk + gn] = kv;
                 T[((r & 3) + 8 * (r >> 2) + 4 * lk) * 33 + li] = kv;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
                 const int c = 2 * j + lk;  // column c of the block = row n0 + 32 t + c of the mirror, this lane its column row0 + li
                 const float kv = T[li * 33 + c];
                 const int mn = n0 + t * 32 + c, mm = row0 + li;
-                if (mm < n && mn < n && mm > mn) Kout[static_cast<int64_t>(mn) * ldk + mm] = kv;
+                if (mm < n && mn < n && mm > mn && (WDG_SG_ABLATE != 3 || kv == 123.456f)) Kout[static_cast<int64_t>(mn) * ldk + mm] = kv;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // (the next output overwrites the tile)
