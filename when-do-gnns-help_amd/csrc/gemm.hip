@@ -439,6 +439,12 @@ __device__ __forceinline__ void split_load_w(global_ptr<const float> W0, int64_t
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // (opaque per call: the eight row addresses are computed here, not hoisted out of the loops and spilled)
     const int col = tid % BRES_COLS, kb = tid / BRES_COLS;
+    if (k0 + SPLIT_KQ <= K && H == BRES_COLS) {  // (uniform) a whole quarter of a full-width W0: eight loads off one pointer
+        const global_ptr<const float> p = W0 + static_cast<int64_t>(k0 + 8 * kb) * ldw0 + col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = p[j * ldw0];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {  // (unconditional loads from clamped addresses, zeroed afterwards: no branch per load)
         const int k = k0 + 8 * kb + j;
@@ -535,9 +541,17 @@ __global__ __launch_bounds__(BRES_THREADS) void mlp2_split_kernel(const wdg_mlp2
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int T = 0; T < NT16; ++T) acc[s][T] = f32x4_acc{0.f, 0.f, 0.f, 0.f};
-        auto load_step = [&](int st, SplitStep &dst) {  // k = 32 st + 8 q + 0..7 of both rows; past K: addresses pulled back, values zeroed
+        auto load_step = [&](int st, SplitStep &dst) {  // k = 32 st + 8 q + 0..7 of both rows
             st = min(st, steps - 1);
-            const int k = 32 * st + 8 * q;
+            if (32 * st + 32 <= K) {  // (uniform) a whole step: plain loads off the lane's row pointers
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    dst.a[s] = *(const global_ptr<const f32x4_t>)(a_row[s] + 8 * q + 32 * st);
+                    dst.b[s] = *(const global_ptr<const f32x4_t>)(a_row[s] + 8 * q + 32 * st + 4);
+                }
+                return;
+            }
+            const int k = 32 * st + 8 * q;  // the last, partial step: addresses pulled back inside the row, values past K zeroed
             const f32x4_t zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
