@@ -1118,6 +1118,32 @@ def test_mlp2_split_operands_are_as_accurate_as_the_fp32_chain(ops, monkeypatch)
     assert worst["1"] <= 2.0 * worst["0"] and mean["1"] <= 2.0 * mean["0"], (worst, mean)
 
 
+def test_mlp2_split_operands_non_finite_inputs(ops, monkeypatch):
+    """documented edge of the split-operand transform (csrc/split_bf16.h): a NaN or an infinity makes its row non-finite and no other
+    (the split turns an infinity into NaN in the first product already, the fp32 chain one layer later); the largest
+    bf16-representable magnitudes and the smallest normal ones are still exact"""
+    rng = np.random.default_rng(3)
+    m, k, h = 64, 64, 8
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    a[3, 5], a[7, 9], a[11, 0], a[12, 1] = np.nan, np.inf, np.float32(3.3e38), np.float32(-1.0e-38)
+    w0 = np.zeros((k, h), np.float32)
+    w0[np.arange(k), np.arange(k) % h] = 1.0 / 1024  # (a power of two: row sums of eight inputs each, scaled exactly)
+    eye = np.eye(h, dtype=np.float32)
+    out = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("WDG_MLP2_SPLIT", split)
+        z = torch.zeros((m, h), device="cuda")
+        ops.Mlp2Batch([(torch.from_numpy(a).cuda(), torch.from_numpy(w0).cuda(), None, torch.from_numpy(eye).cuda(), None, z)], relu=False).launch()
+        torch.cuda.synchronize()
+        out[split] = _np(z)
+    for split in ("0", "1"):
+        assert np.isnan(out[split][3, 5]) and np.isfinite(np.delete(out[split], [3, 7], axis=0)).all()
+    assert not np.isfinite(out["0"][7]).any() and np.isnan(out["1"][7]).all()  # (the chain's infinity meets 0 x inf in the second layer)
+    ref = (a.astype(np.float64) @ w0.astype(np.float64))
+    for row in (11, 12):
+        np.testing.assert_allclose(out["1"][row], ref[row], rtol=2e-6, atol=1e-37)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_resident_gemm_and_mlp2(ops, oracle, seed, monkeypatch=None):
     """Seeded fuzz of the two B-resident kernels over random shapes, leading dimensions, biases and activations: the GEMM

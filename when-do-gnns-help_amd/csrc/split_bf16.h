@@ -5,6 +5,9 @@
 // weight >= 2^-16 are issued by the callers - (l,h) (m,m) (m,h) (h,l) (h,m) (h,h), in that order, every one exact as an input of
 // the fp32 accumulator; what is dropped is below 2^-23 |x w|, one fp32 rounding.  Used by mlp2_split_kernel (gemm.hip) and
 // gram_split_kernel (kernel_reg.hip); measured against fp64 both are closer than the k-ordered fp32 fma chain.
+// Non-finite inputs: a NaN stays a NaN (every piece of it is one); an infinity - and a finite |x| > 3.3895e38, which rounds to
+// the bf16 infinity - gives NaN where the fp32 chain gives +-inf (x - x_h = inf - inf).  Features and weights are finite;
+// WDG_MLP2_SPLIT=0 / WDG_GRAM_SPLIT=0 select the chain for inputs that are not.
 #pragma once
 #include "wdg_common.h"
 
