@@ -190,7 +190,12 @@ __global__ __launch_bounds__(GTHREADS) void gram_map_kernel(const wdg_gram_job *
 //   * The arc-cosine map wants |h_i|^2 = G_ii with the bits of the Gram's own diagonal: gram_diag_split_kernel runs the SAME
 //     instruction sequence on each 32-row block against itself and stores the diagonal (an output element of an MFMA depends on
 //     its row of A, its column of B and its accumulator only).
-constexpr int SGBK = 32, SG_ROW_WORDS = 20;  // k per step; 32-bit words per LDS row (16 of data + 4 of padding)
+#ifndef WDG_SGBK
+#define WDG_SGBK 16  // (16-k steps: 28 KB of LDS per workgroup, four workgroups per CU - 2.13 ms for a shard's 55 Grams; 32-k steps, three per CU: 2.20)
+#endif
+constexpr int SGBK = WDG_SGBK, SG_QPR = SGBK / 4, SG_HALVES = SGBK / 16;  // k per step; quadruples per tile row; MFMAs (16 k) per step
+constexpr int SG_ROW_WORDS = SGBK / 2 + 4;  // 32-bit words per LDS row: the data + 16 bytes of padding (20 / 12 words: rows 5 / 3
+                                            // sixteen-byte units apart, odd - the 16 lanes of a ds_read_b128 start in 16 bank quadruples)
 #ifndef WDG_SGBN
 #define WDG_SGBN 64
 #endif
@@ -262,11 +267,11 @@ __global__ __launch_bounds__(GTHREADS) void gram_diag_split_kernel(const wdg_gra
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            sg_store_quad(As, SG_A_WORDS, e / 8, e % 8, sg_load_quad(A, lda, n, K, vec, m0 + e / 8, k0 + 4 * (e % 8)));
+            sg_store_quad(As, SG_A_WORDS, e / SG_QPR, e % SG_QPR, sg_load_quad(A, lda, n, K, vec, m0 + e / SG_QPR, k0 + 4 * (e % SG_QPR)));
         }
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < SG_HALVES; ++m) {
             const u32x4_t *ap = reinterpret_cast<const u32x4_t *>(As) + (wave * 32 + li) * (SG_ROW_WORDS / 4) + 2 * m + lk;
             const u32x4_t ah = ap[0], am = ap[SG_A_WORDS / 4], al = ap[2 * (SG_A_WORDS / 4)];
             acc = sg_products(ah, am, al, ah, am, al, acc);
@@ -298,13 +303,13 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int e = tid + i * GTHREADS;  // quadruple e: row e / 8 of the tile, k = 4 (e % 8)
-            ra[i] = sg_load_quad(A, lda, n, K, vec, m0 + e / 8, k0 + 4 * (e % 8));
+            const int e = tid + i * GTHREADS;  // quadruple e: row e / SG_QPR of the tile, k = 4 (e % SG_QPR)
+            ra[i] = sg_load_quad(A, lda, n, K, vec, m0 + e / SG_QPR, k0 + 4 * (e % SG_QPR));
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            rb[i] = sg_load_quad(A, lda, n, K, vec, n0 + e / 8, k0 + 4 * (e % 8));
+            rb[i] = sg_load_quad(A, lda, n, K, vec, n0 + e / SG_QPR, k0 + 4 * (e % SG_QPR));
         }
     };
     f32x16 acc[SG_NT];
@@ -317,16 +322,16 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
     for (int k0 = 0; k0 < K; k0 += SGBK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) sg_store_quad(As, SG_A_WORDS, (tid + i * GTHREADS) / 8, (tid + i * GTHREADS) % 8, ra[i]);
+        for (int i = 0; i < A_PER; ++i) sg_store_quad(As, SG_A_WORDS, (tid + i * GTHREADS) / SG_QPR, (tid + i * GTHREADS) % SG_QPR, ra[i]);
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) sg_store_quad(Bs, SG_B_WORDS, (tid + i * GTHREADS) / 8, (tid + i * GTHREADS) % 8, rb[i]);
+        for (int i = 0; i < B_PER; ++i) sg_store_quad(Bs, SG_B_WORDS, (tid + i * GTHREADS) / SG_QPR, (tid + i * GTHREADS) % SG_QPR, rb[i]);
         __syncthreads();
 #if WDG_SG_ABLATE != 1  // (timing experiments: 1 = no tile loads after the first, 2 = no products, 3 = no stores, 4 = no map)
         if (k0 + SGBK < K) load_tiles(k0 + SGBK);
 #endif
 #if WDG_SG_ABLATE != 2
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < SG_HALVES; ++m) {
             const u32x4_t *ap = reinterpret_cast<const u32x4_t *>(As) + (wave * 32 + li) * (SG_ROW_WORDS / 4) + 2 * m + lk;
             const u32x4_t ah = ap[0], am = ap[SG_A_WORDS / 4], al = ap[2 * (SG_A_WORDS / 4)];
 #pragma unroll
