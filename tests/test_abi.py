@@ -108,20 +108,28 @@ def test_no_shipped_kernel_spills_vector_registers():
     assert seen >= 20
 
 
-def test_quad_row_fast_loop_keeps_its_memory_operations_to_itself(tmp_path):
-    """csrc/spmm_quad.hip issues the loads and stores of its pipelined loop from inline asm and waits for them with hand-counted
-    `s_waitcnt vmcnt(n)`: that is only right while the COMPILER puts no memory operation of its own between them (its wait
-    insertion does not see the asm ones, and a spill reload or a conditional global access would shift the counts).  The device
-    code of the shipped flags is generated here and every basic block that holds asm memory operations is checked: no
-    compiler-emitted global / buffer / flat / scratch instruction in it, and no scratch use in the kernel at all."""
+def _quad_device_code(tmp_path, *flags):
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     import subprocess
     out = tmp_path / "quad.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/when-do-gnns-help_amd/csrc", "-S",
-                    "--cuda-device-only", "-o", str(out), f"{ROOT}/when-do-gnns-help_amd/csrc/spmm_quad.hip"], check=True, capture_output=True)
-    text = out.read_text()
+                    "--cuda-device-only", *flags, "-o", str(out), f"{ROOT}/when-do-gnns-help_amd/csrc/spmm_quad.hip"], check=True, capture_output=True)
+    return out.read_text()
+
+
+def test_quad_row_fast_loop_keeps_its_memory_operations_to_itself(tmp_path):
+    """csrc/spmm_quad.hip issues the loads and stores of its pipelined loop from inline asm and waits for them with hand-counted
+    `s_waitcnt vmcnt(n)`: that is only right while the COMPILER puts no memory operation of its own between them (its wait
+    insertion does not see the asm ones, and a spill reload or a conditional global access would shift the counts) and never
+    touches a register whose asm load is still in flight (scripts/check_quad_isa.py: a dataflow over the generated code).
+    The device code of the shipped flags is generated here and checked."""
+    text = _quad_device_code(tmp_path)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_quad_isa", os.path.join(ROOT, "scripts", "check_quad_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
     checked = 0
     for variant in ("IfLb0ELb0E", "ItLb0ELb0E"):  # fp32 / bf16 sources, pattern only, one column block: the pipelined loop
         m = re.search(r"^(_ZN\S*spmm_quad_kernel%s[^:\s]*):[^\n]*\n(.*?)s_endpgm" % variant, text, re.M | re.S)
@@ -148,8 +156,25 @@ def test_quad_row_fast_loop_keeps_its_memory_operations_to_itself(tmp_path):
         assert len(with_asm) >= 10 and sum(b[0] for b in with_asm) >= 40, f"{variant}: the asm loop was not found"
         for n_asm, own in with_asm:
             assert not own, f"{variant}: compiler-emitted memory operations beside {n_asm} asm ones: {own[:3]}"
+        res = chk.check_kernel(text, variant)
+        assert res["depth"] == 1 and res["in_flight"] == 4 and res["loops"] == 2, res  # the shipped pipeline: requests one super-unit ahead
+        assert not res["violations"], f"{variant}: compiler instructions touch registers of loads in flight: {res['violations'][:5]}"
         checked += 1
     assert checked == 2
+
+
+def test_quad_isa_check_sees_a_register_rotation(tmp_path):
+    """the checker itself: at depth 2 requests are in flight across the loop's back edge; with the stage copies left to the
+    compiler (-DWDG_Q_EXPERIMENT_PLAIN_COPIES) it rotates the extents' registers at the back edge while they are in flight -
+    the bug the explicit copies of q_units_fast prevent - and the checker must say so; with them it must stay silent."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_quad_isa", os.path.join(ROOT, "scripts", "check_quad_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    good = chk.check_kernel(_quad_device_code(tmp_path, "-DWDG_Q_FAST_THREADS=768", "-DWDG_Q_DEPTH=2"), "IfLb0ELb0E")
+    assert good["depth"] == 2 and good["in_flight"] == 19 and not good["violations"], good
+    bad = chk.check_kernel(_quad_device_code(tmp_path, "-DWDG_Q_FAST_THREADS=768", "-DWDG_Q_DEPTH=2", "-DWDG_Q_EXPERIMENT_PLAIN_COPIES"), "IfLb0ELb0E")
+    assert bad["violations"], "the checker missed the rotation of registers whose loads are in flight"
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

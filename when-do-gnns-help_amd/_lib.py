@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (loads libamdhip64 before our library needs it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwdg_hip.so")
+# (WDG_LIB_PATH: another build of the same library - the A/B scripts under scripts/dev/ compare kernel variants with it)
+LIB_PATH = os.environ.get("WDG_LIB_PATH") or os.path.join(_HERE, "lib", "libwdg_hip.so")
 
 c_void_p, c_int, c_int32, c_int64, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
                                                ctypes.c_size_t)

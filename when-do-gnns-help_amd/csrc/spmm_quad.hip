@@ -30,6 +30,8 @@
 //     once or twice per launch instead of once per item.
 // Summation order per row = the order of the SELL-16 copy (column blocks ascend; inside a block the bank-aware order,
 // or column order with WDG_SELL_ORDER=0): fixed per graph -> bitwise reproducible.
+#include <type_traits>
+
 #include "wdg_common.h"
 
 namespace wdg {
@@ -42,15 +44,29 @@ namespace {
 
 using namespace wdg;
 
-#ifndef WDG_Q_THREADS  // (experiments: scripts/dev/try_two_wg.py builds 512-thread workgroups, two per CU)
-#define WDG_Q_THREADS 1024
-#define WDG_Q_WGS_PER_CU 1
-#define WDG_Q_OCCUPANCY
-#else
-#define WDG_Q_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))
+// Workgroup shapes.  Phases of several column blocks (q_phase_multi) keep 16 waves: an item of 64 super-units - a whole
+// N = 4000 graph - is 4 super-units per wave.  The one-block phases (q_units_fast / q_units_simple) run Q_FAST_WAVES waves with
+// Q_DEPTH super-units requested ahead.  Shipped: 16 waves, depth 1.  Round 4 built the deeper pipeline the round-3 review asked
+// for (requests two super-units ahead so that no awaited load is younger than the previous iteration's stores; 12 waves x 168
+// registers hold the extra stage) and measured it (scripts/dev/build_quad_variants.sh, ab_quad_variants.py, quad_profile.py with
+// -DWDG_Q_PROFILE): the waves spend 0.01 us per iteration in the end-of-iteration wait at depth 1 already (0.00 at depth 2) and
+// 2.9 of every 3.3 us in the sweep, the launch is the same 102 - 105 us at (16 waves, 1), (12, 1), (12, 2) and slower with 8
+// waves at depth 2 - 4: the loop is bound by the LDS at the 2.0 GHz the chip holds under this load, not by store
+// acknowledgements.  Depths above 1 are an EXPERIMENT: they compute the batched tables' results (verified) but
+// fault on the single-graph entry (not debugged further - nothing to gain).
+#ifndef WDG_Q_FAST_THREADS
+#define WDG_Q_FAST_THREADS 1024
 #endif
-constexpr int Q_THREADS = WDG_Q_THREADS;
-constexpr int Q_WAVES = Q_THREADS / 64;
+#ifndef WDG_Q_DEPTH
+#define WDG_Q_DEPTH 1
+#endif
+constexpr int Q_MULTI_THREADS = 1024;
+constexpr int Q_MULTI_WAVES = Q_MULTI_THREADS / 64;
+constexpr int Q_FAST_THREADS = WDG_Q_FAST_THREADS;
+constexpr int Q_FAST_WAVES = Q_FAST_THREADS / 64;
+constexpr int Q_DEPTH = WDG_Q_DEPTH;
+static_assert(Q_FAST_THREADS % 64 == 0 && Q_FAST_THREADS >= 256 && Q_FAST_THREADS <= 1024, "workgroup shape");
+static_assert(Q_DEPTH >= 1 && Q_DEPTH <= 4, "pipeline depth");
 constexpr int Q_ROWS = 16;             // rows per unit (SELL-16 slice)
 constexpr int Q_CHUNK = 16;            // entries per row and index chunk (one 16-byte load per lane)
 constexpr int Q_CHUNK_INTS = Q_ROWS * Q_CHUNK;
@@ -84,10 +100,17 @@ __device__ unsigned long long wdg_q_stamp_buf[1024 * 8];
 #define Q_STAMP(k) do { } while (0)
 #endif
 
+#ifdef WDG_Q_PROFILE  // diagnostic build only (QUAD_EXTRA=-DWDG_Q_PROFILE): per wave, shader clocks spent in the pipelined loop's
+// parts - {requests issued, sweep + stores, wait for the requests, iterations, whole loop} (scripts/dev/quad_profile.py)
+__device__ unsigned long long wdg_q_profile_buf[1024 * 16 * 8];
+#define Q_CLOCK() __builtin_amdgcn_s_memrealtime()  // 100 MHz
+#endif
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 using lds_cptr = const char __attribute__((address_space(3))) *;
+using lds_iptr = int __attribute__((address_space(3))) *;
 using bf16r_t = unsigned short;
 __device__ __forceinline__ float q_f32(float v) { return v; }
 __device__ __forceinline__ float q_f32(bf16r_t v) { return __uint_as_float(static_cast<unsigned>(v) << 16); }
@@ -508,7 +531,7 @@ __device__ __forceinline__ float q_bcastf(float v) {
 __device__ __forceinline__ void q_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // X[begin : begin + rows, f0 : f0 + 16] -> xs rows 0 .. rows - 1 (64 B each), and the zero row at `zero_row`
-template <typename TIN>
+template <typename TIN, int THREADS>
 __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int zero_row, int f0, float4 *xs, int wave,
                                         int lane, int tid) {
     const int F = h.n_feat;
@@ -521,11 +544,11 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
     // turns every counted wait of the unit pipeline into a wait for the wave's last store.  A workgroup stages a slab once
     // per phase (once or twice per launch), so the extra ds_write_b128 traffic is noise.
     constexpr int NL = 4;  // register-staged loads in flight per thread
-    for (int i0 = 0; i0 < n_stage; i0 += Q_THREADS * NL) {
+    for (int i0 = 0; i0 < n_stage; i0 += THREADS * NL) {
         float4 v[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const int i = i0 + j * Q_THREADS + tid;
+            const int i = i0 + j * THREADS + tid;
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n_stage) {
                 const int row = begin + (i >> 2), f = f0 + (i & 3) * 4;
@@ -546,7 +569,7 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
         }
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const int i = i0 + j * Q_THREADS + tid;
+            const int i = i0 + j * THREADS + tid;
             if (i < n_stage) xs[i] = v[j];
         }
     }
@@ -661,17 +684,39 @@ struct QJobC {
     unsigned ldy4;  // bytes per row of Y
 };
 
+template <int D>
 __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
-                                             int unit_begin, int unit_end, int stride, int f0, lds_cptr slab, bool no_sweep,
-                                             bool no_store, bool no_idx, int wave, int lane) {
-    constexpr int NPRE = 2;        // index chunks per entry (all of them), requested one super-unit ahead
+                                             int unit_begin, int unit_end, int stride, int f0, lds_cptr slab, lds_iptr next_unit,
+                                             bool no_sweep, bool no_store, bool no_idx, int wave, int lane) {
+    constexpr int NPRE = 2;          // index chunks per entry (all of them)
+    constexpr int NS = D + 1;        // register sets per stage: D super-units in flight + the one being consumed
     constexpr bool HAS_VAL = false;  // (explicit values run the plain loop)
     const int r = lane >> 2, p = lane & 3;
     const int loff = p * 16;
     const unsigned lane16 = lane * 16, lane4 = lane * 4, ext_lane = (lane < Q_SU ? lane : Q_SU - 1) * 8;
     const int bperm0 = r * 4;  // ds_bpermute address of lane r: slice i's row r sits in lane 16 i + r of the 64-row registers
-    const int ustep = Q_WAVES * stride;
     const int last_job = first_job + n_jobs - 1;
+
+    // ---- which super-units a wave works on.  The phase's units are numbered idx = 0, 1, ..: unit = unit_begin + idx x stride.
+    //      The first 2 D requests of a wave (the pipeline's prologue, issued before the slab barrier) are dealt statically,
+    //      idx = wave + k x waves; every later one takes the next number from a counter in LDS (q_phase_single set it to
+    //      2 D x waves before the barrier).  Round 3 dealt everything statically, wave w the units w, w + 16, ..: a graph's
+    //      slices are sorted by length, so wave 0 got the widest super-unit of every round of 16 and wave 15 the narrowest - the
+    //      waves of a workgroup ended 9 - 23 us apart (scripts/dev/quad_profile.py), and a workgroup ends with its last wave.
+    //      A wave that falls behind now simply asks later.  Which wave sweeps a unit does not enter its result.
+    int static_idx = wave;
+    auto next_idx = [&](bool from_counter) {
+        int idx = static_idx;
+        static_idx += Q_FAST_WAVES;
+#ifndef WDG_Q_STATIC_DEAL
+        if (from_counter) {
+            int v = 0;
+            if (lane == 0) v = __hip_atomic_fetch_add((int *)next_unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            idx = __builtin_amdgcn_readfirstlane(v);
+        }
+#endif
+        return idx;
+    };
 
     // ---- the super-unit iterator over the phase's concatenated jobs: (it_j, it_su) = job / super-unit of unit it_u;
     //      (req_j, req_su) = what is actually requested: the iterator's while it_u is a unit, then the wave's last unit
@@ -687,9 +732,10 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
         it_su = rest;
     }
     int req_j = first_job, req_su = 0;
-    auto advance = [&]() {
-        it_u += ustep;
-        it_su += ustep;
+    auto seek = [&](int idx) {  // forward only: a wave's numbers ascend
+        const int u = unit_begin + idx * stride, step = u - it_u;
+        it_u = u;
+        it_su += step;
         while (it_su >= it_nsu && it_j < last_job) {
             it_su -= it_nsu;
             ++it_j;
@@ -712,7 +758,9 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
         int rows, scale_bits, j;
         bool ok, has_scale;
     };
-    auto issueE = [&](EStage &e) {
+    constexpr int LOADS_E = 2, LOADS_I = Q_SU * NPRE + 1, STORES = Q_SU;  // memory operations per super-unit and stage
+    auto issueE = [&](EStage &e, int idx) {
+        seek(idx);
         e.ok = it_u < unit_end;
         if (e.ok) {
             req_j = it_j;
@@ -727,13 +775,20 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
         }
         e.ext = q_ld2(je.ext, static_cast<unsigned>(req_su) * (Q_SU * 8) + ext_lane);
         e.rows = q_ld1(je.perm, static_cast<unsigned>(req_su) * (Q_SU_ROWS * 4) + lane4);
-        advance();
     };
     auto issueI = [&](const EStage &e, IStage &s) {
         s.ok = e.ok;
         s.j = e.j;
+        // (copies the compiler cannot fold: left to itself it keeps the landed values where they are, requests the set's next
+        // extents / rows into other registers and rotates them at the back edge - while those requests are in flight)
+#ifndef WDG_Q_EXPERIMENT_PLAIN_COPIES
+        asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+                     : "=&v"(s.rows), "=&v"(s.ext.x), "=&v"(s.ext.y)
+                     : "v"(e.rows), "v"(e.ext.x), "v"(e.ext.y));
+#else  // (tests/test_abi.py: what scripts/check_quad_isa.py must catch)
         s.rows = e.rows;
         s.ext = e.ext;
+#endif
         if (s.j != ij) {
             ij = s.j;
             const q_desc_ptr d = q_desc(jobs, inl, ij);
@@ -789,29 +844,53 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
                   f32x4_t{a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0});
         }
     };
-    // everything requested so far has landed: the registers of the stages named may be read (or copied) from here on
-    auto landed = [&](EStage &e, IStage &s) {
-        asm volatile("" : "+v"(e.ext), "+v"(e.rows), "+v"(s.scale_bits));
+    // the requests of these stages have landed: their registers may be read (or copied) from here on
+    auto landedE = [&](EStage &e) { asm volatile("" : "+v"(e.ext), "+v"(e.rows)); };
+    auto landedI = [&](IStage &s) {
+        asm volatile("" : "+v"(s.scale_bits));
 #pragma unroll
         for (int i = 0; i < Q_SU; ++i)
 #pragma unroll
             for (int c = 0; c < NPRE; ++c) asm volatile("" : "+v"(s.c[i][c]));
     };
 
-    EStage E;
-    IStage C, N;
+    // Super-unit m lives in register set m % NS of both stages.  E(m) is requested in iteration m - 2 D, consumed (its chunk
+    // and scale requests I(m) issued) in iteration m - D, swept in iteration m.  Iteration n therefore issues I(n + D), then
+    // E(n + 2 D), sweeps and stores n, and waits for the requests of iteration n + 1 - D only: the 4 stores of that iteration
+    // and everything of the D - 1 iterations since may still be in flight.  With D = 1 (rounds 2 and 3) that wait names loads
+    // issued BEHIND the previous iteration's stores, i.e. every iteration waited for a store acknowledgement (6 - 10 us
+    // while the write path is busy; at most one iteration of stores - 64 KiB per CU - in flight: 2 - 2.8 TB/s on a write
+    // path that fills at 6.8).  With D = 2 no awaited load is younger than the stores of the iteration before the last one.
+    // The loop is unrolled NS times so that a set's role is fixed at compile time: a request that is still in flight at the
+    // back edge stays in its registers (a rotation `C = N` would copy registers whose loads have not landed).
+    EStage E[NS];
+    IStage S[NS];
 #pragma unroll
-    for (int i = 0; i < Q_SU; ++i)
+    for (int k = 0; k < NS; ++k) {
 #pragma unroll
-        for (int c = 0; c < NPRE; ++c) C.c[i][c] = N.c[i][c] = i32x4{0, 0, 0, 0};
-    C.scale_bits = N.scale_bits = 0;
-    issueE(E);  // super-unit 0
+        for (int i = 0; i < Q_SU; ++i)
+#pragma unroll
+            for (int c = 0; c < NPRE; ++c) S[k].c[i][c] = i32x4{0, 0, 0, 0};
+        S[k].scale_bits = 0;
+        S[k].ok = false;
+        E[k].ext = i32x2{0, 0};
+        E[k].rows = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) issueE(E[k], next_idx(false));  // super-units 0 .. D - 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    landed(E, C);
-    issueI(E, C);
-    issueE(E);  // super-unit 1
+#pragma unroll
+    for (int k = 0; k < D; ++k) landedE(E[k]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) issueI(E[k], S[k]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) issueE(E[(D + k) % NS], next_idx(false));  // super-units D .. 2 D - 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    landed(E, C);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        landedE(E[k]);
+        landedI(S[k]);
+    }
     q_barrier_lds();  // the slab is in place for every wave; from here to the end of the phase the waves run free
 #ifdef WDG_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 1024) {  // the slot after the phase's start stamp (whichever of 2, 4, 6 was written last)
@@ -820,16 +899,68 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
         rec[slot] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    while (C.ok) {
-        issueI(E, N);  // super-unit n + 1
-        issueE(E);     // super-unit n + 2
-        sweep_and_store(C);
-        // the iteration's loads are older than its four stores: they have all landed, the stores may be in flight
-        static_assert(Q_SU == 4, "the wait below names Q_SU");
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        landed(E, N);
-        C = N;
+    constexpr int IN_FLIGHT = STORES + (D - 1) * (LOADS_I + LOADS_E + STORES);
+    static_assert(IN_FLIGHT <= 63, "vmcnt is a 6-bit counter");
+#ifdef WDG_Q_PROFILE
+    unsigned long long prof_issue = 0, prof_sweep = 0, prof_wait = 0, prof_iter = 0;
+    const unsigned long long prof_begin = Q_CLOCK(), prof_begin_clk = __builtin_amdgcn_s_memtime();
+#endif
+    auto iteration = [&](auto K) {  // iteration n, n % NS == K
+        constexpr int k = decltype(K)::value;
+#ifdef WDG_Q_PROFILE
+        const unsigned long long t0 = Q_CLOCK();
+#endif
+        issueI(E[(k + D) % NS], S[(k + D) % NS]);  // super-unit n + D
+        issueE(E[(k + 2 * D) % NS], next_idx(true));  // super-unit n + 2 D
+#ifdef WDG_Q_PROFILE
+        const unsigned long long t1 = Q_CLOCK();
+#endif
+        sweep_and_store(S[k]);
+#ifdef WDG_Q_PROFILE
+        const unsigned long long t2 = Q_CLOCK();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
+        const unsigned long long t3 = Q_CLOCK();
+        prof_issue += t1 - t0;
+        prof_sweep += t2 - t1;
+        prof_wait += t3 - t2;
+        ++prof_iter;
+#endif
+        // (the comment names the iteration's register set for scripts/check_quad_isa.py)
+        asm volatile("s_waitcnt vmcnt(%0) ; q_units_fast set %1 of %2" ::"n"(IN_FLIGHT), "n"(k), "n"(NS) : "memory");
+        landedI(S[(k + 1) % NS]);
+        landedE(E[(k + 1 + D) % NS]);
+    };
+    for (;;) {
+        if (!S[0].ok) break;
+        iteration(std::integral_constant<int, 0>{});
+        if (!S[1 % NS].ok) break;
+        iteration(std::integral_constant<int, 1 % NS>{});
+        if constexpr (NS > 2) {
+            if (!S[2 % NS].ok) break;
+            iteration(std::integral_constant<int, 2 % NS>{});
+        }
+        if constexpr (NS > 3) {
+            if (!S[3 % NS].ok) break;
+            iteration(std::integral_constant<int, 3 % NS>{});
+        }
+        if constexpr (NS > 4) {
+            if (!S[4 % NS].ok) break;
+            iteration(std::integral_constant<int, 4 % NS>{});
+        }
     }
+    // requests past the wave's last super-unit are still in flight (D > 1): their registers are the compiler's again after
+    // the loop, so everything lands here (once per phase)
+    if (D > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WDG_Q_PROFILE
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long *rec = wdg_q_profile_buf + (blockIdx.x * 16 + wave) * 8;
+        const unsigned long long now = Q_CLOCK();
+        rec[0] += prof_issue; rec[1] += prof_sweep; rec[2] += prof_wait; rec[3] += prof_iter; rec[4] += now - prof_begin;
+        rec[5] += __builtin_amdgcn_s_memtime() - prof_begin_clk;  // shader clocks of the same span: rec[5] / rec[4] x 100 MHz = the clock held
+        if (rec[6] == 0) rec[6] = prof_begin;                     // (absolute, 100 MHz: the wave's first loop start / last loop end)
+        rec[7] = now;
+    }
+#endif
 }
 
 // the plain loop: any feature group (ragged, scalar stores), any entry width, explicit values; nothing requested ahead.
@@ -842,7 +973,7 @@ __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const w
     const int r = lane >> 2, p = lane & 3;
     const int loff = p * 16;
     q_barrier_lds();  // the slab is in place for every wave
-    for (int u = unit_begin + wave * stride; u < unit_end; u += Q_WAVES * stride) {
+    for (int u = unit_begin + wave * stride; u < unit_end; u += Q_FAST_WAVES * stride) {
         int j = first_job, su = u;
         for (;;) {
             const int nsu = q_desc(jobs, inl, j)->q_n_entries / Q_SU;
@@ -896,8 +1027,8 @@ __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const w
 
 template <typename TIN, bool HAS_VAL>
 __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
-                                               int unit_begin, int unit_end, int stride, int f0, float4 *xs, bool first_phase,
-                                               bool y_vec_all) {
+                                               int unit_begin, int unit_end, int stride, int f0, float4 *xs, lds_iptr next_unit,
+                                               bool first_phase, bool y_vec_all) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -906,12 +1037,13 @@ __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const w
     const int F = head.n_feat;
     if (f0 >= F) return;  // workgroup-uniform
     if (!first_phase) q_barrier_lds();  // every wave is done with the previous phase's slab
-    q_stage<TIN>(head, 0, head.n_cols, head.block_cols, f0, xs, wave, lane, tid);
+    if (tid == 0) *next_unit = 2 * Q_DEPTH * Q_FAST_WAVES;  // (q_units_fast: the units behind the statically dealt ones; its slab barrier publishes it)
+    q_stage<TIN, Q_FAST_THREADS>(head, 0, head.n_cols, head.block_cols, f0, xs, wave, lane, tid);
     const bool no_sweep = head.reserved & 4, no_store = head.reserved & 1;  // timing ablations (diagnostics)
     // whole feature group and 16-byte stores for every job of the phase (the table's flags vouch for the alignment)
     // (y_vec: the launcher's promise - 16-byte stores, 32-bit offsets, every job in split form; explicit values: plain loop)
     const bool full = (f0 + 16 <= F) && head.y_vec && !HAS_VAL;
-    if (full) q_units_fast(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, no_sweep, no_store, (head.reserved & 8) != 0, wave, lane);
+    if (full) q_units_fast<Q_DEPTH>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, next_unit, no_sweep, no_store, (head.reserved & 8) != 0, wave, lane);
     else q_units_simple<HAS_VAL>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, no_store, wave, lane);
 }
 
@@ -937,8 +1069,7 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
     const int loff = p * 16;
     const lds_cptr slab = (lds_cptr)xs;
     const bool no_sweep = head.reserved & 4, no_store = head.reserved & 1;
-    const int ustep = Q_WAVES * stride;
-    constexpr int MAX_SU = Q_MAXU / Q_SU;
+    const int ustep = Q_MULTI_WAVES * stride;
 
     // the job that holds the item, and the item's range inside it
     int j = first_job, base = 0;
@@ -958,7 +1089,7 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
     for (int blk = 0; blk < head.n_blocks; ++blk) {
         if (blk > 0 || !first_phase) q_barrier_lds();  // the previous block's readers are done
         const int begin = blk * head.block_cols, rows = min(head.block_cols, head.n_cols - begin);
-        q_stage<TIN>(head, begin, rows, head.block_cols, f0, xs, wave, lane, tid);
+        q_stage<TIN, Q_MULTI_THREADS>(head, begin, rows, head.block_cols, f0, xs, wave, lane, tid);
         // lane s < 16: {first chunk, width | flags} of this wave's slice s = (super-unit su_first + (s / 4) ustep, slice s % 4);
         // slices past the item's end: ghosts (nothing to sweep, nothing to store)
         i32x2 ext = {0, Q_CONT};
@@ -1030,12 +1161,16 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
 // items != NULL: segment `seg` = the phases items[seg_ptr[seg] .. seg_ptr[seg + 1]); items == NULL: one job (the by-value
 // descriptor), segment `seg` = its units seg, seg + n_segments, ...
 template <typename TIN, bool HAS_VAL, bool MULTI>
-__global__ __launch_bounds__(Q_THREADS) WDG_Q_OCCUPANCY void spmm_quad_kernel(const wdg_spmm_job *__restrict__ jobs,
+__global__ __launch_bounds__(MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS) void spmm_quad_kernel(const wdg_spmm_job *__restrict__ jobs,
                                                               const wdg_spmm_job inline_job,
                                                               const wdg_spmm_item *__restrict__ items,
                                                               const int32_t *__restrict__ seg_ptr, int subs, int n_groups,
                                                               int y_vec_all, unsigned long long *__restrict__ wg_clock) {
     extern __shared__ float4 q_lds[];
+    // (256 bytes in front of the slab, so that the slab stays aligned to the LDS's 256-byte bank row: the bank-aware entry order
+    // keys on it; [0] = the next super-unit number of the running phase, q_units_fast)
+    __shared__ int q_ctl[64];
+    const lds_iptr next_unit = (lds_iptr)q_ctl;
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
     const int n_local = subs * n_groups;
     bool first_phase = true;
@@ -1055,14 +1190,14 @@ __global__ __launch_bounds__(Q_THREADS) WDG_Q_OCCUPANCY void spmm_quad_kernel(co
                 const int fj = it->first_job, nj = it->n_jobs, ub = it->unit_begin, ue = it->unit_end;
                 Q_STAMP(2 + 2 * min(ph - pb, 2));  // (diagnostic build: start of the phase; + 1: its staging is done)
                 if (MULTI) q_phase_multi<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, first_phase, y_vec_all != 0);
-                else q_phase_single<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, first_phase, y_vec_all != 0);
+                else q_phase_single<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
                 first_phase = false;
             }
         } else {
             const int n_segments = kXcds * subs;
             const int n_units = inline_job.q_n_entries / Q_SU;
             if (MULTI) q_phase_multi<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
-            else q_phase_single<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
+            else q_phase_single<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
             first_phase = false;
         }
     }
@@ -1099,10 +1234,10 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
         configured_dev = dev;
     }
     const int cus = std::max(wdg_device_cus(), 8);
-    const int wgs_per_xcd = std::max(1, std::min(cus * WDG_Q_WGS_PER_CU / kXcds, subs * n_groups));
+    const int wgs_per_xcd = std::max(1, std::min(cus / kXcds, subs * n_groups));
     const dim3 grid(static_cast<unsigned>(wgs_per_xcd * kXcds));
 #define WDG_Q_LAUNCH(V, M)                                                                                             \
-    hipLaunchKernelGGL((spmm_quad_kernel<TIN, V, M>), grid, dim3(Q_THREADS), lds, st, jobs, inl, items, seg_ptr, subs, \
+    hipLaunchKernelGGL((spmm_quad_kernel<TIN, V, M>), grid, dim3(M ? Q_MULTI_THREADS : Q_FAST_THREADS), lds, st, jobs, inl, items, seg_ptr, subs, \
                        n_groups, y_vec_all ? 1 : 0, wg_clock)
     if (multi) {
         if (has_val) WDG_Q_LAUNCH(true, true);
@@ -1154,7 +1289,7 @@ int quad_single(const wdg_spmm_job &j, hipStream_t st) {
     int subs = static_cast<int>(ceil_div(2 * wgs_per_xcd, n_groups));
     subs = std::max(1, std::min(subs, static_cast<int>(ceil_div(n_units, 8 * kXcds))));
     if (j.q_n_blocks > 1) {  // a wave keeps <= Q_MAXU slices across the column blocks
-        const int need = static_cast<int>(ceil_div(n_units, static_cast<int64_t>(Q_MAXU / Q_SU) * Q_WAVES * kXcds));
+        const int need = static_cast<int>(ceil_div(n_units, static_cast<int64_t>(Q_MAXU / Q_SU) * Q_MULTI_WAVES * kXcds));
         subs = std::max(subs, need);
     }
     // 16-byte stores and 32-bit byte offsets into Y and into the index arrays (what the fast loop addresses with)
@@ -1169,6 +1304,17 @@ int quad_single_bf16(const wdg_spmm_job &j, hipStream_t st) { return quad_single
 
 extern "C" {
 
+#ifdef WDG_Q_PROFILE
+int wdg_debug_q_profile(unsigned long long *host_out, int n_blocks, int reset) {  // [n_blocks][16 waves][8]
+    const size_t bytes = sizeof(unsigned long long) * 8 * 16 * n_blocks;
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wdg_q_profile_buf), bytes) != hipSuccess) return -2;
+    if (reset) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(wdg_q_profile_buf)) != hipSuccess || hipMemset(p, 0, sizeof(wdg_q_profile_buf)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
 #ifdef WDG_STAMPS
 int wdg_debug_q_stamps(unsigned long long *host_out, int n_blocks) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wdg_q_stamp_buf), sizeof(unsigned long long) * 8 * n_blocks) == hipSuccess ? 0 : -2;
@@ -1299,7 +1445,7 @@ int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, cons
 int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat) {  // the grid of the batched launch (sizes wg_clock)
     const int n_groups = static_cast<int>(wdg::ceil_div(max_feat, 16));
     const int cus = std::max(wdg_device_cus(), 8);
-    return std::max(1, std::min(cus * WDG_Q_WGS_PER_CU / wdg::kXcds, (n_segments / wdg::kXcds) * n_groups)) * wdg::kXcds;
+    return std::max(1, std::min(cus / wdg::kXcds, (n_segments / wdg::kXcds) * n_groups)) * wdg::kXcds;
 }
 
 }  // extern "C"
