@@ -14,15 +14,28 @@ Workload per rank (weak scaling: fixed per-GPU work): the `data_synthesis/4000`-
   entries per row of A + I), F = 500 fp32 features (the directory name "4000" is k*400, every graph has 2000 nodes -
   SURVEY G3).  `--k 2 --seeds 10` is the `800` set (C2), the round-1 headline; it is emitted as `secondary` when
   `--secondary` is given.
-A step = one pass of the hot path over that batch with all inputs resident in HBM, 5 batched launches:
-  (1) A_hat [X | onehot(y)] aggregation, A_hat = D^-1 (A + I) fused into the SpMM (csrc/spmm_rowlane.hip; graphs of a
-      seed share X; the label aggregation of the LAS metric rides in the last, otherwise mostly empty feature group)
-  (2) edge/label statistics pass (csrc/edge_stats.hip)            (3) LAS counts (csrc/las.hip)
-  (4) GCN-2 feature path with per-graph weights relu(Y W0) W1, fused, fp32 matrix pipe (csrc/gemm.hip)   (5) A_hat (.)
-  (WDG_SWEEP_RIDE_LABELS=0 / WDG_SWEEP_FUSED_MLP=0 restore the separate label aggregation / the two GEMM launches: 7)
-`value` = stored entries of A+I aggregated per second over the whole job (all ranks); the dominant kernel's
-roofline is measured live with HIP events on the launch stream (sampled: 50 launches over the timed region); a bounded CPU sample of the same workload,
-run the way the reference does it, is reported as `cpu_baseline` (rank 0, N=1 only).
+A step = one pass of the hot path over that batch with all inputs resident in HBM, 4 batched launches:
+  (1) A_hat [X | onehot(y)] aggregation, A_hat = D^-1 (A + I) fused into the SpMM (csrc/spmm_quad.hip, spmm_quad_kernel:
+      graphs of a seed share X; the label columns of the LAS metric ride in the last, otherwise mostly empty feature group)
+  (2) LAS counts + the integer edge / label counters derived from the aggregated label columns (csrc/las.hip), on a second
+      stream beside (3)
+  (3) GCN-2 feature path with per-graph weights relu(Y W0) W1, fused, split-bf16 operands on the matrix pipe (csrc/gemm.hip)
+  (4) the logits aggregation A_hat (.) (F = C, csrc/spmm_narrow.hip)
+  (WDG_SWEEP_RIDE_LABELS=0 / WDG_SWEEP_FUSED_MLP=0 / WDG_SWEEP_DERIVE_COUNTS=0 restore the separate label aggregation / the
+  two GEMM launches / the integer pass over the edges: 7)
+`value` = stored entries of A+I aggregated per second over the whole job (all ranks); the dominant kernel's roofline is
+measured live with HIP events on the launch stream (sampled: 50 launches over the timed region); a bounded CPU sample of the
+same workload, run the way the reference does it, is reported as `cpu_baseline` (rank 0, N=1 only).
+
+Beside the headline the N = 1 line carries (each can be switched off, see --help):
+  secondary           the `800` set (k = 2, 100 graphs) through the same step
+  sweep_full / sweep_cold   all nine scalars of the sweep job: replayed on a resident batch / every graph visited once
+  configs             BASELINE.json configs[0], [3], [4] as stated + the literal N = 4000 reading of configs[2]: per launch `us`,
+                      kernel and roofline fraction (scripts/bench_configs.py holds the workloads)
+  train               train + eval sweep (sweep.TrainBatch on the C3 shard): SGC-1 and GCN-2, ms per epoch (hipGraph replay),
+                      graphs/s at 200 epochs
+  scaling_projection  this GPU timing every rank's shard of the 50-job sweep for world sizes 2 / 4 / 8 (sweep.shard_jobs):
+                      a PROJECTION of strong scaling from one device, labelled as such
 """
 import argparse
 import json
@@ -242,14 +255,9 @@ def measure_cold(args, dev):
             t1 = time.perf_counter()
             sb.step()
             ev = None
-            if nine:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-                sb.kr_sets.launch()
-                ev[1].record()
-                sb.gram.launch()
-                sb.ge.launch()
-                sb.kr.launch()
+            if nine:  # the same launch schedule as the pipelined figure beside it (launch_full: the sampler on its side stream)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if sb.kr_sets is not None else None
+                sb.launch_full(sample_events=ev)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             rows = sb.full_metrics() if nine else sb.results().cpu()
@@ -280,6 +288,117 @@ def measure_cold(args, dev):
                        f"F={args.feat}), each visited once: host COO -> batched build -> step -> metric rows on the host; nine_scalars adds "
                        f"Gram + maps, {args.kr_epochs} epochs of device-drawn node sets x 2 classifiers x 2 kernels = "
                        f"{len(shards[0][0]) * args.kr_epochs * 4} regressions per shard, t-tests; per-shard averages, one warm-up shard untimed")
+    return out
+
+
+def measure_configs(args, dev):
+    """BASELINE.json configs[0], [3], [4] as stated (+ the literal N = 4000 reading of configs[2]) in compact form: what each
+    launch takes, on which kernel, at what fraction of its roofline.  The workloads are scripts/bench_configs.py's."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench_configs as bc
+    reps = args.config_reps
+
+    def agg(rec):
+        r = rec["roofline"]
+        return {"workload": rec["workload"], "kernel": rec["kernel"], "us": round(r["avg_launch_us"], 2), "edges_per_s": rec["edges_per_s"],
+                "roofline": {"bound": r["bound"], "frac": round(r["frac"], 4), "achieved": round(r["achieved"], 1), "peak": r["peak"], "unit": r["unit"]},
+                **({"whole_step_us": round(rec["whole_step_us"], 1)} if "whole_step_us" in rec else {})}
+
+    def model(rec):
+        out = {"workload": rec["workload"], **({"forward_us": round(rec["forward_us"], 2)} if "forward_us" in rec else {}),
+               "legs": [{"leg": l["leg"], "us": round(l["us"], 2), "bound": l["roofline"]["bound"], "frac": round(l["roofline"]["frac"], 4)} for l in rec["legs"]]}
+        for k in ("metric_us_10_samples", "agg_homo_soft"):
+            if k in rec:
+                out[k] = rec[k]
+        return out
+
+    out = {}
+    out["C1 cora aggregation"] = agg(bc.c1(reps))
+    c1m = bc.c1_models(reps)
+    out["C1 cora SGC-1 (A X) W"], out["C1 cora SGC-1 A (X W)"] = model(c1m[0]), model(c1m[1])
+    torch.cuda.empty_cache()
+    for name, f in (("squirrel", 2089), ("chameleon", 2325)):
+        out[f"C4 {name} aggregation"] = agg(bc.c4(name, f, reps))
+        m = bc.c4_models(name, f, reps)
+        out[f"C4 {name} GCN-2"], out[f"C4 {name} SGC-1 (A X) W"], out[f"C4 {name} SGC-1 A (X W)"] = model(m[0]), model(m[1]), model(m[2])
+        torch.cuda.empty_cache()
+    sym, rw = bc.c5(reps)
+    out["C5 twitch aggregation sym bf16"], out["C5 twitch aggregation rw bf16"] = agg(sym), agg(rw)
+    m = bc.c5_models(reps)
+    out["C5 twitch agg-homophily (10 samples)"], out["C5 twitch SGC-1 (A X) W"], out["C5 twitch SGC-1 A (X W)"] = model(m[0]), model(m[1]), model(m[2])
+    torch.cuda.empty_cache()
+    out["C3-literal N=4000"] = agg(bc.literal("C3-literal", 4000, 10, 5, reps))
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_train(args, dev):
+    """Train + eval sweep (SURVEY 8(d) "separately train+eval when the model loop exists"; row N4, gnns_on_syn.py:9-154): one
+    model per graph of the C3 shard, all graphs per launch, an epoch (train step + evaluation + selection) = one hipGraph."""
+    import torch
+    from wdg_amd import sweep, synth
+    h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
+    jobs = sweep.make_jobs(h_levels, range(args.seeds), k=args.k, n_nodes=args.nodes)
+    sb = sweep.SweepBatch(jobs, n_feat=args.feat, gcn_hidden=0)
+    for s_ in sb.x:  # features that carry the class (the reference's synthetic features are sampled from real nodes of the class)
+        lab = synth.regular_graph(args.nodes, 5, args.k, 0.5, s_)[2]
+        sb.x[s_].copy_(torch.from_numpy(synth.features(args.nodes, args.feat, s_, labels=lab)))
+    out = {"workload": f"train + eval of one model per graph, {len(jobs)} graphs (k={args.k}, {args.seeds} seeds, N={args.nodes}, F={args.feat}), "
+                       f"Adam, 60/20/20 split, an epoch = train step + evaluation + model selection, replayed as one hipGraph; "
+                       f"{args.train_epochs} epochs timed, graphs/s quoted at the reference's 200 epochs"}
+    for kind, name in (("sgc", "SGC-1"), ("gcn", "GCN-2")):
+        tb = sweep.TrainBatch(sb, kind=kind, hidden=64, seed=1)
+        tb.run(epochs=3, capture=True)  # (capture + first replays)
+        r = tb.run(epochs=args.train_epochs, capture=True)
+        ms = r["seconds"] / r["epochs"] * 1e3
+        out[name] = {"ms_per_epoch": ms, "graphs_per_s_at_200_epochs": tb.J / (ms * 1e-3 * 200), "edges_per_s": sb.edges / (ms * 1e-3),
+                     "mean_test_acc": float(r["test_acc"].mean())}
+        del tb
+        torch.cuda.empty_cache()
+    return out
+
+
+def measure_projection(args, dev, full_ms):
+    """Strong scaling PROJECTED from one device: configs[2]'s 50 jobs sharded by sweep.shard_jobs for world sizes 2 / 4 / 8, every
+    rank's shard built and stepped on THIS GPU (plain launches and the whole step replayed from one hipGraph; the faster is
+    taken, as a rank would).  speedup = T(all jobs on one GPU) / max over ranks T(shard).  No second device is involved: what
+    this cannot see is contention for the host (8 processes enqueueing) and the exchange at the end (KBs)."""
+    import torch
+    from wdg_amd import sweep, synth
+    h_levels = synth.H_LEVELS_10 if args.k == 2 else synth.H_LEVELS_10_K10
+    jobs = sweep.make_jobs(h_levels, range(args.seeds), k=args.k, n_nodes=args.nodes)
+    steps = args.projection_steps
+
+    def time_steps(fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    out = {"note": "PROJECTION from one GPU, not a measurement on N devices", "jobs": len(jobs), "one_gpu_ms_per_step": full_ms, "worlds": {}}
+    for w in (2, 4, 8):
+        per_rank = []
+        for r in range(w):
+            mine = sweep.shard_jobs(jobs, w, r)
+            sb = sweep.SweepBatch(mine, n_feat=args.feat)
+            plain = time_steps(sb.step)
+            graph = time_steps(sb.capture_step()) if mine else plain
+            per_rank.append({"graphs": len(mine), "plain_ms": plain, "graph_ms": graph})
+            del sb
+            torch.cuda.empty_cache()
+        worst = max(min(p["plain_ms"], p["graph_ms"]) for p in per_rank)
+        out["worlds"][str(w)] = {"graphs_per_rank": [p["graphs"] for p in per_rank],
+                                 "ms_per_step_per_rank_plain": [round(p["plain_ms"], 4) for p in per_rank],
+                                 "ms_per_step_per_rank_graph": [round(p["graph_ms"], 4) for p in per_rank],
+                                 "slowest_rank_ms": worst, "projected_strong_speedup": full_ms / worst,
+                                 "projected_strong_speedup_plain_launches": full_ms / max(p["plain_ms"] for p in per_rank),
+                                 "weak_scaling": f"{w}.0 x by construction (every rank steps its own {len(jobs)}-graph shard; no data-path collective)"}
     return out
 
 
@@ -347,6 +466,14 @@ def main():
     ap.add_argument("--cold", type=int, default=1, help="1: also time the one-pass (cold) sweep - distinct shards from host COO to "
                     "metric rows, everything inside the clock - and report it as `sweep_cold` (N=1 only)")
     ap.add_argument("--cold-shards", type=int, default=3)
+    ap.add_argument("--configs", type=int, default=1, help="1: also time BASELINE configs[0], [3], [4] as stated and the literal N = 4000 "
+                    "reading of configs[2] and report them as `configs` (N=1 only)")
+    ap.add_argument("--config-reps", type=int, default=10)
+    ap.add_argument("--train", type=int, default=1, help="1: also time the train + eval sweep (SGC-1, GCN-2) on the shard and report it as `train` (N=1 only)")
+    ap.add_argument("--train-epochs", type=int, default=30)
+    ap.add_argument("--projection", type=int, default=1, help="1: also step every rank's shard of the 50-job sweep for world sizes 2 / 4 / 8 on "
+                    "this GPU and report the projected strong scaling as `scaling_projection` (N=1 only)")
+    ap.add_argument("--projection-steps", type=int, default=100)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: --seeds seeds PER RANK (per-GPU work fixed); "
                     "strong: --seeds seeds in all (configs[2] literally: 50 jobs), sharded over the ranks")
     ap.add_argument("--timeout", type=float, default=1500.0, help="self-launched workers (--gpus N > 1) are stopped after this many seconds")
@@ -411,6 +538,15 @@ def main():
     if world == 1 and args.cold:
         torch.cuda.empty_cache()
         out["sweep_cold"] = measure_cold(args, dev)
+    if world == 1 and args.configs:
+        torch.cuda.empty_cache()
+        out["configs"] = measure_configs(args, dev)
+    if world == 1 and args.train:
+        torch.cuda.empty_cache()
+        out["train"] = measure_train(args, dev)
+    if world == 1 and args.projection:
+        torch.cuda.empty_cache()
+        out["scaling_projection"] = measure_projection(args, dev, out["ms_per_step"])
     if rank == 0:
         if world == 1 and args.cpu_budget > 0:
             from oracle import cpu_ref

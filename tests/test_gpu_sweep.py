@@ -67,6 +67,26 @@ def test_step_rest_graph_replay_equals_plain_launches():
     assert torch.equal(batch.results(), want[1]) and torch.equal(batch.las.counts, want[2])
 
 
+def test_whole_step_graph_replay_of_a_small_shard_equals_plain_launches():
+    """SweepBatch.capture_step(): a 6-graph shard (what a rank holds when configs[2]'s 50 jobs are spread over 8 GPUs) steps
+    from ONE hipGraph - the feature aggregation included - with bit for bit the outputs of the plain launches."""
+    from wdg_amd import sweep, synth
+    jobs = sweep.shard_jobs(sweep.make_jobs(synth.H_LEVELS_10_K10, range(5), k=10, n_nodes=2000), 8, 0)
+    assert 6 <= len(jobs) <= 7
+    batch = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=64)
+    batch.step()
+    torch.cuda.synchronize()
+    want = ([y.clone() for y in batch.y], [l.clone() for l in batch.gcn["logits"]], batch.results().clone(), batch.las.counts.clone())
+    replay = batch.capture_step()
+    for t in list(batch.y) + list(batch.gcn["logits"]):
+        t.fill_(float("nan"))
+    replay()
+    torch.cuda.synchronize()
+    for a, b in zip(list(batch.y) + list(batch.gcn["logits"]), want[0] + want[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(batch.results(), want[2]) and torch.equal(batch.las.counts, want[3])
+
+
 def test_batched_gemm_and_las_mixed_shapes(oracle):
     from wdg_amd import ops
     rng = np.random.default_rng(3)

@@ -91,6 +91,8 @@ def test_welch_p_values_equal_scipys_ttest():
     g[4, 1], x[4, 1] = 0.5, 0.5
     x[5, 0] = g[5, 0] - 0.2  # the graph-aware regression wins every epoch
     x[6, 1] = g[6, 1] + 0.2
+    g[7, 0], x[7, 0] = 1.0, 0.5  # two constant samples with DIFFERENT means: scipy sets df = 1, t = -inf -> p = 0 -> the metric is 1
+    g[8, 1], x[8, 1] = 0.25, 0.75
     got = welch_p_values(g, x)
     assert got.shape == (40, 2)
     with warnings.catch_warnings():
@@ -99,6 +101,7 @@ def test_welch_p_values_equal_scipys_ttest():
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).sum() == 1
     assert np.nanmax(np.abs(got - want)) < 1e-6
     assert got[5, 0] > 1 - 1e-6 and got[6, 1] < 1e-6  # (the reference's side rule: 1 - p / 2 when the graph-aware side wins)
+    assert got[7, 0] == 1.0 and got[8, 1] == 0.0 and want[7, 0] == 1.0 and want[8, 1] == 0.0
 
 
 def test_two_rank_sweep_gloo(tmp_path):

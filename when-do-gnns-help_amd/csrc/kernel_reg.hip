@@ -987,8 +987,11 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     const global_ptr<const int32_t> train = to_global(job->train), val = to_global(job->val), labels = to_global(job->labels);
     const int64_t ldk = job->ldk;
     const int nt = job->n_train, nv = job->n_val, C = job->n_classes;
-    const int ablate = job->reserved;  // timing-only diagnostics (scripts/dev/time_kr_batch.py): 1 no gather, 2 no factorisation,
-                                       // 4 no back substitution, 8 no predictions; 0 on every product path
+#ifdef WDG_KR_ABLATION  // diagnostic build only (make EXTRA=-DWDG_KR_ABLATION; scripts/dev/time_kr_batch.py): timing-only ablations
+    const int ablate = job->reserved;  // 1 no gather, 2 no factorisation, 4 no back substitution, 8 no predictions (results are wrong)
+#else
+    constexpr int ablate = 0;  // (the shipped kernel ignores the descriptor's reserved word: a stray value cannot change a result)
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li_ = lane & 31, h_ = lane >> 5;
     if (nt <= 0 || nt > K2_NB * 32 || C <= 0 || C > KR_MAX_C) {
         if (tid == 0 && job->correct_out) *to_global(job->correct_out) = -1;

@@ -347,7 +347,7 @@ class GraphBatch:
         check(lib.wdg_coo_to_csr_i32(_ptr(src), _ptr(dst), _ptr(val), e_total, self.n_total, flags, _ptr(self.rowptr), _ptr(self.col),
                                      _ptr(self.val), c_void_p(info.data_ptr() + 8), _ptr(ws), ws_bytes, st), "wdg_coo_to_csr_i32")
         # per-graph buffers of the SELL-16 build, pooled; the job table's rowptr / col / val are filled in by the split kernel
-        self.rowptr_pool = torch.empty(self.n_total + G, dtype=torch.int32, device=dev)
+        self.rowptr_pool = torch.zeros(self.n_total + G, dtype=torch.int32, device=dev)  # (zeros: a graph of no nodes keeps rowptr = [0])
         quad = quad and not quad_disabled() and G > 0
         jobs = (_lib.Sell16Job * max(G, 1))()
         if quad:
@@ -379,9 +379,14 @@ class GraphBatch:
               "wdg_csr_split_blockdiag")
         if quad:
             check(lib.wdg_csr_to_sell16_count_batched(_ptr(table), G, max(ns), max(ns), st), "wdg_csr_to_sell16_count_batched")
-        # ---- the shard's ONE host read-back
+        # ---- the shard's ONE host read-back: the info block and, behind it in the same buffer, the pool of extents (64 KB for 50
+        #      graphs: the widths price the aggregation's tape cut, the tails size the index arrays) - one blocking copy
         info[0:1].copy_(bad[0:1])
-        info_h = info.cpu().numpy()
+        if quad:
+            both = torch.cat([info.view(torch.int32), ext]).cpu().numpy()
+            info_h, ext_h = both[:2 * info.numel()].view(np.int64), both[2 * info.numel():]
+        else:
+            info_h = info.cpu().numpy()
         if info_h[0] != 0 or info_h[1] < 0:
             raise IndexError("edge index out of range for its graph")
         nnz_g = info_h[2:2 + G]
@@ -394,7 +399,6 @@ class GraphBatch:
                                         self.val[int(base[g_]):int(base[g_ + 1])], ns[g_], ns[g_]))
         if not quad:
             return
-        ext_h = ext.cpu().numpy()
         want, chunks_g = [], []
         for g_ in range(G):
             tail = ext_h[int(ext_off[g_]) + ext_len[g_] - 2:int(ext_off[g_]) + ext_len[g_]]
@@ -1298,7 +1302,10 @@ class KrBatch:
         tab["correct_out"] = self.correct.data_ptr() + 4 * np.arange(n, dtype=np.int64)
         tab["flags_out"] = self.flags.data_ptr() + 4 * np.arange(n, dtype=np.int64)
         tab["ldk"], tab["n_train"], tab["n_val"], tab["n_classes"] = ldk, n_train, n_val, int(n_classes)
-        tab["reserved"] = int(os.environ.get("WDG_KR_ABLATE", "0"))  # timing-only diagnostics of the blocked solver; 0 = none
+        # (timing-only diagnostics of the blocked solver: honoured only by a library built with -DWDG_KR_ABLATION, and never
+        # mistaken for a result - accuracy() refuses)
+        self.ablate = int(os.environ.get("WDG_KR_ABLATE", "0"))
+        tab["reserved"] = self.ablate
         self.table = torch.from_numpy(tab.view(np.uint8)).to(dev) if n else torch.empty(0, dtype=torch.uint8)
 
     def launch(self):
@@ -1310,6 +1317,8 @@ class KrBatch:
 
     def accuracy(self):
         """[n_problems] fp32 hit rate on the validation rows; raises when the kernel refused a problem (sentinel -1)"""
+        if getattr(self, "ablate", 0):
+            raise _lib.WdgError("KrBatch: WDG_KR_ABLATE is set - the launch was a timing-only ablation, its accuracies mean nothing")
         correct = self.correct[:self.n_jobs]
         if self.n_jobs and bool((correct < 0).any().item()):
             raise _lib.WdgError("wdg_kernel_regress_batched_f32 refused a problem (shape outside the solver's limits)")

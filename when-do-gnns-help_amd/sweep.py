@@ -84,30 +84,39 @@ def shard_jobs(jobs, world_size, rank, slack=0.02):
         seeds[r].add(j.seed)
         owner[i] = r
     # refinement: while it shortens the longest shard, move one of its jobs to - or swap one with - another rank (LPT alone
-    # leaves 50 jobs on 8 ranks 14 % apart; the sweep ends with its slowest rank)
-    for _ in range(4 * len(jobs)):
-        hi = max(range(world_size), key=lambda q: (load[q], -q))
-        best = None  # (new maximum of the pair, i, j | None, other rank)
-        for i in (i for i in order if owner[i] == hi):
-            ci = job_cost(jobs[i])
-            for q in range(world_size):
-                if q == hi:
-                    continue
-                for k in [None] + [k for k in order if owner[k] == q]:
-                    ck = 0 if k is None else job_cost(jobs[k])
-                    if ck >= ci:
-                        continue
-                    top = max(load[hi] - ci + ck, load[q] + ci - ck)
-                    if top < load[hi] and (best is None or top < best[0]):
-                        best = (top, i, k, q)
-        if best is None:
+    # leaves 50 jobs on 8 ranks 14 % apart; the sweep ends with its slowest rank).  Jobs of equal cost are interchangeable,
+    # so a round looks at one representative per (rank, cost) - numpy over the distinct costs - and the rounds stop at the
+    # first one that gains less than 0.01 % of a fair share (the reference's 1 800-job sweep on 8 ranks: milliseconds).
+    cost = np.array([job_cost(j) for j in jobs], dtype=np.int64)
+    owner = np.array(owner, dtype=np.int64)
+    load = np.array(load, dtype=np.int64)
+    for _ in range(min(4 * len(jobs), 256)):
+        hi = int(np.lexsort((np.arange(world_size), -load))[0])  # the heaviest rank, lowest id among equals
+        mine_hi = np.flatnonzero(owner == hi)
+        if mine_hi.size == 0:
+            break
+        ci, first_i = np.unique(cost[mine_hi], return_index=True)
+        best = None  # (new maximum of the pair, job of hi, job of q | -1, q)
+        for q in range(world_size):
+            if q == hi:
+                continue
+            theirs = np.flatnonzero(owner == q)
+            ck, first_k = np.unique(cost[theirs], return_index=True) if theirs.size else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+            ck = np.concatenate([[0], ck])  # (0: a plain move)
+            kid = np.concatenate([[-1], theirs[first_k]]) if theirs.size else np.array([-1])
+            top = np.maximum(load[hi] - ci[:, None] + ck[None, :], load[q] + ci[:, None] - ck[None, :])
+            top = np.where(ck[None, :] < ci[:, None], top, np.iinfo(np.int64).max)
+            a_, b_ = np.unravel_index(np.argmin(top), top.shape)
+            if top[a_, b_] < load[hi] and (best is None or top[a_, b_] < best[0]):
+                best = (int(top[a_, b_]), int(mine_hi[first_i[a_]]), int(kid[b_]), q)
+        if best is None or load[hi] - best[0] < 1e-4 * fair:
             break
         _top, i, k, q = best
-        ci, ck = job_cost(jobs[i]), (0 if k is None else job_cost(jobs[k]))
-        load[hi] += ck - ci
-        load[q] += ci - ck
+        dk = 0 if k < 0 else int(cost[k])
+        load[hi] += dk - cost[i]
+        load[q] += cost[i] - dk
         owner[i] = q
-        if k is not None:
+        if k >= 0:
             owner[k] = hi
     mine = [i for i in range(len(jobs)) if owner[i] == rank]
     return [jobs[i] for i in sorted(mine, key=lambda i: (jobs[i].seed, i))]
@@ -395,6 +404,21 @@ class SweepBatch:
         self._graph = graph  # keep alive
         return graph.replay
 
+    def capture_step(self):
+        """step() - the feature aggregation AND everything behind it, both streams - as ONE hipGraph.  On a 50-graph shard the
+        plain launches are faster (the device is the bound: 0.185 vs 0.20 ms); on the 6 - 7-graph shards of a 50-job sweep
+        spread over 8 GPUs the step's 25 - 35 us of device work sit behind ~50 us of host enqueue, which one graph launch
+        replaces (bench.py `scaling_projection`).  Returns the replay callable; outputs land in the same tensors, bit for
+        bit the plain launches' (tests/test_gpu_sweep.py)."""
+        for _ in range(2):
+            self.step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step()
+        self._step_graph = graph  # keep alive
+        return graph.replay
+
     def _metric_chain(self):
         if self.derive_counts:
             self.las.launch()       # soft / hard LAS counts + the integer counters, derived from the label columns of Y
@@ -547,8 +571,10 @@ class SweepBatch:
             val.data_ptr() + 4 * (pair * epochs + epoch) * val.shape[2], lab_ptr[ji], n_tr[ji], n_va[ji], self.n_classes,
             keep=(train, val, self.gram))
 
-    def launch_full(self):
-        """the launches of the three extra scalars (after the aggregation: they read Y): Gram + maps, edge cosines, regressions"""
+    def launch_full(self, sample_events=None):
+        """the launches of the three extra scalars (after the aggregation: they read Y): Gram + maps, edge cosines, regressions
+        (sample_events: an optional pair of torch events recorded around the node-set sampler on the stream it runs on -
+        bench.py's `sample_ms`; nothing is recorded when the sets were drawn on the host)"""
         side = None
         if self.kr_sets is not None:
             # the epochs' node sets (device sampler; a host-sampled batch uploaded them in prepare_full) depend on nothing the
@@ -560,9 +586,17 @@ class SweepBatch:
                 side = self._side_stream
                 side.wait_stream(cur)  # (the previous batch's regressions have read the old sets)
                 with torch.cuda.stream(side):
+                    if sample_events:
+                        sample_events[0].record()
                     self.kr_sets.launch()
+                    if sample_events:
+                        sample_events[1].record()
             else:
+                if sample_events:
+                    sample_events[0].record()
                 self.kr_sets.launch()
+                if sample_events:
+                    sample_events[1].record()
         self.gram.launch()
         self.ge.launch()
         if side is not None:
@@ -575,9 +609,19 @@ class SweepBatch:
         if not self.jobs:
             return torch.zeros((0, len(METRIC_NAMES)), dtype=torch.float64)
         nj = len(self.jobs)
-        # one copy back: the step's scalars, the edge cosine means and the 4 x epochs accuracies of every job
+        # one copy back: the step's scalars, the edge cosine means, the 4 x epochs accuracies of every job and the count of
+        # train blocks the solver had to regularise
         packed = torch.cat([self.results().to(torch.float64).reshape(-1), self.ge.mean[:nj].to(torch.float64).reshape(-1),
-                            self.kr.accuracy().to(torch.float64).reshape(-1)]).cpu()
+                            self.kr.accuracy().to(torch.float64).reshape(-1), self.kr.ridged().sum().to(torch.float64).reshape(1)]).cpu()
+        # (rank-deficient train blocks: solved with a rounding-level ridge where the reference's pinv inverts the rounding-level
+        # singular values - counted and said once per shard, like utils/homophily_metrics.py does per call)
+        self.kr_ridged = int(packed[-1].item())
+        packed = packed[:-1]
+        if self.kr_ridged and os.environ.get("WDG_KR_QUIET", "0") in ("", "0"):
+            import warnings
+            warnings.warn(f"kernel regression: {self.kr_ridged} of {self.kr.n_jobs} train blocks of this shard were rank-deficient at fp32 "
+                          "rounding level and solved with a ridge; their accuracies can differ from the reference's pseudo-inverse by a "
+                          "few validation rows (WDG_KR_SOLVER=host runs the reference's host path per graph)", stacklevel=2)
         n_base = packed.numel() - nj - nj * 2 * self.kr_epochs * 2
         base = packed[:n_base].reshape(nj, -1)
         ge = packed[n_base:n_base + nj]
@@ -598,7 +642,9 @@ def welch_p_values(g_res, x_res):
     with np.errstate(divide="ignore", invalid="ignore"):
         t = (x.mean(-1) - g.mean(-1)) / np.sqrt(vx + vg)
         df = (vx + vg) ** 2 / (vx ** 2 / (n - 1) + vg ** 2 / (n - 1))
-        p = 2.0 * stdtr(df.astype(np.float64), -np.abs(t).astype(np.float64))  # (NaN when both samples are constant, as scipy propagates it)
+        df = np.where(np.isnan(df), 1, df)  # (both samples constant: scipy's _unequal_var_ttest_denom sets df = 1, so that different
+        # means give t = +-inf -> p = 0 and equal means t = NaN -> p = NaN, which the reference then folds like any p-value)
+        p = 2.0 * stdtr(df.astype(np.float64), -np.abs(t).astype(np.float64))
     better = (np.asarray(g_res, np.float32) > np.asarray(x_res, np.float32)).astype(np.float32).mean(-1)
     return np.where(better <= 0.5, p / 2, 1 - p / 2)
 
