@@ -87,6 +87,36 @@ def test_whole_step_graph_replay_of_a_small_shard_equals_plain_launches():
     assert torch.equal(batch.results(), want[2]) and torch.equal(batch.las.counts, want[3])
 
 
+def test_whole_sweep_over_feature_bases_equals_stand_alone_batches():
+    """sweep.run_bases (synthetic_plot.py:64-109: every adjacency paired with features of every base; graphs built once per
+    shard and shared by the bases, base-shards pipelined over two streams): every (shard, base) gives the rows of a stand-alone
+    SweepBatch over the same inputs with the same node-set keys - uneven shards, widths on both sides of the fused-transform /
+    one-slab limits, two sample sizes."""
+    from wdg_amd import sweep, synth
+    levels, samples = [0.2, 0.5, 0.8], [0, 1]
+    graphs = {(h, s_): synth.regular_graph(600, 5, 4, h, s_) for h in levels for s_ in samples}
+    bases = [("a", {s_: synth.features(600, 40, 10 + s_) for s_ in samples}, 500),
+             ("b", {s_: synth.features(600, 530, 20 + s_) for s_ in samples}, 300),
+             ("c", {s_: synth.features(600, 97, 30 + s_) for s_ in samples}, 500)]
+    shards = []
+    for lv in (levels[:2], levels[2:]):
+        jobs = sweep.make_jobs(lv, samples, k=4, n_nodes=600)
+        shards.append((jobs, [graphs[(j.h, j.seed)] for j in jobs]))
+    got = {(si, bi): rows for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=2, first_seed=5)}
+    assert sorted(got) == [(si, bi) for si in range(2) for bi in range(3)]
+    for (si, bi), rows in got.items():
+        jobs, gi = shards[si]
+        _name, feats, sample_max = bases[bi]
+        sb = sweep.SweepBatch(jobs, n_feat=next(iter(feats.values())).shape[1], gcn_hidden=0,
+                              inputs=[(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, gi)])
+        sb.prepare_full(epochs=6, sample_max=sample_max, base_seed=5 + 1000 * bi + si)
+        sb.step()
+        sb.launch_full()
+        want = sb.full_metrics()
+        assert rows.shape == (len(jobs), 9)
+        assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (si, bi)
+
+
 def test_batched_gemm_and_las_mixed_shapes(oracle):
     from wdg_amd import ops
     rng = np.random.default_rng(3)

@@ -686,6 +686,54 @@ def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symme
         yield fetch()
 
 
+def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0):
+    """The reference's WHOLE sweep (synthetic_plot.py:64-109: 6 feature bases x 30 homophily levels x 10 samples = 1 800 jobs, nine
+    scalars each), one pass, PIPELINED like run_shards: a generator of (shard index, base index, rows [jobs, 9] fp64 on the host).
+
+    shards: list of (jobs, graph_inputs) - graph_inputs[i] = (src, dst, labels) host arrays of job i (an adjacency belongs to a
+            (homophily level, sample) pair: `job.seed` = the sample);
+    bases:  list of (name, features, sample_max) - features[seed] = [n, F_base] fp32 host array of that base's sample `seed`
+            (synthetic_plot.py:81-82), sample_max as synthetic_plot.py:66 (300 for chameleon / film, else 500).
+    A shard's graphs (CSR, SELL-16 copy, degrees, labels) are built ONCE, by its first base; the other bases' batches share them
+    (SweepBatch(share=...)) and aggregate their own feature matrices over them.  Base-shard b runs on HIP stream b mod `depth`
+    and its rows are fetched when `depth` are in flight.  Every (shard, base) computes the rows a stand-alone SweepBatch over
+    the same inputs computes (tests/test_gpu_sweep.py)."""
+    from collections import deque
+    depth = max(1, int(depth))
+    streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
+    in_flight = deque()
+
+    def fetch():
+        si, bi, sb, stream = in_flight.popleft()
+        with torch.cuda.stream(stream):
+            return si, bi, sb.full_metrics()
+
+    n = 0
+    for si, (jobs, graph_inputs) in enumerate(shards):
+        first = None
+        for bi, (_name, feats, sample_max) in enumerate(bases):
+            stream = streams[n % depth]
+            if first is not None and depth > 1:
+                stream.wait_stream(first_stream)  # (the shared graphs are built on the first base's stream)
+            with torch.cuda.stream(stream):
+                inputs = [(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, graph_inputs)]
+                sb = SweepBatch(jobs, n_feat=next(iter(feats.values())).shape[1] if feats else 0, symmetric=symmetric, gcn_hidden=0,
+                                inputs=inputs, share=first)
+                if sb.jobs:
+                    sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + 1000 * bi + si)
+                sb.step()
+                if sb.jobs:
+                    sb.launch_full()
+            if first is None:
+                first, first_stream = sb, stream
+            in_flight.append((si, bi, sb, stream))
+            n += 1
+            if len(in_flight) >= depth:
+                yield fetch()
+    while in_flight:
+        yield fetch()
+
+
 class BaseSweep:
     """The feature bases of the reference's sweep (synthetic_plot.py:64-65,78-82: the 300 synthetic adjacencies are paired
     with features sampled from each of six base datasets, 1 800 jobs): one SweepBatch per base over the SAME jobs, all of
