@@ -284,3 +284,18 @@ def test_epoch_node_sets_reproduce_the_reference_stream(name):
         got = kernel_regression_epoch_indices(labels, kr["sample_max"], kr["epochs"])
         for (tr, va), (tr0, va0) in zip(got, kr[clf]["node_sets"]):
             assert np.array_equal(tr.numpy(), tr0) and np.array_equal(va.numpy(), va0)
+
+
+@pytest.mark.parametrize("name", SYN)
+def test_reference_pattern_restatement_reproduces_the_references_scalars(name):
+    """oracle/ref_pattern.py - the dense-tensor / Python-loop call pattern of utils/homophily_plot.py that bench.py's cpu_baseline
+    times - against the scalars the real reference computed for the same graph: exact to fp32 printing (same operations, same
+    order)."""
+    import torch
+    from oracle import ref_pattern as rp
+    d = load(name)
+    n, lab = int(d["n_nodes"]), np.asarray(d["labels"])
+    adj = rp.normalised_dense_adjacency(d["adj_row"], d["adj_col"], n)
+    got = rp.six_scalars(adj, torch.eye(int(lab.max()) + 1)[torch.as_tensor(lab)])
+    want = [float(d["m_" + k]) for k in ("edge_homo", "node_homo", "class_homo", "adj_homo", "label_info", "soft_las")]
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
