@@ -245,9 +245,13 @@ int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float 
  * CSR -> SELL-16 (the index layout of the quad-row kernel, csrc/spmm_quad.hip): rows sorted by length (q_perm[slot] = row),
  * slices of 16 slots, columns cut into ceil(n_cols / B) blocks of B = wdg_sell16_block_cols(n_cols) <= 2528 (what one
  * 16-feature slab of X occupies in LDS), entries in chunks of 16 per row.  Inside a (row, block) segment the entries are
- * stored in a bank-aware order (the four rows an LDS service group reads together get columns of different classes mod 4
- * wherever the rows allow it), which fixes the order of the row's sum; WDG_SELL_ORDER=0 in the environment of the fill
- * call keeps column order (the sequential CSR order).  The slices are then laid out as ENTRIES, four per super-unit (see
+ * stored in a bank-aware order (the four rows an LDS service group reads together get columns of different classes mod 4),
+ * which fixes the order of the row's sum.  Graphs in split form get the CONFLICT-FREE order (round 4): the fill also decides
+ * which rows of a slice share a service group - it PERMUTES q_rows inside the slice's entries - and reads a shorter row's
+ * padding from one of four zero rows (offsets 64 (B + c), c = 0..3: the kernel appends four zero rows to the slab) at
+ * whichever step keeps the group conflict-free; other graphs keep round 2's greedy order (padding = offset 64 B, at the end).
+ * WDG_SELL_ORDER in the environment of the fill call: 0 = column order (the sequential CSR order), 1 = greedy everywhere.
+ * The slices are then laid out as ENTRIES, four per super-unit (see
  * wdg_spmm_job.q_ext): graphs with one column block and at most 128 entries per row and block in split form.
  * Two calls: count fills q_perm (16 ceil(N/16) entries), q_ext and q_rows - sized for M = wdg_sell16_max_entries(N) entries per
  * block: q_ext 2 (n_blocks M + 1) ints, q_rows 16 M ints; the pair {chunk count, entries per block | WDG_SELL16_CONT if
@@ -260,8 +264,8 @@ size_t wdg_sell16_workspace_bytes(int32_t N, int32_t n_cols);
 int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *q_perm,
                             int32_t *q_ext, int32_t *q_rows, void *workspace, size_t workspace_bytes, wdg_stream_t stream);
 int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
-                           const int32_t *q_rows, const int32_t *q_ext, int32_t n_entries, int32_t *q_col, float *q_val,
-                           wdg_stream_t stream);
+                           int32_t *q_rows /* in / out: see above */, const int32_t *q_ext, int32_t n_entries, int32_t *q_col,
+                           float *q_val, wdg_stream_t stream);
 
 /*
  * The same build for a table of graphs (a sweep shard): count = sort + widths + scan / pack + entries of every graph in four

@@ -72,7 +72,7 @@ constexpr int Q_CHUNK = 16;            // entries per row and index chunk (one 1
 constexpr int Q_CHUNK_INTS = Q_ROWS * Q_CHUNK;
 constexpr int Q_SU = 4;                // slices per super-unit (64 rows): the granule the kernel's waves are dealt
 constexpr int Q_SU_ROWS = Q_SU * Q_ROWS;
-constexpr int Q_MAX_BLOCK_COLS = 2528; // rows of a slab block: (2528 + 1 zero row) x 64 B = 158.1 KiB of the 160 KiB
+constexpr int Q_MAX_BLOCK_COLS = 2528; // rows of a slab block: (2528 + 4 zero rows) x 64 B = 158.3 KiB of the 160 KiB (+ 256 B of q_ctl)
 constexpr int Q_MAX_BLOCKS = 4;        // column blocks (graphs of up to 10 112 columns); more: the CSR kernels
 constexpr int Q_MAXU = 16;             // units (slices) per wave and phase when a graph has several column blocks: 4 super-units
                                        // x 16 waves = 64 super-units = 4096 rows per item - a whole N = 4000 graph, so that a
@@ -285,20 +285,263 @@ __global__ __launch_bounds__(256) void sell16_entries(const int32_t *__restrict_
                         max_entries, ext, rows);
 }
 
+// ---- the CONFLICT-FREE order of a slice (round 4; graphs in split form: one column block, rows of <= 128 entries).
+// The sweep reads, per step, one 64-byte slab row per row of the slice, four rows per LDS cycle ({0,3,5,6}, {1,2,4,7}, + 8): a
+// cycle is conflict-free when its four source rows lie in four different bank windows (column mod 4).  Round 2's greedy order
+// left 1.13 - 1.30 LDS cycles per group and step on the sweep's graphs (measured: SQ_LDS_BANK_CONFLICT = 25 % of the
+// conflict-free cycles, on the pipe that bounds the kernel).  Three freedoms remove most of it:
+//   * WHICH four rows share a cycle: the 16 rows of a slice are equally long, any of them may sit in any slot.  The rows are
+//     dealt to the four groups so that no group holds more than T entries of one window class (T = the steps the slice is swept
+//     for): 64 candidate deals (one per lane: a greedy pass over a pseudo-random row order), the best kept.  q_rows is rewritten;
+//   * WHEN a row's padding is read: a row shorter than T reads the zero row T - len times - at any step, and from any window:
+//     the slab ends in FOUR zero rows, one per class (block_cols is a multiple of 4);
+//   * the order inside a group: with every class total <= T a schedule without conflicts exists (the 4 x 4 count matrix plus the
+//     free padding decomposes into T permutations); per step the 24 permutations of (row -> class) are scored - feasible, keeps
+//     every class total within the steps left, prefers the fullest classes - by 16 lanes per group, the best applied.
+// Simulated on the sweep's graphs: 1.04 - 1.06 cycles per group and step.  A row's sum order changes with it (fixed per graph,
+// as before); WDG_SELL_ORDER=0 keeps column order.  Slices that hold padding slots (a graph's last, N % 16 != 0) keep the greedy
+// order (their duplicate rows must agree entry by entry).
+constexpr int QB_MAXW = 128;  // entries per row in split form
+struct QbShared {
+    int col[Q_ROWS][QB_MAXW];             // the slice's rows, local columns, column order
+    unsigned char order[Q_ROWS][QB_MAXW];  // per row: entry ids sorted by class (stable)
+    unsigned char pick[Q_ROWS][QB_MAXW];   // per NEW slot and step: class | real << 2
+};
+__device__ __forceinline__ int qb_field8(unsigned v, int c) { return (v >> (8 * c)) & 0xff; }
+__device__ __forceinline__ int qb_group_slot(int g, int i) {  // slot of member i of LDS service group g
+    constexpr unsigned long long tbl = 0x6530ull | (0x7421ull << 16) | (0xedb8ull << 32) | (0xfca9ull << 48);
+    return static_cast<int>((tbl >> (16 * g + 4 * i)) & 0xf);
+}
+__device__ __forceinline__ unsigned qb_perm(int id) {  // the id-th permutation of (0,1,2,3), 2 bits per position
+    // lexicographic order; position i (bits 2i, 2i+1) = the class member i takes
+    constexpr unsigned char tbl[24] = {0xe4, 0xb4, 0xd8, 0x78, 0x9c, 0x6c, 0xe1, 0xb1, 0xc9, 0x39, 0x8d, 0x2d,
+                                       0xd2, 0x72, 0xc6, 0x36, 0x4e, 0x1e, 0x93, 0x63, 0x87, 0x27, 0x4b, 0x1b};
+    unsigned long long lo = 0, mid = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        lo |= static_cast<unsigned long long>(tbl[i]) << (8 * i);
+        mid |= static_cast<unsigned long long>(tbl[8 + i]) << (8 * i);
+        hi |= static_cast<unsigned long long>(tbl[16 + i]) << (8 * i);
+    }
+    const unsigned long long w = id < 8 ? lo : (id < 16 ? mid : hi);
+    return static_cast<unsigned>((w >> (8 * (id & 7))) & 0xff);
+}
+// -> true when the slice was laid out here (else the caller's greedy order runs)
+__device__ __forceinline__ bool sell16_fill_balanced(QbShared &sh, int entry, const int32_t *__restrict__ rowptr,
+                                                     const int32_t *__restrict__ col, const float *__restrict__ val, int32_t *rows,
+                                                     int32_t n_entries, int32_t block_cols, const int32_t *__restrict__ ext,
+                                                     int32_t *__restrict__ q_col, float *__restrict__ q_val) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q4 = lane >> 4;
+    const int chunk0 = ext[2 * entry];
+    // ---- the slice's rows (every lane learns row r's extent; lanes r < 16 of quarter 0 speak for it)
+    const int row = rows[entry * Q_ROWS + r];
+    const int row_next = __shfl(row, (lane & 48) + min(r + 1, 15));
+    if (__any(r < 15 && row == row_next)) return false;  // padding slots (duplicate rows): the greedy order keeps them equal
+    const int a = rowptr[row], len = rowptr[row + 1] - a;
+    int width = len;
+    for (int o = 8; o > 0; o >>= 1) width = max(width, __shfl_xor(width, o));
+    if (width > QB_MAXW || width == 0) return false;
+    const int pieces = (width + Q_SPLIT_WIDTH - 1) / Q_SPLIT_WIDTH;
+    const int T = Q_SPLIT_WIDTH * (pieces - 1) + ((width - Q_SPLIT_WIDTH * (pieces - 1) + 3) & ~3);  // steps the kernel sweeps
+    // the entries of the slice's run: this one + the CONT entries behind it (pieces and ghosts: they share q_rows)
+    int run = 1;
+    while (entry + run < n_entries && (ext[2 * (entry + run) + 1] & Q_CONT)) ++run;
+    // ---- columns into LDS, class counts (quarter q4 of the wave counts entries q4, q4 + 4, ..)
+    unsigned cnt = 0;  // 4 x 8 bits
+    for (int j = q4; j < len; j += 4) {
+        const int c = col[a + j];
+        sh.col[r][j] = c;
+        cnt += 1u << (8 * (c & 3));
+    }
+    cnt += __shfl_xor(cnt, 16);
+    cnt += __shfl_xor(cnt, 32);
+    __builtin_amdgcn_wave_barrier();
+    // per row: entry ids sorted by class (lanes < 16; counting sort, stable)
+    if (lane < Q_ROWS) {
+        int at[4] = {0, qb_field8(cnt, 0), qb_field8(cnt, 0) + qb_field8(cnt, 1), qb_field8(cnt, 0) + qb_field8(cnt, 1) + qb_field8(cnt, 2)};
+        for (int j = 0; j < len; ++j) {
+            const int c = sh.col[r][j] & 3;
+            const int p = c == 0 ? at[0]++ : (c == 1 ? at[1]++ : (c == 2 ? at[2]++ : at[3]++));
+            sh.order[r][p] = static_cast<unsigned char>(j);
+        }
+    }
+    // ---- 64 candidate deals of the rows to the four groups; lane 0 takes them in slot order
+    unsigned long long gsum[4] = {0, 0, 0, 0};  // per group: 4 x 16 bits, entries per class
+    int gsize[4] = {0, 0, 0, 0};
+    unsigned assign = 0;  // 2 bits per row
+    {
+        unsigned long long perm = 0xfedcba9876543210ull;  // nibble i = the i-th row dealt
+        unsigned seed = 0x9e3779b9u * (lane + 1) + 0x85ebca6bu * static_cast<unsigned>(entry);
+        if (lane > 0)
+            for (int i = 15; i > 0; --i) {  // Fisher-Yates on nibbles
+                seed = seed * 1664525u + 1013904223u;
+                const int k = static_cast<int>((seed >> 8) % static_cast<unsigned>(i + 1));
+                const unsigned long long ni = (perm >> (4 * i)) & 0xf, nk = (perm >> (4 * k)) & 0xf;
+                perm = (perm & ~((0xfull << (4 * i)) | (0xfull << (4 * k)))) | (nk << (4 * i)) | (ni << (4 * k));
+            }
+        for (int i = 0; i < Q_ROWS; ++i) {
+            const int rr = static_cast<int>((perm >> (4 * i)) & 0xf);
+            const unsigned c8 = __shfl(cnt, rr);
+            const unsigned long long c16 = (c8 & 0xffull) | ((c8 & 0xff00ull) << 8) | ((c8 & 0xff0000ull) << 16) | ((c8 & 0xff000000ull) << 24);
+            int best = -1, best_key = 0x7fffffff;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned long long t = gsum[g] + c16;
+                int over = 0, mx = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int v = static_cast<int>((t >> (16 * c)) & 0xffff);
+                    over += max(v - T, 0);
+                    mx = max(mx, v);
+                }
+                const int key = gsize[g] >= 4 ? 0x7fffffff : ((over << 16) | (mx << 2) | g);
+                if (key < best_key) {
+                    best_key = key;
+                    best = g;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g == best) {
+                    gsum[g] += c16;
+                    ++gsize[g];
+                }
+            assign |= static_cast<unsigned>(best) << (2 * rr);
+        }
+    }
+    int total_over = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) total_over += max(static_cast<int>((gsum[g] >> (16 * c)) & 0xffff) - T, 0);
+    int key = (total_over << 6) | lane;
+    for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));
+    assign = __shfl(assign, key & 63);
+    // ---- slots: member `rank` of group g sits in slot qb_group_slot(g, rank); src_of = the old slot whose row moves to slot r
+    const int my_g = (assign >> (2 * r)) & 3;
+    int rank = 0;
+    for (int o = 0; o < Q_ROWS; ++o) rank += (o < r && static_cast<int>((assign >> (2 * o)) & 3) == my_g) ? 1 : 0;
+    const int new_slot = qb_group_slot(my_g, rank);
+    int src_of = 0;
+    for (int o = 0; o < Q_ROWS; ++o) src_of = (__shfl(new_slot, o) == r) ? o : src_of;
+    const int n_row = __shfl(row, src_of), n_a = __shfl(a, src_of), n_len = __shfl(len, src_of);
+    const unsigned n_cnt = __shfl(cnt, src_of);
+    // ---- the schedule of group q4 (16 lanes: two permutations each for the first eight)
+    {
+        unsigned m[4];
+        int pad[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = qb_group_slot(q4, i);
+            m[i] = __shfl(n_cnt, slot);
+            pad[i] = T - __shfl(n_len, slot);
+        }
+        for (int step = 0; step < T; ++step) {
+            const int left = T - step;
+            int colsum[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) colsum[c] = qb_field8(m[0], c) + qb_field8(m[1], c) + qb_field8(m[2], c) + qb_field8(m[3], c);
+            int best_key = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int id = r + 16 * half;
+                if (id < 24) {
+                    const unsigned p = qb_perm(id);
+                    bool ok = true;
+                    int after[4] = {colsum[0], colsum[1], colsum[2], colsum[3]};
+                    int score = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = (p >> (2 * i)) & 3;
+                        const bool real = qb_field8(m[i], c) > 0;
+                        ok = ok && (real || pad[i] > 0);
+                        if (real) {
+                            score += colsum[c];
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) after[cc] -= (cc == c) ? 1 : 0;
+                        }
+                    }
+                    int over = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) over += max(after[c] - (left - 1), 0);
+                    const int k = ok ? (((1023 - min(over, 1023)) << 18) | (min(score, 2047) << 5) | (31 - id)) : 0;
+                    best_key = max(best_key, k);
+                }
+            }
+            for (int o = 8; o > 0; o >>= 1) best_key = max(best_key, __shfl_xor(best_key, o));
+            unsigned p;
+            if (best_key > 0) {
+                p = qb_perm(31 - (best_key & 31));
+            } else {  // no conflict-free step is left: every row takes the class it holds most of (a padding row: class 0)
+                p = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int bc = 0;
+#pragma unroll
+                    for (int c = 1; c < 4; ++c) bc = qb_field8(m[i], c) > qb_field8(m[i], bc) ? c : bc;
+                    p |= static_cast<unsigned>(bc) << (2 * i);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (p >> (2 * i)) & 3;
+                const bool real = qb_field8(m[i], c) > 0;
+                if (real) m[i] -= 1u << (8 * c);
+                else --pad[i];
+                if (r == i) sh.pick[qb_group_slot(q4, i)][step] = static_cast<unsigned char>(c | (real ? 4 : 0));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- emit: lane s < 16 writes the row now in slot s; padding reads the zero row of the scheduled class
+    if (lane < Q_ROWS) {
+        const int n_chunks = (width + Q_CHUNK - 1) / Q_CHUNK;
+        int32_t *dst = q_col + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + r * Q_CHUNK;
+        float *dstv = q_val ? q_val + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + r * Q_CHUNK : nullptr;
+        int used[4] = {0, 0, 0, 0};
+        const int base1 = qb_field8(n_cnt, 0), base2 = base1 + qb_field8(n_cnt, 1), base3 = base2 + qb_field8(n_cnt, 2);
+        for (int e = 0; e < n_chunks * Q_CHUNK; ++e) {
+            const int at = (e / Q_CHUNK) * Q_CHUNK_INTS + (e % Q_CHUNK);
+            int off = block_cols * 64;
+            float v = 0.f;
+            if (e < T) {
+                const int b = sh.pick[r][e], c = b & 3;
+                if (b & 4) {
+                    const int k = c == 0 ? used[0]++ : (c == 1 ? used[1]++ : (c == 2 ? used[2]++ : used[3]++));
+                    const int j = sh.order[src_of][(c == 0 ? 0 : (c == 1 ? base1 : (c == 2 ? base2 : base3))) + k];
+                    off = sh.col[src_of][j] * 64;
+                    v = val ? val[n_a + j] : 1.f;
+                } else {
+                    off = (block_cols + c) * 64;
+                }
+            }
+            dst[at] = off;
+            if (dstv) dstv[at] = v;
+        }
+        for (int t = 0; t < run; ++t) rows[(entry + t) * Q_ROWS + r] = n_row;
+    }
+    return true;
+}
+
 // One wave per (column block, entry that starts a slice); lane r < 16 orders row r's segment.  Bank-aware order (reorder != 0):
 // the sweep reads, for entry e of all 16 rows, the 64-byte LDS row of each row's column; the four rows of a service group
 // collide when their columns agree mod 4 (64-byte rows: a row's bank window is 16 (column mod 4) .. + 15).  The order of a
 // row's entries inside a block is free, so the rows of a group choose step by step, in rank order, a remaining entry whose
 // class is not taken yet in this step (the class they hold most of first; the first remaining entry of that class).
 __device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                 const float *__restrict__ val, const int32_t *__restrict__ rows,
+                                                 const float *__restrict__ val, int32_t *rows,
                                                  int32_t n_entries, int32_t n_blocks, int32_t block_cols,
                                                  const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
-                                                 float *__restrict__ q_val, int reorder) {
+                                                 float *__restrict__ q_val, int reorder, QbShared *qb) {
     const int lane = threadIdx.x & 63;
     if (task >= n_entries * n_blocks) return;  // (whole waves: a task is a wave)
     const int blk = task / n_entries, entry = task % n_entries;
     if (ext[2 * task + 1] & Q_CONT) return;  // a continuation / ghost entry: its slice's first entry fills the chunks
+    // split form (one column block, <= 128 entries per row): the conflict-free order (reorder 2: WDG_SELL_ORDER=1 keeps round 2's greedy one)
+    if (reorder == 2 && n_blocks == 1 && (ext[2 * n_entries + 1] & Q_CONT) &&
+        sell16_fill_balanced(*qb, entry, rowptr, col, val, rows, n_entries, block_cols, ext, q_col, q_val))
+        return;
     const int chunk0 = ext[2 * task];
     const int r = lane & 15;
     const bool worker = lane < 16;
@@ -370,12 +613,13 @@ __device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__rest
     }
 }
 __global__ __launch_bounds__(256) void sell16_fill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                   const float *__restrict__ val, const int32_t *__restrict__ rows,
+                                                   const float *__restrict__ val, int32_t *rows,
                                                    int32_t n_entries, int32_t n_blocks, int32_t block_cols,
                                                    const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
                                                    float *__restrict__ q_val, int reorder) {
+    __shared__ QbShared qb[4];  // one per wave
     sell16_fill_body((blockIdx.x * 256 + threadIdx.x) >> 6, rowptr, col, val, rows, n_entries, n_blocks, block_cols, ext, q_col, q_val,
-                     reorder);
+                     reorder, &qb[threadIdx.x >> 6]);
 }
 
 // ---- the same build for a TABLE of graphs (wdg_sell16_job; blockIdx.y = graph): a sweep shard's SELL-16 copies in six launches
@@ -473,8 +717,9 @@ __global__ __launch_bounds__(256) void sell16_fill_batched(const wdg_sell16_job 
     if (j.n_rows <= 0 || !j.q_col) return;  // (no SELL-16 copy wanted for this graph: decided by the caller after the count)
     const Sell16Shape sh = sell16_shape(j.n_rows, j.n_cols);
     const int32_t n_entries = j.q_ext[2 * sh.n_blocks * sh.max_entries + 1] & 0x3fffffff;
+    __shared__ QbShared qb[4];  // one per wave
     sell16_fill_body((blockIdx.x * 256 + threadIdx.x) >> 6, j.rowptr, j.col, j.val, j.q_rows, n_entries, sh.n_blocks, sh.block_cols,
-                     j.q_ext, j.q_col, j.q_val, reorder);
+                     j.q_ext, j.q_col, j.q_val, reorder, &qb[threadIdx.x >> 6]);
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -538,7 +783,7 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
     const int n_stage = (h.reserved & 2) ? 0 : rows * 4;  // float4 slots (reserved bit 1: timing ablation)
     const bool x_vec = sizeof(TIN) == 4 && (F % 4 == 0) && (h.ldx % 4 == 0) && (((uintptr_t)h.X & 15) == 0);
     const global_ptr<const TIN> X = (global_ptr<const TIN>)h.X;
-    if (tid < 4) xs[zero_row * 4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 16) xs[zero_row * 4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // FOUR zero rows, one per bank window (sell16_fill_balanced)
     // Staged through registers, NOT by LDS-DMA (global_load_lds): the compiler orders every later ds_read that may alias
     // a DMA's destination behind it with s_waitcnt vmcnt(0) - it cannot see that the phase barrier already did -, which
     // turns every counted wait of the unit pipeline into a wait for the wave's last store.  A workgroup stages a slab once
@@ -1207,9 +1452,11 @@ __global__ __launch_bounds__(MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS) void spmm
 
 int q_block_cols_for(int n_cols) { return q_block_cols_hd(n_cols); }
 
-bool q_reorder_enabled() {  // bank-aware entry order inside (row, block) segments: on unless WDG_SELL_ORDER=0
-    const char *e = getenv("WDG_SELL_ORDER");
-    return !(e && atoi(e) == 0);
+int q_reorder_mode() {  // entry order inside (row, block) segments; WDG_SELL_ORDER: 0 column order, 1 round 2's greedy bank-aware
+    const char *e = getenv("WDG_SELL_ORDER");  // order, 2 (default) the conflict-free order for graphs in split form, greedy for the rest
+    if (!e) return 2;
+    const int v = atoi(e);
+    return v < 0 ? 0 : (v > 2 ? 2 : v);
 }
 
 template <typename TIN>
@@ -1220,7 +1467,7 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
     // every job's block size is <= min(its columns rounded up to 4, 2528): the bound over the table sizes the slab
     const int block_cols = std::min(Q_MAX_BLOCK_COLS, (std::max(max_cols, 1) + 3) & ~3);
     const bool multi = max_cols > Q_MAX_BLOCK_COLS;
-    const size_t lds = (static_cast<size_t>(block_cols) + 1) * 64;
+    const size_t lds = (static_cast<size_t>(block_cols) + 4) * 64;  // + the four zero rows
     const void *kernels[4] = {reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, false>),
                               reinterpret_cast<const void *>(spmm_quad_kernel<TIN, true, false>),
                               reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, true>),
@@ -1369,7 +1616,7 @@ int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N
 }
 
 int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
-                           const int32_t *q_rows, const int32_t *q_ext, int32_t n_entries, int32_t *q_col, float *q_val,
+                           int32_t *q_rows, const int32_t *q_ext, int32_t n_entries, int32_t *q_col, float *q_val,
                            wdg_stream_t stream) {
     WDG_REQUIRE(N >= 0 && n_cols >= 0 && n_entries >= 0 && q_ext && (N == 0 || q_rows), "csr_to_sell16_fill: bad arguments");
     const int block_cols = q_block_cols_for(n_cols);
@@ -1378,7 +1625,7 @@ int wdg_csr_to_sell16_fill(const int32_t *rowptr, const int32_t *col, const floa
     if (tasks == 0) return WDG_OK;
     WDG_REQUIRE(rowptr && q_col, "csr_to_sell16_fill: null rowptr / q_col");
     hipLaunchKernelGGL(sell16_fill, dim3(wdg::ceil_div(tasks * 64, 256)), dim3(256), 0, wdg::as_stream(stream), rowptr, col, val,
-                       q_rows, n_entries, n_blocks, block_cols, q_ext, q_col, q_val, q_reorder_enabled() ? 1 : 0);
+                       q_rows, n_entries, n_blocks, block_cols, q_ext, q_col, q_val, q_reorder_mode());
     return wdg::check_launch("csr_to_sell16_fill");
 }
 
@@ -1417,7 +1664,7 @@ int wdg_csr_to_sell16_fill_batched(const wdg_sell16_job *jobs_dev, int32_t n_job
     const int64_t n_blocks = wdg::ceil_div(max_cols > 0 ? max_cols : 1, q_block_cols_for(max_cols));
     const int64_t tasks = wdg_sell16_max_entries(max_rows) * n_blocks;
     hipLaunchKernelGGL(sell16_fill_batched, dim3(wdg::ceil_div(tasks * 64, 256), static_cast<unsigned>(n_jobs)), dim3(256), 0,
-                       wdg::as_stream(stream), jobs_dev, q_reorder_enabled() ? 1 : 0);
+                       wdg::as_stream(stream), jobs_dev, q_reorder_mode());
     return wdg::check_launch("csr_to_sell16_fill_batched");
 }
 
