@@ -364,6 +364,7 @@ def measure_configs(args, dev):
 
     def model(rec):
         out = {"workload": rec["workload"], **({"forward_us": round(rec["forward_us"], 2)} if "forward_us" in rec else {}),
+               **({"forward_graph_us": round(rec["forward_graph_us"], 2)} if "forward_graph_us" in rec else {}),
                "legs": [{"leg": l["leg"], "us": round(l["us"], 2), "bound": l["roofline"]["bound"], "frac": round(l["roofline"]["frac"], 4)} for l in rec["legs"]]}
         for k in ("metric_us_10_samples", "agg_homo_soft"):
             if k in rec:
@@ -467,8 +468,8 @@ def measure_projection(args, dev, full_ms):
             secs = []
             for r in (range(w) if w == 8 else [0]):
                 mine = sweep.shard_jobs(pairs, w, r)
-                half = (len(mine) + 1) // 2
-                shards = [(mine[a:a + half], [whole["graphs"][(j.h, j.seed)] for j in mine[a:a + half]]) for a in range(0, len(mine), half)]
+                per = len(mine) if len(mine) <= 80 else (len(mine) + 1) // 2  # (one shard per rank while its Grams stay small: fewer tables to build)
+                shards = [(mine[a:a + per], [whole["graphs"][(j.h, j.seed)] for j in mine[a:a + per]]) for a in range(0, len(mine), per)]
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 n_rows = sum(rows.shape[0] for _si, _bi, rows in sweep.run_bases(shards, whole["feats"], epochs=args.kr_epochs, depth=2))

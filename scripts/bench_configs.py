@@ -148,9 +148,11 @@ def sgc1_lines(config, what, g, x, n_classes, symmetric, reps):
         us_head, _ = timed(lambda: ops.gemm_skinny(y, w), reps)
         us_head_mfma, _ = timed(lambda: ops.gemm(y, w), reps)
         us_all, _ = timed(lambda: sgc(adj, x, order="agg_first"), reps)
+        us_all_graph, _ = timed(models.graphed_inference(sgc, adj, x, order="agg_first")[0], reps)
         agg_bytes = 4 * (n + 1) + 4 * e + 4 * n + x.element_size() * n * f + 4 * n * f
         gemm_bytes = 4 * (n * f + f * n_classes + n * n_classes)
         out.append({"config": config, "workload": f"{what}: SGC-1 forward (A_hat X) W, F={f} -> C={n_classes}", "forward_us": us_all,
+                    "forward_graph_us": us_all_graph,
                     "legs": [leg("aggregation F=%d" % f, us_agg, "hbm", agg_bytes, HBM_PEAK_GBS, "GB/s"),
                              leg("head (skinny product)", us_head, "hbm", gemm_bytes, HBM_PEAK_GBS, "GB/s", mfma_tile_kernel_us=us_head_mfma)]})
         sgc._cache = None
@@ -163,9 +165,11 @@ def sgc1_lines(config, what, g, x, n_classes, symmetric, reps):
             sgc._cache = None
             return sgc(adj, x)
         us_all2, _ = timed(head_first, reps)
+        sgc._cache = None
+        us_all2_graph, _ = timed(models.graphed_inference(sgc, adj, x, order="head_first")[0], reps)
         agg2_bytes = 4 * (n + 1) + 4 * e + 4 * n + 4 * n * n_classes * 2
         out.append({"config": config, "workload": f"{what}: SGC-1 forward A_hat (X W) (inference order), F={f} -> C={n_classes}",
-                    "forward_us": us_all2,
+                    "forward_us": us_all2, "forward_graph_us": us_all2_graph,
                     "legs": [leg("head (skinny product)", us_head2, "hbm", gemm_bytes, HBM_PEAK_GBS, "GB/s"),
                              leg("aggregation F=%d" % n_classes, us_agg2, "hbm", agg2_bytes, HBM_PEAK_GBS, "GB/s")]})
     return out
@@ -191,9 +195,10 @@ def gcn2_line(config, what, g, x, n_classes, symmetric, reps, hidden=64):
         lo = ops.spmm(g, z, row_scale=rs, col_scale=cs)
         us_a1, _ = timed(lambda: ops.spmm(g, z, row_scale=rs, col_scale=cs, out=lo), reps)
         us_all, _ = timed(lambda: gcn(adj, x), reps)
+        us_all_graph, _ = timed(models.graphed_inference(gcn, adj, x)[0], reps)
     idx = 4 * (n + 1) + 4 * e + 4 * n
     return {"config": config, "workload": f"{what}: GCN-2 forward A_hat relu(A_hat (X W0)) W1, F={f} -> {hidden} -> C={n_classes}",
-            "forward_us": us_all,
+            "forward_us": us_all, "forward_graph_us": us_all_graph,
             "legs": [leg(f"transform X W0 (K={f}, N={hidden})", us_g0, "mfma", 2.0 * n * f * hidden, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                          hbm_frac=4 * (n * f + f * hidden + n * hidden) / (us_g0 * 1e-6) / 1e9 / HBM_PEAK_GBS),
                      leg(f"aggregation F={hidden}", us_a0, "hbm", idx + 8 * n * hidden, HBM_PEAK_GBS, "GB/s"),

@@ -190,6 +190,30 @@ def test_sgc1_forward_in_both_orders(oracle, name):
         assert torch.equal(cached, agg_first)
 
 
+def test_graphed_inference_replays_the_eager_forward_bitwise():
+    """models.graphed_inference: GCN-2 and SGC-1 (inference order) on the squirrel topology captured as one hipGraph each - the replay
+    recomputes the logits in place, bit for bit the eager forward's, also after the features changed (same tensor, new values)"""
+    from wdg_amd import models, ops
+    rng = np.random.default_rng(9)
+    g0 = load("topo_squirrel")
+    n, f, c = int(g0["n_nodes"]), 2089, 5
+    g = ops.CsrGraph.from_coo(g0["adj_row"], g0["adj_col"], n, None, ops.COO_ADD_SELF_LOOPS)
+    adj = models.NormAdj(g, symmetric=1, add_self_loops=False)
+    x = torch.from_numpy(((rng.random((n, f), dtype=np.float32) < 0.02) * rng.random((n, f), dtype=np.float32)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.random((n, f), dtype=np.float32)).cuda()
+    torch.manual_seed(2)
+    for model, kw in ((models.GCN2(f, c, nhid=64, dropout=0.5).cuda(), {}), (models.SGC1(f, c).cuda(), {"order": "head_first"})):
+        replay, logits = models.graphed_inference(model, adj, x, **kw)
+        for values in (x.clone(), x2):
+            x.copy_(values)
+            with torch.no_grad():
+                want = model(adj, x, **kw).clone()
+            logits.fill_(float("nan"))
+            replay()
+            torch.cuda.synchronize()
+            assert torch.equal(logits, want), type(model).__name__
+
+
 @pytest.mark.parametrize("m,n,k,splits", [(5201, 64, 2089, 0), (2277, 64, 2325, 0), (300, 16, 1500, 4), (129, 33, 1024, 16), (5, 3, 4096, 7)])
 def test_split_k_gemm_against_the_oracle(oracle, monkeypatch, m, n, k, splits):
     """wdg_gemm_splitk_f32 (few output tiles, K >= 1024: the first layer of a GCN on squirrel / chameleon): partial products over

@@ -111,6 +111,26 @@ class GCN2(torch.nn.Module):
         return adj.matmul(_Linear.apply(h, self.w1, False))
 
 
+def graphed_inference(model, adj, x, **forward_kwargs):
+    """One-shot inference `model(adj, x)` (eval mode, no gradients) captured as ONE hipGraph -> (replay, logits).
+
+    A single-graph forward is a chain of four to six small launches (GCN-2 on squirrel: split-K transform + its reduce, the
+    F = 64 aggregation, ReLU, the skinny head, the F = C aggregation), each 15 - 35 us of mostly dispatch and drain: replayed from
+    a graph they run back to back with no host enqueue in between (BASELINE configs[0], [3], [4]; bench.py `configs`).
+    `replay()` recomputes `logits` IN PLACE from the current contents of `x` and of the model's parameters (the graph holds
+    their addresses: same tensors, new values are fine); everything the forward builds lazily - SELL / band copies of the
+    graph, narrow-kernel tables - is built by two eager runs before the capture."""
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            model(adj, x, **forward_kwargs)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            logits = model(adj, x, **forward_kwargs)
+    return graph.replay, logits  # (the bound method keeps the graph alive)
+
+
 def train_eval(model, adj, x, labels, masks=None, epochs=200, lr=0.01, weight_decay=5e-4):
     """Full-batch training with Adam + cross-entropy; model selection on validation accuracy.
     masks = (train, val, test) boolean tensors; default: `random_disassortative_splits` (60/20/20).
