@@ -148,14 +148,9 @@ typedef struct wdg_spmm_job {
     int64_t ldx, ldy;
     int32_t n_rows, n_cols, n_feat;
     int32_t reserved; /* must be 0 (bits 0 .. 3 are timing-only ablation switches of the diagnostics scripts: results are wrong when set) */
-    /* optional column-blocked SELL-64 copy of the same pattern (wdg_csr_to_sell_*): enables the row-lane
-       kernel for graphs of <= 3072 rows; NULL = CSR kernels only */
-    const int32_t *sell_ptr; /* [n_blocks * ceil(n_rows/64) + 1] entry offsets, block-major                */
-    const int32_t *sell_col; /* (block b, slice s): entry e of row 64 s + l at sell_ptr[b*S + s] + 64 e + l */
-    const float *sell_val;   /* same layout, needed when `val` is given                                    */
-    int32_t sell_block_cols; /* columns per block = wdg_sell_block_cols(n_rows, n_cols)                          */
-    int32_t sell_n_blocks;   /* ceil(n_cols / sell_block_cols)                                             */
-    const int32_t *sell_perm; /* [n_rows] SELL slot -> row (rows sorted by length, longest first); NULL = identity */
+    /* (rounds 1-3 carried an optional SELL-64 copy here for the row-lane kernels; round 4 retired that family: sweep batches and
+       small graphs run the quad-row kernel, single wide-feature graphs the band kernel, <= 8 features the narrow kernel, anything
+       else the CSR slab / gather kernels) */
     /* optional SELL-16 copy of the same pattern (wdg_csr_to_sell16_*): enables the quad-row kernel (a quad of lanes per
        row, 16-row slices; graphs of up to 4 column blocks of 2528 columns); NULL = none */
     const int32_t *q_ext;  /* [q_n_blocks * q_n_entries + 1] pairs {first chunk, width | flags} per (block, entry), block-major;
@@ -192,54 +187,22 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
  * (needed on the host to size the grid and LDS without reading the table back).
  * Jobs are started in table order by persistent workgroups: put the jobs with the most stored entries first
  * so that no long job starts last (results do not depend on the order).
- * The row-lane kernels behind this entry (and behind wdg_spmm_csr_* for jobs with a SELL-64 copy) draw their items from
- * work-queue counters in one of 256 device-resident slots, given to a launch when it is enqueued (a launch recorded into a
- * hipGraph keeps its slot for every replay; recorded and eager launches draw from different halves).  The caller keeps:
- * at most 128 such launches in flight at a time, at most 128 recorded per process, and no recorded launch running
- * concurrently with itself on two streams.  The quad-row and band kernels have no queues and no such limits.
+ * This entry runs the CSR families (LDS column slab, row gather); sweep batches take wdg_spmm_quad_batched_f32 /
+ * wdg_spmm_narrow_batched_f32 below.
  */
-#define WDG_SPMM_ALL_SELL 1 /* every job of the table carries sell_ptr / sell_col            */
-#define WDG_SPMM_ANY_VAL 2  /* some job has explicit values (then sell_val must be set too) */
-#define WDG_SPMM_DMA_OK 4   /* every job: X and Y 16-byte aligned, ldx, ldy and n_feat multiples of 4, col_scale NULL:
-                               X rows may be staged by LDS-DMA; with WDG_SPMM_PIPELINED=1 in the environment such
-                               batches run the pipelined row-lane kernel (family 3), an opt-in schedule */
+#define WDG_SPMM_ANY_VAL 2  /* some job has explicit values (a SELL-16 copy then carries q_val) */
+#define WDG_SPMM_DMA_OK 4   /* every job: X and Y 16-byte aligned, ldx, ldy and n_feat multiples of 4, col_scale NULL (16-byte
+                               loads and stores throughout: what the quad-row kernel's pipelined loop needs) */
 #define WDG_SPMM_SMALL_OFFSETS 8 /* every job: n_rows x ldy < 2^30 elements, fewer than 2^22 index chunks (byte offsets into Y and
                                    into q_col / q_val fit 32 bits) and a SELL-16 copy in split form (WDG_SELL16_SPLIT): with
                                    WDG_SPMM_DMA_OK the quad-row kernel's pipelined loop */
 #define WDG_SPMM_ANY_COL_SCALE 16 /* some job has a column scale (wdg_spmm_narrow_batched_f32 gathers it per entry) */
-#define WDG_SPMM_SHARED_X(r) (((r) & 0xff) << 8) /* every aligned group of r (2..255) consecutive jobs of the table has the
-                               same X, ldx, n_cols and n_feat (the h-levels of one seed): with WDG_SPMM_ALL_SELL |
-                               WDG_SPMM_DMA_OK, <= 2032 columns and <= 2048 rows the shared-X row-lane kernel (family 4)
-                               stages each 16-feature slab of X once per group instead of once per job */
 int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
                          int32_t max_feat, int flags, wdg_stream_t stream);
-/* Which kernel family a batch of n_jobs such shapes dispatches to (0 = LDS column-slab, 1 = row gather,
- * 2 = row-lane when `flags` has WDG_SPMM_ALL_SELL, 3 = pipelined row-lane when it also has WDG_SPMM_DMA_OK and
- * WDG_SPMM_PIPELINED=1 is set, 4 = shared-X row-lane when it also has WDG_SPMM_SHARED_X);
- * for tests/bench. */
+/* Which kernel family a batch of n_jobs such shapes dispatches to behind wdg_spmm_batched_f32 / wdg_spmm_csr_* without SELL-16 copy
+ * or band plan (0 = LDS column-slab, 1 = row gather); *slab_out / *threads_out = its template parameters; for tests/bench. */
 int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int flags, int *slab_out,
                   int *threads_out);
-
-/*
- * CSR -> column-blocked SELL-64: the columns are cut into ceil(n_cols / B) blocks of B = wdg_sell_block_cols(n_rows, n_cols)
- * (what one LDS pass of the row-lane kernel can stage); inside a block the rows are grouped in slices of 64, stored
- * entry-major, padded with 0x7fffffff / value 0.  Column indices stay global.  Inside a (row, block) segment the entries
- * are stored in a bank-aware order (the four lanes of an LDS service group that read the same chunk position get
- * columns of different classes mod 4 wherever the rows allow it), which fixes the order of the row's sum; with
- * WDG_SELL_ORDER=0 in the environment of the build call the segment keeps column order (the sequential CSR order).
- * Rows are first sorted (sell_perm[slot] = row, ties by row id) so that a slice holds rows of similar length and
- * pads by percents instead of multiples: by total length, longest first, for skewed graphs (longest row > 4x the
- * mean) or more than 4 column blocks; otherwise lexicographically by the per-block lengths (block 0 first).
- * Two calls: count fills sell_ptr (entry offsets; the last one = padded entry count, read it back to size
- * sell_col / sell_val), then fill.  One-time per graph, like the CSR build.
- */
-int32_t wdg_sell_block_cols(int32_t n_rows, int32_t n_cols);
-size_t wdg_sell_workspace_bytes(int32_t N, int32_t n_cols);
-int wdg_csr_to_sell_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *sell_perm,
-                          int32_t *sell_ptr, void *workspace, size_t workspace_bytes, wdg_stream_t stream);
-int wdg_csr_to_sell_fill(const int32_t *rowptr, const int32_t *col, const float *val, int32_t N, int32_t n_cols,
-                         const int32_t *sell_perm, const int32_t *sell_ptr, int32_t *sell_col, float *sell_val,
-                         wdg_stream_t stream);
 
 /*
  * CSR -> SELL-16 (the index layout of the quad-row kernel, csrc/spmm_quad.hip): rows sorted by length (q_perm[slot] = row),

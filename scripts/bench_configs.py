@@ -68,9 +68,8 @@ def single_graph(config, workload, g, x, reps, elem=4, norm=1, **extra):
     elif quad:
         kernel = f"spmm_quad_kernel ({quad['n_blocks']} column block(s) of {quad['block_cols']})"
     else:
-        flags = ops.SPMM_ALL_SELL if getattr(g, "sell", None) else 0
-        fam = ops.spmm_plan(n, g.n_cols, f, 1, flags)
-        kernel = {0: "spmm_slab_kernel", 1: "spmm_gather_kernel", 2: "spmm_rowlane_kernel", 3: "spmm_rowlane_kernel (pipelined)"}.get(fam[0], str(fam))
+        fam = ops.spmm_plan(n, g.n_cols, f, 1, 0)
+        kernel = {0: "spmm_slab_kernel", 1: "spmm_gather_kernel"}.get(fam[0], str(fam))
     return line(config, workload, kernel, alg, e, us, med, **extra)
 
 

@@ -7,7 +7,7 @@ import sys
 
 path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-big = [i for i, r in enumerate(rows) if "spmm_rowlane" in r["Kernel_Name"]]
+big = [i for i, r in enumerate(rows) if "spmm_quad" in r["Kernel_Name"]]
 i0 = big[len(big) // 2]
 i1 = big[len(big) // 2 + 1]
 t0 = int(rows[i0]["Start_Timestamp"])

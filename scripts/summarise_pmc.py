@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 out_dir = sys.argv[1]
-want = ("spmm_quad", "spmm_band", "spmm_narrow", "narrow_pack", "kr_solve", "gram_map", "spmm_rowlane", "spmm_slab", "spmm_gather", "edge_stats", "gemm_f32", "gemm_bres", "mlp2_bres", "las_")  # (rowlane: every variant)
+want = ("spmm_quad", "spmm_band", "spmm_narrow", "narrow_pack", "kr_solve", "gram_map", "gram_split", "mlp2_split", "spmm_slab", "spmm_gather", "edge_stats", "gemm_f32", "gemm_bres", "mlp2_bres", "las_")
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(out_dir, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):

@@ -50,7 +50,7 @@ def test_c4_real_topology(oracle, name, f):
         want = oracle.spmm_csr(rowptr, col, vhat, x)
         np.testing.assert_allclose(_np(y), want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
         print(f"[C4 {name} mode={mode}] {col.shape[0] / dt / 1e6:.0f} M edges/s, {dt * 1e6:.0f} us "
-              f"(plan {ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL if g.sell else 0)})")
+              f"(plan {ops.spmm_plan(n, n, f, 1, 0)})")
     # GCN-2 vs SGC-1 forward on this topology (config C4): finite, and SGC equals the oracle chain
     adj = models.NormAdj(g, symmetric=1, add_self_loops=False)  # g already holds A + I
     torch.manual_seed(0)

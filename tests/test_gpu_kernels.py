@@ -21,7 +21,7 @@ def ops():
 
 @pytest.fixture
 def old_families(monkeypatch):
-    """keep a test on the round-1 kernel families (slab / gather / row-lane): the quad-row kernel would take the call"""
+    """keep a test on the CSR kernel families (slab / gather): the quad-row kernel would take the call"""
     monkeypatch.setenv("WDG_SPMM_NO_QUAD", "1")
     monkeypatch.setenv("WDG_SPMM_BAND", "0")
 
@@ -237,7 +237,6 @@ def _check_spmm(ops, oracle, rowptr, col, val, x, row_scale=None, col_scale=None
                                    (300, 64, 5000), (1200, 33, 9000), (4000, 128, 60000), (5201, 131, 50000),
                                    (1, 1, 1), (64, 3, 0), (5000, 20, 40000)])
 def test_spmm_slab_family_shapes(ops, oracle, n, f, e, monkeypatch, old_families):
-    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")  # keep the column-slab kernel covered
     rng = np.random.default_rng(n + f)
     src, dst = _rand_graph(rng, n, e)
     rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
@@ -252,7 +251,6 @@ def test_spmm_slab_family_shapes(ops, oracle, n, f, e, monkeypatch, old_families
 @pytest.mark.parametrize("slab", [4, 8, 16, 32])
 @pytest.mark.parametrize("threads", [512, 1024])
 def test_spmm_every_slab_variant(ops, oracle, slab, threads, monkeypatch, old_families):
-    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")
     monkeypatch.setenv("WDG_SPMM_SLAB", str(slab))
     monkeypatch.setenv("WDG_SPMM_THREADS", str(threads))
     rng = np.random.default_rng(slab)
@@ -396,185 +394,6 @@ def test_spmm_full_size_properties(ops):
 
 
 # --------------------------------------------------------------------------------------------- SELL-64 + row-lane kernel
-@pytest.mark.parametrize("column_order", [False, True])
-def test_sell_layout_matches_csr(ops, oracle, monkeypatch, column_order):
-    """Every (row, block) segment holds exactly the row's entries of that block - in column order with WDG_SELL_ORDER=0,
-    in the bank-aware order otherwise - padded with the sentinel."""
-    if column_order:
-        monkeypatch.setenv("WDG_SELL_ORDER", "0")
-    rng = np.random.default_rng(31)
-    for n, e in ((1, 1), (64, 500), (65, 700), (2000, 20000), (3000, 9000), (130, 0), (2561, 40000), (3072, 7000)):
-        src, dst = _rand_graph(rng, n, e)
-        rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
-        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, n)
-        if not g.ensure_sell(max_padding=1e9):
-            assert col.shape[0] == 0
-            continue
-        sp, sc, sv = (_np(t) for t in g.sell[:3])
-        bc, nb = g.sell[3], g.sell[4]
-        assert nb == (n + bc - 1) // bc and bc * 128 <= 160 * 1024
-        n_slices = (n + 63) // 64
-        perm = _np(g.sell[5])  # slot -> row (see sell_sort_rows: by total length if skewed, else by block lengths)
-        lens = np.diff(rowptr)
-        skewed = int(lens.max()) * n > 4 * int(lens.sum())
-        if skewed or nb < 2 or nb > 4:
-            want_perm = np.argsort(-lens, kind="stable")
-        else:
-            rows_of = np.repeat(np.arange(n), lens)
-            per_block = [np.bincount(rows_of[col // bc == b], minlength=n) for b in range(nb)]
-            want_perm = np.lexsort([np.arange(n)] + [-per_block[b] for b in reversed(range(nb))])
-        np.testing.assert_array_equal(perm, want_perm)
-        for b in range(nb):
-            for s in range(n_slices):
-                t = b * n_slices + s
-                rows = perm[s * 64:min(n, s * 64 + 64)]
-                width = (sp[t + 1] - sp[t]) // 64
-                blk_c = sc[sp[t]:sp[t + 1]].reshape(width, 64)
-                blk_v = sv[sp[t]:sp[t + 1]].reshape(width, 64)
-                longest = 0
-                for lane, r in enumerate(rows):
-                    cr, vr = col[rowptr[r]:rowptr[r + 1]], val[rowptr[r]:rowptr[r + 1]]
-                    sel = (cr >= b * bc) & (cr < (b + 1) * bc)
-                    l = int(sel.sum())
-                    longest = max(longest, l)
-                    if column_order:
-                        np.testing.assert_array_equal(blk_c[:l, lane], cr[sel])
-                        np.testing.assert_array_equal(blk_v[:l, lane], vr[sel])
-                    else:  # same (column, value) pairs, any order; columns are unique inside a row
-                        order = np.argsort(blk_c[:l, lane])
-                        np.testing.assert_array_equal(blk_c[:l, lane][order], cr[sel])
-                        np.testing.assert_array_equal(blk_v[:l, lane][order], vr[sel])
-                    assert (blk_c[l:, lane] == 0x7fffffff).all() and (blk_v[l:, lane] == 0).all()
-                assert width == longest
-                assert (blk_c[:, rows.size:] == 0x7fffffff).all()
-
-
-@pytest.mark.parametrize("n,f,e", [(2000, 500, 20000), (2000, 500, 82000), (2708, 1433, 13264), (1000, 32, 6000),
-                                   (3072, 64, 30000), (3000, 17, 20000), (100, 8, 300), (2048, 100, 2048), (1025, 33, 9000),
-                                   (2700, 500, 100000), (64, 129, 64)])
-def test_spmm_rowlane_family_shapes(ops, oracle, n, f, e, old_families):
-    rng = np.random.default_rng(n * 7 + f)
-    src, dst = _rand_graph(rng, n, e)
-    rowptr, col, val = oracle.coo_to_csr(src, dst, n, rng.random(e, dtype=np.float32))
-    x = rng.standard_normal((n, f)).astype(np.float32)
-    g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), n, n)
-    assert g.ensure_sell(max_padding=1e9)
-    assert ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL)[0] == 2
-
-    def run(use_values, rs, cs, dtype=torch.float32):
-        xt = torch.from_numpy(x).cuda().to(dtype)
-        y = _np(ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
-                         col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values))
-        v = val.copy() if use_values else np.ones_like(val)
-        if cs is not None:
-            v = v * cs[col]
-        xr = _np(xt.float())
-        ref, ref64 = oracle.spmm_csr(rowptr, col, v, xr), oracle.spmm_csr(rowptr, col, v, xr, f64acc=True)
-        if rs is not None:
-            ref, ref64 = ref * rs[:, None], ref64 * rs[:, None]
-        scale = np.abs(ref64).max() + 1e-30
-        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6 * scale)
-        np.testing.assert_allclose(y, ref64, rtol=1e-5, atol=1e-6 * scale)
-
-    d = rng.random(n, dtype=np.float32)
-    run(True, None, None)
-    run(False, d, None)
-    run(False, d, d)
-    run(True, d, d, torch.bfloat16)
-
-
-def test_spmm_rowlane_equals_slab_bitwise(ops, monkeypatch, old_families):
-    """With the SELL copy in column order (WDG_SELL_ORDER=0) both LDS kernels sum a row in CSR column order: results
-    must be bit-identical.  (The default bank-aware order changes the order of a row's sum: covered by the 1e-5 tests.)"""
-    monkeypatch.setenv("WDG_SELL_ORDER", "0")
-    rng = np.random.default_rng(77)
-    n, f, e = 2000, 500, 40000
-    src, dst = _rand_graph(rng, n, e)
-    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
-    x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
-    d = ops.degree_norm(g, ops.NORM_SYM)["dinv"]
-    y_rl = ops.spmm(g, x, row_scale=d, col_scale=d).clone()
-    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")
-    y_slab = ops.spmm(g, x, row_scale=d, col_scale=d)
-    assert ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL)[0] == 0
-    assert torch.equal(y_rl, y_slab)
-
-
-@pytest.mark.parametrize("n,f,e,power_law", [(2000, 500, 20000, False), (1000, 64, 9000, False), (3000, 100, 30000, False),
-                                              (3072, 36, 50000, True), (700, 16, 0, False), (2277, 2324, 60000, True)])
-def test_spmm_pipelined_variant_bitwise(ops, oracle, monkeypatch, n, f, e, power_law, old_families):
-    """The opt-in pipelined schedule (WDG_SPMM_PIPELINED=1, family 3) sums in the same order as the default row-lane
-    kernel: bit-identical results, single-graph and batched, with and without explicit values."""
-    from wdg_amd import synth
-    rng = np.random.default_rng(n + f)
-    src, dst = synth.random_graph(n, max(e, 1), seed=n, power_law=power_law)
-    src, dst = src[:e], dst[:e]
-    g = ops.CsrGraph.from_coo(src, dst, n, rng.random(e, dtype=np.float32) if e else None, ops.COO_ADD_SELF_LOOPS)
-    x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
-    d = ops.degree_norm(g, ops.NORM_RW)["dinv"]
-    assert g.ensure_sell(max_padding=1e9)  # keep the skewed cases on the row-lane family whatever they pad
-    for use_values in (False, True):
-        monkeypatch.delenv("WDG_SPMM_PIPELINED", raising=False)
-        y0 = ops.spmm(g, x, row_scale=d, use_values=use_values).clone()
-        monkeypatch.setenv("WDG_SPMM_PIPELINED", "1")
-        assert ops.spmm_plan(n, n, f, 1, ops.SPMM_ALL_SELL | ops.SPMM_DMA_OK)[0] == 3
-        y1 = ops.spmm(g, x, row_scale=d, use_values=use_values).clone()
-        ys = [torch.empty_like(y0) for _ in range(3)]
-        monkeypatch.setenv("WDG_SPMM_RUN", "0")  # (the three jobs share X: keep them off the shared-X kernel here)
-        batch = ops.SpmmBatch([(g, x, y, d, None, use_values) for y in ys])
-        monkeypatch.delenv("WDG_SPMM_RUN")
-        assert batch.plan()[0] == 3
-        batch.launch()
-        torch.cuda.synchronize()
-        assert torch.equal(y0, y1)
-        for y in ys:
-            assert torch.equal(y0, y)
-    rowptr, col, val = (_np(t) for t in (g.rowptr, g.col, g.val))
-    want = oracle.spmm_csr(rowptr, col, val * _np(d)[np.repeat(np.arange(n), np.diff(rowptr))], _np(x))
-    np.testing.assert_allclose(_np(y1), want, rtol=1e-5, atol=1e-6 * max(np.abs(want).max(), 1e-30))
-
-
-@pytest.mark.parametrize("n,f,groups,use_values", [(2000, 500, (10,), False), (700, 36, (4, 6), True), (2032, 64, (3, 3, 3), False),
-                                                     (1500, 100, (2, 8), True), (64, 16, (2,), False)])
-def test_spmm_shared_x_kernel_bitwise(ops, monkeypatch, n, f, groups, use_values, old_families):
-    """Graphs that aggregate the same X run in aligned runs on the shared-X kernel (family 4): every Y must be
-    bit-identical to the single-graph call, whatever the run length, for ragged feature groups and explicit values."""
-    rng = np.random.default_rng(n * 3 + f)
-    entries, want = [], []
-    for gi, size in enumerate(groups):
-        x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
-        for j in range(size):
-            e = int(n * (2 + 3 * j))
-            src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
-            g = ops.CsrGraph.from_coo(src, dst, n, rng.random(e, dtype=np.float32), ops.COO_ADD_SELF_LOOPS)
-            d = ops.degree_norm(g, ops.NORM_RW)["dinv"]
-            want.append(ops.spmm(g, x, row_scale=d, use_values=use_values).clone())
-            entries.append((g, x, torch.zeros_like(want[-1]), d, None, use_values))
-    batch = ops.SpmmBatch(entries)
-    assert batch.run >= 2 and batch.plan()[0] == 4, (batch.run, batch.plan())
-    batch.launch()
-    torch.cuda.synchronize()
-    for (_, _, y, _, _, _), w in zip(entries, want):
-        assert torch.equal(y, w)
-    monkeypatch.setenv("WDG_SPMM_SHARED8", "1")  # opt-in variant: 8-feature items, two workgroups per CU
-    for e in entries:
-        e[2].zero_()
-    batch.launch()
-    torch.cuda.synchronize()
-    for (_, _, y, _, _, _), w in zip(entries, want):
-        assert torch.equal(y, w)
-    monkeypatch.delenv("WDG_SPMM_SHARED8")
-    monkeypatch.setenv("WDG_SPMM_NO_SHARED_X", "1")  # same table on the per-graph kernels
-    for e in entries:
-        e[2].zero_()
-    assert batch.plan()[0] in (2, 0)
-    batch.launch()
-    torch.cuda.synchronize()
-    for (_, _, y, _, _, _), w in zip(entries, want):
-        assert torch.equal(y, w)
-
-
-# --------------------------------------------------------------------------------------------- SELL-16 + quad-row kernel
 def _skewed_graph(rng, n, e):
     """power-law rows: a few hubs, many short rows, some empty"""
     w = 1.0 / np.arange(1, n + 1) ** 0.9
@@ -775,7 +594,7 @@ def test_spmm_quad_family_shapes(ops, oracle, monkeypatch, n, m, f, e):
         xt = torch.from_numpy(x).cuda().to(dtype)
         y = _np(ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
                          col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values))
-        assert g.sell is None, "the call must have gone to the quad-row kernel (no SELL-64 copy was built)"
+        assert g.quad, "the call must have gone to the quad-row kernel"
         v = val.copy() if use_values else np.ones_like(val)
         if cs is not None:
             v = v * cs[col]
@@ -806,10 +625,9 @@ def test_spmm_quad_column_order_equals_sequential_sum_bitwise(ops, monkeypatch):
     x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
     d = ops.degree_norm(g, ops.NORM_RW)["dinv"]
     y_quad = ops.spmm(g, x, row_scale=d).clone()
-    assert g.quad and g.sell is None
+    assert g.quad
     g2 = ops.CsrGraph(g.rowptr, g.col, g.val, n, n)
     monkeypatch.setenv("WDG_SPMM_NO_QUAD", "1")
-    monkeypatch.setenv("WDG_SPMM_NO_ROWLANE", "1")
     y_slab = ops.spmm(g2, x, row_scale=d)
     assert not g2.quad
     assert torch.equal(y_quad, y_slab)
@@ -1502,7 +1320,7 @@ def test_spmm_band_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, hub
         y = ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
                      col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values,
                      out=None if out is None else out[:, 2:2 + f])
-        assert g.band and g.quad is None and g.sell is None, "the call must have gone to the band kernel"
+        assert g.band and g.quad is None, "the call must have gone to the band kernel"
         assert g.band["n_hub"] == int((deg > 256).sum())
         if out is not None:
             assert float(out[:, :2].min()) == 7.0 and float(out[:, 2 + f:].min()) == 7.0  # nothing written beside Y
@@ -1600,7 +1418,7 @@ def test_spmm_narrow_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, h
         y = ops.spmm(g, xt, row_scale=None if rs is None else torch.from_numpy(rs).cuda(),
                      col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values,
                      out=None if out is None else out[:, 1:1 + f])
-        assert g.narrow_ws is not None and g.quad is None and g.sell is None, "the call must have gone to the narrow kernel"
+        assert g.narrow_ws is not None and g.quad is None, "the call must have gone to the narrow kernel"
         cuts = _np(g.band["cuts"])
         assert cuts[18] == int((deg > 2048).sum()) and cuts[19] == int((deg > 128).sum())
         if out is not None:

@@ -149,15 +149,11 @@ def test_batched_gemm_and_las_mixed_shapes(oracle):
         assert abs(int(got[i, 0]) - s) <= 1 and abs(int(got[i, 1]) - hd) <= 1
 
 
-@pytest.mark.parametrize("variant,env,family", [("row-lane", {"WDG_SPMM_NO_QUAD": "1", "WDG_SPMM_RUN": "0"}, 2),
-                                                ("shared-X", {"WDG_SPMM_NO_QUAD": "1"}, 4),
-                                                ("pipelined", {"WDG_SPMM_NO_QUAD": "1", "WDG_SPMM_RUN": "0", "WDG_SPMM_PIPELINED": "1"}, 3),
-                                                ("quad-row", {}, 5)])
+@pytest.mark.parametrize("variant,env,family", [("column slab", {"WDG_SPMM_NO_QUAD": "1"}, 0), ("quad-row", {}, 5)])
 def test_full_sweep_batch_every_item_exactly_once(monkeypatch, variant, env, family):
-    """The bench-size batch (100 graphs, 1 600 / 3 200 / 640 queue items over 256 persistent workgroups, with stealing at
-    the end): every (graph, feature group) item must be produced by every launch - outputs are pre-filled with NaN - and
-    repeated launches must be bitwise equal to the per-graph calls (regression: a steal that claimed two items but
-    processed one)."""
+    """The bench-size batch of the `800` set (100 graphs) on the quad-row kernel (dynamic dealing of super-units inside a
+    workgroup) and, with WDG_SPMM_NO_QUAD=1, on the CSR column-slab kernel: every (graph, feature group) piece must be produced
+    by every launch - outputs are pre-filled with NaN - and repeated launches must be bitwise equal to the per-graph calls."""
     from wdg_amd import ops, sweep, synth
     for k, v in env.items():
         monkeypatch.setenv(k, v)

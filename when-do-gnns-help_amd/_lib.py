@@ -28,8 +28,6 @@ class SpmmJob(ctypes.Structure):
     _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p),
                 ("col_scale", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("ldx", c_int64), ("ldy", c_int64),
                 ("n_rows", c_int32), ("n_cols", c_int32), ("n_feat", c_int32), ("reserved", c_int32),
-                ("sell_ptr", c_void_p), ("sell_col", c_void_p), ("sell_val", c_void_p),
-                ("sell_block_cols", c_int32), ("sell_n_blocks", c_int32), ("sell_perm", c_void_p),
                 ("q_ext", c_void_p), ("q_col", c_void_p), ("q_val", c_void_p), ("q_perm", c_void_p), ("q_rows", c_void_p),
                 ("q_block_cols", c_int32), ("q_n_blocks", c_int32), ("q_n_entries", c_int32), ("q_flags", c_int32),
                 ("band_perm", c_void_p), ("band_cuts", c_void_p), ("band_n_hub", c_int32), ("band_reserved", c_int32)]
@@ -74,12 +72,6 @@ SIGNATURES = {
     "wdg_spmm_csr_bf16": (c_int, [ctypes.POINTER(SpmmJob), c_void_p]),
     "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
-    "wdg_sell_block_cols": (c_int32, [c_int32, c_int32]),
-    "wdg_sell_workspace_bytes": (c_size_t, [c_int32, c_int32]),
-    "wdg_csr_to_sell_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
-                                      c_void_p]),
-    "wdg_csr_to_sell_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p]),
     "wdg_sell16_block_cols": (c_int32, [c_int32]),
     "wdg_sell16_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "wdg_sell16_max_entries": (c_int64, [c_int32]),

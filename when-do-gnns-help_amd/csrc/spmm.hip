@@ -23,13 +23,8 @@
 #include "wdg_common.h"
 #include "spmm_job_view.h"
 
-namespace wdg {  // row-lane family (spmm_rowlane.hip)
-bool rowlane_eligible(int max_rows, int max_cols, int max_feat);
-bool rowlane_pipelined(int max_rows, int flags);
-int rowlane_dispatch_f32(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, bool, int, hipStream_t);
-bool rowlane_shared_x(int n_jobs, int max_rows, int max_cols, int max_feat, int flags);
-int rowlane_dispatch_bf16(const wdg_spmm_job *, const wdg_spmm_job &, int, int, int, int, bool, hipStream_t);
-// quad-row family (spmm_quad.hip)
+namespace wdg {
+// quad-row family (spmm_quad.hip), band kernel (spmm_band.hip)
 bool quad_eligible_single(const wdg_spmm_job &j);
 bool band_eligible_single(const wdg_spmm_job &j);
 int band_single_f32(const wdg_spmm_job &j, hipStream_t st);
@@ -455,13 +450,6 @@ template <typename TIN>
 int dispatch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int n_jobs, int max_rows, int max_cols, int max_feat,
              int flags, hipStream_t st) {
     if (n_jobs == 0 || max_rows == 0 || max_feat == 0) return WDG_OK;
-    if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, max_feat)) {
-        const bool has_val = (flags & WDG_SPMM_ANY_VAL) != 0;
-        if (sizeof(TIN) == 4)
-            return rowlane_dispatch_f32(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, (flags & WDG_SPMM_DMA_OK) != 0,
-                                        (flags >> 8) & 0xff, st);
-        return rowlane_dispatch_bf16(jobs, inl, n_jobs, max_rows, max_cols, max_feat, has_val, st);
-    }
     const Plan p = make_plan(max_rows, max_cols, max_feat, n_jobs);
     if (p.family == 0) {
 #define WDG_SLAB_CASE(S, T) \
@@ -495,7 +483,6 @@ int single(const wdg_spmm_job *job_host, wdg_stream_t stream) {
     if (int e = validate_job(job_host)) return e;
     if (job_host->n_rows == 0 || job_host->n_feat == 0) return WDG_OK;
     int flags = 0;
-    if (job_host->sell_ptr && job_host->sell_col && (!job_host->val || job_host->sell_val)) flags |= WDG_SPMM_ALL_SELL;
     if (job_host->val) flags |= WDG_SPMM_ANY_VAL;
     const auto aligned16 = [](const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
     if (sizeof(TIN) == 4 && !job_host->col_scale && aligned16(job_host->X) && aligned16(job_host->Y) &&
@@ -534,16 +521,7 @@ int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t m
 
 int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_feat, int flags, int *slab_out,
                   int *threads_out) {
-    if ((flags & WDG_SPMM_ALL_SELL) && rowlane_eligible(max_rows, max_cols, n_feat)) {
-        const int rpt = (max_rows + 1023) / 1024;
-        if (slab_out) *slab_out = ((rpt <= 2) && n_feat > 16 && !rowlane_pipelined(max_rows, flags)) ? 32 : 16;  // features per item
-        if (threads_out) *threads_out = 1024;
-        if (rowlane_shared_x(n_jobs, max_rows, max_cols, n_feat, flags)) {
-            if (slab_out) *slab_out = 16;
-            return 4;
-        }
-        return rowlane_pipelined(max_rows, flags) ? 3 : 2;
-    }
+    (void)flags;
     const Plan p = make_plan(max_rows, max_cols, n_feat, n_jobs > 0 ? n_jobs : 1);
     if (slab_out) *slab_out = p.slab;
     if (threads_out) *threads_out = p.threads;

@@ -3,10 +3,10 @@
 // replaces: torch.spmm / torch.mm(adj, X) - same call sites as csrc/spmm.hip.
 //
 // What bounds the aggregation on this chip is the LDS: every stored entry (row i, column j) of every 16-feature group
-// costs one 64-byte read of X[j, group] from the slab staged in LDS (256 B/clk/CU with ds_read_b128).  The row-lane
-// kernels (spmm_rowlane.hip: lane <-> row, 64-row slices) pay on top of that a transpose of every finished row
-// through LDS (ds_write_b128: 13 cycles per wave-instruction), 18 vector instructions per four reads, and stores that
-// the same wave must issue between its sweeps.  Here a QUAD of lanes owns a row:
+// costs one 64-byte read of X[j, group] from the slab staged in LDS (256 B/clk/CU with ds_read_b128).  Round 1's row-lane
+// kernels (lane <-> row, 64-row slices; retired in round 4, `git show 54979c9:when-do-gnns-help_amd/csrc/spmm_rowlane.hip`) paid
+// on top of that a transpose of every finished row through LDS (ds_write_b128: 13 cycles per wave-instruction), 18 vector
+// instructions per four reads, and stores that the same wave had to issue between its sweeps.  Here a QUAD of lanes owns a row:
 //
 //   * lane (r, p) = (lane / 4, lane % 4) holds floats 4p .. 4p+3 of row r's 16-feature group: a wave sweeps 16 rows
 //     (a "unit" = one SELL-16 slice), one entry of each per step: ONE v_add_u32_dpp (the entry's byte offset, broadcast

@@ -51,12 +51,9 @@ class CsrGraph:
     reference gets from `.coalesce()` on a torch COO tensor, with 4-byte instead of 8-byte indices.
     """
 
-    SELL_MAX_ROWS = 3072  # the row-lane kernel keeps every row of a graph in one workgroup's registers (3 per thread)
-
     def __init__(self, rowptr, col, val, n_rows, n_cols):
         self.rowptr, self.col, self.val = rowptr, col, val
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
-        self.sell = None  # (sell_ptr, sell_col, sell_val|None): SELL-64 copy of the pattern, built on demand
         self.quad = None  # SELL-16 copy (dict) for the quad-row kernel, built on demand; False = decided against
         self.band = None  # band plan (dict) for the band kernel, built on demand; False = not applicable
         self.narrow_ws = None  # packed-source workspace of the narrow kernel (one per graph: calls on one stream)
@@ -71,36 +68,6 @@ class CsrGraph:
         if self._unit_values is None:
             self._unit_values = bool((self.val == 1).all().item()) if self.val.numel() else True
         return self._unit_values
-
-    def ensure_sell(self, max_padding=3.0):
-        """Build the SELL-64 copy (wdg_csr_to_sell_*) that the row-lane SpMM consumes.  One-time per graph.
-        Skipped (returns False) for graphs too large for that kernel or whose slices would pad too much."""
-        if self.sell is not None:
-            return self.sell is not False
-        if self.n_rows == 0 or self.n_rows > self.SELL_MAX_ROWS or self.nnz == 0:
-            self.sell = False  # decided once: later calls (and hipGraph captures) never redo the count / host sync
-            return False
-        dev = self.device
-        n_slices = (self.n_rows + 63) // 64
-        block_cols = lib.wdg_sell_block_cols(self.n_rows, self.n_cols)
-        n_blocks = (self.n_cols + block_cols - 1) // block_cols
-        sell_ptr = torch.empty(n_slices * n_blocks + 1, dtype=torch.int32, device=dev)
-        sell_perm = torch.empty(self.n_rows, dtype=torch.int32, device=dev)
-        ws_bytes = lib.wdg_sell_workspace_bytes(self.n_rows, self.n_cols)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        check(lib.wdg_csr_to_sell_count(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, _ptr(sell_perm),
-                                        _ptr(sell_ptr), _ptr(ws), ws_bytes, stream_handle()), "wdg_csr_to_sell_count")
-        total = int(sell_ptr[-1].item())
-        if total > max_padding * self.nnz + 64 * 64 * n_blocks:
-            self.sell = False  # very skewed rows: the CSR kernels are the better fit (remembered)
-            return False
-        sell_col = torch.empty(total, dtype=torch.int32, device=dev)
-        sell_val = torch.empty(total, dtype=torch.float32, device=dev) if self.val is not None else None
-        check(lib.wdg_csr_to_sell_fill(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), self.n_rows, self.n_cols,
-                                       _ptr(sell_perm), _ptr(sell_ptr), _ptr(sell_col), _ptr(sell_val), stream_handle()),
-              "wdg_csr_to_sell_fill")
-        self.sell = (sell_ptr, sell_col, sell_val, block_cols, n_blocks, sell_perm)
-        return True
 
     QUAD_SLAB_COLS = 2528  # columns of X the quad-row kernel holds in LDS at once (one column block)
 
@@ -505,14 +472,6 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
     job.n_rows, job.n_cols, job.n_feat = g.n_rows, g.n_cols, x.shape[1]
     job.reserved = ABLATE_BITS  # 0 on every product path; only scripts/ablate_*.py assign the module variable
     wants_val = bool(job.val)
-    if g.sell and (not wants_val or g.sell[2] is not None):
-        job.sell_ptr, job.sell_col = g.sell[0].data_ptr(), g.sell[1].data_ptr()
-        job.sell_val = g.sell[2].data_ptr() if (wants_val and g.sell[2] is not None) else 0
-        job.sell_block_cols, job.sell_n_blocks = g.sell[3], g.sell[4]
-        job.sell_perm = g.sell[5].data_ptr()
-    else:
-        job.sell_ptr = job.sell_col = job.sell_val = job.sell_perm = 0
-        job.sell_block_cols = job.sell_n_blocks = 0
     q = g.quad
     if q and (not wants_val or q["val"] is not None):
         job.q_ext, job.q_col, job.q_perm = q["ext"].data_ptr(), q["col"].data_ptr(), q["perm"].data_ptr()
@@ -536,7 +495,7 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
 
 
 def quad_disabled():
-    """WDG_SPMM_NO_QUAD=1: keep every aggregation on the round-1 kernel families (A/B comparisons, tests)"""
+    """WDG_SPMM_NO_QUAD=1: keep every aggregation off the quad-row kernel (the CSR slab / gather kernels: A/B comparisons, tests)"""
     return os.environ.get("WDG_SPMM_NO_QUAD", "0") not in ("", "0")
 
 
@@ -545,40 +504,6 @@ def _sharing_groups(entries):
     for i, (g, x, *_rest) in enumerate(entries):
         groups.setdefault((x.data_ptr(), _ld(x), g.n_cols, x.shape[1]), []).append(i)
     return list(groups.values())
-
-
-def _shared_x_run(entries):
-    """Run length for WDG_SPMM_SHARED_X: divides every sharing group, 2..8, as long as possible while the launch keeps
-    >= 2 items per CU (items = runs x 16-feature groups; measured on the 100-graph sweep batch: runs of 5 = 640 items
-    220 us, runs of 2 = 1600 items 243 us, no sharing 250 us); 0 = no sharing."""
-    forced = os.environ.get("WDG_SPMM_RUN")
-    groups = _sharing_groups(entries)
-    if not entries or min(len(g) for g in groups) < 2:
-        return 0
-    feat_groups = max((e[1].shape[1] + 15) // 16 for e in entries)
-    best = 0
-    for r in range(2, 9):
-        if any(len(g) % r for g in groups):
-            continue
-        if forced is not None and int(forced) == r:
-            return r
-        if best == 0 or (len(entries) // r) * feat_groups >= 2 * 256:
-            best = r
-    return 0 if forced is not None and int(forced) < 2 else best
-
-
-def _shared_x_order(entries, run):
-    runs = []
-    for grp in _sharing_groups(entries):
-        grp = sorted(grp, key=lambda i: -entries[i][0].nnz)
-        n_runs = len(grp) // run
-        cut = [[] for _ in range(n_runs)]
-        for pos, i in enumerate(grp):  # boustrophedon deal: balanced entry counts per run
-            rnd, k = divmod(pos, n_runs)
-            cut[k if rnd % 2 == 0 else n_runs - 1 - k].append(i)
-        runs.extend(cut)
-    runs.sort(key=lambda r: -sum(entries[i][0].nnz for i in r))
-    return [i for r in runs for i in r]
 
 
 def _dma_ok(job):
@@ -619,8 +544,8 @@ def spmm(g, x, row_scale=None, col_scale=None, use_values=True, out=None):
         check(fn(ctypes.byref(job), _ptr(part_ptr), _ptr(g.narrow_ws), ws_bytes, stream_handle()), "wdg_spmm_narrow")
         return y
     band = x.dtype == torch.float32 and g.prefers_band(x.shape[1])  # one-time plan -> band kernel (wide features, skew)
-    if not band and x.shape[1] >= 8 and not g.ensure_quad():  # one-time SELL-16 copy -> quad-row kernel (<= 10 112 columns)
-        g.ensure_sell()  # else the SELL-64 copy -> row-lane kernels for graphs of <= 3072 rows
+    if not band and x.shape[1] >= 8:
+        g.ensure_quad()  # one-time SELL-16 copy -> quad-row kernel (<= 10 112 columns); else the CSR slab / gather kernels
     job = _fill_job(SpmmJob(), g, x, y, row_scale, col_scale, use_values, band=band)
     fn = lib.wdg_spmm_csr_bf16 if x.dtype == torch.bfloat16 else lib.wdg_spmm_csr_f32
     check(fn(ctypes.byref(job), stream_handle()), "wdg_spmm_csr")
@@ -779,7 +704,7 @@ class SpmmBatch:
         self.keep = entries  # tensors must outlive the table
         arr = (SpmmJob * len(entries))()
         self.max_rows = self.max_cols = self.max_feat = 0
-        all_sell, any_val, dma_ok = len(entries) > 0, False, len(entries) > 0
+        any_val, dma_ok = False, len(entries) > 0
         for g, x, *_ in entries:
             if x.dtype != torch.float32 or x.stride(1) != 1:
                 raise ValueError("SpmmBatch: X must be fp32 with unit inner stride")
@@ -795,24 +720,13 @@ class SpmmBatch:
         order = sorted(range(len(entries)), key=lambda i: -entries[i][0].nnz)
         if os.environ.get("WDG_SPMM_ORDER") == "0":
             order = list(range(len(entries)))
-        self.run = 0
         if self.quad:
             # graphs that aggregate the same X adjacent (largest first inside a group, groups by total entries)
             groups = _sharing_groups(entries)
             groups.sort(key=lambda grp: -sum(entries[i][0].nnz for i in grp))
             order = [i for grp in groups for i in sorted(grp, key=lambda i: -entries[i][0].nnz)]
-        else:
-            # graphs aggregating the SAME feature matrix (the h-levels of a seed) are laid out in aligned runs of `run` jobs,
-            # so that the shared-X kernel stages each slab of X once per run (WDG_SPMM_SHARED_X): every sharing group is cut
-            # into runs of equal length with balanced entry counts, the runs go largest first
-            self.run = _shared_x_run(entries)
-            if self.run >= 2:
-                order = _shared_x_order(entries, self.run)
         for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
-            if x.shape[1] >= 8 and not self.quad and not self.narrow:
-                g.ensure_sell()
             _fill_job(job, g, x, y, rs, cs, uv)
-            all_sell = all_sell and bool(job.sell_ptr)
             any_val = any_val or bool(job.val)
             dma_ok = dma_ok and _dma_ok(job)
             self.max_rows, self.max_cols = max(self.max_rows, g.n_rows), max(self.max_cols, g.n_cols)
@@ -821,11 +735,9 @@ class SpmmBatch:
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
         self.table = host.to(dev)
         self.edges = sum(e[0].nnz for e in entries)
-        self.flags = (SPMM_ALL_SELL if all_sell else 0) | (SPMM_ANY_VAL if any_val else 0) | (SPMM_DMA_OK if dma_ok else 0)
+        self.flags = (SPMM_ANY_VAL if any_val else 0) | (SPMM_DMA_OK if dma_ok else 0)
         if any(e[4] is not None for e in entries):
             self.flags |= SPMM_ANY_COL_SCALE
-        if self.run >= 2 and all_sell and dma_ok:
-            self.flags |= (self.run & 0xff) << 8  # WDG_SPMM_SHARED_X(run)
         if self.quad:
             if all(e[0].n_rows * _ld(e[2]) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 and e[0].quad["split"] for e in entries):
                 self.flags |= SPMM_SMALL_OFFSETS
@@ -850,8 +762,6 @@ class SpmmBatch:
             job = _fill_job(SpmmJob(), g, x, ref, rs, cs, uv)
             job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0  # no SELL copies: the CSR families
             job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
-            job.sell_ptr = job.sell_col = job.sell_val = job.sell_perm = 0
-            job.sell_block_cols = job.sell_n_blocks = 0
             check(lib.wdg_spmm_csr_f32(ctypes.byref(job), stream_handle()), "wdg_spmm_csr_f32")
             torch.cuda.synchronize()
             err = float((got[:, :x.shape[1]] - ref).abs().max()) if ref.numel() else 0.0
@@ -942,23 +852,18 @@ class SpmmBatch:
     def kernel_name(self):
         """name of the kernel this table launches, as rocprofv3 prints it (bench.py / scripts/bench_configs.py)"""
         fam, slab, threads = self.plan()
-        rpt = (self.max_rows + 1023) // 1024
         val = "true" if self.flags & SPMM_ANY_VAL else "false"
         return {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
-                2: f"spmm_rowlane_kernel<{slab // 4},{rpt},float,{val}>",
-                3: f"spmm_rowlane_pipe_kernel<{slab // 4},{rpt},{val}>",
-                4: f"spmm_rowlane_shared_kernel<{rpt},{val}>",
                 5: f"spmm_quad_kernel<float,{val},{'true' if self.max_cols > 2528 else 'false'}>",
                 6: "spmm_narrow_batched_kernel"}.get(fam, f"family {fam}")
 
 
-SPMM_ALL_SELL, SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS, SPMM_ANY_COL_SCALE = 1, 2, 4, 8, 16
+SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS, SPMM_ANY_COL_SCALE = 2, 4, 8, 16
 GEMM_A_VEC4 = 1
 
 
 def spmm_plan(n_rows, n_cols, n_feat, n_jobs=1, flags=0):
-    """(family, width, threads): 0 = LDS column slab, 1 = row gather, 2 = row-lane (needs SPMM_ALL_SELL),
-    3 = pipelined row-lane (SPMM_ALL_SELL | SPMM_DMA_OK)."""
+    """(family, width, threads) of the CSR kernels behind wdg_spmm_batched_f32: 0 = LDS column slab, 1 = row gather."""
     slab, threads = ctypes.c_int(0), ctypes.c_int(0)
     fam = lib.wdg_spmm_plan(n_jobs, n_rows, n_cols, n_feat, flags, ctypes.byref(slab), ctypes.byref(threads))
     return fam, slab.value, threads.value
