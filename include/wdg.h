@@ -62,6 +62,10 @@ size_t wdg_coo_to_csr_workspace_bytes(int64_t E, int32_t N, int flags);
 int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val, int64_t E, int32_t N, int flags,
                        int32_t *rowptr, int32_t *col, float *outval, int64_t *nnz_out, void *workspace,
                        size_t workspace_bytes, wdg_stream_t stream);
+/* the same build from 4-byte indices (what wdg_host_pack_coo_i32 produces: half the bytes across PCIe) */
+int wdg_coo32_to_csr_i32(const int32_t *src, const int32_t *dst, const float *val, int64_t E, int32_t N, int flags,
+                         int32_t *rowptr, int32_t *col, float *outval, int64_t *nnz_out, void *workspace,
+                         size_t workspace_bytes, wdg_stream_t stream);
 
 /*
  * A whole sweep shard through ONE COO -> CSR build (the reference's loop builds a graph per iteration, synthetic_plot.py:84-92;
@@ -77,6 +81,15 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
  *     wdg_csr_to_sell16_count_batched can follow on the same stream without the host knowing where a graph's entries start.
  * replaces: the per-iteration `adj + eye` / `.to_sparse()` / `.coalesce()` of synthetic_plot.py:85-92, homophily_tests.py:83-85.
  */
+/*
+ * HOST helper of the same shard build (no device call, no stream): the per-graph COO arrays (host pointers, node ids local to each
+ * graph, elem_bytes 8 = int64 as the reference's loaders leave them, or 4) -> one pair of int32 arrays of lens[0] + .. entries
+ * holding the ids of the block-diagonal union (id + node_ptr[g]) - what wdg_coo_blockdiag_offset does on the device, done while
+ * the data is copied into the (ideally page-locked) upload buffer by `threads` threads.  An id outside [0, n_g) becomes -1 and
+ * sets *bad_out (host int32) to 1.  replaces: the host side of synthetic_plot.py:85-92's per-iteration torch.load -> dense.
+ */
+int wdg_host_pack_coo_i32(const void *const *src_ptrs, const void *const *dst_ptrs, const int64_t *lens, const int32_t *node_ptr,
+                          int32_t n_graphs, int elem_bytes, int32_t *out_src, int32_t *out_dst, int32_t *bad_out, int threads);
 int wdg_coo_blockdiag_offset(int64_t *src, int64_t *dst, const int64_t *edge_ptr_dev, const int32_t *node_ptr_dev, int32_t n_graphs,
                              int64_t n_edges, int32_t *bad_out, wdg_stream_t stream);
 struct wdg_sell16_job;

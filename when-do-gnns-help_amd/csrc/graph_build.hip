@@ -2,6 +2,11 @@
 // normalisation coefficients, dense row scaling.  Integer outputs are bit-exact restatements of what the
 // reference obtains from torch `.coalesce()`, `to_undirected`, `adj + eye`, scipy row sums (SURVEY.md K2/K3,
 // rows A1-A5).  All fp sums run in a fixed order -> bitwise reproducible.
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
 #include "wdg_common.h"
 
 namespace {
@@ -132,7 +137,8 @@ size_t coo_ws_layout(int64_t E, int32_t N, int flags, char *base, CooWs *ws) {
 }
 
 // decode expanded entry e -> (row, col, valid)
-__device__ __forceinline__ bool expanded_entry(const int64_t *src, const int64_t *dst, long long e, long long E,
+template <typename IDX>  // int64_t (torch's COO index dtype) or int32_t (a shard packed by wdg_host_pack_coo_i32)
+__device__ __forceinline__ bool expanded_entry(const IDX *src, const IDX *dst, long long e, long long E,
                                                int flags, int32_t N, int &row, int &col, int *bad) {
     const bool mirror = e >= E;
     const long long i = mirror ? e - E : e;
@@ -150,7 +156,8 @@ __device__ __forceinline__ bool expanded_entry(const int64_t *src, const int64_t
     return true;
 }
 
-__global__ void coo_count(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, long long E,
+template <typename IDX>
+__global__ void coo_count(const IDX *__restrict__ src, const IDX *__restrict__ dst, long long E,
                           long long cap, int flags, int32_t N, int32_t *__restrict__ rowcnt, int *bad) {
     const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (e >= cap) return;
@@ -158,7 +165,8 @@ __global__ void coo_count(const int64_t *__restrict__ src, const int64_t *__rest
     if (expanded_entry(src, dst, e, E, flags, N, r, c, bad)) atomicAdd(&rowcnt[r], 1);
 }
 
-__global__ void coo_scatter(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, long long E,
+template <typename IDX>
+__global__ void coo_scatter(const IDX *__restrict__ src, const IDX *__restrict__ dst, long long E,
                             long long cap, int flags, int32_t N, const int32_t *__restrict__ rowstart,
                             int32_t *__restrict__ cursor, u64 *__restrict__ bucket) {
     const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -591,6 +599,12 @@ __global__ __launch_bounds__(256) void unpack_bits_kernel(const uint32_t *__rest
 
 }  // namespace
 
+namespace {
+template <typename IDX>
+int coo_to_csr_impl(const IDX *src, const IDX *dst, const float *val, int64_t E, int32_t N, int flags, int32_t *rowptr, int32_t *col,
+                    float *outval, int64_t *nnz_out, void *workspace, size_t workspace_bytes, wdg_stream_t stream);
+}  // namespace
+
 namespace wdg {
 int exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int64_t *total64, void *ws, hipStream_t st) {
     return exclusive_scan(in, n, out, total64, ws, st);
@@ -613,6 +627,71 @@ size_t wdg_coo_to_csr_workspace_bytes(int64_t E, int32_t N, int flags) {
 int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val, int64_t E, int32_t N, int flags,
                        int32_t *rowptr, int32_t *col, float *outval, int64_t *nnz_out, void *workspace,
                        size_t workspace_bytes, wdg_stream_t stream) {
+    return coo_to_csr_impl<int64_t>(src, dst, val, E, N, flags, rowptr, col, outval, nnz_out, workspace, workspace_bytes, stream);
+}
+
+int wdg_coo32_to_csr_i32(const int32_t *src, const int32_t *dst, const float *val, int64_t E, int32_t N, int flags,
+                         int32_t *rowptr, int32_t *col, float *outval, int64_t *nnz_out, void *workspace,
+                         size_t workspace_bytes, wdg_stream_t stream) {
+    return coo_to_csr_impl<int32_t>(src, dst, val, E, N, flags, rowptr, col, outval, nnz_out, workspace, workspace_bytes, stream);
+}
+
+// Host side of a shard's build (no device call): the per-graph COO arrays of a shard -> ONE pair of int32 arrays holding the ids
+// of the block-diagonal union (id + node_ptr[g]; an id outside its graph becomes -1 and sets *bad_out), written by `threads`
+// threads - into page-locked memory when the caller provides it - so that the shard's edge lists cross PCIe once, as 4-byte
+// indices, without the interpreter concatenating them (ops.GraphBatch: 2.8 of a shard's 7.6 ms of build were numpy
+// concatenation + two pageable int64 uploads).  elem_bytes: 8 (int64 inputs) or 4 (int32).
+int wdg_host_pack_coo_i32(const void *const *src_ptrs, const void *const *dst_ptrs, const int64_t *lens, const int32_t *node_ptr,
+                          int32_t n_graphs, int elem_bytes, int32_t *out_src, int32_t *out_dst, int32_t *bad_out, int threads) {
+    WDG_REQUIRE(n_graphs >= 0 && (elem_bytes == 8 || elem_bytes == 4) && bad_out, "host_pack_coo: bad arguments");
+    *bad_out = 0;
+    if (n_graphs == 0) return WDG_OK;
+    WDG_REQUIRE(src_ptrs && dst_ptrs && lens && node_ptr && out_src && out_dst, "host_pack_coo: null array");
+    std::vector<int64_t> first(static_cast<size_t>(n_graphs) + 1, 0);
+    for (int g = 0; g < n_graphs; ++g) first[g + 1] = first[g] + lens[g];
+    const int64_t total = first[n_graphs];
+    threads = std::max(1, std::min(threads, 64));
+    std::atomic<int> bad{0};
+    auto work = [&](int t) {
+        const int64_t a = total * t / threads, b = total * (t + 1) / threads;
+        int g = static_cast<int>(std::upper_bound(first.begin(), first.end(), a) - first.begin()) - 1;
+        int64_t e = a;
+        while (e < b) {
+            while (g + 1 < n_graphs && first[g + 1] <= e) ++g;
+            const int64_t end = std::min<int64_t>(b, first[g + 1]), off = node_ptr[g], n = node_ptr[g + 1] - off, k0 = e - first[g];
+            auto pack = [&](auto *ps, auto *pd) {
+                for (int64_t k = k0; k < k0 + (end - e); ++k) {
+                    const int64_t sv = ps[k], dv = pd[k];
+                    const bool ok = sv >= 0 && dv >= 0 && sv < n && dv < n;
+                    if (!ok) bad.store(1, std::memory_order_relaxed);
+                    out_src[first[g] + k] = ok ? static_cast<int32_t>(sv + off) : -1;
+                    out_dst[first[g] + k] = ok ? static_cast<int32_t>(dv + off) : -1;
+                }
+            };
+            if (elem_bytes == 8) pack(static_cast<const int64_t *>(src_ptrs[g]), static_cast<const int64_t *>(dst_ptrs[g]));
+            else pack(static_cast<const int32_t *>(src_ptrs[g]), static_cast<const int32_t *>(dst_ptrs[g]));
+            e = end;
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    *bad_out = bad.load();
+    return WDG_OK;
+}
+
+}  // extern "C"
+
+namespace {
+template <typename IDX>
+int coo_to_csr_impl(const IDX *src, const IDX *dst, const float *val, int64_t E, int32_t N, int flags,
+                    int32_t *rowptr, int32_t *col, float *outval, int64_t *nnz_out, void *workspace,
+                    size_t workspace_bytes, wdg_stream_t stream) {
     WDG_REQUIRE(E >= 0 && N >= 0, "coo_to_csr: negative size");
     WDG_REQUIRE(rowptr && nnz_out, "coo_to_csr: null rowptr / nnz_out");
     WDG_REQUIRE(E == 0 || (src && dst), "coo_to_csr: null src / dst");
@@ -627,12 +706,12 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
     const size_t head = reinterpret_cast<char *>(ws.bucket) - reinterpret_cast<char *>(ws.rowcnt);
     hipMemsetAsync(ws.rowcnt, 0, head, st);  // counts, cursors, long-row list, flags
     if (cap > 0) {
-        hipLaunchKernelGGL(coo_count, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst, static_cast<long long>(E),
+        hipLaunchKernelGGL(coo_count<IDX>, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst, static_cast<long long>(E),
                            cap, flags, N, ws.rowcnt, ws.bad);
     }
     if (int e = exclusive_scan(ws.rowcnt, N, ws.rowstart, nullptr, ws.scan_ws, st)) return e;
     if (cap > 0) {
-        hipLaunchKernelGGL(coo_scatter, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst,
+        hipLaunchKernelGGL(coo_scatter<IDX>, dim3(ceil_div(cap, 256)), dim3(256), 0, st, src, dst,
                            static_cast<long long>(E), cap, flags, N, ws.rowstart, ws.cursor, ws.bucket);
         if (N > 0) {
             hipLaunchKernelGGL(sort_rows_wave, dim3(wave_sort_grid(N)), dim3(256), 0, st, ws.rowstart, N, wave_sort_rows_per_wg(N), ws.bucket,
@@ -663,6 +742,9 @@ int wdg_coo_to_csr_i32(const int64_t *src, const int64_t *dst, const float *val,
     hipLaunchKernelGGL(coo_finish, dim3(1), dim3(1), 0, st, ws.bad, nnz_out);
     return check_launch("coo_to_csr");
 }
+}  // namespace
+
+extern "C" {
 
 int wdg_coo_blockdiag_offset(int64_t *src, int64_t *dst, const int64_t *edge_ptr_dev, const int32_t *node_ptr_dev, int32_t n_graphs,
                              int64_t n_edges, int32_t *bad_out, wdg_stream_t stream) {

@@ -39,9 +39,64 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
 
 
+class _PinnedArena:
+    """One page-locked buffer per process, handed out as a ring: a slice is reused only after the copy that last read it has
+    completed (an event per copy; by the time the ring comes round the copy is long done).  torch's own pinned allocator
+    cannot reuse a block while its copy is queued behind kernels, and every NEW pinned block is a hipHostMalloc - measured:
+    an occasional 90 ms in the middle of a shard's table uploads."""
+
+    def __init__(self, nbytes=128 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.size, self.off, self.pending = nbytes, 0, []  # pending: (start, end, event), in issue order
+
+    def take(self, nbytes):
+        n = (nbytes + 255) & ~255
+        if self.off + n > self.size:
+            self.off = 0
+        a, b = self.off, self.off + n
+        while self.pending and self.pending[0][0] < b and a < self.pending[0][1]:
+            self.pending.pop(0)[2].synchronize()
+        self.off = b
+        return a, self.buf[a:a + nbytes]
+
+    def issued(self, start, nbytes):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((start, start + ((nbytes + 255) & ~255), ev))
+
+
+_ARENA = None
+
+
+def _h2d(host, dev=None):
+    """A host array (job table, offsets, labels, a feature matrix) -> device tensor WITHOUT blocking the host on what the stream
+    has queued: through the page-locked arena and a non-blocking copy.  (`tensor.to(dev)` from pageable memory returns only when
+    the copy has run, i.e. after every kernel queued before it - a shard's ~70 small uploads then serialise the host with the
+    build kernels.)  Arrays of more than a quarter of the arena take the plain blocking copy."""
+    global _ARENA
+    dev = dev or require_gpu()
+    t = torch.from_numpy(host) if isinstance(host, np.ndarray) else host
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        return torch.empty(t.shape, dtype=t.dtype, device=dev)
+    if _ARENA is None:
+        _ARENA = _PinnedArena()
+    if nbytes > _ARENA.size // 4:
+        return t.to(dev)
+    start, piece = _ARENA.take(nbytes)
+    p = piece.view(t.dtype).view(t.shape)
+    # (numpy's memcpy, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware thread of the host -
+    # measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
+    np.copyto(p.numpy(), t.numpy())
+    out = p.to(dev, non_blocking=True)
+    _ARENA.issued(start, nbytes)
+    return out
+
+
 def _table(arr):
     """ctypes array of job descriptors -> device bytes (an empty table stays a host tensor: its pointer is NULL)"""
-    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(require_gpu()) if len(arr) else torch.empty(0, dtype=torch.uint8)
+    return _h2d(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)) if len(arr) else torch.empty(0, dtype=torch.uint8)
 
 
 class CsrGraph:
@@ -263,6 +318,48 @@ class CsrGraph:
         return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)  # SELL copy (holds values) not shared
 
 
+_PACK_STAGING = {}  # device index -> a ring of page-locked int32 staging tensors, grown on demand, reused shard after shard
+
+
+def _host_pack_coo(coos, lens, node_ptr_h, e_total, dev):
+    """-> (src, dst) int32 device tensors holding the shard's edge lists as ids of the block-diagonal union, or None when the
+    inputs are not plain contiguous host arrays of one integer width (the caller then takes the torch path).  Raises IndexError
+    for an id outside its graph."""
+    arrs = [(c[0], c[1]) for c in coos]
+    kinds = {a.dtype for pair in arrs for a in pair if isinstance(a, np.ndarray)}
+    if len(kinds) != 1 or not all(isinstance(a, np.ndarray) and a.flags.c_contiguous and a.ndim == 1 for pair in arrs for a in pair):
+        return None
+    kind = kinds.pop()
+    if kind not in (np.dtype(np.int64), np.dtype(np.int32)):
+        return None
+    G = len(coos)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ring = _PACK_STAGING.setdefault(key, {"next": 0, "bufs": [None] * 3})  # (three: pipelined shards keep two uploads in flight)
+    slot = ring["next"]
+    ring["next"] = (slot + 1) % len(ring["bufs"])
+    stage = ring["bufs"][slot]
+    if stage is None or stage.numel() < 2 * e_total:
+        stage = ring["bufs"][slot] = torch.empty(int(2 * e_total * 1.25) + 1024, dtype=torch.int32).pin_memory()
+    elif getattr(stage, "_busy", None) is not None:
+        stage._busy.synchronize()  # the copy that last read this buffer (three shards ago) has left it
+    ptrs = ctypes.c_void_p * G
+    sp, dp = ptrs(*[a.ctypes.data for a, _b in arrs]), ptrs(*[b.ctypes.data for _a, b in arrs])
+    lens_a = np.asarray(lens, np.int64)
+    nptr = np.ascontiguousarray(node_ptr_h, np.int32)
+    bad = ctypes.c_int32(0)
+    host = stage.numpy()
+    threads = int(os.environ.get("WDG_HOST_PACK_THREADS", "8"))
+    check(lib.wdg_host_pack_coo_i32(sp, dp, lens_a.ctypes.data, nptr.ctypes.data, G, kind.itemsize, host[:e_total].ctypes.data,
+                                    host[e_total:2 * e_total].ctypes.data, ctypes.byref(bad), threads), "wdg_host_pack_coo_i32")
+    if bad.value:
+        raise IndexError("edge index out of range for its graph")
+    both = stage[:2 * e_total].to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    stage._busy = ev  # the next shard may not overwrite the staging buffer before this copy has left it
+    return both[:e_total], both[e_total:]
+
+
 class GraphBatch:
     """A sweep shard's graphs built together: ONE COO -> CSR build of their block-diagonal union (wdg_coo_blockdiag_offset,
     wdg_coo_to_csr_i32, wdg_csr_split_blockdiag), the SELL-16 copies of all of them in five more launches
@@ -293,26 +390,37 @@ class GraphBatch:
             host = np.concatenate([np.asarray(p_.cpu() if isinstance(p_, torch.Tensor) else p_) for p_ in parts]) if parts else np.empty(0)
             return torch.from_numpy(np.ascontiguousarray(host)).to(device=dev, dtype=dtype)
 
-        src, dst = cat([c[0] for c in coos], torch.int64), cat([c[1] for c in coos], torch.int64)
+        # host arrays of one integer width: packed by the library's host threads straight into a page-locked int32 buffer, ids
+        # already those of the block-diagonal union (wdg_host_pack_coo_i32) - one upload of 4-byte indices instead of numpy
+        # concatenation + two pageable int64 uploads + the offset kernel
+        packed = None
+        if G and e_total and os.environ.get("WDG_SWEEP_HOST_PACK", "1") != "0":
+            packed = _host_pack_coo(coos, es, node_ptr_h, e_total, dev)
+        if packed is None:
+            src, dst = cat([c[0] for c in coos], torch.int64), cat([c[1] for c in coos], torch.int64)
         val = None
         if any_val:
             val = cat([(c[3] if len(c) > 3 and c[3] is not None else np.ones(es[i], np.float32)) for i, c in enumerate(coos)], torch.float32)
-        node_ptr = torch.from_numpy(node_ptr_h.astype(np.int32)).to(dev)
-        edge_ptr = torch.from_numpy(edge_ptr_h).to(dev)
+        node_ptr = _h2d(node_ptr_h.astype(np.int32), dev)
+        edge_ptr = _h2d(edge_ptr_h, dev)
         st = stream_handle()
         # everything the host wants to know afterwards, in one buffer: [bad, nnz of the union, nnz per graph ...]
         info = torch.zeros(2 + max(G, 1), dtype=torch.int64, device=dev)
         bad = torch.zeros(2, dtype=torch.int32, device=dev)
-        check(lib.wdg_coo_blockdiag_offset(_ptr(src), _ptr(dst), _ptr(edge_ptr), _ptr(node_ptr), G, e_total, _ptr(bad), st),
-              "wdg_coo_blockdiag_offset")
+        if packed is None:
+            check(lib.wdg_coo_blockdiag_offset(_ptr(src), _ptr(dst), _ptr(edge_ptr), _ptr(node_ptr), G, e_total, _ptr(bad), st),
+                  "wdg_coo_blockdiag_offset")
+        else:
+            src, dst = packed  # (range-checked on the host: _host_pack_coo raised already)
         cap = lib.wdg_coo_to_csr_capacity(e_total, self.n_total, flags)
         self.rowptr = torch.empty(self.n_total + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(cap, dtype=torch.int32, device=dev)
         self.val = torch.empty(cap, dtype=torch.float32, device=dev)
         ws_bytes = lib.wdg_coo_to_csr_workspace_bytes(e_total, self.n_total, flags)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        check(lib.wdg_coo_to_csr_i32(_ptr(src), _ptr(dst), _ptr(val), e_total, self.n_total, flags, _ptr(self.rowptr), _ptr(self.col),
-                                     _ptr(self.val), c_void_p(info.data_ptr() + 8), _ptr(ws), ws_bytes, st), "wdg_coo_to_csr_i32")
+        build = lib.wdg_coo_to_csr_i32 if packed is None else lib.wdg_coo32_to_csr_i32
+        check(build(_ptr(src), _ptr(dst), _ptr(val), e_total, self.n_total, flags, _ptr(self.rowptr), _ptr(self.col),
+                    _ptr(self.val), c_void_p(info.data_ptr() + 8), _ptr(ws), ws_bytes, st), "wdg_coo_to_csr_i32")
         # per-graph buffers of the SELL-16 build, pooled; the job table's rowptr / col / val are filled in by the split kernel
         self.rowptr_pool = torch.zeros(self.n_total + G, dtype=torch.int32, device=dev)  # (zeros: a graph of no nodes keeps rowptr = [0])
         quad = quad and not quad_disabled() and G > 0
@@ -571,6 +679,18 @@ def _quad_unit_cost(widths):
     return per_slice.reshape(-1, 4).sum(1)
 
 
+def _quad_unit_costs(widths_list):
+    """_quad_unit_cost for many graphs in one pass over the concatenation of their slices (a cold shard prices 50 graphs: one
+    interpolation instead of 50) -> list of per-graph arrays"""
+    if not widths_list:
+        return []
+    sizes = [w.shape[1] for w in widths_list]
+    allw = np.concatenate([w.sum(0) for w in widths_list])[None, :] if len(widths_list) > 1 else widths_list[0]
+    cost = _quad_unit_cost(allw)
+    cuts = np.cumsum([sz // 4 for sz in sizes])[:-1]
+    return np.split(cost, cuts)
+
+
 # what a phase costs a workgroup beside its super-units: staging the slab, two barriers, the pipeline's prologue and the
 # ragged end of the 16 waves (measured as the extra time of XCDs whose segment holds two phases)
 _QUAD_PHASE_NS = 0.0
@@ -633,14 +753,14 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
         g, x, _y, _rs, cs = entries[i][:5]
         keys.append((x.data_ptr(), _ld(x), g.n_cols, x.shape[1], 0 if cs is None else cs.data_ptr()))
     groups, costs, multi = [], [], False  # groups: (first position in `order`, n_jobs, n_units)
+    unit_costs = _quad_unit_costs([entries[i][0].quad["widths"] for i in order])  # (per position in `order`)
     pos = 0
     while pos < len(order):
         end = pos + 1
         while end < len(order) and keys[end] == keys[pos]:
             end += 1
-        qs = [entries[order[k]][0].quad for k in range(pos, end)]
-        multi = multi or any(q["n_blocks"] > 1 for q in qs)
-        seq = np.concatenate([_quad_unit_cost(q["widths"]) for q in qs])
+        multi = multi or any(entries[order[k]][0].quad["n_blocks"] > 1 for k in range(pos, end))
+        seq = np.concatenate(unit_costs[pos:end]) if end - pos > 1 else unit_costs[pos]
         groups.append((pos, end - pos, len(seq)))
         costs.append(seq)
         pos = end
@@ -732,8 +852,7 @@ class SpmmBatch:
             self.max_rows, self.max_cols = max(self.max_rows, g.n_rows), max(self.max_cols, g.n_cols)
             self.max_feat = max(self.max_feat, x.shape[1])
         self.n_jobs = len(entries)
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
-        self.table = host.to(dev)
+        self.table = _table(arr)
         self.edges = sum(e[0].nnz for e in entries)
         self.flags = (SPMM_ANY_VAL if any_val else 0) | (SPMM_DMA_OK if dma_ok else 0)
         if any(e[4] is not None for e in entries):
@@ -778,8 +897,8 @@ class SpmmBatch:
         iarr = (SpmmItem * max(len(items), 1))()
         for it, (fj, nj, ub, ue) in zip(iarr, items):
             it.first_job, it.n_jobs, it.unit_begin, it.unit_end = fj, nj, ub, ue
-        self.items = torch.frombuffer(bytearray(bytes(iarr)), dtype=torch.uint8).to(dev)
-        self.seg_ptr = torch.tensor(seg_ptr, dtype=torch.int32, device=dev)
+        self.items = _h2d(torch.frombuffer(bytearray(bytes(iarr)), dtype=torch.uint8), dev)
+        self.seg_ptr = _h2d(np.asarray(seg_ptr, np.int32), dev)
         self.n_items = len(items)
         self.items_host, self.seg_ptr_host, self.phase_ns, self.shares = items, seg_ptr, phase_ns, shares  # (scripts read them)
 
@@ -908,16 +1027,22 @@ class StatsBatch:
         self.rows = torch.zeros((self.n_jobs, 3, max(self.max_rows, 1)), dtype=torch.int32, device=dev)
         self.labels = [_dev(l, torch.int32, dev) for l in labels_list]
         self.keep = graphs
-        arr = (StatsJob * self.n_jobs)()
-        for i, (job, g) in enumerate(zip(arr, graphs)):
-            job.rowptr, job.col, job.labels = g.rowptr.data_ptr(), g.col.data_ptr(), self.labels[i].data_ptr()
-            job.totals, job.compat, job.classdeg = (self.totals[i].data_ptr(), self.compat[i].data_ptr(),
-                                                    self.classdeg[i].data_ptr())
-            job.row_nnz, job.row_nnz_noself, job.row_match_noself = (self.rows[i, 0].data_ptr(), self.rows[i, 1].data_ptr(),
-                                                                     self.rows[i, 2].data_ptr())
-            job.n_rows, job.n_classes = g.n_rows, c
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
-        self.table = host.to(dev)
+        # the table by column arithmetic (a structured array with the descriptor's layout): the outputs are slices of pools at
+        # regular strides, so only the graphs' own pointers are read one by one
+        tab = np.zeros(self.n_jobs, np.dtype(StatsJob))
+        idx = np.arange(self.n_jobs, dtype=np.int64)
+        tab["rowptr"] = [g.rowptr.data_ptr() for g in graphs]
+        tab["col"] = [g.col.data_ptr() for g in graphs]
+        tab["labels"] = [l.data_ptr() for l in self.labels]
+        tab["totals"] = self.totals.data_ptr() + 8 * 6 * idx
+        tab["compat"] = self.compat.data_ptr() + 8 * c * c * idx
+        tab["classdeg"] = self.classdeg.data_ptr() + 8 * c * idx
+        row_stride = 4 * self.rows.shape[2]
+        for k, name in enumerate(("row_nnz", "row_nnz_noself", "row_match_noself")):
+            tab[name] = self.rows.data_ptr() + row_stride * (3 * idx + k)
+        tab["n_rows"] = [g.n_rows for g in graphs]
+        tab["n_classes"] = c
+        self.table = _h2d(tab.view(np.uint8), dev) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
 
     def zero(self):
         """the counters must be zero when the kernel starts (launch() does it; callers that want the memset off a
@@ -944,27 +1069,29 @@ class LasBatch:
         self.keep = (entries, counts, row_scales)
         self.n_jobs, self.c = len(entries), int(n_classes)
         self.counts = torch.zeros((self.n_jobs, 2), dtype=torch.int64, device=dev)
-        self.n = torch.tensor([h.shape[0] for h, _ in entries], dtype=torch.float32, device=dev)
+        self.n = _h2d(np.array([h.shape[0] for h, _ in entries], np.float32), dev)
         sizes = [lib.wdg_las_workspace_bytes(h.shape[0], h.shape[1], self.c) for h, _ in entries]
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         self.ws = torch.empty(int(offs[-1]) + 256, dtype=torch.uint8, device=dev)
-        arr = (_lib.LasJob * self.n_jobs)()
-        self.max_n = self.max_f = 0
-        for i, (job, (h, lab)) in enumerate(zip(arr, entries)):
-            job.H, job.labels, job.rows, job.W_out = h.data_ptr(), lab.data_ptr(), 0, 0
-            job.count_out, job.workspace = self.counts[i].data_ptr(), self.ws.data_ptr() + int(offs[i])
-            job.ldh, job.n, job.F, job.C = _ld(h), h.shape[0], h.shape[1], self.c
-            self.max_n, self.max_f = max(self.max_n, h.shape[0]), max(self.max_f, h.shape[1])
+        tab = np.zeros(self.n_jobs, np.dtype(_lib.LasJob))
+        idx = np.arange(self.n_jobs, dtype=np.int64)
+        tab["H"] = [h.data_ptr() for h, _ in entries]
+        tab["labels"] = [lab.data_ptr() for _, lab in entries]
+        tab["count_out"] = self.counts.data_ptr() + 16 * idx
+        tab["workspace"] = self.ws.data_ptr() + offs[:-1]
+        tab["ldh"] = [_ld(h) for h, _ in entries]
+        tab["n"] = [h.shape[0] for h, _ in entries]
+        tab["F"] = [h.shape[1] for h, _ in entries]
+        tab["C"] = self.c
+        self.max_n = int(tab["n"].max()) if self.n_jobs else 0
+        self.max_f = int(tab["F"].max()) if self.n_jobs else 0
         self.derives_counts = bool(counts is not None and row_scales is not None and self.n_jobs and counts.n_jobs == self.n_jobs
                                    and all(h.shape[1] == self.c for h, _ in entries)
                                    and lib.wdg_las_fused_eligible(self.max_n, self.max_f, self.c))
         if self.derives_counts:
-            sj = ctypes.sizeof(StatsJob)
-            for i, job in enumerate(arr):
-                job.counts = counts.table.data_ptr() + i * sj
-                job.row_scale = row_scales[i].data_ptr()
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
-        self.table = host.to(dev)
+            tab["counts"] = counts.table.data_ptr() + ctypes.sizeof(StatsJob) * idx
+            tab["row_scale"] = [r.data_ptr() for r in row_scales]
+        self.table = _h2d(tab.view(np.uint8), dev) if self.n_jobs else torch.empty(0, dtype=torch.uint8)
 
     def launch(self):
         check(lib.wdg_las_batched_f32(_ptr(self.table), self.n_jobs, self.max_n, self.max_f, self.c, stream_handle()),

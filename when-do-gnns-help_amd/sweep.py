@@ -208,8 +208,8 @@ class SweepBatch:
             coos.append((src, dst, j.n_nodes))
             labs_host.append(lab)
             if j.seed not in feats:
-                x = torch.from_numpy(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
-                                     else np.ascontiguousarray(x_host, np.float32)).to(dev)
+                x = ops._h2d(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
+                             else np.ascontiguousarray(x_host, np.float32), dev)
                 if ride:
                     xa = torch.zeros((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev)
                     xa[:, :n_feat] = x
@@ -233,7 +233,7 @@ class SweepBatch:
                 self.dinv.append(ops.degree_norm(g, mode, ops.PREC_F32, use_values=True)["dinv"])
         # labels of every graph: one pooled upload
         lab_ptr = np.concatenate([[0], np.cumsum([len(l) for l in labs_host])]).astype(np.int64)
-        lab_pool = torch.from_numpy(np.concatenate(labs_host).astype(np.int32) if labs_host else np.zeros(0, np.int32)).to(dev)
+        lab_pool = ops._h2d(np.concatenate(labs_host).astype(np.int32) if labs_host else np.zeros(0, np.int32), dev)
         self.labels = [lab_pool[int(lab_ptr[i]):int(lab_ptr[i + 1])] for i in range(len(self.jobs))]
         self.labels_host = labs_host
         for j in self.jobs:
