@@ -66,13 +66,15 @@ class _PinnedArena:
 
 
 _ARENA = None
+_H2D_MAX_BYTES = int(float(os.environ.get("WDG_H2D_MAX_MB", "8")) * (1 << 20))  # larger arrays: the plain (blocking, pageable) copy
 
 
 def _h2d(host, dev=None):
     """A host array (job table, offsets, labels, a feature matrix) -> device tensor WITHOUT blocking the host on what the stream
     has queued: through the page-locked arena and a non-blocking copy.  (`tensor.to(dev)` from pageable memory returns only when
     the copy has run, i.e. after every kernel queued before it - a shard's ~70 small uploads then serialise the host with the
-    build kernels.)  Arrays of more than a quarter of the arena take the plain blocking copy."""
+    build kernels.)  Arrays of more than WDG_H2D_MAX_MB (8) MB take the plain blocking copy: the wide bases' 30-MB feature matrices
+    through a single-threaded memcpy and a 128-MB ring cost the whole sweep 10 % (0.80 -> 0.88 s)."""
     global _ARENA
     dev = dev or require_gpu()
     t = torch.from_numpy(host) if isinstance(host, np.ndarray) else host
@@ -82,7 +84,7 @@ def _h2d(host, dev=None):
         return torch.empty(t.shape, dtype=t.dtype, device=dev)
     if _ARENA is None:
         _ARENA = _PinnedArena()
-    if nbytes > _ARENA.size // 4:
+    if nbytes > _H2D_MAX_BYTES:
         return t.to(dev)
     start, piece = _ARENA.take(nbytes)
     p = piece.view(t.dtype).view(t.shape)
