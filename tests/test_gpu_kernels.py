@@ -706,6 +706,54 @@ def test_spmm_quad_fuzz_batches(ops, oracle, seed):
         np.testing.assert_allclose(_np(ent[2]), ref, **tol)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_spmm_quad_pipelined_loop_fuzz(ops, oracle, seed):
+    """random pattern-only batches that take the quad-row kernel's PIPELINED loop (whole 16-feature groups, 16-byte stores, split
+    form: one column block, rows of <= 128 entries - hand-counted waits, super-units dealt from an LDS counter, the conflict-free
+    SELL-16 order with its permuted slot rows and four zero rows): ragged row lengths incl. empty rows and rows of exactly 32 / 64 /
+    128 entries, node counts around the slice / super-unit / segment granules, graphs sharing X, row scales - against the oracle,
+    launched twice (bitwise equal), every output pre-filled with NaN"""
+    rng = np.random.default_rng(9000 + seed)
+    entries, want = [], []
+    shared = None
+    for case in range(int(rng.integers(1, 9))):
+        n = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 300, 1024, 2000, 2528]))
+        if shared is not None and rng.random() < 0.5:
+            x = shared
+            n_cols = x.shape[0]
+        else:
+            n_cols = n if rng.random() < 0.7 else int(rng.choice([4, 100, 2528]))
+            x = torch.from_numpy(rng.standard_normal((n_cols, int(rng.choice([16, 32, 64, 512])))).astype(np.float32)).cuda()
+            shared = x
+        lens = rng.choice([0, 1, 2, 5, 31, 32, 33, 63, 64, 65, 127, 128], n) if rng.random() < 0.5 else rng.integers(0, min(n_cols, 128) + 1, n)
+        lens = np.minimum(lens, min(n_cols, 128))
+        cols = np.concatenate([np.sort(rng.choice(n_cols, int(l), replace=False)) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+        if len(cols) == 0:
+            continue
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        g = ops.CsrGraph(torch.from_numpy(rowptr).cuda(), torch.from_numpy(cols).cuda(), None, n, n_cols)
+        rs = torch.from_numpy(rng.random(n, dtype=np.float32)).cuda() if rng.random() < 0.6 else None
+        v = np.ones(len(cols), np.float32) if rs is None else _np(rs)[np.repeat(np.arange(n), lens)]
+        ref = oracle.spmm_csr(rowptr, cols, v, _np(x))
+        entries.append((g, x, torch.full((n, x.shape[1]), float("nan"), device="cuda"), rs, None, False))
+        want.append((ref, dict(rtol=2e-5, atol=2e-6 * max(float(np.abs(ref).max()), 1e-30))))
+    if not entries:
+        return
+    batch = ops.SpmmBatch(entries)
+    assert batch.quad and all(e[0].quad["split"] for e in entries)
+    assert batch.flags & ops.SPMM_DMA_OK and batch.flags & ops.SPMM_SMALL_OFFSETS  # (what selects the pipelined loop)
+    batch.launch()
+    torch.cuda.synchronize()
+    first = [e[2].clone() for e in entries]
+    for ent, (ref, tol) in zip(entries, want):
+        np.testing.assert_allclose(_np(ent[2]), ref, **tol)
+        ent[2].fill_(float("nan"))
+    batch.launch()
+    torch.cuda.synchronize()
+    for ent, y in zip(entries, first):
+        assert torch.equal(ent[2], y)
+
+
 # --------------------------------------------------------------------------------------------- edge / label stats
 STAT_KEYS =("totals", "row_nnz", "row_nnz_noself", "row_match_noself", "compat", "classdeg")
 
