@@ -150,6 +150,7 @@ int wdg_unpack_bits_f32(const uint32_t *words, int64_t ldw, int32_t N, int32_t F
  */
 #define WDG_SELL16_CONT (1 << 30) /* flag in the width word of a q_ext pair */
 #define WDG_SELL16_SPLIT 1        /* wdg_spmm_job.q_flags */
+#define WDG_SELL16_HALF 2         /* wdg_spmm_job.q_flags: offsets over 32-byte slab rows (wdg_sell16_row_bytes(n_cols) == 32) */
 typedef struct wdg_spmm_job {
     const int32_t *rowptr;
     const int32_t *col;
@@ -210,6 +211,8 @@ int wdg_spmm_csr_bf16(const wdg_spmm_job *job_host, wdg_stream_t stream);
                                    into q_col / q_val fit 32 bits) and a SELL-16 copy in split form (WDG_SELL16_SPLIT): with
                                    WDG_SPMM_DMA_OK the quad-row kernel's pipelined loop */
 #define WDG_SPMM_ANY_COL_SCALE 16 /* some job has a column scale (wdg_spmm_narrow_batched_f32 gathers it per entry) */
+#define WDG_SPMM_HALF_SLAB 32 /* wdg_spmm_quad_batched_f32: EVERY job has 2529 .. 5056 columns, i.e. a SELL-16 copy over 32-byte
+                                 slab rows (WDG_SELL16_HALF); a table must not mix such jobs with others */
 int wdg_spmm_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols,
                          int32_t max_feat, int flags, wdg_stream_t stream);
 /* Which kernel family a batch of n_jobs such shapes dispatches to behind wdg_spmm_batched_f32 / wdg_spmm_csr_* without SELL-16 copy
@@ -235,6 +238,11 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
  * 256 entries per chunk PLUS two chunks of slack that the kernel may read but never uses; then fill.  One-time per graph.
  */
 int32_t wdg_sell16_block_cols(int32_t n_cols);
+/* Bytes of a slab row the copy's offsets are scaled by: 64 (16 features of X per workgroup), or 32 for graphs of 2529 .. 5056
+ * columns (HALF slabs, round 4: ONE column block of 8-feature rows - the whole graph's X[:, f0 : f0 + 8] in the 160 KiB of LDS, a
+ * quad of lanes reads a row with ds_read_b64 - instead of two blocks of 16-feature rows staged one after the other; such graphs
+ * are in split form like the smaller ones and run the same pipelined loop). */
+int32_t wdg_sell16_row_bytes(int32_t n_cols);
 int64_t wdg_sell16_max_entries(int32_t N);
 size_t wdg_sell16_workspace_bytes(int32_t N, int32_t n_cols);
 int wdg_csr_to_sell16_count(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t n_cols, int32_t *q_perm,
@@ -332,13 +340,13 @@ typedef struct wdg_spmm_item {
 int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
                               const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat, int flags,
                               wdg_stream_t stream);
-/* The same launch; wg_clock_dev (may be NULL): [2 x wdg_spmm_quad_workgroups(n_segments, max_feat)] 64-bit words that receive
+/* The same launch; wg_clock_dev (may be NULL): [2 x wdg_spmm_quad_workgroups(n_segments, max_feat, flags)] 64-bit words that receive
  * every workgroup's start and end on the device's 100 MHz clock (workgroup b belongs to XCD b % 8 and serves the segments
  * of that XCD): the caller can balance the segments by what they really cost (ops.SpmmBatch.balance). */
 int wdg_spmm_quad_batched_clocked_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
                                       const int32_t *seg_ptr_dev, int32_t n_segments, int32_t max_cols, int32_t max_feat,
                                       int flags, uint64_t *wg_clock_dev, wdg_stream_t stream);
-int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat);
+int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat, int flags);
 /* diagnostics: one thread stores the device's 100 MHz clock to out_dev, in stream order */
 int wdg_debug_clock(uint64_t *out_dev, wdg_stream_t stream);
 

@@ -192,7 +192,7 @@ def check_kernel(text, variant):
 def main():
     text = open(sys.argv[1]).read()
     bad = 0
-    for variant in ("IfLb0ELb0E", "ItLb0ELb0E"):
+    for variant in ("IfLb0ELi0E", "ItLb0ELi0E", "IfLb0ELi2E", "ItLb0ELi2E"):
         res = check_kernel(text, variant)
         print(variant, {k: v for k, v in res.items() if k != "violations"}, "violations:", len(res["violations"]))
         for v in res["violations"][:20]:

@@ -88,8 +88,8 @@ def test_no_shipped_kernel_spills_vector_registers():
     # ... and the several-column-block variants of the quad-row kernel (MULTI = true) hold 16 slices of accumulators per wave
     # across the blocks - a whole N = 4000 graph per item - and park 4 (pattern only) / 16 (explicit values) registers
     allowed = {"gemm_bres_kernelILi2E": 13, "mlp2_bres_kernelILi2E": 9, "kr_solve_kernel": 16, "kr_solve_blocked_kernel": 12,
-               "spmm_quad_kernelIfLb0ELb1E": 4, "spmm_quad_kernelItLb0ELb1E": 4, "spmm_quad_kernelIfLb1ELb1E": 16,
-               "spmm_quad_kernelItLb1ELb1E": 16}
+               "spmm_quad_kernelIfLb0ELi1E": 4, "spmm_quad_kernelItLb0ELi1E": 4, "spmm_quad_kernelIfLb1ELi1E": 16,
+               "spmm_quad_kernelItLb1ELi1E": 16}
     seen = 0
     for path in reports:
         name = None
@@ -131,7 +131,7 @@ def test_quad_row_fast_loop_keeps_its_memory_operations_to_itself(tmp_path):
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
     checked = 0
-    for variant in ("IfLb0ELb0E", "ItLb0ELb0E"):  # fp32 / bf16 sources, pattern only, one column block: the pipelined loop
+    for variant in ("IfLb0ELi0E", "ItLb0ELi0E", "IfLb0ELi2E", "ItLb0ELi2E"):  # fp32 / bf16 sources, pattern only, one column block: the pipelined loop
         m = re.search(r"^(_ZN\S*spmm_quad_kernel%s[^:\s]*):[^\n]*\n(.*?)s_endpgm" % variant, text, re.M | re.S)
         assert m, f"spmm_quad_kernel<{variant}> not found in the generated code"
         body = m.group(2)
@@ -160,7 +160,7 @@ def test_quad_row_fast_loop_keeps_its_memory_operations_to_itself(tmp_path):
         assert res["depth"] == 1 and res["in_flight"] == 4 and res["loops"] == 2, res  # the shipped pipeline: requests one super-unit ahead
         assert not res["violations"], f"{variant}: compiler instructions touch registers of loads in flight: {res['violations'][:5]}"
         checked += 1
-    assert checked == 2
+    assert checked == 4
 
 
 def test_quad_isa_check_sees_a_register_rotation(tmp_path):
@@ -171,9 +171,9 @@ def test_quad_isa_check_sees_a_register_rotation(tmp_path):
     spec = importlib.util.spec_from_file_location("check_quad_isa", os.path.join(ROOT, "scripts", "check_quad_isa.py"))
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
-    good = chk.check_kernel(_quad_device_code(tmp_path, "-DWDG_Q_FAST_THREADS=768", "-DWDG_Q_DEPTH=2"), "IfLb0ELb0E")
+    good = chk.check_kernel(_quad_device_code(tmp_path, "-DWDG_Q_FAST_THREADS=768", "-DWDG_Q_DEPTH=2"), "IfLb0ELi0E")
     assert good["depth"] == 2 and good["in_flight"] == 19 and not good["violations"], good
-    bad = chk.check_kernel(_quad_device_code(tmp_path, "-DWDG_Q_FAST_THREADS=768", "-DWDG_Q_DEPTH=2", "-DWDG_Q_EXPERIMENT_PLAIN_COPIES"), "IfLb0ELb0E")
+    bad = chk.check_kernel(_quad_device_code(tmp_path, "-DWDG_Q_FAST_THREADS=768", "-DWDG_Q_DEPTH=2", "-DWDG_Q_EXPERIMENT_PLAIN_COPIES"), "IfLb0ELi0E")
     assert bad["violations"], "the checker missed the rotation of registers whose loads are in flight"
 
 

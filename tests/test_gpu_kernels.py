@@ -421,7 +421,8 @@ def _expected_entries(widths_blk0, n_blocks):
 
 @pytest.mark.parametrize("column_order", [False, True])
 def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
-    """wdg_csr_to_sell16_*: rows by length (ties by id), slices of 16, column blocks of <= 2528, chunks of 16 entries per
+    """wdg_csr_to_sell16_*: rows by length (ties by id), slices of 16, column blocks of <= 2528 (graphs of 2529 .. 5056 columns:
+    ONE block over 32-byte slab rows), chunks of 16 entries per
     row; every (row, block) segment holds exactly the row's entries of that block as pre-scaled local offsets - in column
     order with WDG_SELL_ORDER=0, in the bank-aware order otherwise - and pads with the zero row's offset / value 0; the
     slices are laid out as entries, four per super-unit: split into pieces of <= 32 entries per row (CONT) when the graph
@@ -431,7 +432,8 @@ def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
     rng = np.random.default_rng(32)
     for n, m, e, skew in ((1, 1, 1, False), (16, 16, 100, False), (17, 40, 300, False), (2000, 2000, 60000, False),
                           (130, 130, 0, False), (5201, 5201, 50000, True), (3000, 2529, 9000, False), (700, 9000, 20000, True),
-                          (2000, 2000, 90000, True), (300, 2000, 30000, False)):
+                          (2000, 2000, 90000, True), (300, 2000, 30000, False), (4000, 4000, 60000, False), (900, 5056, 30000, True),
+                          (900, 5057, 30000, False)):
         src, dst = _skewed_graph(rng, n, e) if skew else _rand_graph(rng, n, e)
         dst = dst % m
         key = np.unique(src * m + dst)
@@ -445,7 +447,10 @@ def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
         q = g.quad
         bc, nb, ne = q["block_cols"], q["n_blocks"], q["n_entries"]
         real = (n + 15) // 16
-        assert bc % 4 == 0 and bc <= 2528 and nb == (m + bc - 1) // bc and ne % 4 == 0
+        rb = 32 if 2528 < m <= 5056 else 64  # bytes of a slab row
+        assert rb == ops.lib.wdg_sell16_row_bytes(m) and q["half"] == (rb == 32)
+        assert bc % 4 == 0 and bc <= 2528 * 64 // rb and nb == (m + bc - 1) // bc and ne % 4 == 0
+        assert nb == 1 or rb == 64
         lens = np.diff(rowptr)
         perm_all = _np(q["perm"])
         perm = perm_all[:n]
@@ -496,7 +501,7 @@ def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
                     cr, vr = col[rowptr[r]:rowptr[r + 1]], val[rowptr[r]:rowptr[r + 1]]
                     sel = (cr >= b * bc) & (cr < (b + 1) * bc)
                     l = int(sel.sum())
-                    want_off = (cr[sel] - b * bc) * 64
+                    want_off = (cr[sel] - b * bc) * rb
                     if int(r) in seen_first:  # a padding slot: the last row's entries in the last row's order
                         np.testing.assert_array_equal(blk_c[r16], blk_c[seen_first[int(r)]])
                         np.testing.assert_array_equal(blk_v[r16], blk_v[seen_first[int(r)]])
@@ -510,19 +515,19 @@ def test_sell16_layout_matches_csr(ops, oracle, monkeypatch, column_order):
                         np.testing.assert_array_equal(blk_c[r16, :l][o], want_off)
                         np.testing.assert_array_equal(blk_v[r16, :l][o], vr[sel])
                     else:  # split form: the padding (one of FOUR zero rows, value 0) may stand anywhere among the steps
-                        real = blk_c[r16] < bc * 64
+                        real = blk_c[r16] < bc * rb
                         assert real.sum() == l
                         o = np.argsort(blk_c[r16][real])
                         np.testing.assert_array_equal(blk_c[r16][real][o], want_off)
                         np.testing.assert_array_equal(blk_v[r16][real][o], vr[sel])
-                        assert ((blk_c[r16][~real] - bc * 64) % 64 == 0).all() and (blk_c[r16][~real] < (bc + 4) * 64).all()
+                        assert ((blk_c[r16][~real] - bc * rb) % rb == 0).all() and (blk_c[r16][~real] < (bc + 4) * rb).all()
                         assert (blk_v[r16][~real] == 0).all()
                         # every real entry lies among the steps the kernel sweeps: 32 per full piece + the last piece rounded to 4
                         w_ = width[b, s_]
                         swept = 32 * ((w_ - 1) // 32) + -(-(w_ - 32 * ((w_ - 1) // 32)) // 4) * 4 if w_ else 0
                         assert not real[swept:].any()
                         continue
-                    assert (blk_c[r16, l:] == bc * 64).all() and (blk_v[r16, l:] == 0).all()
+                    assert (blk_c[r16, l:] == bc * rb).all() and (blk_v[r16, l:] == 0).all()
         assert tuple(ext[nb * ne]) == (chunk, ne | (CONT if split else 0)) and q["chunks"] == chunk
 
 
@@ -571,7 +576,9 @@ def test_sell16_bank_aware_order_reduces_conflicts(ops, oracle, monkeypatch, ord
 
 QUAD_SHAPES = [(2000, 2000, 512, 60000), (2000, 2000, 500, 20000), (2708, 2708, 1433, 13264), (100, 100, 8, 300),
                (1, 1, 16, 1), (17, 33, 40, 200), (3000, 2528, 64, 20000), (3000, 2529, 36, 20000), (5201, 5201, 130, 100000),
-               (700, 9000, 24, 30000), (4000, 4000, 100, 100000), (2048, 2048, 10, 2048), (1500, 1500, 9, 9000)]
+               (700, 9000, 24, 30000), (4000, 4000, 100, 100000), (2048, 2048, 10, 2048), (1500, 1500, 9, 9000),
+               # HALF slabs (2529 .. 5056 columns: one block of 32-byte rows, feature groups of 8): whole / ragged groups, odd F
+               (4000, 4000, 512, 90000), (5056, 5056, 8, 30000), (3000, 5056, 67, 40000), (4000, 4000, 13, 200000)]
 
 
 @pytest.mark.parametrize("n,m,f,e", QUAD_SHAPES)
@@ -669,9 +676,14 @@ def test_spmm_quad_fuzz_batches(ops, oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     entries, want = [], []
     shared = None
+    half = seed % 3 == 2  # a quad table holds graphs of 2529 .. 5056 columns (32-byte slab rows) only, or none of them
     for case in range(8):
-        n_rows = int(rng.choice([1, 15, 16, 17, 300, 1000, 2000, 2600, 5000]))
-        n_cols = n_rows if rng.random() < 0.6 else int(rng.choice([1, 7, 64, 500, 2528, 2529, 3000, 6000]))
+        if half:
+            n_rows = int(rng.choice([1, 17, 300, 2600, 4000, 5000, 7000]))
+            n_cols = n_rows if 2528 < n_rows <= 5056 and rng.random() < 0.6 else int(rng.choice([2529, 3000, 4000, 5056]))
+        else:
+            n_rows = int(rng.choice([1, 15, 16, 17, 300, 1000, 2000, 2528, 6000]))
+            n_cols = n_rows if rng.random() < 0.6 else int(rng.choice([1, 7, 64, 500, 2528, 5057, 6000]))
         f = int(rng.choice([8, 9, 12, 16, 17, 32, 36, 64, 100]))
         if shared is not None and rng.random() < 0.5:
             x = shared
@@ -699,11 +711,44 @@ def test_spmm_quad_fuzz_batches(ops, oracle, seed):
     if not entries:
         return
     batch = ops.SpmmBatch(entries)
-    assert batch.quad
+    assert batch.quad and bool(batch.flags & ops.SPMM_HALF_SLAB) == half
     batch.launch()
     torch.cuda.synchronize()
     for ent, (ref, tol) in zip(entries, want):
         np.testing.assert_allclose(_np(ent[2]), ref, **tol)
+
+
+def test_spmm_batch_of_half_slab_and_other_graphs_takes_the_csr_kernels(ops, oracle):
+    """graphs of 2529 .. 5056 columns carry SELL-16 copies over 32-byte slab rows, the others over 64-byte rows: one quad-row
+    launch serves one kind, so a table that mixes them runs on the CSR families (same results); the C entry refuses a
+    half-sized table that does not vouch for its jobs (WDG_SPMM_HALF_SLAB)"""
+    rng = np.random.default_rng(77)
+    entries, want = [], []
+    for n in (3000, 1000, 4000):
+        e = 6 * n
+        src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+        g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+        x = torch.from_numpy(rng.standard_normal((n, 40)).astype(np.float32)).cuda()
+        rowptr, col = _np(g.rowptr), _np(g.col)
+        want.append(oracle.spmm_csr(rowptr, col, np.ones(len(col), np.float32), _np(x)))
+        entries.append((g, x, torch.full((n, 40), float("nan"), device="cuda"), None, None, False))
+    batch = ops.SpmmBatch(entries)
+    assert not batch.quad and entries[0][0].quad["half"] and not entries[1][0].quad["half"]
+    batch.launch()
+    torch.cuda.synchronize()
+    for ent, ref in zip(entries, want):
+        np.testing.assert_allclose(_np(ent[2]), ref, rtol=1e-5, atol=1e-6 * float(np.abs(ref).max()))
+    halves = ops.SpmmBatch([entries[0], entries[2]])
+    assert halves.quad and halves.flags & ops.SPMM_HALF_SLAB
+    for ent in entries:
+        ent[2].fill_(float("nan"))
+    halves.launch()
+    torch.cuda.synchronize()
+    for i in (0, 2):
+        np.testing.assert_allclose(_np(entries[i][2]), want[i], rtol=1e-5, atol=1e-6 * float(np.abs(want[i]).max()))
+    rc = ops.lib.wdg_spmm_quad_batched_f32(halves.table.data_ptr(), halves.n_jobs, halves.items.data_ptr(), halves.seg_ptr.data_ptr(),
+                                           halves.n_segments, halves.max_cols, halves.max_feat, halves.flags & ~ops.SPMM_HALF_SLAB, 0)
+    assert rc != 0
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -180,14 +180,15 @@ def test_full_c3_sweep_shard_on_the_quad_kernel(oracle, seeds, n_nodes):
     stored entries per row, the wide graphs split into CONT entries) x 5 (10) seeds, N = 2000, F = 500 (+ the label columns):
     every (graph, feature group) item is produced by every launch (outputs pre-filled with NaN), repeated launches are
     bitwise equal to the single-graph calls, and sampled graphs match the oracle within 1e-5.  n_nodes = 4000 / 800: the
-    LITERAL reading of configs[2] / configs[1] (4000 nodes: two column blocks of 2000, the whole graph one item of the
-    several-block path; 800 nodes: one small block)."""
+    LITERAL reading of configs[2] / configs[1] (4000 nodes: one column block of 32-byte slab rows - feature groups of 8 - on
+    the same pipelined loop; 800 nodes: one small block)."""
     from wdg_amd import ops, sweep, synth
     jobs = sweep.make_jobs(synth.H_LEVELS_10_K10, range(seeds), k=10, n_nodes=n_nodes)
     sb = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0)
     assert sb.spmm.plan()[0] == 5 and sb.spmm.quad
-    assert bool(sb.spmm.flags & ops.SPMM_SMALL_OFFSETS) == (n_nodes <= 2528)  # (split-form entries: one column block only)
-    assert sb.graphs[0].quad["n_blocks"] == (2 if n_nodes == 4000 else 1)
+    assert sb.spmm.flags & ops.SPMM_SMALL_OFFSETS and sb.spmm.flags & ops.SPMM_DMA_OK  # (split-form entries: the pipelined loop)
+    assert sb.graphs[0].quad["n_blocks"] == 1 and sb.graphs[0].quad["half"] == (n_nodes == 4000)
+    assert bool(sb.spmm.flags & ops.SPMM_HALF_SLAB) == (n_nodes == 4000)
     assert sb.edges == seeds * n_nodes * sum(int(10 / h) + 1 for h in synth.H_LEVELS_10_K10)
     sample = sorted({0, 3, 9, len(jobs) // 2, len(jobs) - 7, len(jobs) - 1})
     want = {}
@@ -201,10 +202,8 @@ def test_full_c3_sweep_shard_on_the_quad_kernel(oracle, seeds, n_nodes):
         torch.cuda.synchronize()
         for i, (_g, _x, y, _d, _cs, _uv) in enumerate(sb.spmm.keep):
             assert not bool(torch.isnan(y).any()), (launch, i)
-            if i in want and n_nodes <= 2528:
+            if i in want:
                 assert torch.equal(y, want[i]), (launch, i)
-            elif i in want:  # the single-graph call of a two-block graph takes the band kernel (CSR order): same sums, other order
-                torch.testing.assert_close(y, want[i], rtol=1e-5, atol=1e-6 * float(want[i].abs().max()))
     for i in sample:  # against the oracle: D^-1 (A + I) [X | onehot | 0]
         j = jobs[i]
         src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)

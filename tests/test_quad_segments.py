@@ -26,7 +26,7 @@ class _G:
         assert widths.shape[1] % 4 == 0
         self.n_rows, self.n_cols = n_rows, n_cols
         self.quad = dict(widths=widths, n_slices=widths.shape[1], n_entries=widths.shape[1], n_su=widths.shape[1] // 4,
-                         n_blocks=widths.shape[0])
+                         n_blocks=widths.shape[0], half=widths.shape[0] == 1 and 2528 < n_cols <= 5056)
 
 
 def _units_of(entries, order, item):

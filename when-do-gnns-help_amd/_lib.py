@@ -76,6 +76,7 @@ SIGNATURES = {
     "wdg_spmm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "wdg_spmm_plan": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "wdg_sell16_block_cols": (c_int32, [c_int32]),
+    "wdg_sell16_row_bytes": (c_int32, [c_int32]),
     "wdg_sell16_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "wdg_sell16_max_entries": (c_int64, [c_int32]),
     "wdg_csr_to_sell16_count": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
@@ -94,7 +95,7 @@ SIGNATURES = {
     "wdg_spmm_narrow_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "wdg_spmm_quad_batched_clocked_f32": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p,
                                                   c_void_p]),
-    "wdg_spmm_quad_workgroups": (c_int32, [c_int32, c_int32]),
+    "wdg_spmm_quad_workgroups": (c_int32, [c_int32, c_int32, c_int]),
     "wdg_debug_clock": (c_int, [c_void_p, c_void_p]),
     "wdg_spmm_quad_batched_f32": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int,
                                           c_void_p]),

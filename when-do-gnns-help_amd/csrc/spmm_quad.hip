@@ -79,10 +79,18 @@ constexpr int Q_MAXU = 16;             // units (slices) per wave and phase when
                                        // (graph, feature group) item stages each column block of X once (round 2: 8 -> two
                                        // items per such graph, every block staged twice: 728 us for the 50-graph shard)
 
+// Graphs of 2 529 .. 5 056 columns keep ONE column block by staging 8 features per source row instead of 16 (HALF slabs, round
+// 4: 32-byte slab rows, index offsets pre-scaled by 32, a quad of lanes reads a row with ds_read_b64): the literal N = 4000
+// reading of BASELINE configs[2] ran the several-block path at 0.20 of the roofline, staging every block of X per graph.
+constexpr int Q_HALF_MAX_BLOCK_COLS = 2 * Q_MAX_BLOCK_COLS;
+__host__ __device__ inline bool q_half_hd(int n_cols) { return n_cols > Q_MAX_BLOCK_COLS && n_cols <= Q_HALF_MAX_BLOCK_COLS; }
+__host__ __device__ inline int q_row_bytes_hd(int n_cols) { return q_half_hd(n_cols) ? 32 : 64; }
+
 // columns per slab block: the columns cut into the fewest blocks of <= 2528, evenly, a multiple of 4 (column class mod 4 =
-// local class mod 4: what the bank-aware order of sell16_fill keys on)
+// local class mod 4: what the bank-aware order of sell16_fill keys on); HALF slabs: one block of all columns
 __host__ __device__ inline int q_block_cols_hd(int n_cols) {
     const int c = n_cols > 0 ? n_cols : 1;
+    if (q_half_hd(c)) return (c + 3) & ~3;
     const int blocks = (c + Q_MAX_BLOCK_COLS - 1) / Q_MAX_BLOCK_COLS;
     const int even = (c + blocks - 1) / blocks;
     const int rounded = (even + 3) & ~3;
@@ -539,7 +547,8 @@ __device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__rest
     const int blk = task / n_entries, entry = task % n_entries;
     if (ext[2 * task + 1] & Q_CONT) return;  // a continuation / ghost entry: its slice's first entry fills the chunks
     // split form (one column block, <= 128 entries per row): the conflict-free order (reorder 2: WDG_SELL_ORDER=1 keeps round 2's greedy one)
-    if (reorder == 2 && n_blocks == 1 && (ext[2 * n_entries + 1] & Q_CONT) &&
+    const int rb = (n_blocks == 1 && block_cols > Q_MAX_BLOCK_COLS) ? 32 : 64;  // bytes of a slab row (HALF slabs: 8 features)
+    if (reorder == 2 && rb == 64 && n_blocks == 1 && (ext[2 * n_entries + 1] & Q_CONT) &&
         sell16_fill_balanced(*qb, entry, rowptr, col, val, rows, n_entries, block_cols, ext, q_col, q_val))
         return;
     const int chunk0 = ext[2 * task];
@@ -563,40 +572,44 @@ __device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__rest
     width = __shfl(width, 0);
     const int n_chunks = (width + Q_CHUNK - 1) / Q_CHUNK;
     const int col0 = blk * block_cols;
-    const int zero_off = block_cols * 64;  // the all-zero row behind the block's rows
+    const int zero_off = block_cols * rb;  // the (first) all-zero row behind the block's rows
     // service groups of ds_read_b128 in quads (= rows): {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}
     const int x = r & 7;
     const bool g0 = (x == 0 || x == 3 || x == 5 || x == 6);
     const int m0 = g0 ? 0 : 1, m1 = g0 ? 3 : 2, m2 = g0 ? 5 : 4, m3 = g0 ? 6 : 7;
     const int rank = (x == m0) ? 0 : (x == m1) ? 1 : (x == m2) ? 2 : 3;
     const int hi = r & 8;
-    int cnt[4] = {0, 0, 0, 0}, cur[4] = {0, 0, 0, 0};
+    // HALF slabs (32-byte rows, ds_read_b64: service groups of 32 lanes = rows 0-7 / 8-15, a row's bank window is
+    // 8 (column mod 8) .. + 7): eight classes, the eight rows of a group choose in row order
+    const int n_cls = rb == 32 ? 8 : 4, cmask = n_cls - 1;
+    const int my_rank = rb == 32 ? x : rank;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (reorder)
-        for (int j = 0; j < len; ++j) ++cnt[(col[a + j] - col0) & 3];
+        for (int j = 0; j < len; ++j) ++cnt[(col[a + j] - col0) & cmask];
     int32_t *dst = q_col + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + r * Q_CHUNK;
     float *dstv = q_val ? q_val + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + r * Q_CHUNK : nullptr;
     for (int e = 0; e < n_chunks * Q_CHUNK; ++e) {
         int pick = -1;
         if (reorder) {
             unsigned used = 0;
-            for (int rk = 0; rk < 4; ++rk) {
+            for (int rk = 0; rk < n_cls; ++rk) {
                 int cls = -1;
-                if (worker && !ghost && rank == rk && e < len) {
+                if (worker && !ghost && my_rank == rk && e < len) {
                     int best = -1, best_any = -1;
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        if (cnt[c4] == 0) continue;
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        if (c4 >= n_cls || cnt[c4] == 0) continue;
                         if (best_any < 0 || cnt[c4] > cnt[best_any]) best_any = c4;
                         if (!((used >> c4) & 1u) && (best < 0 || cnt[c4] > cnt[best])) best = c4;
                     }
                     cls = best >= 0 ? best : best_any;
                     int j = cur[cls];
-                    while (((col[a + j] - col0) & 3) != cls) ++j;
+                    while (((col[a + j] - col0) & cmask) != cls) ++j;
                     pick = j;
                     cur[cls] = j + 1;
                     --cnt[cls];
                 }
-                const int src_lane = hi + (rk == 0 ? m0 : rk == 1 ? m1 : rk == 2 ? m2 : m3);
+                const int src_lane = hi + (rb == 32 ? rk : (rk == 0 ? m0 : rk == 1 ? m1 : rk == 2 ? m2 : m3));
                 const int got = __shfl(cls, src_lane);
                 if (got >= 0) used |= 1u << got;
             }
@@ -607,7 +620,7 @@ __device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__rest
         if (ghost) pick = pick_last;
         if (worker) {
             const int at = (e / Q_CHUNK) * Q_CHUNK_INTS + (e % Q_CHUNK);
-            dst[at] = pick >= 0 ? (col[a + pick] - col0) * 64 : zero_off;
+            dst[at] = pick >= 0 ? (col[a + pick] - col0) * rb : zero_off;
             if (dstv) dstv[at] = pick >= 0 ? (val ? val[a + pick] : 1.f) : 0.f;
         }
     }
@@ -775,15 +788,17 @@ __device__ __forceinline__ float q_bcastf(float v) {
 // workgroup barrier that waits for this wave's LDS traffic only (global stores and loads stay in flight across it)
 __device__ __forceinline__ void q_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// X[begin : begin + rows, f0 : f0 + 16] -> xs rows 0 .. rows - 1 (64 B each), and the zero row at `zero_row`
-template <typename TIN, int THREADS>
+// X[begin : begin + rows, f0 : f0 + 16] -> xs rows 0 .. rows - 1 (64 B each), and the zero rows at `zero_row`
+// (HALF: f0 .. f0 + 8, 32-byte rows)
+template <typename TIN, int THREADS, bool HALF = false>
 __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int zero_row, int f0, float4 *xs, int wave,
                                         int lane, int tid) {
+    constexpr int SL = HALF ? 2 : 4;  // float4 slots per slab row
     const int F = h.n_feat;
-    const int n_stage = (h.reserved & 2) ? 0 : rows * 4;  // float4 slots (reserved bit 1: timing ablation)
+    const int n_stage = (h.reserved & 2) ? 0 : rows * SL;  // float4 slots (reserved bit 1: timing ablation)
     const bool x_vec = sizeof(TIN) == 4 && (F % 4 == 0) && (h.ldx % 4 == 0) && (((uintptr_t)h.X & 15) == 0);
     const global_ptr<const TIN> X = (global_ptr<const TIN>)h.X;
-    if (tid < 16) xs[zero_row * 4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // FOUR zero rows, one per bank window (sell16_fill_balanced)
+    if (tid < 4 * SL) xs[zero_row * SL + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // FOUR zero rows, one per bank window (sell16_fill_balanced)
     // Staged through registers, NOT by LDS-DMA (global_load_lds): the compiler orders every later ds_read that may alias
     // a DMA's destination behind it with s_waitcnt vmcnt(0) - it cannot see that the phase barrier already did -, which
     // turns every counted wait of the unit pipeline into a wait for the wave's last store.  A workgroup stages a slab once
@@ -796,7 +811,7 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
             const int i = i0 + j * THREADS + tid;
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n_stage) {
-                const int row = begin + (i >> 2), f = f0 + (i & 3) * 4;
+                const int row = begin + i / SL, f = f0 + (i % SL) * 4;
                 const global_ptr<const TIN> src = X + static_cast<int64_t>(row) * h.ldx + f;
                 if (x_vec) {
                     if (f < F) v[j] = load_f32x4((global_ptr<const float>)src);
@@ -825,17 +840,22 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
 // its own, 16 waves x 2 reads cover about half of the LDS pipe's latency (measured: LDS 58 % busy, waves 67 % waiting).  The
 // entries are therefore read a quad at a time into four register sets, quad q + 1 requested before quad q is added
 // (scheduling barriers keep the order): four to eight reads in flight per wave.
-#define WDG_Q_READ(J, R, V)                                                                     \
-    const f32x4_t V = *(const f32x4_t __attribute__((address_space(3))) *)(slab + (q_bcast<J>(cc[R]) + loff));
-#define WDG_Q_ADD(J, R, V)                                                                      \
-    if (HAS_VAL) {                                                                              \
-        const float wv = q_bcastf<J>(wc[R]);                                                    \
-        a0 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{V.x, V.y}, a0);                     \
-        a1 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{V.z, V.w}, a1);                     \
-    } else {                                                                                    \
-        a0 += f32x2{V.x, V.y};                                                                  \
-        a1 += f32x2{V.z, V.w};                                                                  \
-    }
+// (QV, in the scope of the expansion: f32x4_t - a lane's 16 bytes of a 64-byte slab row, ds_read_b128 - or, HALF slabs, f32x2 -
+// 8 bytes of a 32-byte row, ds_read_b64, one packed add)
+__device__ __forceinline__ void q_acc(f32x2 &a0, f32x2 &a1, const f32x4_t &v) {
+    a0 += f32x2{v.x, v.y};
+    a1 += f32x2{v.z, v.w};
+}
+__device__ __forceinline__ void q_acc(f32x2 &a0, f32x2 &, const f32x2 &v) { a0 += v; }
+__device__ __forceinline__ void q_accw(f32x2 &a0, f32x2 &a1, const f32x4_t &v, float wv) {
+    a0 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{v.x, v.y}, a0);
+    a1 = __builtin_elementwise_fma(f32x2{wv, wv}, f32x2{v.z, v.w}, a1);
+}
+__device__ __forceinline__ void q_accw(f32x2 &a0, f32x2 &, const f32x2 &v, float wv) { a0 = __builtin_elementwise_fma(f32x2{wv, wv}, v, a0); }
+#define WDG_Q_READ(J, R, V) const QV V = *(const QV __attribute__((address_space(3))) *)(slab + (q_bcast<J>(cc[R]) + loff));
+#define WDG_Q_ADD(J, R, V)                                \
+    if (HAS_VAL) q_accw(a0, a1, V, q_bcastf<J>(wc[R]));   \
+    else q_acc(a0, a1, V);
 #define WDG_Q_READ4(J, P) WDG_Q_READ(J, 0, P##0) WDG_Q_READ(J, 1, P##1) WDG_Q_READ(J, 2, P##2) WDG_Q_READ(J, 3, P##3)
 #define WDG_Q_ADD4(J, P) WDG_Q_ADD(J, 0, P##0) WDG_Q_ADD(J, 1, P##1) WDG_Q_ADD(J, 2, P##2) WDG_Q_ADD(J, 3, P##3)
 // one quad of entries, on its own (partial chunks)
@@ -916,6 +936,10 @@ __device__ __forceinline__ void q_st4(global_ptr<float> base, unsigned voff, f32
     asm volatile("global_store_dwordx4 %0, %1, %2 " WDG_Q_STORE_POLICY "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
 }
 
+__device__ __forceinline__ void q_st2(global_ptr<float> base, unsigned voff, f32x2 v) {  // HALF slabs: 8 bytes per lane
+    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(base) : "memory");
+}
+
 struct QJobE {  // what stage E needs of a job (SGPRs; re-read from the table when the stage moves to another job)
     global_ptr<const int32_t> ext, perm;
     int n_su;
@@ -929,15 +953,16 @@ struct QJobC {
     unsigned ldy4;  // bytes per row of Y
 };
 
-template <int D>
+template <int D, bool HALF>
 __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                              int unit_begin, int unit_end, int stride, int f0, lds_cptr slab, lds_iptr next_unit,
                                              bool no_sweep, bool no_store, bool no_idx, int wave, int lane) {
     constexpr int NPRE = 2;          // index chunks per entry (all of them)
     constexpr int NS = D + 1;        // register sets per stage: D super-units in flight + the one being consumed
     constexpr bool HAS_VAL = false;  // (explicit values run the plain loop)
+    using QV = std::conditional_t<HALF, f32x2, f32x4_t>;
     const int r = lane >> 2, p = lane & 3;
-    const int loff = p * 16;
+    const int loff = p * (HALF ? 8 : 16);
     const unsigned lane16 = lane * 16, lane4 = lane * 4, ext_lane = (lane < Q_SU ? lane : Q_SU - 1) * 8;
     const int bperm0 = r * 4;  // ds_bpermute address of lane r: slice i's row r sits in lane 16 i + r of the 64-row registers
     const int last_job = first_job + n_jobs - 1;
@@ -1085,8 +1110,9 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
             const int sb = __builtin_amdgcn_ds_bpermute(bperm0 + i * (Q_ROWS * 4), cur.scale_bits);
             const float scale0 = cur.has_scale ? __int_as_float(sb) : 1.f;
             const unsigned row0 = no_store ? static_cast<unsigned>(r) : static_cast<unsigned>(row);  // (timing ablation: rows 0..15)
-            q_st4(jc.Y, row0 * jc.ldy4 + static_cast<unsigned>(f0 * 4 + loff),
-                  f32x4_t{a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0});
+            if (HALF) q_st2(jc.Y, row0 * jc.ldy4 + static_cast<unsigned>(f0 * 4 + loff), f32x2{a0.x * scale0, a0.y * scale0});
+            else q_st4(jc.Y, row0 * jc.ldy4 + static_cast<unsigned>(f0 * 4 + loff),
+                       f32x4_t{a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0});
         }
     };
     // the requests of these stages have landed: their registers may be read (or copied) from here on
@@ -1211,12 +1237,13 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
 // the plain loop: any feature group (ragged, scalar stores), any entry width, explicit values; nothing requested ahead.
 // Units are super-units of four entries as well; a CONT entry keeps the accumulators of the entry before it, and the rows
 // are stored once, after the slice's last entry (ghost entries: nothing to do).
-template <bool HAS_VAL>
+template <bool HAS_VAL, bool HALF>
 __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                                int unit_begin, int unit_end, int stride, int f0, int F, lds_cptr slab,
                                                bool no_sweep, bool no_store, int wave, int lane) {
+    using QV = std::conditional_t<HALF, f32x2, f32x4_t>;
     const int r = lane >> 2, p = lane & 3;
-    const int loff = p * 16;
+    const int loff = p * (HALF ? 8 : 16);
     q_barrier_lds();  // the slab is in place for every wave
     for (int u = unit_begin + wave * stride; u < unit_end; u += Q_FAST_WAVES * stride) {
         int j = first_job, su = u;
@@ -1253,12 +1280,19 @@ __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const w
             if (!last) continue;
             const int row = job.perm[entry * Q_ROWS + r];
             const float scale0 = job.row_scale ? job.row_scale[row] : 1.f;
-            const int f = f0 + p * 4;
+            const int f = f0 + p * (HALF ? 2 : 4);
             const int row0 = no_store ? r : row;
             const global_ptr<float> dst = job.Y + static_cast<uint64_t>(static_cast<unsigned>(row0)) * ldy + f;
             const float4 o = make_float4(a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0);
             const bool y_vec = (F % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
-            if (y_vec) {
+            if (HALF) {  // two features per lane
+                if (y_vec) {
+                    if (f < F) *(global_ptr<f32x2>)dst = f32x2{o.x, o.y};
+                } else {
+                    if (f + 0 < F) dst[0] = o.x;
+                    if (f + 1 < F) dst[1] = o.y;
+                }
+            } else if (y_vec) {
                 if (f < F) store_f32x4(dst, o);
             } else {
                 if (f + 0 < F) dst[0] = o.x;
@@ -1270,7 +1304,7 @@ __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const w
     }
 }
 
-template <typename TIN, bool HAS_VAL>
+template <typename TIN, bool HAS_VAL, bool HALF>
 __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                                int unit_begin, int unit_end, int stride, int f0, float4 *xs, lds_iptr next_unit,
                                                bool first_phase, bool y_vec_all) {
@@ -1283,13 +1317,13 @@ __device__ __forceinline__ void q_phase_single(const wdg_spmm_job *jobs, const w
     if (f0 >= F) return;  // workgroup-uniform
     if (!first_phase) q_barrier_lds();  // every wave is done with the previous phase's slab
     if (tid == 0) *next_unit = 2 * Q_DEPTH * Q_FAST_WAVES;  // (q_units_fast: the units behind the statically dealt ones; its slab barrier publishes it)
-    q_stage<TIN, Q_FAST_THREADS>(head, 0, head.n_cols, head.block_cols, f0, xs, wave, lane, tid);
+    q_stage<TIN, Q_FAST_THREADS, HALF>(head, 0, head.n_cols, head.block_cols, f0, xs, wave, lane, tid);
     const bool no_sweep = head.reserved & 4, no_store = head.reserved & 1;  // timing ablations (diagnostics)
     // whole feature group and 16-byte stores for every job of the phase (the table's flags vouch for the alignment)
     // (y_vec: the launcher's promise - 16-byte stores, 32-bit offsets, every job in split form; explicit values: plain loop)
-    const bool full = (f0 + 16 <= F) && head.y_vec && !HAS_VAL;
-    if (full) q_units_fast<Q_DEPTH>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, next_unit, no_sweep, no_store, (head.reserved & 8) != 0, wave, lane);
-    else q_units_simple<HAS_VAL>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, no_store, wave, lane);
+    const bool full = (f0 + (HALF ? 8 : 16) <= F) && head.y_vec && !HAS_VAL;
+    if (full) q_units_fast<Q_DEPTH, HALF>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, (lds_cptr)xs, next_unit, no_sweep, no_store, (head.reserved & 8) != 0, wave, lane);
+    else q_units_simple<HAS_VAL, HALF>(jobs, inl, first_job, n_jobs, unit_begin, unit_end, stride, f0, F, (lds_cptr)xs, no_sweep, no_store, wave, lane);
 }
 
 // ---- a phase whose graphs have SEVERAL column blocks (more than 2528 columns; N = 4000: two blocks of 2000): the blocks of
@@ -1303,6 +1337,7 @@ template <typename TIN, bool HAS_VAL>
 __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int first_job, int n_jobs,
                                               int unit_begin, int unit_end, int stride, int f0, float4 *xs, bool first_phase,
                                               bool y_vec_all) {
+    using QV = f32x4_t;  // (64-byte slab rows)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -1405,8 +1440,11 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
 // (segment s, feature group g), lw = s * n_groups + g, dealt to the XCD's workgroups round-robin.
 // items != NULL: segment `seg` = the phases items[seg_ptr[seg] .. seg_ptr[seg + 1]); items == NULL: one job (the by-value
 // descriptor), segment `seg` = its units seg, seg + n_segments, ...
-template <typename TIN, bool HAS_VAL, bool MULTI>
-__global__ __launch_bounds__(MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS) void spmm_quad_kernel(const wdg_spmm_job *__restrict__ jobs,
+// MODE: Q_ONE one column block of 64-byte slab rows (<= 2528 columns), Q_MULTI several of them, Q_HALF one block of 32-byte rows
+// (<= 5056 columns, feature groups of 8)
+enum { Q_ONE = 0, Q_MULTI = 1, Q_HALF = 2 };
+template <typename TIN, bool HAS_VAL, int MODE>
+__global__ __launch_bounds__(MODE == Q_MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS) void spmm_quad_kernel(const wdg_spmm_job *__restrict__ jobs,
                                                               const wdg_spmm_job inline_job,
                                                               const wdg_spmm_item *__restrict__ items,
                                                               const int32_t *__restrict__ seg_ptr, int subs, int n_groups,
@@ -1425,7 +1463,7 @@ __global__ __launch_bounds__(MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS) void spmm
     if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     for (int lw = wg; lw < n_local; lw += wgs_per_xcd) {
         const int seg = xcd * subs + lw / n_groups;
-        const int f0 = (lw % n_groups) * 16;
+        const int f0 = (lw % n_groups) * (MODE == Q_HALF ? 8 : 16);
         if (items) {
             typedef const int32_t __attribute__((address_space(4))) *cptr;
             const int pb = ((cptr)seg_ptr)[seg], pe = ((cptr)seg_ptr)[seg + 1];
@@ -1434,15 +1472,15 @@ __global__ __launch_bounds__(MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS) void spmm
                 const iptr it = (iptr)(items + ph);
                 const int fj = it->first_job, nj = it->n_jobs, ub = it->unit_begin, ue = it->unit_end;
                 Q_STAMP(2 + 2 * min(ph - pb, 2));  // (diagnostic build: start of the phase; + 1: its staging is done)
-                if (MULTI) q_phase_multi<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, first_phase, y_vec_all != 0);
-                else q_phase_single<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
+                if (MODE == Q_MULTI) q_phase_multi<TIN, HAS_VAL>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, first_phase, y_vec_all != 0);
+                else q_phase_single<TIN, HAS_VAL, MODE == Q_HALF>(jobs, inline_job, fj, nj, ub, ue, 1, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
                 first_phase = false;
             }
         } else {
             const int n_segments = kXcds * subs;
             const int n_units = inline_job.q_n_entries / Q_SU;
-            if (MULTI) q_phase_multi<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
-            else q_phase_single<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
+            if (MODE == Q_MULTI) q_phase_multi<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
+            else q_phase_single<TIN, HAS_VAL, MODE == Q_HALF>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
             first_phase = false;
         }
     }
@@ -1461,17 +1499,20 @@ int q_reorder_mode() {  // entry order inside (row, block) segments; WDG_SELL_OR
 
 template <typename TIN>
 int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_item *items, const int32_t *seg_ptr,
-             int subs, int max_cols, int max_feat, bool has_val, bool y_vec_all, hipStream_t st,
+             int subs, int max_cols, int max_feat, bool has_val, bool y_vec_all, bool half, hipStream_t st,
              unsigned long long *wg_clock = nullptr) {
-    const int n_groups = static_cast<int>(ceil_div(max_feat, 16));
-    // every job's block size is <= min(its columns rounded up to 4, 2528): the bound over the table sizes the slab
-    const int block_cols = std::min(Q_MAX_BLOCK_COLS, (std::max(max_cols, 1) + 3) & ~3);
-    const bool multi = max_cols > Q_MAX_BLOCK_COLS;
-    const size_t lds = (static_cast<size_t>(block_cols) + 4) * 64;  // + the four zero rows
-    const void *kernels[4] = {reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, false>),
-                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, true, false>),
-                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, true>),
-                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, true, true>)};
+    // half: EVERY job of the launch has 2528 < n_cols <= 5056, i.e. a SELL-16 copy over 32-byte slab rows (the callers check)
+    const int n_groups = static_cast<int>(ceil_div(max_feat, half ? 8 : 16));
+    // every job's block size is <= min(its columns rounded up to 4, 2528 / 5056): the bound over the table sizes the slab
+    const int block_cols = std::min(half ? Q_HALF_MAX_BLOCK_COLS : Q_MAX_BLOCK_COLS, (std::max(max_cols, 1) + 3) & ~3);
+    const bool multi = !half && max_cols > Q_MAX_BLOCK_COLS;
+    const size_t lds = (static_cast<size_t>(block_cols) + 4) * (half ? 32 : 64);  // + the four zero rows
+    const void *kernels[6] = {reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, Q_ONE>),
+                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, true, Q_ONE>),
+                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, Q_MULTI>),
+                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, true, Q_MULTI>),
+                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, false, Q_HALF>),
+                              reinterpret_cast<const void *>(spmm_quad_kernel<TIN, true, Q_HALF>)};
     static thread_local int configured_dev = -1;
     const int dev = current_device();
     if (configured_dev != dev) {
@@ -1484,14 +1525,17 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
     const int wgs_per_xcd = std::max(1, std::min(cus / kXcds, subs * n_groups));
     const dim3 grid(static_cast<unsigned>(wgs_per_xcd * kXcds));
 #define WDG_Q_LAUNCH(V, M)                                                                                             \
-    hipLaunchKernelGGL((spmm_quad_kernel<TIN, V, M>), grid, dim3(M ? Q_MULTI_THREADS : Q_FAST_THREADS), lds, st, jobs, inl, items, seg_ptr, subs, \
+    hipLaunchKernelGGL((spmm_quad_kernel<TIN, V, M>), grid, dim3(M == Q_MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS), lds, st, jobs, inl, items, seg_ptr, subs, \
                        n_groups, y_vec_all ? 1 : 0, wg_clock)
     if (multi) {
-        if (has_val) WDG_Q_LAUNCH(true, true);
-        else WDG_Q_LAUNCH(false, true);
+        if (has_val) WDG_Q_LAUNCH(true, Q_MULTI);
+        else WDG_Q_LAUNCH(false, Q_MULTI);
+    } else if (half) {
+        if (has_val) WDG_Q_LAUNCH(true, Q_HALF);
+        else WDG_Q_LAUNCH(false, Q_HALF);
     } else {
-        if (has_val) WDG_Q_LAUNCH(true, false);
-        else WDG_Q_LAUNCH(false, false);
+        if (has_val) WDG_Q_LAUNCH(true, Q_ONE);
+        else WDG_Q_LAUNCH(false, Q_ONE);
     }
 #undef WDG_Q_LAUNCH
     return check_launch("spmm_quad_kernel");
@@ -1529,7 +1573,8 @@ bool quad_eligible_single(const wdg_spmm_job &j) {
 
 template <typename TIN>
 int quad_single(const wdg_spmm_job &j, hipStream_t st) {
-    const int n_groups = static_cast<int>(ceil_div(j.n_feat, 16));
+    const bool half = q_half_hd(j.n_cols);  // (the layout functions key on the same test)
+    const int n_groups = static_cast<int>(ceil_div(j.n_feat, half ? 8 : 16));
     const int n_units = j.q_n_entries / Q_SU;  // super-units
     const int wgs_per_xcd = std::max(wdg_device_cus(), 8) / kXcds;
     // segments per XCD: enough (segment, group) pairs to fill the XCD's workgroups about twice, at least 8 super-units each
@@ -1542,7 +1587,7 @@ int quad_single(const wdg_spmm_job &j, hipStream_t st) {
     // 16-byte stores and 32-bit byte offsets into Y and into the index arrays (what the fast loop addresses with)
     const bool y_vec = (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.n_feat % 4 == 0 &&
                        static_cast<int64_t>(j.n_rows) * j.ldy < (1ll << 30) && (j.q_flags & WDG_SELL16_SPLIT) != 0;
-    return q_launch<TIN>(nullptr, j, nullptr, nullptr, subs, j.n_cols, j.n_feat, j.val != nullptr, y_vec, st);
+    return q_launch<TIN>(nullptr, j, nullptr, nullptr, subs, j.n_cols, j.n_feat, j.val != nullptr, y_vec, half, st);
 }
 int quad_single_f32(const wdg_spmm_job &j, hipStream_t st) { return quad_single<float>(j, st); }
 int quad_single_bf16(const wdg_spmm_job &j, hipStream_t st) { return quad_single<bf16r_t>(j, st); }
@@ -1569,6 +1614,7 @@ int wdg_debug_q_stamps(unsigned long long *host_out, int n_blocks) {
 #endif
 
 int32_t wdg_sell16_block_cols(int32_t n_cols) { return q_block_cols_for(n_cols); }
+int32_t wdg_sell16_row_bytes(int32_t n_cols) { return q_row_bytes_hd(n_cols); }
 
 static int64_t q_real_slices(int32_t N) { return (static_cast<int64_t>(N) + Q_ROWS - 1) / Q_ROWS; }
 
@@ -1677,9 +1723,14 @@ int wdg_spmm_quad_batched_clocked_f32(const wdg_spmm_job *jobs_dev, int32_t n_jo
     WDG_REQUIRE(n_segments % wdg::kXcds == 0, "spmm_quad_batched: n_segments must be a multiple of 8");
     if (wdg::ceil_div(max_cols > 0 ? max_cols : 1, q_block_cols_for(max_cols)) > Q_MAX_BLOCKS)
         return wdg::fail(WDG_ERR_UNSUPPORTED, "spmm_quad_batched: more than %d column blocks", Q_MAX_BLOCKS);
+    // graphs of 2529 .. 5056 columns carry SELL-16 copies over 32-byte slab rows: a table holds them only, or none of them
+    const bool half = (flags & WDG_SPMM_HALF_SLAB) != 0;
+    WDG_REQUIRE(!half || q_half_hd(max_cols), "spmm_quad_batched: WDG_SPMM_HALF_SLAB with max_cols outside 2529 .. 5056");
+    if (!half && q_half_hd(max_cols))
+        return wdg::fail(WDG_ERR_UNSUPPORTED, "spmm_quad_batched: max_cols %d needs WDG_SPMM_HALF_SLAB (every job 2529 .. 5056 columns)", max_cols);
     return q_launch<float>(jobs_dev, wdg_spmm_job{}, items_dev, seg_ptr_dev, n_segments / wdg::kXcds, max_cols, max_feat,
                            (flags & WDG_SPMM_ANY_VAL) != 0, (flags & WDG_SPMM_DMA_OK) != 0 && (flags & WDG_SPMM_SMALL_OFFSETS) != 0,
-                           wdg::as_stream(stream), reinterpret_cast<unsigned long long *>(wg_clock_dev));
+                           half, wdg::as_stream(stream), reinterpret_cast<unsigned long long *>(wg_clock_dev));
 }
 
 int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, const wdg_spmm_item *items_dev,
@@ -1689,8 +1740,8 @@ int wdg_spmm_quad_batched_f32(const wdg_spmm_job *jobs_dev, int32_t n_jobs, cons
                                              nullptr, stream);
 }
 
-int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat) {  // the grid of the batched launch (sizes wg_clock)
-    const int n_groups = static_cast<int>(wdg::ceil_div(max_feat, 16));
+int32_t wdg_spmm_quad_workgroups(int32_t n_segments, int32_t max_feat, int flags) {  // the grid of the batched launch (sizes wg_clock)
+    const int n_groups = static_cast<int>(wdg::ceil_div(max_feat, (flags & WDG_SPMM_HALF_SLAB) ? 8 : 16));
     const int cus = std::max(wdg_device_cus(), 8);
     return std::max(1, std::min(cus / wdg::kXcds, (n_segments / wdg::kXcds) * n_groups)) * wdg::kXcds;
 }

@@ -148,7 +148,7 @@ class CsrGraph:
 
     def prefers_band(self, n_feat):
         """the band kernel (L2 gathers, a wave per row) rather than the quad-row kernel (LDS slabs) for a single aggregation:
-        wide features and either more columns than one LDS slab holds or rows too long for 16-row slices (> 128 entries).
+        wide features and either more columns than one LDS slab holds (5056, as 8-feature rows) or rows too long for 16-row slices (> 128 entries).
         WDG_SPMM_BAND=1 / 0 forces / forbids it."""
         force = os.environ.get("WDG_SPMM_BAND", "")
         if force == "0" or n_feat < 16:
@@ -157,7 +157,7 @@ class CsrGraph:
             return False
         if force not in ("", "0"):
             return True
-        return n_feat >= 64 and (self.n_cols > self.QUAD_SLAB_COLS or self.band["n_hub"] > 0)
+        return n_feat >= 64 and (self.n_cols > 2 * self.QUAD_SLAB_COLS or self.band["n_hub"] > 0)  # (<= 5056 columns: one block, 32-byte rows)
 
     QUAD_MAX_BLOCKS = 4  # column blocks of <= 2528 columns the quad-row kernel sweeps (csrc/spmm_quad.hip)
 
@@ -200,7 +200,7 @@ class CsrGraph:
         widths = (ext_host[:tasks, 1] & 0x3fffffff).reshape(n_blocks, n_entries).copy()
         self.quad = dict(ext=ext[:2 * (tasks + 1)], col=q_col, val=q_val, perm=perm, rows=rows[:16 * n_entries],
                          block_cols=block_cols, n_blocks=n_blocks, n_entries=n_entries, n_su=n_entries // 4, split=split,
-                         widths=widths, chunks=chunks, n_slices=n_entries)
+                         widths=widths, chunks=chunks, n_slices=n_entries, half=lib.wdg_sell16_row_bytes(self.n_cols) == 32)
         return True
 
     @property
@@ -510,7 +510,8 @@ class GraphBatch:
                            val=q_val[a:b] if quad_values else None,
                            perm=perm[int(perm_off[g_]):int(perm_off[g_]) + perm_len[g_]], rows=rows[int(rows_off[g_]):int(rows_off[g_]) + 16 * n_entries],
                            block_cols=int(lib.wdg_sell16_block_cols(ns[g_])), n_blocks=n_blocks[g_], n_entries=n_entries,
-                           n_su=n_entries // 4, split=split, widths=widths, chunks=chunks_g[g_], n_slices=n_entries)
+                           n_su=n_entries // 4, split=split, widths=widths, chunks=chunks_g[g_], n_slices=n_entries,
+                           half=lib.wdg_sell16_row_bytes(ns[g_]) == 32)
 
     def degree_norm(self, mode=NORM_RW, prec=PREC_F32, use_values=True):
         """-> list (one dict per graph, like ops.degree_norm) of views into the union's arrays: one launch for the shard"""
@@ -588,7 +589,7 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
         job.q_rows = q["rows"].data_ptr()
         job.q_val = q["val"].data_ptr() if (wants_val and q["val"] is not None) else 0
         job.q_block_cols, job.q_n_blocks = q["block_cols"], q["n_blocks"]
-        job.q_n_entries, job.q_flags = q["n_entries"], (1 if q["split"] else 0)
+        job.q_n_entries, job.q_flags = q["n_entries"], (1 if q["split"] else 0) | (2 if q["half"] else 0)
     else:
         job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0
         job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
@@ -748,7 +749,8 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
 
     The tape is the concatenation of the PHASE GROUPS' super-units: a phase group is a run of consecutive jobs that aggregate
     the same X (same X, ldx, n_cols, n_feat, col_scale); an item is a range of one phase group's super-units."""
-    n_groups = (n_feat + 15) // 16
+    half = len(order) > 0 and entries[order[0]][0].quad["half"]  # (32-byte slab rows: feature groups of 8; all jobs or none)
+    n_groups = (n_feat + 7) // 8 if half else (n_feat + 15) // 16
     per_xcd = max(cus // 8, 1)
     keys = []
     for i in order:
@@ -837,7 +839,9 @@ class SpmmBatch:
                        and all(e[1].data_ptr() % 16 == 0 and _ld(e[1]) % 4 == 0 and _ld(e[1]) >= need_ld for e in entries))
         self.quad = (len(entries) > 0 and not self.narrow and not quad_disabled() and min(feats) >= 8
                      and all(e[0].ensure_quad() for e in entries)
-                     and all((not (e[5] and e[0].val is not None)) or e[0].quad["val"] is not None for e in entries))
+                     and all((not (e[5] and e[0].val is not None)) or e[0].quad["val"] is not None for e in entries)
+                     # graphs of 2529 .. 5056 columns carry copies over 32-byte slab rows: a quad table holds them only, or none
+                     and len({e[0].quad["half"] for e in entries}) == 1)
         # the kernels start jobs in table order: most stored entries first, so the long jobs do not end up in the tail
         order = sorted(range(len(entries)), key=lambda i: -entries[i][0].nnz)
         if os.environ.get("WDG_SPMM_ORDER") == "0":
@@ -862,6 +866,8 @@ class SpmmBatch:
         if self.quad:
             if all(e[0].n_rows * _ld(e[2]) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 and e[0].quad["split"] for e in entries):
                 self.flags |= SPMM_SMALL_OFFSETS
+            if entries[0][0].quad["half"]:
+                self.flags |= SPMM_HALF_SLAB
             self.order = order
             self._set_segments(None)
             if os.environ.get("WDG_QUAD_VERIFY", "0") not in ("", "0"):
@@ -942,7 +948,7 @@ class SpmmBatch:
 
     def new_clock(self):
         """device buffer for launch(clock=...): start / end of every workgroup of the quad-row launch"""
-        n = int(lib.wdg_spmm_quad_workgroups(self.n_segments, self.max_feat))
+        n = int(lib.wdg_spmm_quad_workgroups(self.n_segments, self.max_feat, self.flags))
         return torch.zeros(2 * n, dtype=torch.int64, device=self.table.device)
 
     def launch(self, clock=None):
@@ -975,11 +981,11 @@ class SpmmBatch:
         fam, slab, threads = self.plan()
         val = "true" if self.flags & SPMM_ANY_VAL else "false"
         return {0: f"spmm_slab_kernel<{slab},{threads},float>", 1: "spmm_gather_kernel",
-                5: f"spmm_quad_kernel<float,{val},{'true' if self.max_cols > 2528 else 'false'}>",
+                5: f"spmm_quad_kernel<float,{val},{2 if self.flags & SPMM_HALF_SLAB else (1 if self.max_cols > 2528 else 0)}>",
                 6: "spmm_narrow_batched_kernel"}.get(fam, f"family {fam}")
 
 
-SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS, SPMM_ANY_COL_SCALE = 2, 4, 8, 16
+SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS, SPMM_ANY_COL_SCALE, SPMM_HALF_SLAB = 2, 4, 8, 16, 32
 GEMM_A_VEC4 = 1
 
 
