@@ -17,8 +17,8 @@ sys.path.insert(0, %r)
 import torch
 from wdg_amd import sweep, synth
 out = {}
-for k, seeds, levels in ((10, 5, synth.H_LEVELS_10_K10), (2, 10, synth.H_LEVELS_10)):
-    jobs = sweep.make_jobs(levels, range(seeds), k=k)
+for k, seeds, levels, nodes in ((10, 5, synth.H_LEVELS_10_K10, 2000), (2, 10, synth.H_LEVELS_10, 2000), (10, 5, synth.H_LEVELS_10_K10, 4000)):
+    jobs = sweep.make_jobs(levels, range(seeds), k=k, n_nodes=nodes)
     batch = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0)
     batch.spmm.verify()
     for _ in range(5):
@@ -33,7 +33,7 @@ for k, seeds, levels in ((10, 5, synth.H_LEVELS_10_K10), (2, 10, synth.H_LEVELS_
         b.record()
         torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) / 20 * 1e3)
-    out["k%%d_isolated_us" %% k] = round(best, 1)
+    out["k%%d%%s_isolated_us" %% (k, "" if nodes == 2000 else "_n%%d" %% nodes)] = round(best, 1)
     del batch
 print("RESULT " + json.dumps(out))
 ''' % ROOT
@@ -51,7 +51,7 @@ def main():
         else:
             line.update(json.loads(res[0][7:]))
             b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--cpu-budget", "0",
-                                "--secondary", "0", "--full-metrics", "0", "--cold", "0"], env=env, capture_output=True, text=True, timeout=900)
+                                "--secondary", "0", "--full-metrics", "0", "--cold", "0", "--configs", "0", "--train", "0", "--projection", "0", "--whole", "0"], env=env, capture_output=True, text=True, timeout=900)
             try:
                 j = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
                 line.update(step_ms=j["ms_per_step"], launch_us=j["roofline"].get("avg_launch_us"), frac=j["roofline"]["frac"])

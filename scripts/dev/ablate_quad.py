@@ -17,7 +17,7 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 codes = [int(a) for a in sys.argv[3:]] or [0, 1, 4, 5, 2]
 levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
-jobs = sweep.make_jobs(levels, range(seeds), k=k)
+jobs = sweep.make_jobs(levels, range(seeds), k=k, n_nodes=int(os.environ.get("N", 2000)))  # (N=4000: HALF slabs)
 names = {0: "full", 1: "stores to L2 only", 2: "no X staging", 4: "no sweep", 5: "pipeline + L2 stores only", 3: "sweep only", 8: "no index stream", 12: "no sweep, no index stream", 13: "no sweep, no index stream, L2 stores"}
 lib = ctypes.CDLL(LIB_PATH)
 for ab in codes:

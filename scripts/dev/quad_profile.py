@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the waves of the quad-row kernel's pipelined loop spend their clocks (dev tool; needs a library built with
 QUAD_EXTRA=-DWDG_Q_PROFILE scripts/dev/build_quad_variants.sh ..., passed through WDG_LIB_PATH).
-usage: quad_profile.py [k] [seeds]"""
+usage: [N=4000] quad_profile.py [k] [seeds]"""
 import ctypes
 import os
 import sys
@@ -16,7 +16,7 @@ from wdg_amd._lib import LIB_PATH
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10
-jobs = sweep.make_jobs(levels, range(seeds), k=k)
+jobs = sweep.make_jobs(levels, range(seeds), k=k, n_nodes=int(os.environ.get("N", 2000)))  # (N=4000: HALF slabs)
 lib = ctypes.CDLL(LIB_PATH)
 batch = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0)
 if os.environ.get("TUNE", "1") != "0":

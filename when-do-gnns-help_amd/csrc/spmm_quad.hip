@@ -853,9 +853,13 @@ __device__ __forceinline__ void q_accw(f32x2 &a0, f32x2 &a1, const f32x4_t &v, f
 }
 __device__ __forceinline__ void q_accw(f32x2 &a0, f32x2 &, const f32x2 &v, float wv) { a0 = __builtin_elementwise_fma(f32x2{wv, wv}, v, a0); }
 #define WDG_Q_READ(J, R, V) const QV V = *(const QV __attribute__((address_space(3))) *)(slab + (q_bcast<J>(cc[R]) + loff));
+#ifndef WDG_Q_ABLATE_ADDS
 #define WDG_Q_ADD(J, R, V)                                \
     if (HAS_VAL) q_accw(a0, a1, V, q_bcastf<J>(wc[R]));   \
     else q_acc(a0, a1, V);
+#else  // (diagnostic build, scripts/dev/build_quad_variants.sh: the reads stay, their packed adds go - what the VALU costs the sweep)
+#define WDG_Q_ADD(J, R, V) asm volatile("" ::"v"(V));
+#endif
 #define WDG_Q_READ4(J, P) WDG_Q_READ(J, 0, P##0) WDG_Q_READ(J, 1, P##1) WDG_Q_READ(J, 2, P##2) WDG_Q_READ(J, 3, P##3)
 #define WDG_Q_ADD4(J, P) WDG_Q_ADD(J, 0, P##0) WDG_Q_ADD(J, 1, P##1) WDG_Q_ADD(J, 2, P##2) WDG_Q_ADD(J, 3, P##3)
 // one quad of entries, on its own (partial chunks)
