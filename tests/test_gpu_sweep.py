@@ -202,8 +202,10 @@ def test_full_c3_sweep_shard_on_the_quad_kernel(oracle, seeds, n_nodes):
         torch.cuda.synchronize()
         for i, (_g, _x, y, _d, _cs, _uv) in enumerate(sb.spmm.keep):
             assert not bool(torch.isnan(y).any()), (launch, i)
-            if i in want:
+            if i in want and n_nodes <= 2528:
                 assert torch.equal(y, want[i]), (launch, i)
+            elif i in want:  # the single-graph call of a wide 4000-node graph takes the band kernel (CSR order): same sums, other order
+                torch.testing.assert_close(y, want[i], rtol=1e-5, atol=1e-6 * float(want[i].abs().max()))
     for i in sample:  # against the oracle: D^-1 (A + I) [X | onehot | 0]
         j = jobs[i]
         src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)

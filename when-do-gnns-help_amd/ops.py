@@ -148,7 +148,7 @@ class CsrGraph:
 
     def prefers_band(self, n_feat):
         """the band kernel (L2 gathers, a wave per row) rather than the quad-row kernel (LDS slabs) for a single aggregation:
-        wide features and either more columns than one LDS slab holds (5056, as 8-feature rows) or rows too long for 16-row slices (> 128 entries).
+        wide features and either more columns than one 16-feature LDS slab holds or rows too long for 16-row slices (> 128 entries).
         WDG_SPMM_BAND=1 / 0 forces / forbids it."""
         force = os.environ.get("WDG_SPMM_BAND", "")
         if force == "0" or n_feat < 16:
@@ -157,7 +157,9 @@ class CsrGraph:
             return False
         if force not in ("", "0"):
             return True
-        return n_feat >= 64 and (self.n_cols > 2 * self.QUAD_SLAB_COLS or self.band["n_hub"] > 0)  # (<= 5056 columns: one block, 32-byte rows)
+        # (2 529 .. 5 056 columns fit one block of 32-byte rows since round 4, but ONE graph there is still the band kernel's: Cora
+        # 21 us against 105, a 4000-node sweep graph 17 against 42 - a slab per feature group is worth staging for a batch)
+        return n_feat >= 64 and (self.n_cols > self.QUAD_SLAB_COLS or self.band["n_hub"] > 0)
 
     QUAD_MAX_BLOCKS = 4  # column blocks of <= 2528 columns the quad-row kernel sweeps (csrc/spmm_quad.hip)
 
