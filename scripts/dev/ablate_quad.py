@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import torch
 
-from wdg_amd import ops, sweep, synth
+from wdg_amd import aggregate, ops, sweep, synth  # noqa: F401
 from wdg_amd._lib import LIB_PATH
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 10
@@ -21,7 +21,7 @@ jobs = sweep.make_jobs(levels, range(seeds), k=k, n_nodes=int(os.environ.get("N"
 names = {0: "full", 1: "stores to L2 only", 2: "no X staging", 4: "no sweep", 5: "pipeline + L2 stores only", 3: "sweep only", 8: "no index stream", 12: "no sweep, no index stream", 13: "no sweep, no index stream, L2 stores"}
 lib = ctypes.CDLL(LIB_PATH)
 for ab in codes:
-    ops.ABLATE_BITS = ab
+    aggregate.ABLATE_BITS = ab
     batch = sweep.SweepBatch(jobs, n_feat=500, gcn_hidden=0)
     for _ in range(3):
         batch.spmm.launch()

@@ -10,7 +10,8 @@ import torch
 
 from wdg_amd import ops
 
-ops.ABLATE_BITS = int(os.environ.get("WDG_ABLATE", "0"))
+from wdg_amd import aggregate
+aggregate.ABLATE_BITS = int(os.environ.get("WDG_ABLATE", "0"))
 only = os.environ.get("ONLY")
 
 n, m, f, e = [int(a) for a in sys.argv[1:5]] if len(sys.argv) > 4 else (2000, 2000, 512, 60000)

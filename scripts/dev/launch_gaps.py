@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from wdg_amd import sweep, synth
 from wdg_amd.ops import lib, _ptr, stream_handle, check
-from wdg_amd import ops as _ops
+from wdg_amd import aggregate as _ops
 _ops.ABLATE_BITS = int(os.environ.get("WDG_GAPS_ABLATE", "0"))  # (timing-only ablations of scripts/dev/ablate_quad.py)
 for k, seeds in ((10, 5), (2, 10)):
     levels = synth.H_LEVELS_10 if k == 2 else synth.H_LEVELS_10_K10

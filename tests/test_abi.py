@@ -211,3 +211,17 @@ def test_random_disassortative_splits_matches_reference_rng():
         torch.manual_seed(0)
         m, _, _ = random_disassortative_splits(labels, labels.max() + 1, 0.3)
         assert (m.cpu().numpy() == g["las_mask"]).all()
+
+
+def test_no_function_of_the_package_reads_an_undefined_global():
+    """most of the package only runs on a GPU box: a static pass (scripts/check_names.py) over every module and bench.py finds the
+    NameError a code path would raise there - a helper that stayed behind when ops.py was split, a renamed constant"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_names", os.path.join(ROOT, "scripts", "check_names.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "when-do-gnns-help_amd", "**", "*.py"), recursive=True)) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    assert len(files) > 15
+    bad = [(os.path.relpath(f, ROOT), scope, name) for f in files for scope, _line, name in chk.undefined(f)]
+    assert not bad, bad

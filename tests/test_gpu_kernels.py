@@ -1494,7 +1494,8 @@ def test_spmm_narrow_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, h
     """the narrow kernel through ops.spmm: all three row classes (16 lanes / a wave / a workgroup per row), every feature
     count, fp32 and bf16 sources with any leading dimension, explicit values, row / column scales, strided Y, empty rows;
     one column range and several (partial rows combined in range order)"""
-    monkeypatch.setattr(ops, "NARROW_MIN_ENTRIES", 0)
+    from wdg_amd import aggregate
+    monkeypatch.setattr(aggregate, "NARROW_MIN_ENTRIES", 0)
     if parts:  # force the column-part variant (else only tables beyond an XCD's L2 take it: 70 000 columns here do)
         monkeypatch.setenv("WDG_NARROW_PARTS", str(parts))
     rng = np.random.default_rng(n + 13 * f)

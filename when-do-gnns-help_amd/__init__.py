@@ -3,7 +3,8 @@
 Layout (only what the hot path needs):
   csrc/    hand-written HIP kernels + the C ABI of include/wdg.h  -> lib/libwdg_hip.so
   _lib.py  ctypes binding (fails loudly when the library is missing; no CPU fallback)
-  ops.py   torch-tensor front end: CsrGraph, spmm, edge_label_stats, las, gemm, batched job tables
+  ops.py   torch-tensor front end, one namespace: CsrGraph, spmm, edge_label_stats, las, gemm, batched job tables - the code in
+           graphs.py / aggregate.py / stats.py / gemm.py / kernel_regression.py (+ _rt.py: flags, pointers, the upload arena)
   utils/   drop-in twins of the reference's utils.util_funcs / utils.homophily_metrics / utils.homophily_plot
 """
 __version__ = "0.1.0"

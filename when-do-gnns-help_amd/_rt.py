@@ -1,0 +1,107 @@
+"""Plumbing shared by the front-end modules (graphs / aggregate / stats / kernel_regression / gemm): the flag values of
+include/wdg.h, pointer and leading-dimension helpers, and the page-locked arena every small host-to-device copy goes through.
+PyTorch is plumbing here (device memory, the current HIP stream); nothing in this package computes on the CPU or falls back."""
+__all__ = ["COO_SYMMETRISE", "COO_BINARISE", "COO_ADD_SELF_LOOPS", "COO_DROP_SELF_LOOPS", "COO_KEEP_DUPLICATES", "NORM_RW", "NORM_SYM",
+           "PREC_F32", "PREC_F64", "ACT_NONE", "ACT_RELU", "SPMM_ANY_VAL", "SPMM_DMA_OK", "SPMM_SMALL_OFFSETS", "SPMM_ANY_COL_SCALE",
+           "SPMM_HALF_SLAB", "GEMM_A_VEC4"]  # what `from ._rt import *` hands the front-end modules: the flag values only
+
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SpmmItem, SpmmJob, StatsJob, c_void_p, check, lib, require_gpu, stream_handle
+
+# flags / modes of include/wdg.h
+COO_SYMMETRISE, COO_BINARISE, COO_ADD_SELF_LOOPS, COO_DROP_SELF_LOOPS, COO_KEEP_DUPLICATES = 1, 2, 4, 8, 16
+NORM_RW, NORM_SYM = 0, 1
+PREC_F32, PREC_F64 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+
+
+def _ptr(t):
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dev(t, dtype, dev):
+    """tensor / ndarray / list -> contiguous device tensor of `dtype` (no copy when already there)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=dev, dtype=dtype).contiguous()
+
+
+def _ld(t):
+    """Leading dimension of a row-major matrix for the C ABI.  torch / numpy report an arbitrary stride for a dimension
+    of size 1 (a [1, K] view of a [K, 1] array has stride(0) == 1): with one row any value >= the row length is valid."""
+    return t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
+
+
+class _PinnedArena:
+    """One page-locked buffer per process, handed out as a ring: a slice is reused only after the copy that last read it has
+    completed (an event per copy; by the time the ring comes round the copy is long done).  torch's own pinned allocator
+    cannot reuse a block while its copy is queued behind kernels, and every NEW pinned block is a hipHostMalloc - measured:
+    an occasional 90 ms in the middle of a shard's table uploads."""
+
+    def __init__(self, nbytes=128 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.size, self.off, self.pending = nbytes, 0, []  # pending: (start, end, event), in issue order
+
+    def take(self, nbytes):
+        n = (nbytes + 255) & ~255
+        if self.off + n > self.size:
+            self.off = 0
+        a, b = self.off, self.off + n
+        while self.pending and self.pending[0][0] < b and a < self.pending[0][1]:
+            self.pending.pop(0)[2].synchronize()
+        self.off = b
+        return a, self.buf[a:a + nbytes]
+
+    def issued(self, start, nbytes):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((start, start + ((nbytes + 255) & ~255), ev))
+
+
+_ARENA = None
+_H2D_MAX_BYTES = int(float(os.environ.get("WDG_H2D_MAX_MB", "8")) * (1 << 20))  # larger arrays: the plain (blocking, pageable) copy
+
+
+def _h2d(host, dev=None):
+    """A host array (job table, offsets, labels, a feature matrix) -> device tensor WITHOUT blocking the host on what the stream
+    has queued: through the page-locked arena and a non-blocking copy.  (`tensor.to(dev)` from pageable memory returns only when
+    the copy has run, i.e. after every kernel queued before it - a shard's ~70 small uploads then serialise the host with the
+    build kernels.)  Arrays of more than WDG_H2D_MAX_MB (8) MB take the plain blocking copy: the wide bases' 30-MB feature matrices
+    through a single-threaded memcpy and a 128-MB ring cost the whole sweep 10 % (0.80 -> 0.88 s)."""
+    global _ARENA
+    dev = dev or require_gpu()
+    t = torch.from_numpy(host) if isinstance(host, np.ndarray) else host
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        return torch.empty(t.shape, dtype=t.dtype, device=dev)
+    if _ARENA is None:
+        _ARENA = _PinnedArena()
+    if nbytes > _H2D_MAX_BYTES:
+        return t.to(dev)
+    start, piece = _ARENA.take(nbytes)
+    p = piece.view(t.dtype).view(t.shape)
+    # (numpy's memcpy, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware thread of the host -
+    # measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
+    np.copyto(p.numpy(), t.numpy())
+    out = p.to(dev, non_blocking=True)
+    _ARENA.issued(start, nbytes)
+    return out
+
+
+def _table(arr):
+    """ctypes array of job descriptors -> device bytes (an empty table stays a host tensor: its pointer is NULL)"""
+    return _h2d(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)) if len(arr) else torch.empty(0, dtype=torch.uint8)
+
+
+# flags of wdg_spmm_batched_f32 / wdg_spmm_quad_batched_f32 and of the GEMM tables (include/wdg.h)
+SPMM_ANY_VAL, SPMM_DMA_OK, SPMM_SMALL_OFFSETS, SPMM_ANY_COL_SCALE, SPMM_HALF_SLAB = 2, 4, 8, 16, 32
+GEMM_A_VEC4 = 1

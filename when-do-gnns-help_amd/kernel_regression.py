@@ -1,0 +1,194 @@
+"""The kernel-regression metric on the device (reference: utils/homophily_metrics.py:190-349): batched Grams with the fused
+arc-cosine map, the generalized edge homophily gathered from a Gram, the device sampler of the node sets and the batched solver."""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_void_p, check, lib, require_gpu, stream_handle
+from ._rt import *  # noqa: F401,F403  (the flag values of include/wdg.h)
+from ._rt import _dev, _h2d, _ld, _ptr, _table
+
+
+# ------------------------------------------------------------------------------------------- kernel-regression metric
+class GramBatch:
+    """Job table for wdg_gram_map_batched_f32: K = map(A A^T) of every A of a batch (all nodes), linear and / or arc-cosine."""
+
+    def __init__(self, mats, linear=True, arccos=True):
+        """mats: list of A [n, F] fp32 device tensors (unit inner stride) -> self.k_linear[i], self.k_arccos[i] ([n, n] or None)"""
+        dev = require_gpu()
+        self.keep = mats
+        self.n_jobs = len(mats)
+        self.max_n = max([a.shape[0] for a in mats], default=0)
+        self.norm2 = [torch.empty(a.shape[0], dtype=torch.float32, device=dev) for a in mats]
+        self.k_linear = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if linear else None for a in mats]
+        self.k_arccos = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if arccos else None for a in mats]
+        arr = (_lib.GramJob * self.n_jobs)()
+        for job, a, n2, kl, ka in zip(arr, mats, self.norm2, self.k_linear, self.k_arccos):
+            if a.dtype != torch.float32 or a.stride(1) != 1:
+                raise ValueError("GramBatch: A must be fp32 with unit inner stride")
+            job.A, job.norm2 = a.data_ptr(), n2.data_ptr()
+            job.K_linear = 0 if kl is None else kl.data_ptr()
+            job.K_arccos = 0 if ka is None else ka.data_ptr()
+            job.lda, job.ldk, job.n, job.F = _ld(a), a.shape[0], a.shape[0], a.shape[1]
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_gram_map_batched_f32(_ptr(self.table), self.n_jobs, self.max_n, stream_handle()), "wdg_gram_map_batched_f32")
+
+
+class EdgeGramBatch:
+    """Job table for wdg_edge_gram_mean_batched_f32: mean edge cosine (generalized edge homophily) of many graphs from the Grams
+    of their feature matrices."""
+
+    def __init__(self, problems):
+        """problems: list of (CsrGraph, K_linear [n, n], norm2 [n]) -> self.mean [n_problems] fp64 after launch()"""
+        dev = require_gpu()
+        self.keep = problems
+        self.n_jobs = len(problems)
+        self.max_rows = max([p[0].n_rows for p in problems], default=0)
+        self.mean = torch.zeros(max(self.n_jobs, 1), dtype=torch.float64, device=dev)
+        self.ws_bytes = lib.wdg_edge_gram_workspace_bytes(self.n_jobs, self.max_rows)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        arr = (_lib.EdgeGramJob * self.n_jobs)()
+        for i, (job, (g, k, n2)) in enumerate(zip(arr, problems)):
+            job.rowptr, job.col, job.K_linear, job.norm2 = g.rowptr.data_ptr(), g.col.data_ptr(), k.data_ptr(), n2.data_ptr()
+            job.mean_out = self.mean.data_ptr() + 8 * i
+            job.ldk, job.n_rows = _ld(k), g.n_rows
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_edge_gram_mean_batched_f32(_ptr(self.table), self.n_jobs, self.max_rows, _ptr(self.ws), self.ws_bytes,
+                                                 stream_handle()), "wdg_edge_gram_mean_batched_f32")
+
+
+def kr_split_sizes(labels, sample_max):
+    """Per class: how many members an epoch's sample holds (s_c) and how many of those train (t_c) - the sizes the
+    reference's two random_disassortative_splits calls produce (utils/homophily_metrics.py:269-279 with utils/util_funcs.py:
+    454-475; Python's banker's `round`, classes counted as max label + 1, a class smaller than its share gives all it has).
+    labels: host int array -> (s_c, t_c) int32 [C]"""
+    labels = np.asarray(labels).reshape(-1)
+    n = labels.shape[0]
+    c = int(labels.max()) + 1 if n else 0
+    n_c = np.bincount(labels[labels >= 0], minlength=c).astype(np.int64)
+    if n <= sample_max:
+        s_c = n_c.copy()
+    else:
+        s_c = np.minimum(n_c, int(round((sample_max / n) * (n / c))))
+    present = np.flatnonzero(s_c)
+    c2 = int(present.max()) + 1 if present.size else 1       # labels_sample.max() + 1
+    t_c = np.minimum(s_c, int(round(0.6 * (int(s_c.sum()) / c2))))
+    return s_c.astype(np.int32), t_c.astype(np.int32)
+
+
+class KrSets:
+    """Job table for wdg_kr_sample_sets: the (train, validation) node sets of every epoch of many (graph, classifier) pairs,
+    drawn on the device in one launch (Philox4x32-10 keyed per pair; include/wdg.h documents the generator).
+    self.train [pairs, epochs, n_train], self.val [pairs, epochs, n_val] int32, ascending ids; pairs whose graphs differ in
+    class sizes are padded to the widest (self.n_train / self.n_val hold the true lengths)."""
+
+    def __init__(self, entries, epochs):
+        """entries: list of (labels int32 device [n], s_c, t_c (kr_split_sizes), seed int)"""
+        dev = require_gpu()
+        self.keep = entries
+        self.n_pairs, self.epochs = len(entries), int(epochs)
+        self.n_train = np.array([int(np.sum(t)) for _l, _s, t, _seed in entries], np.int64)
+        self.n_val = np.array([int(np.sum(s_) - np.sum(t)) for _l, s_, t, _seed in entries], np.int64)
+        self.train_stride, self.val_stride = int(self.n_train.max(initial=0)), int(self.n_val.max(initial=0))
+        self.train = torch.zeros((self.n_pairs, self.epochs, max(self.train_stride, 1)), dtype=torch.int32, device=dev)
+        self.val = torch.zeros((self.n_pairs, self.epochs, max(self.val_stride, 1)), dtype=torch.int32, device=dev)
+        self.max_n = max([int(e[0].shape[0]) for e in entries], default=0)
+        cls = np.concatenate([np.concatenate([np.asarray(s_, np.int32), np.asarray(t, np.int32)]) for _l, s_, t, _seed in entries]) \
+            if entries else np.zeros(0, np.int32)
+        self.class_tables = torch.from_numpy(cls).to(dev)
+        arr = (_lib.KrSampleJob * self.n_pairs)()
+        off = 0
+        for i, (job, (lab, s_, t, seed)) in enumerate(zip(arr, entries)):
+            c = len(s_)
+            if c > 64:
+                raise ValueError("KrSets: more than 64 classes")
+            job.labels = lab.data_ptr()
+            job.sample_per_class = self.class_tables.data_ptr() + 4 * off
+            job.train_per_class = self.class_tables.data_ptr() + 4 * (off + c)
+            off += 2 * c
+            job.train_out, job.val_out = self.train[i].data_ptr(), self.val[i].data_ptr()
+            job.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            job.n, job.n_classes, job.n_sets, job.first_set = int(lab.shape[0]), c, self.epochs, i * self.epochs
+            job.train_stride, job.val_stride = self.train.shape[2], self.val.shape[2]
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_kr_sample_sets(_ptr(self.table), self.n_pairs, self.n_pairs * self.epochs, self.max_n, stream_handle()),
+              "wdg_kr_sample_sets")
+
+
+_KR_JOB_DTYPE = np.dtype([("K", "<u8"), ("train", "<u8"), ("val", "<u8"), ("labels", "<u8"), ("correct_out", "<u8"), ("flags_out", "<u8"),
+                          ("ldk", "<i8"), ("n_train", "<i4"), ("n_val", "<i4"), ("n_classes", "<i4"), ("reserved", "<i4")])
+assert _KR_JOB_DTYPE.itemsize == ctypes.sizeof(_lib.KrJob)
+
+
+class KrBatch:
+    """Job table for wdg_kernel_regress_batched_f32: many (kernel, train rows, validation rows) problems in one launch."""
+
+    MAX_TRAIN = 320
+    MAX_CLASSES = 8  # KR_MAX_C of csrc/kernel_reg.hip: the right-hand sides a problem's workgroup carries
+
+    def __init__(self, problems, n_classes):
+        """problems: list of (K [n, n] fp32 device, train int32 device [nt], val int32 device [nv], labels int32 device [n])
+        -> self.correct [n_problems] int32 after launch().  Shapes the solver does not hold (more than 8 classes, more than
+        320 or fewer than 1 train rows) raise here: the kernel would answer them with the sentinel -1, and an accuracy of
+        -1 / n_val fed to the t-test is a silently wrong p-value (callers with such label sets take the host path)."""
+        self.keep = problems
+        n = len(problems)
+        col = lambda f: np.fromiter((f(p_) for p_ in problems), np.int64, n)  # noqa: E731
+        self._build(col(lambda p_: p_[0].data_ptr()), col(lambda p_: _ld(p_[0])), col(lambda p_: p_[1].data_ptr()),
+                    col(lambda p_: p_[2].data_ptr()), col(lambda p_: p_[3].data_ptr()), col(lambda p_: p_[1].shape[0]),
+                    col(lambda p_: p_[2].shape[0]), n_classes)
+
+    @classmethod
+    def from_arrays(cls, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes, keep=None):
+        """the same table from per-problem numpy columns (device addresses and sizes): a sweep shard's 20 000 problems are
+        described by arithmetic on a few base pointers, not by 20 000 tensor objects"""
+        self = cls.__new__(cls)
+        self.keep = keep
+        self._build(*(np.asarray(a, np.int64) for a in (k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val)), n_classes)
+        return self
+
+    def _build(self, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes):
+        dev = require_gpu()
+        n = self.n_jobs = int(k_ptr.shape[0])
+        if n and not 1 <= int(n_classes) <= self.MAX_CLASSES:
+            raise ValueError(f"KrBatch: {n_classes} classes, the solver holds 1..{self.MAX_CLASSES}")
+        if n and not (1 <= int(n_train.min()) and int(n_train.max()) <= self.MAX_TRAIN):
+            raise ValueError(f"KrBatch: {int(n_train.min())}..{int(n_train.max())} train rows, the solver holds blocks of 1..{self.MAX_TRAIN}")
+        self.correct = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)  # bit 0: the ridge refactorisation ran
+        self.n_val = torch.from_numpy(n_val.astype(np.float32)).to(dev)
+        tab = np.zeros(n, _KR_JOB_DTYPE)
+        tab["K"], tab["train"], tab["val"], tab["labels"] = k_ptr, train_ptr, val_ptr, labels_ptr
+        tab["correct_out"] = self.correct.data_ptr() + 4 * np.arange(n, dtype=np.int64)
+        tab["flags_out"] = self.flags.data_ptr() + 4 * np.arange(n, dtype=np.int64)
+        tab["ldk"], tab["n_train"], tab["n_val"], tab["n_classes"] = ldk, n_train, n_val, int(n_classes)
+        # (timing-only diagnostics of the blocked solver: honoured only by a library built with -DWDG_KR_ABLATION, and never
+        # mistaken for a result - accuracy() refuses)
+        self.ablate = int(os.environ.get("WDG_KR_ABLATE", "0"))
+        tab["reserved"] = self.ablate
+        self.table = torch.from_numpy(tab.view(np.uint8)).to(dev) if n else torch.empty(0, dtype=torch.uint8)
+
+    def launch(self):
+        check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")
+
+    def ridged(self):
+        """[n_problems] bool: the train block was rank deficient in fp32 and was solved with the rounding-level ridge"""
+        return (self.flags[:self.n_jobs] & 1).bool()
+
+    def accuracy(self):
+        """[n_problems] fp32 hit rate on the validation rows; raises when the kernel refused a problem (sentinel -1)"""
+        if getattr(self, "ablate", 0):
+            raise _lib.WdgError("KrBatch: WDG_KR_ABLATE is set - the launch was a timing-only ablation, its accuracies mean nothing")
+        correct = self.correct[:self.n_jobs]
+        if self.n_jobs and bool((correct < 0).any().item()):
+            raise _lib.WdgError("wdg_kernel_regress_batched_f32 refused a problem (shape outside the solver's limits)")
+        return correct.to(torch.float32) / self.n_val
