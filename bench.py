@@ -482,7 +482,7 @@ def measure_projection(args, dev, full_ms):
     return out
 
 
-def traffic_for(n_graphs, n_feat, k):
+def traffic_for(n_graphs, n_feat, k, n_nodes=2000):
     """PMC-derived HBM bytes per aggregation launch of the same workload (profiles/traffic.json: one record per k)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -490,7 +490,8 @@ def traffic_for(n_graphs, n_feat, k):
     except Exception:
         return None
     for rec in (tj if isinstance(tj, list) else [tj]):
-        if rec.get("graphs_per_launch") == n_graphs and rec.get("n_feat") == n_feat and rec.get("k") == k:
+        if (rec.get("graphs_per_launch") == n_graphs and rec.get("n_feat") == n_feat and rec.get("k") == k
+                and rec.get("n_nodes", 2000) == n_nodes):
             return rec.get("hbm_bytes_per_launch")
     return None
 
@@ -501,7 +502,7 @@ def roofline_of(args, m):
     spmm_avg_ms = sum(spmm_ms) / len(spmm_ms)
     alg = batch.spmm_algorithmic_bytes()
     achieved = alg / (spmm_avg_ms * 1e-3) / 1e9
-    traffic = traffic_for(len(m["mine"]), args.feat, m["k"])
+    traffic = traffic_for(len(m["mine"]), args.feat, m["k"], args.nodes)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             # the same launch priced by the bytes the chip really moved (PMC): X is fetched once per group of graphs that

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the PMC summaries of scripts/profile_pmc.sh: one record per sweep configuration (keyed on k,
 graphs per launch and feature width) holding the HBM bytes one aggregation launch moved.
-usage: make_traffic_json.py <k>:<graphs>:<summary.json>:<source note> ... > profiles/traffic.json"""
+usage: make_traffic_json.py <k>[@<nodes>]:<graphs>:<summary.json>:<source note> ... > profiles/traffic.json"""
 import json
 import sys
 
 recs = []
 for arg in sys.argv[1:]:
     k, graphs, path, source = arg.split(":", 3)
+    k, _, nodes = k.partition("@")  # "<k>@<nodes>": a shard of other than 2000-node graphs
+    nodes = int(nodes) if nodes else 2000
     s = json.load(open(path))
     name = next(n for n in s if n.startswith("spmm_"))
     c = s[name]
     fetch_raw, write = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
     recs.append({
-        "kernel": name, "graphs_per_launch": int(graphs), "n_feat": 500, "agg_feat": 512, "k": int(k),
+        "kernel": name, "graphs_per_launch": int(graphs), "n_nodes": nodes, "n_feat": 500, "agg_feat": 512, "k": int(k),
         "fetch_size_raw_bytes": fetch_raw, "fetch_corrected_bytes": 2 * fetch_raw, "write_size_bytes": write,
         "fetch_correction": "x2: gfx950 FETCH_SIZE counts 128-B requests of wide (16 B/lane) coalesced reads as 64 B "
                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact for 16-B/lane stores",
