@@ -934,8 +934,18 @@ __device__ __forceinline__ int q_ld1(global_ptr<const int32_t> base, unsigned vo
 __device__ __forceinline__ void q_st4(global_ptr<float> base, unsigned voff, f32x4_t v) {
     // (s_nop: a VALU write of the data registers right behind a store of more than 8 bytes is a hazard the compiler
     // resolves for its own stores, not for this one)
-#ifndef WDG_Q_STORE_POLICY
+#ifndef WDG_Q_STORE_POLICY  // (A/B of the cache policy bits of the running-sum stores: -DWDG_Q_STORE_POLICY_ID=1..4)
+#if WDG_Q_STORE_POLICY_ID == 1
+#define WDG_Q_STORE_POLICY "nt"
+#elif WDG_Q_STORE_POLICY_ID == 2
+#define WDG_Q_STORE_POLICY "sc1"
+#elif WDG_Q_STORE_POLICY_ID == 3
+#define WDG_Q_STORE_POLICY "sc0 sc1"
+#elif WDG_Q_STORE_POLICY_ID == 4
+#define WDG_Q_STORE_POLICY "nt sc1"
+#else
 #define WDG_Q_STORE_POLICY ""
+#endif
 #endif
     asm volatile("global_store_dwordx4 %0, %1, %2 " WDG_Q_STORE_POLICY "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
 }
