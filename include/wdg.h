@@ -228,7 +228,9 @@ int wdg_spmm_plan(int32_t n_jobs, int32_t max_rows, int32_t max_cols, int32_t n_
  * which fixes the order of the row's sum.  Graphs in split form get the CONFLICT-FREE order (round 4): the fill also decides
  * which rows of a slice share a service group - it PERMUTES q_rows inside the slice's entries - and reads a shorter row's
  * padding from one of four zero rows (offsets 64 (B + c), c = 0..3: the kernel appends four zero rows to the slab) at
- * whichever step keeps the group conflict-free; other graphs keep round 2's greedy order (padding = offset 64 B, at the end).
+ * whichever step keeps the group conflict-free; other graphs keep round 2's greedy order (padding = offset 64 B, at the end) -
+ * among them the graphs of 2529 .. 5056 columns (32-byte slab rows, wdg_sell16_row_bytes: the greedy order over their EIGHT
+ * bank windows, rows 0-7 / 8-15 of a slice read together; padding = offset 32 B).
  * WDG_SELL_ORDER in the environment of the fill call: 0 = column order (the sequential CSR order), 1 = greedy everywhere.
  * The slices are then laid out as ENTRIES, four per super-unit (see
  * wdg_spmm_job.q_ext): graphs with one column block and at most 128 entries per row and block in split form.
