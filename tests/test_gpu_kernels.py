@@ -642,7 +642,7 @@ def test_spmm_quad_column_order_equals_sequential_sum_bitwise(ops, monkeypatch):
 
 @pytest.mark.parametrize("n,f,groups,use_values", [(2000, 512, (10, 10), False), (700, 36, (4, 6), True), (2528, 64, (3, 3, 3), False),
                                                      (1500, 100, (2, 8, 1), True), (64, 16, (2,), False), (4000, 48, (3, 2), False),
-                                                     (40, 2089, (3,), True)])
+                                                     (40, 2089, (3,), True), (3000, 24, (2, 2), True), (5056, 17, (2,), False)])
 def test_spmm_quad_batched_equals_single_bitwise(ops, n, f, groups, use_values):
     """The batched entry (tape of units cut into equal-cost segments, phases of graphs that share X) must give every graph
     the bits of its single-graph call: a row's sum depends on the SELL-16 copy only, not on how the units were dealt."""
