@@ -191,6 +191,12 @@ typedef struct wdg_spmm_job {
                                  2048 / 128 entries (the narrow kernel's row classes); the rest 0                                  */
     int32_t band_n_hub;       /* rows of more than 128 entries (each is swept by a whole workgroup)                              */
     int32_t band_reserved;    /* 0 */
+    int64_t y_group_stride;   /* 0: Y is row-major, element (row, f) at Y[row ldy + f].  > 0 (the quad-row kernel only: jobs with a
+                                 SELL-16 copy through wdg_spmm_csr_* / wdg_spmm_quad_batched_f32): Y is TILED by 16-feature groups,
+                                 element (row, f) at Y[(f / 16) y_group_stride + row ldy + f % 16] with ldy >= 16 - a workgroup (one
+                                 feature group) then stores inside one contiguous region instead of 64-byte pieces ldy floats
+                                 apart (round 4: the store-heavy k = 2 sweep launch 160 -> 133 us).  wdg_mlp2_job.a_group_stride
+                                 reads such a matrix back; every other entry point wants row-major operands */
 } wdg_spmm_job;
 
 int wdg_spmm_csr_f32(const wdg_spmm_job *job_host, wdg_stream_t stream);
@@ -517,6 +523,9 @@ typedef struct wdg_mlp2_job {
     float *Z;          /* [M,C] */
     int64_t lda, ldw0, ldw1, ldz;
     int32_t M, K, H, C, act, reserved; /* act on the hidden layer: WDG_ACT_* */
+    int64_t a_group_stride; /* 0: A row-major.  > 0: A tiled by 16-column groups as wdg_spmm_job.y_group_stride writes it, element
+                               (m, k) at A[(k / 16) a_group_stride + m lda + k % 16] (the split-operand kernel, the default; with
+                               WDG_MLP2_SPLIT=0 in the environment A must be row-major) */
 } wdg_mlp2_job;
 int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
                          int32_t max_C, wdg_stream_t stream);

@@ -7,6 +7,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _rowmajor(y):
+    """the aggregation's output as a row-major tensor (a tiled Y - ops.Tiled, 16-feature groups - copied out)"""
+    return y.rowmajor() if hasattr(y, "rowmajor") else y
+
+
+
 @pytest.mark.parametrize("fused_mlp,ride_labels", [("1", "1"), ("0", "0"), ("1", "0")])
 @pytest.mark.parametrize("symmetric", [0, 1])
 def test_sweep_step_against_oracle(oracle, symmetric, fused_mlp, ride_labels, monkeypatch):
@@ -164,11 +170,12 @@ def test_full_sweep_batch_every_item_exactly_once(monkeypatch, variant, env, fam
         g, x, _y, d, _cs, _uv = sb.spmm.keep[i]
         want[i] = ops.spmm(g, x, row_scale=d, use_values=False).clone()
     for launch in range(6):
-        for y in sb.y:
+        for y in sb.y_agg:
             y.fill_(float("nan"))
         sb.spmm.launch()
         torch.cuda.synchronize()
         for i, (_g, _x, y, _d, _cs, _uv) in enumerate(sb.spmm.keep):
+            y = _rowmajor(y)
             assert not bool(torch.isnan(y).any()), (variant, launch, i)
             if i in want:
                 assert torch.equal(y, want[i]), (variant, launch, i)
@@ -201,6 +208,7 @@ def test_full_c3_sweep_shard_on_the_quad_kernel(oracle, seeds, n_nodes):
         sb.spmm.launch()
         torch.cuda.synchronize()
         for i, (_g, _x, y, _d, _cs, _uv) in enumerate(sb.spmm.keep):
+            y = _rowmajor(y)
             assert not bool(torch.isnan(y).any()), (launch, i)
             if i in want and n_nodes <= 2528:
                 assert torch.equal(y, want[i]), (launch, i)
@@ -531,3 +539,63 @@ def test_step_scalars_kernel_edge_cases():
     want = np.stack([edge, node, cls, (edge - s2) / (1 - s2), 2 - (pc * np.log(pc)).sum((1, 2)) / (pb * np.log(pb)).sum(1), f(las[:, 0]) / las_n], 1)
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=5e-6, atol=2e-6)
     assert np.isfinite(out.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("k,seeds,n_feat,hidden", [(10, 2, 500, 64), (2, 3, 96, 32), (10, 1, 36, 0)])
+def test_tiled_aggregation_output_equals_row_major_bitwise(monkeypatch, k, seeds, n_feat, hidden):
+    """The sweep keeps the aggregated features tiled by 16-feature groups (ops.Tiled; wdg_spmm_job.y_group_stride written by the
+    quad-row kernel, wdg_mlp2_job.a_group_stride read by the fused transform, the label columns of LAS a strided view): where an
+    element is stored does not enter any sum, so every output - Y, the LAS / counter scalars, the GCN-2 logits, and the nine
+    scalars behind prepare_full's row-major copy - is the row-major batch's (WDG_SWEEP_TILED_Y=0) bit for bit."""
+    from wdg_amd import ops, sweep, synth
+    levels = synth.H_LEVELS_10_K10[:4] if k == 10 else synth.H_LEVELS_10[:4]
+    jobs = sweep.make_jobs(levels, range(seeds), k=k, n_nodes=1500)
+    got = {}
+    for tiled in ("1", "0"):
+        monkeypatch.setenv("WDG_SWEEP_TILED_Y", tiled)
+        sb = sweep.SweepBatch(jobs, n_feat=n_feat, gcn_hidden=hidden)
+        assert sb.tiled_y == (tiled == "1") and isinstance(sb.y_agg[0], ops.Tiled) == sb.tiled_y
+        for y in sb.y_agg:
+            y.fill_(float("nan"))
+        sb.step()
+        sb.step()
+        torch.cuda.synchronize()
+        ys = [y.clone() for y in sb.y]
+        agg = [(_rowmajor(y)).clone() for y in sb.y_agg]  # incl. the label and zero columns
+        logits = [l.clone() for l in sb.gcn["logits"]] if hidden else []
+        rows = sb.results().clone()
+        full = None
+        if hidden == 64:
+            sb.prepare_full(epochs=3, sample_max=200)
+            sb.step()
+            sb.launch_full()
+            full = sb.full_metrics().clone()
+        got[tiled] = (ys, agg, logits, rows, full)
+    a, b = got["1"], got["0"]
+    for ta, tb in zip(a[0] + a[1] + a[2], b[0] + b[1] + b[2]):
+        assert not bool(torch.isnan(ta).any()) and torch.equal(ta, tb)
+    assert torch.equal(a[3], b[3])
+    if a[4] is not None:
+        np.testing.assert_array_equal(a[4].numpy(), b[4].numpy())
+
+
+def test_tiled_output_is_refused_off_the_quad_kernel(monkeypatch):
+    """only the quad-row kernel writes a tiled Y: a table that cannot run there refuses it, and so does the single-graph entry"""
+    from wdg_amd import ops
+    rng = np.random.default_rng(5)
+    n, f = 600, 32
+    src, dst = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+    x = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).cuda()
+    y = ops.Tiled(torch.empty((2, n, 16), device="cuda"))
+    ref = torch.empty((n, f), device="cuda")
+    ops.SpmmBatch([(g, x, ref, None, None, False)]).launch()
+    batch = ops.SpmmBatch([(g, x, y, None, None, False)])
+    assert batch.quad
+    batch.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(y.rowmajor(), ref)  # (the tiled launch: the same sums in other places)
+    monkeypatch.setenv("WDG_SPMM_NO_QUAD", "1")
+    g2 = ops.CsrGraph(g.rowptr, g.col, g.val, n, n)
+    with pytest.raises(ValueError):
+        ops.SpmmBatch([(g2, x, y, None, None, False)])

@@ -30,7 +30,8 @@ class SpmmJob(ctypes.Structure):
                 ("n_rows", c_int32), ("n_cols", c_int32), ("n_feat", c_int32), ("reserved", c_int32),
                 ("q_ext", c_void_p), ("q_col", c_void_p), ("q_val", c_void_p), ("q_perm", c_void_p), ("q_rows", c_void_p),
                 ("q_block_cols", c_int32), ("q_n_blocks", c_int32), ("q_n_entries", c_int32), ("q_flags", c_int32),
-                ("band_perm", c_void_p), ("band_cuts", c_void_p), ("band_n_hub", c_int32), ("band_reserved", c_int32)]
+                ("band_perm", c_void_p), ("band_cuts", c_void_p), ("band_n_hub", c_int32), ("band_reserved", c_int32),
+                ("y_group_stride", c_int64)]
 
 
 class SpmmItem(ctypes.Structure):
@@ -179,7 +180,8 @@ class Mlp2Job(ctypes.Structure):
     """mirror of `wdg_mlp2_job` (include/wdg.h)"""
     _fields_ = [("A", c_void_p), ("W0", c_void_p), ("b0", c_void_p), ("W1", c_void_p), ("b1", c_void_p), ("Z", c_void_p),
                 ("lda", c_int64), ("ldw0", c_int64), ("ldw1", c_int64), ("ldz", c_int64),
-                ("M", c_int32), ("K", c_int32), ("H", c_int32), ("C", c_int32), ("act", c_int32), ("reserved", c_int32)]
+                ("M", c_int32), ("K", c_int32), ("H", c_int32), ("C", c_int32), ("act", c_int32), ("reserved", c_int32),
+                ("a_group_stride", c_int64)]
 
 
 if not os.path.exists(LIB_PATH):

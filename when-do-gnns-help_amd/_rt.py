@@ -3,7 +3,7 @@ include/wdg.h, pointer and leading-dimension helpers, and the page-locked arena 
 PyTorch is plumbing here (device memory, the current HIP stream); nothing in this package computes on the CPU or falls back."""
 __all__ = ["COO_SYMMETRISE", "COO_BINARISE", "COO_ADD_SELF_LOOPS", "COO_DROP_SELF_LOOPS", "COO_KEEP_DUPLICATES", "NORM_RW", "NORM_SYM",
            "PREC_F32", "PREC_F64", "ACT_NONE", "ACT_RELU", "SPMM_ANY_VAL", "SPMM_DMA_OK", "SPMM_SMALL_OFFSETS", "SPMM_ANY_COL_SCALE",
-           "SPMM_HALF_SLAB", "GEMM_A_VEC4"]  # what `from ._rt import *` hands the front-end modules: the flag values only
+           "SPMM_HALF_SLAB", "GEMM_A_VEC4", "Tiled"]  # what `from ._rt import *` hands the front-end modules: the flag values only
 
 import ctypes
 import os
@@ -95,6 +95,42 @@ def _h2d(host, dev=None):
     out = p.to(dev, non_blocking=True)
     _ARENA.issued(start, nbytes)
     return out
+
+
+class Tiled:
+    """A [rows, cols] fp32 matrix stored in 16-column groups: element (r, c) lives at t[c // 16, r, c % 16] of a device tensor
+    t [groups, rows, 16] (wdg_spmm_job.y_group_stride / wdg_mlp2_job.a_group_stride of include/wdg.h).  The quad-row aggregation
+    writes such a Y - one workgroup (= one feature group) stores inside one contiguous plane instead of 64-byte pieces a whole
+    row apart - and the fused transform reads it back; everything else takes `rowmajor()` (a copy)."""
+
+    def __init__(self, t, cols=None):
+        if t.dim() != 3 or t.shape[2] != 16 or t.stride(2) != 1 or t.dtype != torch.float32:
+            raise ValueError("Tiled: a [groups, rows, 16] fp32 tensor expected")
+        self.t, self.cols = t, int(t.shape[0] * 16 if cols is None else cols)
+        if not 0 <= self.cols <= t.shape[0] * 16:
+            raise ValueError("Tiled: more columns than the groups hold")
+
+    shape = property(lambda self: (int(self.t.shape[1]), self.cols))
+    dtype = property(lambda self: self.t.dtype)
+    device = property(lambda self: self.t.device)
+    ld = property(lambda self: int(self.t.stride(1)))             # floats between consecutive rows inside a group
+    group_stride = property(lambda self: int(self.t.stride(0)))   # floats between consecutive groups
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def columns(self, cols):
+        """the first `cols` columns (a view)"""
+        return Tiled(self.t, cols)
+
+    def rowmajor(self):
+        """-> a row-major [rows, cols] COPY"""
+        g, n, _ = self.t.shape
+        return self.t.permute(1, 0, 2).reshape(n, g * 16)[:, :self.cols]
+
+    def fill_(self, v):
+        self.t.fill_(v)
+        return self
 
 
 def _table(arr):

@@ -27,7 +27,12 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
     job.row_scale = 0 if row_scale is None else row_scale.data_ptr()
     job.col_scale = 0 if col_scale is None else col_scale.data_ptr()
     job.X, job.Y = x.data_ptr(), y.data_ptr()
-    job.ldx, job.ldy = _ld(x), _ld(y)
+    if isinstance(y, Tiled):  # Y in 16-feature groups (the quad-row kernel only: SpmmBatch checks)
+        if y.cols != x.shape[1] or y.shape[0] != g.n_rows:
+            raise ValueError("spmm: a tiled Y must hold exactly the product's rows and columns")
+        job.ldx, job.ldy, job.y_group_stride = _ld(x), y.ld, y.group_stride
+    else:
+        job.ldx, job.ldy, job.y_group_stride = _ld(x), _ld(y), 0
     job.n_rows, job.n_cols, job.n_feat = g.n_rows, g.n_cols, x.shape[1]
     job.reserved = ABLATE_BITS  # 0 on every product path; only scripts/ablate_*.py assign the module variable
     wants_val = bool(job.val)
@@ -51,6 +56,11 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
         job.band_n_hub = 0
     job.band_reserved = 0
     return job
+
+
+def _y_span(y, n_rows):
+    """floats between the first and the last element of Y (the pipelined loop addresses it with 32-bit byte offsets)"""
+    return y.t.shape[0] * y.group_stride + n_rows * y.ld if isinstance(y, Tiled) else n_rows * _ld(y)
 
 
 def _sharing_groups(entries):
@@ -294,6 +304,8 @@ class SpmmBatch:
             groups = _sharing_groups(entries)
             groups.sort(key=lambda grp: -sum(entries[i][0].nnz for i in grp))
             order = [i for grp in groups for i in sorted(grp, key=lambda i: -entries[i][0].nnz)]
+        if any(isinstance(e[2], Tiled) for e in entries) and not (self.quad and not entries[0][0].quad["half"]):
+            raise ValueError("SpmmBatch: a tiled Y needs the quad-row kernel (SELL-16 copies over 64-byte slab rows, F >= 8)")
         for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
             _fill_job(job, g, x, y, rs, cs, uv)
             any_val = any_val or bool(job.val)
@@ -307,7 +319,7 @@ class SpmmBatch:
         if any(e[4] is not None for e in entries):
             self.flags |= SPMM_ANY_COL_SCALE
         if self.quad:
-            if all(e[0].n_rows * _ld(e[2]) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 and e[0].quad["split"] for e in entries):
+            if all(_y_span(e[2], e[0].n_rows) < (1 << 30) and e[0].quad["chunks"] < (1 << 22) - 2 and e[0].quad["split"] for e in entries):
                 self.flags |= SPMM_SMALL_OFFSETS
             if entries[0][0].quad["half"]:
                 self.flags |= SPMM_HALF_SLAB
@@ -327,7 +339,7 @@ class SpmmBatch:
         self.launch()
         torch.cuda.synchronize()
         for i, (g, x, y, rs, cs, uv) in enumerate(self.keep):
-            got = y.clone()
+            got = y.rowmajor() if isinstance(y, Tiled) else y.clone()
             ref = torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=y.device)
             job = _fill_job(SpmmJob(), g, x, ref, rs, cs, uv)
             job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0  # no SELL copies: the CSR families

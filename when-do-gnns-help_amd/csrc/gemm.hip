@@ -511,6 +511,7 @@ __global__ __launch_bounds__(BRES_THREADS) void mlp2_split_kernel(const wdg_mlp2
     const global_ptr<const float> W1 = to_global(job->W1), b1 = to_global(job->b1);
     const global_ptr<float> Z = to_global(job->Z);
     const int64_t lda = job->lda, ldw0 = job->ldw0, ldw1 = job->ldw1, ldz = job->ldz;
+    const int64_t ags = job->a_group_stride > 0 ? job->a_group_stride : 16;  // floats between consecutive 16-column groups of a row of A
     const int M = job->M, K = job->K, H = job->H, C = job->C, act = job->act;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
     if (M <= 0 || H <= 0 || C <= 0) return;
@@ -534,7 +535,9 @@ __global__ __launch_bounds__(BRES_THREADS) void mlp2_split_kernel(const wdg_mlp2
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int gm = tile * 32 + 16 * s + n;
-            a_row[s] = A + static_cast<int64_t>(have && gm < M ? gm : M - 1) * lda;
+            // (k = 32 st + 8 q + 0..7 of the lane's row: row-major at row lda + k; A tiled by 16-column groups - what the quad-row
+            // aggregation writes with y_group_stride - at (k / 16) ags + row lda + k % 16, i.e. plane 2 st + q / 2, position 8 (q & 1))
+            a_row[s] = A + static_cast<int64_t>(have && gm < M ? gm : M - 1) * lda + (q >> 1) * ags + (q & 1) * 8;
         }
         f32x4_acc acc[2][NT16];
 #pragma unroll
@@ -546,8 +549,8 @@ __global__ __launch_bounds__(BRES_THREADS) void mlp2_split_kernel(const wdg_mlp2
             if (32 * st + 32 <= K) {  // (uniform) a whole step: plain loads off the lane's row pointers
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    dst.a[s] = *(const global_ptr<const f32x4_t>)(a_row[s] + 8 * q + 32 * st);
-                    dst.b[s] = *(const global_ptr<const f32x4_t>)(a_row[s] + 8 * q + 32 * st + 4);
+                    dst.a[s] = *(const global_ptr<const f32x4_t>)(a_row[s] + 2 * ags * st);
+                    dst.b[s] = *(const global_ptr<const f32x4_t>)(a_row[s] + 2 * ags * st + 4);
                 }
                 return;
             }
@@ -555,8 +558,10 @@ __global__ __launch_bounds__(BRES_THREADS) void mlp2_split_kernel(const wdg_mlp2
             const f32x4_t zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const f32x4_t va = *(const global_ptr<const f32x4_t>)(a_row[s] + min(k, K - 4));
-                const f32x4_t vb = *(const global_ptr<const f32x4_t>)(a_row[s] + min(k + 4, K - 4));
+                const global_ptr<const float> row0 = a_row[s] - ((q >> 1) * ags + (q & 1) * 8);  // (the row's k = 0)
+                const int ka = min(k, K - 4), kb = min(k + 4, K - 4);
+                const f32x4_t va = *(const global_ptr<const f32x4_t>)(row0 + (ka >> 4) * ags + (ka & 15));
+                const f32x4_t vb = *(const global_ptr<const f32x4_t>)(row0 + (kb >> 4) * ags + (kb & 15));
                 dst.a[s] = k < K ? va : zero;
                 dst.b[s] = k + 4 < K ? vb : zero;
             }

@@ -472,7 +472,12 @@ int validate_job(const wdg_spmm_job *j) {
     WDG_REQUIRE(j->n_rows >= 0 && j->n_cols >= 0 && j->n_feat >= 0, "spmm: negative size");
     if (j->n_rows == 0 || j->n_feat == 0) return WDG_OK;
     WDG_REQUIRE(j->rowptr && j->Y, "spmm: null rowptr / Y");
-    WDG_REQUIRE(j->ldx >= j->n_feat && j->ldy >= j->n_feat, "spmm: leading dimension smaller than n_feat");
+    WDG_REQUIRE(j->y_group_stride >= 0, "spmm: negative y_group_stride");
+    if (j->y_group_stride > 0)  // Y tiled by 16-feature groups (the quad-row kernel only)
+        WDG_REQUIRE(j->ldx >= j->n_feat && j->ldy >= 16 && j->y_group_stride >= static_cast<int64_t>(j->n_rows - 1) * j->ldy + 16,
+                    "spmm: tiled Y needs ldy >= 16 and group planes that do not overlap");
+    else
+        WDG_REQUIRE(j->ldx >= j->n_feat && j->ldy >= j->n_feat, "spmm: leading dimension smaller than n_feat");
     return WDG_OK;
 }
 
@@ -489,11 +494,13 @@ int single(const wdg_spmm_job *job_host, wdg_stream_t stream) {
         job_host->ldx % 4 == 0 && job_host->ldy % 4 == 0 && job_host->n_feat % 4 == 0)
         flags |= WDG_SPMM_DMA_OK;
     // a band plan and no SELL-16 copy in split form (wide features; several column blocks or rows too long for slices)
-    if (sizeof(TIN) == 4 && band_eligible_single(*job_host) &&
+    const bool tiled_y = job_host->y_group_stride > 0;  // (only the quad-row kernel writes a tiled Y)
+    if (sizeof(TIN) == 4 && !tiled_y && band_eligible_single(*job_host) &&
         !(quad_eligible_single(*job_host) && (job_host->q_flags & WDG_SELL16_SPLIT)))
         return band_single_f32(*job_host, as_stream(stream));
     if (quad_eligible_single(*job_host))  // the SELL-16 copy is there: quad-row kernel (csrc/spmm_quad.hip)
         return sizeof(TIN) == 4 ? quad_single_f32(*job_host, as_stream(stream)) : quad_single_bf16(*job_host, as_stream(stream));
+    if (tiled_y) return fail(WDG_ERR_UNSUPPORTED, "spmm: y_group_stride needs the quad-row kernel (a SELL-16 copy, >= 8 features)");
     return dispatch<TIN>(nullptr, *job_host, 1, job_host->n_rows, job_host->n_cols, job_host->n_feat, flags,
                          as_stream(stream));
 }

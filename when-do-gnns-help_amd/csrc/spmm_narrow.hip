@@ -337,6 +337,7 @@ static int narrow_launch(const wdg_spmm_job *j, bool bf16, const int32_t *part_p
     WDG_REQUIRE(j->rowptr && j->Y && (j->n_cols == 0 || j->X), "spmm_narrow: null rowptr / X / Y");
     WDG_REQUIRE(j->band_perm && j->band_cuts, "spmm_narrow: the job carries no band plan (wdg_csr_band_plan)");
     WDG_REQUIRE(j->ldx >= j->n_feat && j->ldy >= j->n_feat, "spmm_narrow: leading dimension smaller than n_feat");
+    WDG_REQUIRE(j->y_group_stride == 0, "spmm_narrow: Y must be row-major (y_group_stride is the quad-row kernel's)");
     const int col_bytes = wdg_spmm_narrow_col_bytes(j->n_feat, bf16 ? 1 : 0, j->col_scale ? 1 : 0);
     const int table = col_bytes == 32 ? TABLE_F32X8 : (j->n_feat <= 4 ? TABLE_F32X4 : TABLE_BF16X8);
     const int parts = wdg_spmm_narrow_parts(j->n_cols, col_bytes);

@@ -741,9 +741,11 @@ struct QJob {
     global_ptr<const int32_t> ext, col, perm;
     global_ptr<const float> val, row_scale;
     global_ptr<float> Y;
-    int64_t ldy;
+    int64_t ldy, ygs;      // ygs: floats between consecutive 16-feature groups of a row (16: row-major; y_group_stride: tiled Y)
     int32_t n_rows, n_su;  // n_su = super-units = q_n_entries / 4
 };
+// element offset of feature f inside a row of Y (row-major: f; tiled: its group's plane + the position in the group)
+__device__ __forceinline__ int64_t q_feat_off(int f, int64_t ygs) { return static_cast<int64_t>(f >> 4) * ygs + (f & 15); }
 struct QHead {  // what a phase needs of its first job (the jobs of a phase agree in these)
     global_ptr<const void> X;
     global_ptr<const float> col_scale;
@@ -761,6 +763,7 @@ __device__ __forceinline__ QJob q_load_job(const wdg_spmm_job *jobs, const wdg_s
     v.ext = to_global(j->q_ext); v.col = to_global(j->q_col); v.perm = to_global(j->q_rows);
     v.val = to_global(j->q_val); v.row_scale = to_global(j->row_scale); v.Y = to_global(j->Y);
     v.ldy = j->ldy;
+    v.ygs = j->y_group_stride > 0 ? j->y_group_stride : 16;
     v.n_rows = j->n_rows;
     v.n_su = j->q_n_entries / Q_SU;
     return v;
@@ -965,6 +968,8 @@ struct QJobI {
 struct QJobC {
     global_ptr<float> Y;
     unsigned ldy4;  // bytes per row of Y
+    unsigned lane_off;  // byte offset of the lane's piece of the workgroup's feature group inside a row (row-major: 4 f0 + the
+                        // lane's 16 bytes; tiled Y: the group's plane + the same)
 };
 
 template <int D, bool HALF>
@@ -1096,6 +1101,9 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
             const q_desc_ptr d = q_desc(jobs, inl, cj);
             jc.Y = to_global(d->Y);
             jc.ldy4 = static_cast<unsigned>(d->ldy) * 4u;
+            // (32-bit and wave-uniform: the launcher vouches for offsets below 2^32 bytes, y_vec)
+            const unsigned ygs32 = d->y_group_stride > 0 ? static_cast<unsigned>(d->y_group_stride) : 16u;
+            jc.lane_off = (static_cast<unsigned>(f0 >> 4) * ygs32 + static_cast<unsigned>(f0 & 15)) * 4u + static_cast<unsigned>(loff);
         }
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
         [[maybe_unused]] const f32x4_t wc = {1.f, 1.f, 1.f, 1.f};
@@ -1124,8 +1132,8 @@ __device__ __forceinline__ void q_units_fast(const wdg_spmm_job *jobs, const wdg
             const int sb = __builtin_amdgcn_ds_bpermute(bperm0 + i * (Q_ROWS * 4), cur.scale_bits);
             const float scale0 = cur.has_scale ? __int_as_float(sb) : 1.f;
             const unsigned row0 = no_store ? static_cast<unsigned>(r) : static_cast<unsigned>(row);  // (timing ablation: rows 0..15)
-            if (HALF) q_st2(jc.Y, row0 * jc.ldy4 + static_cast<unsigned>(f0 * 4 + loff), f32x2{a0.x * scale0, a0.y * scale0});
-            else q_st4(jc.Y, row0 * jc.ldy4 + static_cast<unsigned>(f0 * 4 + loff),
+            if (HALF) q_st2(jc.Y, row0 * jc.ldy4 + jc.lane_off, f32x2{a0.x * scale0, a0.y * scale0});
+            else q_st4(jc.Y, row0 * jc.ldy4 + jc.lane_off,
                        f32x4_t{a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0});
         }
     };
@@ -1296,9 +1304,9 @@ __device__ __forceinline__ void q_units_simple(const wdg_spmm_job *jobs, const w
             const float scale0 = job.row_scale ? job.row_scale[row] : 1.f;
             const int f = f0 + p * (HALF ? 2 : 4);
             const int row0 = no_store ? r : row;
-            const global_ptr<float> dst = job.Y + static_cast<uint64_t>(static_cast<unsigned>(row0)) * ldy + f;
+            const global_ptr<float> dst = job.Y + static_cast<uint64_t>(static_cast<unsigned>(row0)) * ldy + q_feat_off(f, job.ygs);  // (a lane's features share a group)
             const float4 o = make_float4(a0.x * scale0, a0.y * scale0, a1.x * scale0, a1.y * scale0);
-            const bool y_vec = (F % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
+            const bool y_vec = (F % 4 == 0) && (ldy % 4 == 0) && (job.ygs % 4 == 0) && (((uintptr_t)job.Y & 15) == 0);
             if (HALF) {  // two features per lane
                 if (y_vec) {
                     if (f < F) *(global_ptr<f32x2>)dst = f32x2{o.x, o.y};
@@ -1431,9 +1439,9 @@ __device__ __forceinline__ void q_phase_multi(const wdg_spmm_job *jobs, const wd
                     const int row = j0.perm[slice * Q_ROWS + r];  // (padding slots / slices repeat rows: always a row)
                     const float sc = j0.row_scale ? j0.row_scale[row] : 1.f;
                     const int f = f0 + p * 4;
-                    const global_ptr<float> dst = j0.Y + static_cast<int64_t>(row) * j0.ldy + f;
+                    const global_ptr<float> dst = j0.Y + static_cast<int64_t>(row) * j0.ldy + q_feat_off(f, j0.ygs);
                     const float4 o = make_float4(a0.x * sc, a0.y * sc, a1.x * sc, a1.y * sc);
-                    const bool y_vec = (F % 4 == 0) && (j0.ldy % 4 == 0) && (((uintptr_t)j0.Y & 15) == 0);
+                    const bool y_vec = (F % 4 == 0) && (j0.ldy % 4 == 0) && (j0.ygs % 4 == 0) && (((uintptr_t)j0.Y & 15) == 0);
                     if (y_vec) {
                         if (f < F) store_f32x4(dst, o);
                     } else {
@@ -1599,8 +1607,9 @@ int quad_single(const wdg_spmm_job &j, hipStream_t st) {
         subs = std::max(subs, need);
     }
     // 16-byte stores and 32-bit byte offsets into Y and into the index arrays (what the fast loop addresses with)
-    const bool y_vec = (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.n_feat % 4 == 0 &&
-                       static_cast<int64_t>(j.n_rows) * j.ldy < (1ll << 30) && (j.q_flags & WDG_SELL16_SPLIT) != 0;
+    const bool y_vec = (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.y_group_stride % 4 == 0 && j.n_feat % 4 == 0 &&
+                       static_cast<int64_t>(j.n_rows) * j.ldy + (static_cast<int64_t>(j.n_feat) / 16) * j.y_group_stride < (1ll << 30) &&
+                       (j.q_flags & WDG_SELL16_SPLIT) != 0;
     return q_launch<TIN>(nullptr, j, nullptr, nullptr, subs, j.n_cols, j.n_feat, j.val != nullptr, y_vec, half, st);
 }
 int quad_single_f32(const wdg_spmm_job &j, hipStream_t st) { return quad_single<float>(j, st); }

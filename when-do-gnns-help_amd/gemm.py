@@ -55,9 +55,21 @@ class Mlp2Batch:
     def eligible(cls, entries):
         for a, w0, b0, w1, b1, z in entries:
             k, h, c = a.shape[1], w0.shape[1], w1.shape[1]
-            if h > cls.MAX_H or c > cls.MAX_C or k > cls.MAX_K or k % 4 or k == 0 or a.data_ptr() % 16 or _ld(a) % 4:
+            lda = a.ld if isinstance(a, Tiled) else _ld(a)
+            if h > cls.MAX_H or c > cls.MAX_C or k > cls.MAX_K or k % 4 or k == 0 or a.data_ptr() % 16 or lda % 4:
                 return False
+            if isinstance(a, Tiled) and (a.group_stride % 4 or not cls.split_kernel()):
+                return False  # (A tiled by 16-column groups: the split-operand kernel reads it, the fp32 chain does not)
         return len(entries) > 0
+
+    @staticmethod
+    def split_kernel():
+        """the launcher's own rule (csrc/gemm.hip, wdg_mlp2_batched_f32): split-operand products unless WDG_MLP2_SPLIT=0"""
+        e = os.environ.get("WDG_MLP2_SPLIT")
+        try:
+            return True if e is None else int(e) != 0
+        except ValueError:
+            return False
 
     def __init__(self, entries, relu=True):
         """entries: list of (A [M,K], W0 [K,H], b0 [H]|None, W1 [H,C], b1 [C]|None, Z [M,C]) fp32 device tensors."""
@@ -71,12 +83,13 @@ class Mlp2Batch:
         for job, (a, w0, b0, w1, b1, z) in zip(arr, entries):
             (m, k), h, c = a.shape, w0.shape[1], w1.shape[1]
             if w0.shape[0] != k or w1.shape[0] != h or tuple(z.shape) != (m, c) or \
-                    any(t.stride(1) != 1 or t.dtype != torch.float32 for t in (a, w0, w1, z)):
+                    any(t.stride(1) != 1 or t.dtype != torch.float32 for t in (w0, w1, z) + (() if isinstance(a, Tiled) else (a,))):
                 raise ValueError("Mlp2Batch: shape / layout mismatch")
             job.A, job.W0, job.W1, job.Z = a.data_ptr(), w0.data_ptr(), w1.data_ptr(), z.data_ptr()
             job.b0 = 0 if b0 is None else b0.data_ptr()
             job.b1 = 0 if b1 is None else b1.data_ptr()
-            job.lda, job.ldw0, job.ldw1, job.ldz = _ld(a), _ld(w0), _ld(w1), _ld(z)
+            job.lda, job.ldw0, job.ldw1, job.ldz = (a.ld if isinstance(a, Tiled) else _ld(a)), _ld(w0), _ld(w1), _ld(z)
+            job.a_group_stride = a.group_stride if isinstance(a, Tiled) else 0
             job.M, job.K, job.H, job.C, job.act = m, k, h, c, (ACT_RELU if relu else ACT_NONE)
             self.max_m, self.max_k = max(self.max_m, m), max(self.max_k, k)
             self.max_h, self.max_c = max(self.max_h, h), max(self.max_c, c)

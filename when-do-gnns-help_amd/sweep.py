@@ -173,7 +173,14 @@ class SweepBatch:
         their block-diagonal union, the SELL-16 copies in five launches, ONE host read-back; "per_graph" - round 2's
         CsrGraph.from_coo + ensure_quad per graph (~20 launches and two host syncs each), kept for A/B runs and tests.
         tune: balance the aggregation's tape cut by feedback (tune() below: ~40 extra steps) - worth it for a batch that is
-        replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut."""
+        replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut.
+
+        The aggregated features are kept TILED by 16-feature groups (ops.Tiled: y_agg[i].t is [groups, n, 16]) when everything
+        that reads them inside the step can - the label columns of LAS as a strided view, the fused transform through
+        wdg_mlp2_job.a_group_stride: a workgroup of the aggregation (one feature group) then stores into one contiguous plane
+        per graph instead of 64-byte pieces a row apart (the k = 2 launch 160 -> 133 us, the k = 10 one 98 -> 94).  `y` (a list of
+        row-major [n, n_feat] tensors, as before) is then a COPY refreshed on access; prepare_full() / TrainBatch, whose kernels read
+        row-major operands, refresh it after every aggregation.  WDG_SWEEP_TILED_Y=0: row-major, as in rounds 1 - 3."""
         from . import ops
         self.ops = ops
         self.jobs = list(jobs)
@@ -192,8 +199,9 @@ class SweepBatch:
         self.agg_feat = (n_feat + n_classes + align - 1) // align * align if ride else n_feat
         self.alg_feat = n_feat + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
         build = build or os.environ.get("WDG_SWEEP_BUILD", "batched")
-        feats, self.graphs, self.dinv, self.labels, self.y = {}, [], [], [], []
+        feats, self.graphs, self.dinv, self.labels, self._y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
+        self.tiled_y, self._y_rm, self._untile_each_step = False, None, False
         coos, labs_host = [], []
         for ji, j in enumerate(self.jobs):
             if inputs is not None:
@@ -236,9 +244,23 @@ class SweepBatch:
         lab_pool = ops._h2d(np.concatenate(labs_host).astype(np.int32) if labs_host else np.zeros(0, np.int32), dev)
         self.labels = [lab_pool[int(lab_ptr[i]):int(lab_ptr[i + 1])] for i in range(len(self.jobs))]
         self.labels_host = labs_host
-        for j in self.jobs:
-            self.y_agg.append(torch.empty((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev))
-            self.y.append(self.y_agg[-1][:, :n_feat])  # the feature part (a view: leading dimension agg_feat)
+        # Y tiled by 16-feature groups (see the docstring) when every reader inside the step takes it that way: the label columns
+        # inside one group, graphs of one size on the quad-row kernel's 64-byte slabs, the fused split-operand transform (or none)
+        nodes = {j.n_nodes for j in self.jobs}
+        mlp_ok = (not gcn_hidden) or (os.environ.get("WDG_SWEEP_FUSED_MLP", "1") != "0" and ops.Mlp2Batch.split_kernel()
+                                      and gcn_hidden <= ops.Mlp2Batch.MAX_H and n_classes <= ops.Mlp2Batch.MAX_C
+                                      and 0 < n_feat <= ops.Mlp2Batch.MAX_K and n_feat % 4 == 0)
+        self.tiled_y = bool(os.environ.get("WDG_SWEEP_TILED_Y", "1") != "0" and ride and self.agg_feat % 16 == 0 and len(nodes) == 1
+                            and (n_feat % 16) + n_classes <= 16 and mlp_ok and not ops.quad_disabled()
+                            and all(g.ensure_quad() and not g.quad["half"] for g in self.graphs))
+        if self.tiled_y:
+            n = next(iter(nodes))
+            self.y_pool = torch.empty((len(self.jobs), self.agg_feat // 16, n, 16), dtype=torch.float32, device=dev)
+            self.y_agg = [ops.Tiled(self.y_pool[i]) for i in range(len(self.jobs))]
+        else:
+            for j in self.jobs:
+                self.y_agg.append(torch.empty((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev))
+                self._y.append(self.y_agg[-1][:, :n_feat])  # the feature part (a view: leading dimension agg_feat)
         self.x_agg = feats                                        # what the aggregation reads: [X | onehot | 0]
         self.x = {s: x[:, :n_feat] for s, x in feats.items()}     # the features proper (views)
         # A + I has unit values except a doubled pre-existing loop; the generator emits no loops -> pattern only
@@ -255,7 +277,11 @@ class SweepBatch:
         # aggregation homophily (soft LAS, synthetic_plot.py:106): H = A_hat Z with one-hot Z, then W = H (H^T Y)
         self.h_las = []
         if ride:
-            self.h_las = [ya[:, n_feat:n_feat + n_classes] for ya in self.y_agg]  # written by the feature aggregation
+            if self.tiled_y:  # the label columns lie inside one 16-feature group: [n, C] views with a row stride of 16 floats
+                g_lab, off = n_feat // 16, n_feat % 16
+                self.h_las = [ya.t[g_lab][:, off:off + n_classes] for ya in self.y_agg]
+            else:
+                self.h_las = [ya[:, n_feat:n_feat + n_classes] for ya in self.y_agg]  # written by the feature aggregation
             self.spmm_las = None
         else:
             las_entries = []
@@ -287,18 +313,40 @@ class SweepBatch:
             # (rows of 8 floats: the logits aggregation reads a source row as two aligned float4 - ops.SpmmBatch narrow family)
             z2 = [torch.zeros((j.n_nodes, 8 if n_classes <= 8 else n_classes), dtype=torch.float32, device=dev)[:, :n_classes] for j in self.jobs]
             out = [torch.empty((j.n_nodes, n_classes), dtype=torch.float32, device=dev) for j in self.jobs]
-            mlp = [(y, a, None, b, None, z) for y, a, b, z in zip(self.y, w0, w1, z2)]
+            y_in = [ya.columns(n_feat) for ya in self.y_agg] if self.tiled_y else self._y
+            mlp = [(y, a, None, b, None, z) for y, a, b, z in zip(y_in, w0, w1, z2)]
             fused = os.environ.get("WDG_SWEEP_FUSED_MLP", "1") != "0" and ops.Mlp2Batch.eligible(mlp)
+            if self.tiled_y and not fused:
+                raise RuntimeError("SweepBatch: the tiled Y was chosen for a transform that cannot read it (WDG_SWEEP_TILED_Y=0)")
             self.gcn = dict(w0=w0, w1=w1, hid=None if fused else hid, z2=z2, logits=out,
                             # fused: relu(Y W0) W1 in one pass over Y, the hidden layer stays in registers
                             mlp=ops.Mlp2Batch(mlp, relu=True) if fused else None,
-                            gemm1=ops.GemmBatch([(y, a, h, None) for y, a, h in zip(self.y, w0, hid)], relu=True),
-                            gemm2=ops.GemmBatch([(h, b, z, None) for h, b, z in zip(hid, w1, z2)]),
+                            gemm1=None if fused else ops.GemmBatch([(y, a, h, None) for y, a, h in zip(self._y, w0, hid)], relu=True),
+                            gemm2=None if fused else ops.GemmBatch([(h, b, z, None) for h, b, z in zip(hid, w1, z2)]),
                             spmm=ops.SpmmBatch([(g, z, o, d, scale(d), False)
                                                 for g, z, o, d in zip(self.graphs, z2, out, self.dinv)]))
 
         if tune or os.environ.get("WDG_QUAD_TUNE", "") == "1":
             self.tune()
+
+    # -- the aggregated features as row-major matrices ------------------------------------------------------------
+    @property
+    def y(self):
+        """list of [n, n_feat] row-major tensors, one per job (views of the aggregation's output - or, with a tiled Y, of a
+        row-major copy refreshed by this access: stable addresses, so job tables built on them stay valid)"""
+        if self.tiled_y:
+            self.untile()
+            return [self._y_rm[i][:, :self.n_feat] for i in range(len(self.jobs))]
+        return self._y
+
+    def untile(self):
+        """tiled Y -> the row-major copy (one strided copy kernel for the whole shard); no-op for a row-major batch"""
+        if not self.tiled_y:
+            return
+        j, g, n, _ = self.y_pool.shape
+        if self._y_rm is None:
+            self._y_rm = torch.empty((j, n, g * 16), dtype=torch.float32, device=self.y_pool.device)
+        self._y_rm.view(j, n, g, 16).copy_(self.y_pool.permute(0, 2, 1, 3))
 
     def tune(self, rounds=6, steps=5):
         """Balance the aggregation's eight segments (one per XCD) by what they really cost INSIDE the step.  The modelled cut
@@ -356,6 +404,8 @@ class SweepBatch:
         """one pass of the hot path over the batch (synthetic_plot.py:92-108 minus the kernel-regression metric):
         feature aggregation, integer edge/label pass, label aggregation + LAS, GCN-2 forward"""
         self.spmm.launch()        # Y = A_hat X                       (F = n_feat)   dominant kernel
+        if self._untile_each_step:  # (a tiled Y and row-major readers behind the step: prepare_full's Grams, training)
+            self.untile()
         self.step_rest()
 
     def step_rest(self):
@@ -523,7 +573,9 @@ class SweepBatch:
             raise ValueError(f"SweepBatch.prepare_full: {self.n_classes} classes, the device solver holds {ops.KrBatch.MAX_CLASSES}; "
                              "use utils.homophily_metrics.classifier_based_performance_metric (host path) per graph")
         # kernels: [aggregated features of every job] + [raw features of every feature matrix], linear and arc-cosine
-        self.gram = ops.GramBatch([self.y[i] for i in range(J)] + [self.x[s] for s in seeds])
+        ys = self.y  # (row-major: with a tiled Y the copy, refreshed behind every aggregation from here on)
+        self._untile_each_step = self.tiled_y
+        self.gram = ops.GramBatch([ys[i] for i in range(J)] + [self.x[s] for s in seeds])
         x_slot = {s: J + i for i, s in enumerate(seeds)}
         self.ge = ops.EdgeGramBatch([(g, self.gram.k_linear[x_slot[j.seed]], self.gram.norm2[x_slot[j.seed]])
                                      for j, g in zip(self.jobs, self.graphs)])
@@ -818,11 +870,12 @@ class TrainBatch:
         if kind == "sgc":
             sb.spmm.launch()  # Y_j = A_hat_j X, once
             torch.cuda.synchronize()
-            self.yt = torch.stack([y.t().contiguous() for y in sb.y])  # [J, F, n] for dW = Y^T dlogits
+            ys = sb.y  # (row-major; a tiled Y is copied out here, once: the aggregation above is the only one)
+            self.yt = torch.stack([y.t().contiguous() for y in ys])  # [J, F, n] for dW = Y^T dlogits
             self.w = torch.nn.Parameter(xavier(J, f, c))
             self.w.grad = torch.zeros_like(self.w)
             self.params = [self.w]
-            self.fwd = [ops.GemmBatch([(sb.y[j], self.w.data[j], self.logits[j], None) for j in range(J)])]
+            self.fwd = [ops.GemmBatch([(ys[j], self.w.data[j], self.logits[j], None) for j in range(J)])]
             self.bwd = [ops.GemmBatch([(self.yt[j], self.dlogits[j], self.w.grad[j], None) for j in range(J)])]
         elif kind == "gcn":
             xt = {s: x.t().contiguous() for s, x in sb.x.items()}  # X^T per seed, for dW0 = X^T dP
