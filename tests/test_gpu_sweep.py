@@ -541,15 +541,16 @@ def test_step_scalars_kernel_edge_cases():
     assert np.isfinite(out.cpu().numpy()).all()
 
 
-@pytest.mark.parametrize("k,seeds,n_feat,hidden", [(10, 2, 500, 64), (2, 3, 96, 32), (10, 1, 36, 0)])
-def test_tiled_aggregation_output_equals_row_major_bitwise(monkeypatch, k, seeds, n_feat, hidden):
+@pytest.mark.parametrize("k,seeds,n_feat,hidden,n_nodes", [(10, 2, 500, 64, 1500), (2, 3, 96, 32, 1500), (10, 1, 36, 0, 1500),
+                                                           (10, 1, 72, 32, 3000)])  # (3000 nodes: HALF slabs, 8-feature groups)
+def test_tiled_aggregation_output_equals_row_major_bitwise(monkeypatch, k, seeds, n_feat, hidden, n_nodes):
     """The sweep keeps the aggregated features tiled by 16-feature groups (ops.Tiled; wdg_spmm_job.y_group_stride written by the
     quad-row kernel, wdg_mlp2_job.a_group_stride read by the fused transform, the label columns of LAS a strided view): where an
     element is stored does not enter any sum, so every output - Y, the LAS / counter scalars, the GCN-2 logits, and the nine
     scalars behind prepare_full's row-major copy - is the row-major batch's (WDG_SWEEP_TILED_Y=0) bit for bit."""
     from wdg_amd import ops, sweep, synth
     levels = synth.H_LEVELS_10_K10[:4] if k == 10 else synth.H_LEVELS_10[:4]
-    jobs = sweep.make_jobs(levels, range(seeds), k=k, n_nodes=1500)
+    jobs = sweep.make_jobs(levels, range(seeds), k=k, n_nodes=n_nodes)
     got = {}
     for tiled in ("1", "0"):
         monkeypatch.setenv("WDG_SWEEP_TILED_Y", tiled)

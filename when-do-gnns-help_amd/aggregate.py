@@ -304,8 +304,8 @@ class SpmmBatch:
             groups = _sharing_groups(entries)
             groups.sort(key=lambda grp: -sum(entries[i][0].nnz for i in grp))
             order = [i for grp in groups for i in sorted(grp, key=lambda i: -entries[i][0].nnz)]
-        if any(isinstance(e[2], Tiled) for e in entries) and not (self.quad and not entries[0][0].quad["half"]):
-            raise ValueError("SpmmBatch: a tiled Y needs the quad-row kernel (SELL-16 copies over 64-byte slab rows, F >= 8)")
+        if any(isinstance(e[2], Tiled) for e in entries) and not self.quad:
+            raise ValueError("SpmmBatch: a tiled Y needs the quad-row kernel (SELL-16 copies, F >= 8)")
         for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
             _fill_job(job, g, x, y, rs, cs, uv)
             any_val = any_val or bool(job.val)

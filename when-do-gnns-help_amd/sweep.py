@@ -245,14 +245,14 @@ class SweepBatch:
         self.labels = [lab_pool[int(lab_ptr[i]):int(lab_ptr[i + 1])] for i in range(len(self.jobs))]
         self.labels_host = labs_host
         # Y tiled by 16-feature groups (see the docstring) when every reader inside the step takes it that way: the label columns
-        # inside one group, graphs of one size on the quad-row kernel's 64-byte slabs, the fused split-operand transform (or none)
+        # inside one group, graphs of one size on the quad-row kernel, the fused split-operand transform (or none)
         nodes = {j.n_nodes for j in self.jobs}
         mlp_ok = (not gcn_hidden) or (os.environ.get("WDG_SWEEP_FUSED_MLP", "1") != "0" and ops.Mlp2Batch.split_kernel()
                                       and gcn_hidden <= ops.Mlp2Batch.MAX_H and n_classes <= ops.Mlp2Batch.MAX_C
                                       and 0 < n_feat <= ops.Mlp2Batch.MAX_K and n_feat % 4 == 0)
         self.tiled_y = bool(os.environ.get("WDG_SWEEP_TILED_Y", "1") != "0" and ride and self.agg_feat % 16 == 0 and len(nodes) == 1
                             and (n_feat % 16) + n_classes <= 16 and mlp_ok and not ops.quad_disabled()
-                            and all(g.ensure_quad() and not g.quad["half"] for g in self.graphs))
+                            and all(g.ensure_quad() for g in self.graphs))
         if self.tiled_y:
             n = next(iter(nodes))
             self.y_pool = torch.empty((len(self.jobs), self.agg_feat // 16, n, 16), dtype=torch.float32, device=dev)
