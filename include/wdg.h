@@ -551,6 +551,9 @@ typedef struct wdg_gram_job {
     float *K_arccos;  /* [n, n] or NULL */
     int64_t lda, ldk;
     int32_t n, F;
+    int64_t a_group_stride; /* 0: A row-major.  > 0: A tiled by 16-column groups (wdg_spmm_job.y_group_stride), element (i, k) at
+                               A[(k / 16) a_group_stride + i lda + k % 16] - the split-operand kernels (the default; with
+                               WDG_GRAM_SPLIT=0 in the environment A must be row-major) */
 } wdg_gram_job;
 int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream);
 

@@ -142,7 +142,7 @@ class Sell16Job(ctypes.Structure):
 class GramJob(ctypes.Structure):
     """mirror of `wdg_gram_job` (include/wdg.h)"""
     _fields_ = [("A", c_void_p), ("norm2", c_void_p), ("K_linear", c_void_p), ("K_arccos", c_void_p), ("lda", c_int64),
-                ("ldk", c_int64), ("n", c_int32), ("F", c_int32)]
+                ("ldk", c_int64), ("n", c_int32), ("F", c_int32), ("a_group_stride", c_int64)]
 
 
 class EdgeGramJob(ctypes.Structure):

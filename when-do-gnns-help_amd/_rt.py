@@ -37,6 +37,8 @@ def _dev(t, dtype, dev):
 def _ld(t):
     """Leading dimension of a row-major matrix for the C ABI.  torch / numpy report an arbitrary stride for a dimension
     of size 1 (a [1, K] view of a [K, 1] array has stride(0) == 1): with one row any value >= the row length is valid."""
+    if isinstance(t, Tiled):
+        return t.ld
     return t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
 
 
@@ -118,6 +120,9 @@ class Tiled:
 
     def data_ptr(self):
         return self.t.data_ptr()
+
+    def stride(self, dim):
+        return {0: self.ld, 1: 1}[dim]
 
     def columns(self, cols):
         """the first `cols` columns (a view)"""

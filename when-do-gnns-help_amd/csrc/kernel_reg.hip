@@ -231,10 +231,12 @@ __device__ __forceinline__ f32x16 sg_products(const u32x4_t &ah, const u32x4_t &
 }
 
 // a tile row's quadruple of k (zero past the matrix); vec: 16-byte aligned rows
-__device__ __forceinline__ float4 sg_load_quad(global_ptr<const float> A, int64_t lda, int n, int K, bool vec, int row, int gk) {
+// (ags: floats between consecutive 16-column groups of a row - 16 for a row-major A, wdg_gram_job.a_group_stride for a tiled one;
+// gk is a multiple of 4: the quadruple lies inside one group)
+__device__ __forceinline__ float4 sg_load_quad(global_ptr<const float> A, int64_t lda, int64_t ags, int n, int K, bool vec, int row, int gk) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < n) {
-        const global_ptr<const float> p = A + static_cast<int64_t>(row) * lda + gk;
+        const global_ptr<const float> p = A + static_cast<int64_t>(row) * lda + static_cast<int64_t>(gk >> 4) * ags + (gk & 15);
         if (vec && gk + 3 < K) {
             const f32x4_t q = *(global_ptr<const f32x4_t>)p;
             v = make_float4(q[0], q[1], q[2], q[3]);
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(GTHREADS) void gram_diag_split_kernel(const wdg_gra
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
     const int m0 = blockIdx.x * SGBM;
     if (m0 >= n) return;
-    const bool vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(job->A) & 15) == 0;
+    const int64_t ags = job->a_group_stride > 0 ? job->a_group_stride : 16;
+    const bool vec = (lda & 3) == 0 && (ags & 3) == 0 && (reinterpret_cast<uintptr_t>(job->A) & 15) == 0;
     constexpr int A_PER = SGBM * SGBK / GTHREADS / 4;
     f32x16 acc;
 #pragma unroll
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(GTHREADS) void gram_diag_split_kernel(const wdg_gra
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            sg_store_quad(As, SG_A_WORDS, e / SG_QPR, e % SG_QPR, sg_load_quad(A, lda, n, K, vec, m0 + e / SG_QPR, k0 + 4 * (e % SG_QPR)));
+            sg_store_quad(As, SG_A_WORDS, e / SG_QPR, e % SG_QPR, sg_load_quad(A, lda, ags, n, K, vec, m0 + e / SG_QPR, k0 + 4 * (e % SG_QPR)));
         }
         __syncthreads();
 #pragma unroll
@@ -298,18 +301,19 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
     if (m0 >= n || n0 >= n) return;
     if (n0 >= m0 + SGBM) return;  // entirely above the diagonal: written mirrored by the tile below
     constexpr int A_PER = SGBM * SGBK / GTHREADS / 4, B_PER = SGBN * SGBK / GTHREADS / 4;  // quadruples per thread: 4, 2 (SGBN = 64)
-    const bool vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(job->A) & 15) == 0;
+    const int64_t ags = job->a_group_stride > 0 ? job->a_group_stride : 16;
+    const bool vec = (lda & 3) == 0 && (ags & 3) == 0 && (reinterpret_cast<uintptr_t>(job->A) & 15) == 0;
     float4 ra[A_PER], rb[B_PER];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int e = tid + i * GTHREADS;  // quadruple e: row e / SG_QPR of the tile, k = 4 (e % SG_QPR)
-            ra[i] = sg_load_quad(A, lda, n, K, vec, m0 + e / SG_QPR, k0 + 4 * (e % SG_QPR));
+            ra[i] = sg_load_quad(A, lda, ags, n, K, vec, m0 + e / SG_QPR, k0 + 4 * (e % SG_QPR));
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int e = tid + i * GTHREADS;
-            rb[i] = sg_load_quad(A, lda, n, K, vec, n0 + e / SG_QPR, k0 + 4 * (e % SG_QPR));
+            rb[i] = sg_load_quad(A, lda, ags, n, K, vec, n0 + e / SG_QPR, k0 + 4 * (e % SG_QPR));
         }
     };
     f32x16 acc[SG_NT];

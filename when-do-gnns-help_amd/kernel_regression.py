@@ -17,7 +17,8 @@ class GramBatch:
     """Job table for wdg_gram_map_batched_f32: K = map(A A^T) of every A of a batch (all nodes), linear and / or arc-cosine."""
 
     def __init__(self, mats, linear=True, arccos=True):
-        """mats: list of A [n, F] fp32 device tensors (unit inner stride) -> self.k_linear[i], self.k_arccos[i] ([n, n] or None)"""
+        """mats: list of A [n, F] fp32 device tensors (unit inner stride; or ops.Tiled - 16-column groups, the sweep's aggregated
+        features - when the split-operand kernels run: `tiled_ok()`) -> self.k_linear[i], self.k_arccos[i] ([n, n] or None)"""
         dev = require_gpu()
         self.keep = mats
         self.n_jobs = len(mats)
@@ -29,11 +30,23 @@ class GramBatch:
         for job, a, n2, kl, ka in zip(arr, mats, self.norm2, self.k_linear, self.k_arccos):
             if a.dtype != torch.float32 or a.stride(1) != 1:
                 raise ValueError("GramBatch: A must be fp32 with unit inner stride")
+            if isinstance(a, Tiled) and not self.tiled_ok():
+                raise ValueError("GramBatch: a tiled A needs the split-operand kernels (WDG_GRAM_SPLIT=0 is set)")
+            job.a_group_stride = a.group_stride if isinstance(a, Tiled) else 0
             job.A, job.norm2 = a.data_ptr(), n2.data_ptr()
             job.K_linear = 0 if kl is None else kl.data_ptr()
             job.K_arccos = 0 if ka is None else ka.data_ptr()
             job.lda, job.ldk, job.n, job.F = _ld(a), a.shape[0], a.shape[0], a.shape[1]
         self.table = _table(arr)
+
+    @staticmethod
+    def tiled_ok():
+        """the launcher's own rule (csrc/kernel_reg.hip, wdg_gram_map_batched_f32): split-operand kernels unless WDG_GRAM_SPLIT=0"""
+        e = os.environ.get("WDG_GRAM_SPLIT")
+        try:
+            return True if e is None else int(e) != 0
+        except ValueError:
+            return False
 
     def launch(self):
         check(lib.wdg_gram_map_batched_f32(_ptr(self.table), self.n_jobs, self.max_n, stream_handle()), "wdg_gram_map_batched_f32")

@@ -573,8 +573,11 @@ class SweepBatch:
             raise ValueError(f"SweepBatch.prepare_full: {self.n_classes} classes, the device solver holds {ops.KrBatch.MAX_CLASSES}; "
                              "use utils.homophily_metrics.classifier_based_performance_metric (host path) per graph")
         # kernels: [aggregated features of every job] + [raw features of every feature matrix], linear and arc-cosine
-        ys = self.y  # (row-major: with a tiled Y the copy, refreshed behind every aggregation from here on)
-        self._untile_each_step = self.tiled_y
+        if self.tiled_y and ops.GramBatch.tiled_ok():  # the Gram kernels read the tiled aggregation output as it is
+            ys = [ya.columns(self.n_feat) for ya in self.y_agg]
+        else:  # row-major: with a tiled Y the copy, refreshed behind every aggregation from here on
+            ys = self.y
+            self._untile_each_step = self.tiled_y
         self.gram = ops.GramBatch([ys[i] for i in range(J)] + [self.x[s] for s in seeds])
         x_slot = {s: J + i for i, s in enumerate(seeds)}
         self.ge = ops.EdgeGramBatch([(g, self.gram.k_linear[x_slot[j.seed]], self.gram.norm2[x_slot[j.seed]])
