@@ -130,7 +130,14 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     jobs = sweep.make_jobs(h_levels, range(n_seeds), k=k, n_nodes=args.nodes) if rank == 0 else []
     jobs = sweep.broadcast_jobs(jobs, dev)
     mine = sweep.shard_jobs(jobs, world, rank)
-    batch = sweep.SweepBatch(mine, n_feat=args.feat, tune=True)  # (replayed `steps` times: the feedback-balanced tape cut pays)
+    batch = sweep.SweepBatch(mine, n_feat=args.feat)
+    # First use of every kernel and of the tail ops (their code objects load lazily: ~15 ms of host time with the GPU idle) BEFORE
+    # the tape cut is balanced, so that nothing but the W warm-up steps and a synchronisation lies between the tuner's steps and the
+    # clock: behind >= 5 ms of idling the chip runs steps ~10 - 35 of the next burst 8 - 12 % slower (scripts/dev/step_transient.py),
+    # which a 20-step timed region would otherwise sit in.
+    batch.step()
+    sweep.gather_results(batch.results(), dev)
+    batch.tune()  # (replayed `steps` times: the feedback-balanced tape cut pays; ~40 untimed steps)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -138,9 +145,6 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        batch.step()
-    sweep.gather_results(batch.results(), dev)  # untimed: first use of the tail ops loads their code objects
     # WDG_BENCH_GRAPH=1 replays everything after the aggregation launch from one captured hipGraph (the launches of both
     # streams -> 1); measured slower than the plain launches (0.517 vs 0.486 ms per step), so off by default
     step_rest = batch.capture_rest() if os.environ.get("WDG_BENCH_GRAPH", "0") == "1" else batch.step_rest
@@ -151,6 +155,8 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     # right behind the synchronisation - 20-25 us of wake-up on top of the kernel - is not one of five samples)
     stride = max(4, steps // 50)
     ev = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for s in range(min(2, steps - 1), steps, stride)}
+    for _ in range(warmup):
+        batch.step()
     sync_all()
     t0 = time.perf_counter()
     for s in range(steps):

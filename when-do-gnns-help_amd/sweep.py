@@ -348,15 +348,15 @@ class SweepBatch:
             self._y_rm = torch.empty((j, n, g * 16), dtype=torch.float32, device=self.y_pool.device)
         self._y_rm.view(j, n, g, 16).copy_(self.y_pool.permute(0, 2, 1, 3))
 
-    def tune(self, rounds=6, steps=5):
+    def tune(self, rounds=6, steps=5, confirm=24):
         """Balance the aggregation's eight segments (one per XCD) by what they really cost INSIDE the step.  The modelled cut
         leaves the XCDs 25 - 40 % apart (a segment that holds two phase groups stages a second slab while the other XCDs' stores
         fill the write path: 10 - 55 us, depending on when), and the launch ends with the slowest.  The kernel can record
         every workgroup's start and end on the device clock (wdg_spmm_quad_batched_clocked_f32); here the step is run a few
         times, each segment's share of the modelled cost is scaled by (mean span / its span) ^ 0.7, the tape is cut again,
         and the cut with the shortest launch (HIP events around the launch, median over `steps` steps) is kept.
-        rounds x (2 + steps) steps, once per batch; every cut computes the same bits (a row's sum order is fixed by the
-        SELL-16 copy)."""
+        rounds x (2 + steps) + 2 x (1 + confirm) steps, once per batch; every cut computes the same bits (a row's sum order is
+        fixed by the SELL-16 copy)."""
         sp = self.spmm
         if not sp.quad or sp.n_segments != 8 or sp.n_items <= sp.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":  # noqa: E501
             return None
@@ -381,7 +381,28 @@ class SweepBatch:
                 best = (t, None if rnd == 0 else shares.copy(), spans.copy())
             shares = shares * (spans.mean() / spans) ** 0.7
             shares /= shares.sum() / 8
-        sp._set_segments(0, best[1])
+        # Confirmation in the regime the batch will run in: the rounds above synchronise after every step (they read the clocks
+        # back), a replay does not.  The modelled cut and the best balanced one are stepped `confirm` times back to back each; the
+        # faster stays.  (It also leaves the chip in its steady state: behind the tuner's stop-and-go the first ~30 steps of a
+        # burst run 5 - 8 % slower - scripts/dev/step_transient.py.)
+        if best[1] is not None and confirm > 0:
+            burst = {}
+            for name, cut in (("modelled", None), ("balanced", best[1])):
+                sp._set_segments(0, cut)
+                self.step()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(confirm):
+                    self.step()
+                b.record()
+                torch.cuda.synchronize()
+                burst[name] = a.elapsed_time(b) / confirm
+            if burst["modelled"] < burst["balanced"]:
+                sp._set_segments(0, None)
+                best = (best[0], None, best[2])
+            best = best + (burst,)
+        else:
+            sp._set_segments(0, best[1])
         sp.tuned = best
         return best
 
