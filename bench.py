@@ -137,7 +137,7 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     # which a 20-step timed region would otherwise sit in.
     batch.step()
     sweep.gather_results(batch.results(), dev)
-    batch.tune()  # (replayed `steps` times: the feedback-balanced tape cut pays; ~40 untimed steps)
+    batch.tune()  # (replayed `steps` times: the feedback-balanced tape cut pays; ~90 untimed steps)
 
     def sync_all():
         torch.cuda.synchronize()

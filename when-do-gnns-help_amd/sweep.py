@@ -172,7 +172,7 @@ class SweepBatch:
         build: "batched" (default; WDG_SWEEP_BUILD) - all graphs of the shard through ops.GraphBatch: one COO -> CSR build of
         their block-diagonal union, the SELL-16 copies in five launches, ONE host read-back; "per_graph" - round 2's
         CsrGraph.from_coo + ensure_quad per graph (~20 launches and two host syncs each), kept for A/B runs and tests.
-        tune: balance the aggregation's tape cut by feedback (tune() below: ~40 extra steps) - worth it for a batch that is
+        tune: balance the aggregation's tape cut by feedback (tune() below: ~90 extra steps) - worth it for a batch that is
         replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut.
 
         The aggregated features are kept TILED by 16-feature groups (ops.Tiled: y_agg[i].t is [groups, n, 16]) when everything
