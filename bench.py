@@ -604,7 +604,11 @@ def main():
                        # what the step's GCN-2 feature transform computes in (the aggregation itself: fp32 sources, fp32 adds)
                        "feature_transform": ("fp32 chain on v_mfma_f32_32x32x2_f32 (WDG_MLP2_SPLIT=0)" if os.environ.get("WDG_MLP2_SPLIT", "1") == "0" else
                                              "fp32 products from 3 bf16 pieces per operand (6 piece products on v_mfma_f32_16x16x32_bf16, fp32 accumulation; "
-                                             "measured error against fp64 below the fp32 chain's - DESIGN 4.7; WDG_MLP2_SPLIT=0 for the chain)")},
+                                             "measured error against fp64 below the fp32 chain's - DESIGN 4.7; WDG_MLP2_SPLIT=0 for the chain)"),
+                       # where the aggregation's output lives (values and sum orders are the row-major batch's bit for bit)
+                       "aggregation_output": ("tiled by 16-feature groups: one contiguous [n, 16] plane per workgroup of the aggregation; the "
+                                              "fused transform and LAS read it in place (DESIGN 3, 4.1; WDG_SWEEP_TILED_Y=0: row-major)"
+                                              if getattr(batch, "tiled_y", False) else "row-major [n, F_agg]")},
             "graphs_per_s": m["n_graphs"] * args.steps / m["elapsed"],
             "edge_features_per_s": m["total_edges"] * args.feat * args.steps / m["elapsed"],
             "host_enqueue_ms_per_step": m["enqueue_s"] / args.steps * 1e3,
