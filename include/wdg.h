@@ -150,6 +150,7 @@ int wdg_unpack_bits_f32(const uint32_t *words, int64_t ldw, int32_t N, int32_t F
  */
 #define WDG_SELL16_CONT (1 << 30) /* flag in the width word of a q_ext pair */
 #define WDG_SELL16_SPLIT 1        /* wdg_spmm_job.q_flags */
+#define WDG_BAND_HUB_ON_DEVICE (-1) /* wdg_spmm_job.band_n_hub: the kernel takes the count from band_cuts[8] */
 #define WDG_SELL16_HALF 2         /* wdg_spmm_job.q_flags: offsets over 32-byte slab rows (wdg_sell16_row_bytes(n_cols) == 32) */
 typedef struct wdg_spmm_job {
     const int32_t *rowptr;
@@ -189,7 +190,8 @@ typedef struct wdg_spmm_job {
     const int32_t *band_perm; /* [wdg_csr_band_perm_len(n_rows)] rows by length, longest first; the first band_n_hub are the hub rows */
     const int32_t *band_cuts; /* [24] cost cuts of the hub rows [0..8] and of the other rows [9..17]; [18], [19] = rows of more than
                                  2048 / 128 entries (the narrow kernel's row classes); the rest 0                                  */
-    int32_t band_n_hub;       /* rows of more than 128 entries (each is swept by a whole workgroup)                              */
+    int32_t band_n_hub;       /* hub rows = rows of more than 256 entries (each is swept by a team of waves), a prefix of band_perm:
+                                 the count, or WDG_BAND_HUB_ON_DEVICE = "read band_cuts[8]" for callers that never fetched it      */
     int32_t band_reserved;    /* 0 */
     int64_t y_group_stride;   /* 0: Y is row-major, element (row, f) at Y[row ldy + f].  > 0 (the quad-row kernel only: jobs with a
                                  SELL-16 copy through wdg_spmm_csr_* / wdg_spmm_quad_batched_f32): Y is TILED by 16-feature groups,
@@ -287,14 +289,17 @@ int wdg_csr_to_sell16_fill_batched(const wdg_sell16_job *jobs_dev, int32_t n_job
  * wdg_spmm_csr_f32 run that kernel for fp32 X of >= 16 features when the job carries the plan and no SELL-16 copy in split
  * form): band_perm = the rows by length, longest first (<= 16 384 rows: ties by row index; more: rows of equal length in no
  * particular order - the order only schedules, every row's sum has a fixed order), wdg_csr_band_perm_len(N) ints;
- * band_cuts = 24 ints; *n_hub_host = the number of rows with more than 256 entries (a prefix of band_perm), read back on
- * `stream` (the call synchronises it).  One-time per graph; nothing of the plan depends on the feature width.
- * Replaces, with wdg_spmm_csr_f32, `torch.spmm(adj, x)` of models/baseline_models.py:62-75 for single wide-feature graphs.
+ * band_cuts = 24 ints (layout: wdg_spmm_job.band_cuts); the number of hub rows - rows with more than 256 entries, a prefix of
+ * band_perm - is band_cuts[8] and STAYS ON THE DEVICE (round 5: the call used to read it back and synchronise the stream; now it
+ * only enqueues, like every other entry point): a job passes band_n_hub = WDG_BAND_HUB_ON_DEVICE and the kernel reads the word,
+ * or the caller copies band_cuts[8] back whenever it wants the number.  One-time per graph; nothing depends on the feature width.
+ * Replaces, with wdg_spmm_csr_f32, `torch.spmm(adj, features)` of utils/homophily_metrics.py:199-200,234-235 for single
+ * wide-feature graphs (the full feature matrix of Cora / squirrel / chameleon as classifier_based_performance_metric passes it).
  */
 size_t wdg_csr_band_plan_workspace_bytes(int32_t N);
 int32_t wdg_csr_band_perm_len(int32_t N);
-int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, int32_t *n_hub_host,
-                      void *workspace, size_t workspace_bytes, wdg_stream_t stream);
+int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, void *workspace,
+                      size_t workspace_bytes, wdg_stream_t stream);
 
 /*
  * The aggregation for ONE graph with at most 8 features (csrc/spmm_narrow.hip; config C5: twitch-gamers scale with 7 bf16

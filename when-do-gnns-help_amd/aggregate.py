@@ -47,7 +47,8 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
         job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0
         job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
     if band and g.band:
-        job.band_perm, job.band_cuts, job.band_n_hub = g.band["perm"].data_ptr(), g.band["cuts"].data_ptr(), g.band["n_hub"]
+        job.band_perm, job.band_cuts = g.band["perm"].data_ptr(), g.band["cuts"].data_ptr()
+        job.band_n_hub = g.band.get("n_hub", -1)  # (-1 = WDG_BAND_HUB_ON_DEVICE: nobody has read cuts[8] back yet)
         # (the single-graph entry point prefers a split-form SELL-16 copy: this call asked for the band kernel)
         job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0
         job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0

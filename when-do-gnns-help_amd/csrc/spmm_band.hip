@@ -1,7 +1,7 @@
 // Band kernel: the aggregation Y = diag(rs) A diag(cs) X for ONE graph with WIDE features whose X does not fit the LDS
 // slabs of the quad-row kernel or whose rows are too skewed for its slices (Cora F = 1433, squirrel F = 2089 with a
-// 1904-entry hub row, chameleon F = 2325: BASELINE configs C1 / C4; reference call sites models/baseline_models.py:62-75
-// `torch.spmm(adj, x)` behind utils/util_funcs.py:109-125 normalisation).
+// 1904-entry hub row, chameleon F = 2325: BASELINE configs C1 / C4; reference call sites utils/homophily_metrics.py:199-200,234-235
+// `torch.spmm(adj, features)` on the adjacency normalised by utils/util_funcs.py:383-390,418-426).
 //
 // No staging: X is gathered straight from L2.  The feature axis is cut into BANDS of 64 * VEC floats (VEC = 4 from 129
 // features on, else 2 or 1), and every XCD walks a contiguous range of the (band, row) items, so its 32 CUs gather from the
@@ -157,8 +157,9 @@ __global__ __launch_bounds__(B_THREADS) void spmm_band_kernel(const wdg_spmm_job
     __shared__ float part[2][B_WAVES][kWave * VEC];
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int N = job.n_rows, F = job.n_feat, R = job.band_n_hub;
     const ci32 perm = (ci32)job.band_perm, cuts = (ci32)job.band_cuts, rowptr = (ci32)job.rowptr, col = (ci32)job.col;
+    // (the hub count stays on the device: a caller that never read it back passes WDG_BAND_HUB_ON_DEVICE and the plan's own word is used)
+    const int N = job.n_rows, F = job.n_feat, R = job.band_n_hub < 0 ? cuts[8] : job.band_n_hub;
     const cf32 val = (cf32)job.val, cs = (cf32)job.col_scale, rs = (cf32)job.row_scale;
     const global_ptr<const char> X = (global_ptr<const char>)job.X;
     const global_ptr<float> Y = to_global(job.Y);
@@ -430,7 +431,7 @@ namespace wdg {
 bool band_eligible_single(const wdg_spmm_job &j) {
     if (const char *s = getenv("WDG_SPMM_NO_BAND"))
         if (atoi(s)) return false;
-    if (!j.band_perm || !j.band_cuts || j.band_n_hub < 0 || j.band_n_hub > j.n_rows) return false;
+    if (!j.band_perm || !j.band_cuts || j.band_n_hub < WDG_BAND_HUB_ON_DEVICE || j.band_n_hub > j.n_rows) return false;
     if (j.n_feat < 16 || j.n_cols < 1 || !j.col) return false;
     // item indices (band x row) and byte offsets inside an X row are 32-bit
     if (static_cast<int64_t>(ceil_div(j.n_feat, kWave)) * j.n_rows >= (1ll << 31) || j.n_feat >= (1 << 28)) return false;
@@ -472,9 +473,9 @@ size_t wdg_csr_band_plan_workspace_bytes(int32_t N) {
 
 int32_t wdg_csr_band_perm_len(int32_t N) { return (N + 15) / 16 * 16; }
 
-int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, int32_t *n_hub_host,
-                      void *workspace, size_t workspace_bytes, wdg_stream_t stream) {
-    WDG_REQUIRE(N >= 0 && band_cuts && n_hub_host && (N == 0 || (rowptr && band_perm)), "csr_band_plan: bad arguments");
+int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, void *workspace,
+                      size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && band_cuts && (N == 0 || (rowptr && band_perm)), "csr_band_plan: bad arguments");
     if (!workspace || workspace_bytes < wdg_csr_band_plan_workspace_bytes(N)) return wdg::fail(WDG_ERR_WORKSPACE, "csr_band_plan: workspace too small");
     hipStream_t st = wdg::as_stream(stream);
     char *ws = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
@@ -500,10 +501,7 @@ int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int3
     hipLaunchKernelGGL(band_cost_partials, dim3(n_wgs), dim3(CUT_THREADS), 0, st, rowptr, band_perm, N, hub_len, partials);
     hipLaunchKernelGGL(band_cut_targets, dim3(1), dim3(CUT_MAX_WGS), 0, st, partials, n_wgs, N, targets, band_cuts, n_hub_dev);
     hipLaunchKernelGGL(band_cut_find, dim3(n_wgs), dim3(CUT_THREADS), 0, st, rowptr, band_perm, N, hub_len, targets, band_cuts);
-    if (int e = wdg::check_launch("csr_band_plan")) return e;
-    if (hipMemcpyAsync(n_hub_host, n_hub_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return wdg::fail(WDG_ERR_LAUNCH, "csr_band_plan: reading the hub count back failed");
-    return WDG_OK;
+    return wdg::check_launch("csr_band_plan");  // (no read-back: the hub count is band_cuts[8], on the device like everything else)
 }
 
 }  // extern "C"

@@ -18,6 +18,17 @@ def quad_disabled():
     return os.environ.get("WDG_SPMM_NO_QUAD", "0") not in ("", "0")
 
 
+class _BandPlan(dict):
+    """perm / cuts of wdg_csr_band_plan; `["n_hub"]` reads cuts[8] back the first time somebody asks (a host decision such as
+    `CsrGraph.prefers_band` on a graph of <= 2 528 columns) - the launches themselves pass WDG_BAND_HUB_ON_DEVICE until then"""
+
+    def __missing__(self, key):
+        if key != "n_hub":
+            raise KeyError(key)
+        self[key] = int(self["cuts"][8].item())
+        return self[key]
+
+
 class CsrGraph:
     """Device-resident CSR adjacency: int32 rowptr[n_rows+1], int32 col[nnz], optional fp32 val[nnz].
 
@@ -46,7 +57,8 @@ class CsrGraph:
     QUAD_SLAB_COLS = 2528  # columns of X the quad-row kernel holds in LDS at once (one column block)
 
     def ensure_band(self):
-        """Build the band plan (wdg_csr_band_plan): rows by length, hub count, cost cuts.  One-time per graph, one host sync."""
+        """Build the band plan (wdg_csr_band_plan): rows by length, hub count, cost cuts.  One-time per graph; nothing is read
+        back (the hub count stays in cuts[8]: `band["n_hub"]` fetches it on first use, the kernels read it on the device)."""
         if self.band is not None:
             return self.band is not False
         if self.n_rows == 0 or self.nnz == 0 or self.n_cols == 0:
@@ -57,10 +69,9 @@ class CsrGraph:
         cuts = torch.empty(24, dtype=torch.int32, device=dev)
         ws_bytes = lib.wdg_csr_band_plan_workspace_bytes(self.n_rows)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        n_hub = ctypes.c_int32(0)
-        check(lib.wdg_csr_band_plan(_ptr(self.rowptr), self.n_rows, _ptr(perm), _ptr(cuts), ctypes.byref(n_hub), _ptr(ws), ws_bytes,
-                                    stream_handle()), "wdg_csr_band_plan")
-        self.band = dict(perm=perm, cuts=cuts, n_hub=int(n_hub.value))
+        check(lib.wdg_csr_band_plan(_ptr(self.rowptr), self.n_rows, _ptr(perm), _ptr(cuts), _ptr(ws), ws_bytes, stream_handle()),
+              "wdg_csr_band_plan")
+        self.band = _BandPlan(perm=perm, cuts=cuts, ws=ws)  # (ws: alive until the plan's kernels have run)
         return True
 
     def prefers_band(self, n_feat):
