@@ -534,6 +534,15 @@ typedef struct wdg_mlp2_job {
 } wdg_mlp2_job;
 int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
                          int32_t max_C, wdg_stream_t stream);
+/* The same launch with the kernel NAMED by the caller instead of read from the environment at launch time (a table built for the
+ * split-operand kernel - a tiled A - must never be read by the chain kernel, whatever the environment says by then):
+ *   WDG_KERNEL_SPLIT / WDG_KERNEL_CHAIN  which kernel (neither: as wdg_mlp2_batched_f32 - the environment decides);
+ *   WDG_OPERAND_TILED                    some job of the table has a_group_stride > 0: the chain refuses it (WDG_ERR_UNSUPPORTED). */
+#define WDG_KERNEL_SPLIT 1u
+#define WDG_KERNEL_CHAIN 2u
+#define WDG_OPERAND_TILED 4u
+int wdg_mlp2_batched_flags_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
+                               int32_t max_C, uint32_t flags, wdg_stream_t stream);
 
 /* ------------------------------------------------------------------ kernel-regression metric (Gram kernels + solver) */
 /*
@@ -561,6 +570,8 @@ typedef struct wdg_gram_job {
                                WDG_GRAM_SPLIT=0 in the environment A must be row-major) */
 } wdg_gram_job;
 int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream);
+/* the kernel named by the caller (WDG_KERNEL_SPLIT / WDG_KERNEL_CHAIN / WDG_OPERAND_TILED as for wdg_mlp2_batched_flags_f32) */
+int wdg_gram_map_batched_flags_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, uint32_t flags, wdg_stream_t stream);
 
 /*
  * Generalized edge homophily from a Gram: mean over the stored non-loop entries (u, v) of cos(x_u, x_v) = 2 K_linear[u, v] /

@@ -120,6 +120,34 @@ def test_aggregation_homophily(mods, name):
     assert abs(_f(hm.similarity(onehot, adj_raw, onehot, hard=1, ifsum=0)) - 0.5 * (hard + 1)) <= 0.5
 
 
+@pytest.mark.parametrize("name", ["texas", "cora"])
+def test_similarity_with_soft_labels_follows_the_reference_arithmetic(mods, name):
+    """a `label` matrix that is NOT one-hot (smoothed labels): the reference's `degs_label = sum(label label^T, 1)`
+    (utils/homophily_metrics.py:210) is no longer the class size, so the twin must leave the kernel's count path for the
+    weights path - compared with the oracle's restatement of :190-229 (fp64 weights both sides: the threshold metric may differ
+    by the borderline nodes of quirk Q7 only)"""
+    from oracle import oracle as orc
+    _, hm, _ = mods
+    g0 = load("real_" + name)
+    adj_raw, _, labels = _raw(g0)
+    n, c = labels.shape[0], int(labels.max()) + 1
+    onehot = torch.eye(c)[labels]
+    soft_label = 0.8 * onehot + 0.2 / c          # rows sum to 1, arg-max = the class, not one-hot
+    rowptr, col, val = orc.coo_to_csr(g0["adj_row"], g0["adj_col"], n, g0["adj_val"], 0)
+    for kw in (dict(), dict(hard=1), dict(idx_train=torch.from_numpy(g0["las_mask"]))):
+        okw = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        want = float(orc.similarity(onehot.numpy(), rowptr, col, val, soft_label.numpy(), f64=True, **okw))
+        got = _f(hm.similarity(onehot, adj_raw, soft_label, **kw))
+        m = int(g0["las_mask"].sum()) if "idx_train" in kw else n
+        assert abs(got - want) <= 2.01 / m, (kw.keys(), got, want)
+    # and the answer differs from what the one-hot count path would have returned for the soft branch on at least one fixture
+    # (texas: smoothing moves degs_label from the class size to a mixture of all sizes) - the check is not vacuous
+    if name == "texas":
+        a = _f(hm.similarity(onehot, adj_raw, soft_label))
+        b = _f(hm.similarity(onehot, adj_raw, onehot))
+        assert a != b
+
+
 @pytest.mark.parametrize("name", ["cora", "texas"])
 def test_similarity_with_real_features(mods, name):
     uf, hm, _ = mods

@@ -393,7 +393,7 @@ def test_spmm_full_size_properties(ops):
     assert all(torch.equal(a, e[2]) for a, e in zip(first, entries))
 
 
-# --------------------------------------------------------------------------------------------- SELL-64 + row-lane kernel
+# --------------------------------------------------------------------------------------------- skewed graphs, SELL-16 + quad-row kernel
 def _skewed_graph(rng, n, e):
     """power-law rows: a few hubs, many short rows, some empty"""
     w = 1.0 / np.arange(1, n + 1) ** 0.9

@@ -121,9 +121,11 @@ SIGNATURES = {
     "wdg_gemm_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_gemm_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
     "wdg_mlp2_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_mlp2_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
     "wdg_las_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_las_fused_eligible": (c_int, [c_int32, c_int32, c_int32]),
     "wdg_gram_map_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    "wdg_gram_map_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_uint32, c_void_p]),
     "wdg_kernel_regress_max_train": (c_int32, []),
     "wdg_edge_gram_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "wdg_edge_gram_mean_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),

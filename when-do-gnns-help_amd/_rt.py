@@ -43,29 +43,44 @@ def _ld(t):
 
 
 class _PinnedArena:
-    """One page-locked buffer per process, handed out as a ring: a slice is reused only after the copy that last read it has
-    completed (an event per copy; by the time the ring comes round the copy is long done).  torch's own pinned allocator
-    cannot reuse a block while its copy is queued behind kernels, and every NEW pinned block is a hipHostMalloc - measured:
-    an occasional 90 ms in the middle of a shard's table uploads."""
+    """One page-locked buffer per process, handed out as a ring: a slice is reused only after EVERY copy that read any part of it
+    has completed (an event per copy).  torch's own pinned allocator cannot reuse a block while its copy is queued behind
+    kernels, and every NEW pinned block is a hipHostMalloc - measured: an occasional 90 ms in the middle of a shard's table
+    uploads.  `pending` holds the slices whose copies may still be in flight; `take` waits for all of them that overlap the
+    slice it hands out, whatever their position in the list (round 4 tested the oldest only: after a wrap the oldest entry lies
+    at the END of the buffer and does not overlap the new low-offset slices, so younger entries at the front were overwritten
+    while their copies were still queued), and forgets the ones whose events have already fired."""
 
-    def __init__(self, nbytes=128 << 20):
-        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-        self.size, self.off, self.pending = nbytes, 0, []  # pending: (start, end, event), in issue order
+    def __init__(self, nbytes=128 << 20, buf=None, new_event=None):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if buf is None else buf
+        self.size, self.off, self.pending = nbytes, 0, []  # pending: (start, end, event)
+        self._new_event = new_event or self._recorded_event
+
+    @staticmethod
+    def _recorded_event():
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
 
     def take(self, nbytes):
         n = (nbytes + 255) & ~255
+        if n > self.size:
+            raise ValueError(f"_PinnedArena: {nbytes} bytes do not fit the {self.size}-byte ring")
         if self.off + n > self.size:
             self.off = 0
         a, b = self.off, self.off + n
-        while self.pending and self.pending[0][0] < b and a < self.pending[0][1]:
-            self.pending.pop(0)[2].synchronize()
+        keep = []
+        for start, end, ev in self.pending:
+            if start < b and a < end:
+                ev.synchronize()       # its copy still reads these bytes (or has just finished)
+            elif not ev.query():
+                keep.append((start, end, ev))
+        self.pending = keep
         self.off = b
         return a, self.buf[a:a + nbytes]
 
     def issued(self, start, nbytes):
-        ev = torch.cuda.Event()
-        ev.record()
-        self.pending.append((start, start + ((nbytes + 255) & ~255), ev))
+        self.pending.append((start, start + ((nbytes + 255) & ~255), self._new_event()))
 
 
 _ARENA = None
@@ -131,7 +146,10 @@ class Tiled:
     def rowmajor(self):
         """-> a row-major [rows, cols] COPY"""
         g, n, _ = self.t.shape
-        return self.t.permute(1, 0, 2).reshape(n, g * 16)[:, :self.cols]
+        out = self.t.permute(1, 0, 2).reshape(n, g * 16)
+        if out.data_ptr() == self.t.data_ptr():  # (a single group: reshape returned a view of the tiled storage itself)
+            out = out.clone()
+        return out[:, :self.cols]
 
     def fill_(self, v):
         self.t.fill_(v)

@@ -924,6 +924,13 @@ int wdg_gemm_batched_f32(const wdg_gemm_job *jobs_dev, int32_t n_jobs, int32_t m
 
 int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
                          int32_t max_C, wdg_stream_t stream) {
+    return wdg_mlp2_batched_flags_f32(jobs_dev, n_jobs, max_M, max_K, max_H, max_C, 0u, stream);
+}
+
+int wdg_mlp2_batched_flags_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t max_M, int32_t max_K, int32_t max_H,
+                               int32_t max_C, uint32_t flags, wdg_stream_t stream) {
+    WDG_REQUIRE((flags & ~(WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN | WDG_OPERAND_TILED)) == 0 &&
+                    (flags & (WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN)) != (WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN), "mlp2_batched: bad flags");
     WDG_REQUIRE(n_jobs >= 0 && max_M >= 0 && max_K >= 0 && max_H >= 0 && max_C >= 0, "mlp2_batched: negative size");
     if (n_jobs == 0 || max_M == 0 || max_H == 0 || max_C == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev != nullptr, "mlp2_batched: null job table");
@@ -942,8 +949,13 @@ int wdg_mlp2_batched_f32(const wdg_mlp2_job *jobs_dev, int32_t n_jobs, int32_t m
     const int parts = bres_parts(n_jobs, max_M);
     const dim3 grid(static_cast<unsigned>(n_jobs) * parts);
     hipStream_t st = wdg::as_stream(stream);
-    bool split = true;  // split-operand products on the bf16 matrix pipe (mlp2_split_kernel); WDG_MLP2_SPLIT=0: the fp32 chain
-    if (const char *e = getenv("WDG_MLP2_SPLIT")) split = atoi(e) != 0;
+    // split-operand products on the bf16 matrix pipe (mlp2_split_kernel) unless the caller names the kernel (a table built for one
+    // of them must not be read by the other: the chain kernel knows no tiled A) or, with neither flag, WDG_MLP2_SPLIT=0 asks for the chain
+    bool split = (flags & WDG_KERNEL_CHAIN) == 0;
+    if (!(flags & (WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN)))
+        if (const char *e = getenv("WDG_MLP2_SPLIT")) split = atoi(e) != 0;
+    if (!split && (flags & WDG_OPERAND_TILED))
+        return wdg::fail(WDG_ERR_UNSUPPORTED, "mlp2_batched: the fp32-chain kernel reads row-major A only (the table holds a tiled A)");
     {
         if (split) {
             const size_t lds_split = (2 * SPLIT_BUF_WORDS + BRES_COLS * MLP2_MAX_C + BRES_COLS) * sizeof(float);

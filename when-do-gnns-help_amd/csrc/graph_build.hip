@@ -648,7 +648,11 @@ int wdg_host_pack_coo_i32(const void *const *src_ptrs, const void *const *dst_pt
     if (n_graphs == 0) return WDG_OK;
     WDG_REQUIRE(src_ptrs && dst_ptrs && lens && node_ptr && out_src && out_dst, "host_pack_coo: null array");
     std::vector<int64_t> first(static_cast<size_t>(n_graphs) + 1, 0);
-    for (int g = 0; g < n_graphs; ++g) first[g + 1] = first[g] + lens[g];
+    for (int g = 0; g < n_graphs; ++g) {  // (a malformed shard must fail here, not as a read past a buffer from 64 host threads)
+        WDG_REQUIRE(lens[g] >= 0 && node_ptr[g + 1] >= node_ptr[g], "host_pack_coo: negative length or node_ptr not ascending");
+        WDG_REQUIRE(lens[g] == 0 || (src_ptrs[g] && dst_ptrs[g]), "host_pack_coo: null edge list");
+        first[g + 1] = first[g] + lens[g];
+    }
     const int64_t total = first[n_graphs];
     threads = std::max(1, std::min(threads, 64));
     std::atomic<int> bad{0};

@@ -1377,12 +1377,23 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
 extern "C" {
 
 int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream) {
+    return wdg_gram_map_batched_flags_f32(jobs_dev, n_jobs, max_n, 0u, stream);
+}
+
+int wdg_gram_map_batched_flags_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, uint32_t flags, wdg_stream_t stream) {
+    WDG_REQUIRE((flags & ~(WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN | WDG_OPERAND_TILED)) == 0 &&
+                    (flags & (WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN)) != (WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN), "gram_map_batched: bad flags");
     WDG_REQUIRE(n_jobs >= 0 && max_n >= 0, "gram_map_batched: negative size");
     if (n_jobs == 0 || max_n == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev != nullptr, "gram_map_batched: null job table");
     hipStream_t st = wdg::as_stream(stream);
-    bool split = true;  // split bf16 operands (gram_split_kernel); WDG_GRAM_SPLIT=0: the k-ordered fp32 chain (gram_map_kernel)
-    if (const char *e = getenv("WDG_GRAM_SPLIT")) split = atoi(e) != 0;
+    // split bf16 operands (gram_split_kernel) unless the caller names the kernel or, with neither flag, WDG_GRAM_SPLIT=0 asks for
+    // the k-ordered fp32 chain (gram_map_kernel, row_norm2_kernel: row-major A only)
+    bool split = (flags & WDG_KERNEL_CHAIN) == 0;
+    if (!(flags & (WDG_KERNEL_SPLIT | WDG_KERNEL_CHAIN)))
+        if (const char *e = getenv("WDG_GRAM_SPLIT")) split = atoi(e) != 0;
+    if (!split && (flags & WDG_OPERAND_TILED))
+        return wdg::fail(WDG_ERR_UNSUPPORTED, "gram_map_batched: the fp32-chain kernels read row-major A only (the table holds a tiled A)");
     if (split) {
         hipLaunchKernelGGL(gram_diag_split_kernel, dim3(wdg::ceil_div(max_n, SGBM), n_jobs), dim3(GTHREADS), 0, st, jobs_dev);
         hipLaunchKernelGGL(gram_split_kernel, dim3(wdg::ceil_div(max_n, SGBM), wdg::ceil_div(max_n, SGBN), n_jobs), dim3(GTHREADS), 0, st,

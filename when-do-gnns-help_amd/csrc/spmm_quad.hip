@@ -52,8 +52,8 @@ using namespace wdg;
 // -DWDG_Q_PROFILE): the waves spend 0.01 us per iteration in the end-of-iteration wait at depth 1 already (0.00 at depth 2) and
 // 2.9 of every 3.3 us in the sweep, the launch is the same 102 - 105 us at (16 waves, 1), (12, 1), (12, 2) and slower with 8
 // waves at depth 2 - 4: the loop is bound by the LDS at the 2.0 GHz the chip holds under this load, not by store
-// acknowledgements.  Depths above 1 are an EXPERIMENT: they compute the batched tables' results (verified) but
-// fault on the single-graph entry (not debugged further - nothing to gain).
+// acknowledgements.  Depths above 1 are an EXPERIMENT: they compute the batched tables' results (verified);
+// the single-graph entry keeps the plain loop in such builds (its one-job tapes faulted in the deep loop; not debugged - nothing to gain).
 #ifndef WDG_Q_FAST_THREADS
 #define WDG_Q_FAST_THREADS 1024
 #endif
@@ -1607,7 +1607,9 @@ int quad_single(const wdg_spmm_job &j, hipStream_t st) {
         subs = std::max(subs, need);
     }
     // 16-byte stores and 32-bit byte offsets into Y and into the index arrays (what the fast loop addresses with)
-    const bool y_vec = (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.y_group_stride % 4 == 0 && j.n_feat % 4 == 0 &&
+    // (experimental builds with a deeper request pipeline - WDG_Q_DEPTH > 1 - fault in the fast loop on this entry's single-job
+    // tapes: such a build keeps single graphs on the plain loop instead of handing a variant library a way to fault the device)
+    const bool y_vec = Q_DEPTH == 1 && (reinterpret_cast<uintptr_t>(j.Y) & 15) == 0 && j.ldy % 4 == 0 && j.y_group_stride % 4 == 0 && j.n_feat % 4 == 0 &&
                        static_cast<int64_t>(j.n_rows) * j.ldy + (static_cast<int64_t>(j.n_feat) / 16) * j.y_group_stride < (1ll << 30) &&
                        (j.q_flags & WDG_SELL16_SPLIT) != 0;
     return q_launch<TIN>(nullptr, j, nullptr, nullptr, subs, j.n_cols, j.n_feat, j.val != nullptr, y_vec, half, st);

@@ -96,10 +96,13 @@ class Mlp2Batch:
             self.flops += 2 * m * h * (k + c)
         self.n_jobs = len(entries)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        # the kernel is chosen HERE, with the table, and named at every launch (1 = WDG_KERNEL_SPLIT, 2 = WDG_KERNEL_CHAIN,
+        # 4 = WDG_OPERAND_TILED): the environment may change between build and launch, the table's layout does not
+        self.flags = (1 if self.split_kernel() else 2) | (4 if any(isinstance(e[0], Tiled) for e in entries) else 0)
 
     def launch(self):
-        check(lib.wdg_mlp2_batched_f32(_ptr(self.table), self.n_jobs, self.max_m, self.max_k, self.max_h, self.max_c,
-                                       stream_handle()), "wdg_mlp2_batched_f32")
+        check(lib.wdg_mlp2_batched_flags_f32(_ptr(self.table), self.n_jobs, self.max_m, self.max_k, self.max_h, self.max_c, self.flags,
+                                             stream_handle()), "wdg_mlp2_batched_flags_f32")
 
 
 # ------------------------------------------------------------------------------------------- GEMM

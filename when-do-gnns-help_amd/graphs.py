@@ -258,6 +258,9 @@ def _host_pack_coo(coos, lens, node_ptr_h, e_total, dev):
     inputs are not plain contiguous host arrays of one integer width (the caller then takes the torch path).  Raises IndexError
     for an id outside its graph."""
     arrs = [(c[0], c[1]) for c in coos]
+    for i, (a, b) in enumerate(arrs):  # (the library's host threads read lens[i] entries of BOTH arrays)
+        if len(a) != len(b) or len(a) != lens[i]:
+            raise ValueError(f"graph {i}: src and dst hold {len(a)} and {len(b)} entries")
     kinds = {a.dtype for pair in arrs for a in pair if isinstance(a, np.ndarray)}
     if len(kinds) != 1 or not all(isinstance(a, np.ndarray) and a.flags.c_contiguous and a.ndim == 1 for pair in arrs for a in pair):
         return None

@@ -38,6 +38,9 @@ class GramBatch:
             job.K_arccos = 0 if ka is None else ka.data_ptr()
             job.lda, job.ldk, job.n, job.F = _ld(a), a.shape[0], a.shape[0], a.shape[1]
         self.table = _table(arr)
+        # the kernel family is chosen with the table and named at every launch (1 = WDG_KERNEL_SPLIT, 2 = WDG_KERNEL_CHAIN,
+        # 4 = WDG_OPERAND_TILED): see Mlp2Batch
+        self.flags = (1 if self.tiled_ok() else 2) | (4 if any(isinstance(a, Tiled) for a in mats) else 0)
 
     @staticmethod
     def tiled_ok():
@@ -49,7 +52,8 @@ class GramBatch:
             return False
 
     def launch(self):
-        check(lib.wdg_gram_map_batched_f32(_ptr(self.table), self.n_jobs, self.max_n, stream_handle()), "wdg_gram_map_batched_f32")
+        check(lib.wdg_gram_map_batched_flags_f32(_ptr(self.table), self.n_jobs, self.max_n, self.flags, stream_handle()),
+              "wdg_gram_map_batched_flags_f32")
 
 
 class EdgeGramBatch:

@@ -179,8 +179,9 @@ class SweepBatch:
         that reads them inside the step can - the label columns of LAS as a strided view, the fused transform through
         wdg_mlp2_job.a_group_stride: a workgroup of the aggregation (one feature group) then stores into one contiguous plane
         per graph instead of 64-byte pieces a row apart (the k = 2 launch 160 -> 133 us, the k = 10 one 98 -> 94).  `y` (a list of
-        row-major [n, n_feat] tensors, as before) is then a COPY refreshed on access; prepare_full() / TrainBatch, whose kernels read
-        row-major operands, refresh it after every aggregation.  WDG_SWEEP_TILED_Y=0: row-major, as in rounds 1 - 3."""
+        row-major [n, n_feat] tensors, as before) is then a COPY, refreshed on the first access after an aggregation; prepare_full(), whose
+        kernels read row-major operands on the chain variants, refreshes it after every aggregation; TrainBatch("sgc") aggregates
+        ONCE and builds its tables on that copy.  WDG_SWEEP_TILED_Y=0: row-major, as in rounds 1 - 3."""
         from . import ops
         self.ops = ops
         self.jobs = list(jobs)
@@ -201,7 +202,7 @@ class SweepBatch:
         build = build or os.environ.get("WDG_SWEEP_BUILD", "batched")
         feats, self.graphs, self.dinv, self.labels, self._y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
-        self.tiled_y, self._y_rm, self._untile_each_step = False, None, False
+        self.tiled_y, self._y_rm, self._untile_each_step, self._y_dirty = False, None, False, True
         coos, labs_host = [], []
         for ji, j in enumerate(self.jobs):
             if inputs is not None:
@@ -267,6 +268,13 @@ class SweepBatch:
         entries = [(g, self.x_agg[j.seed], y, d, d if symmetric else None, False)
                    for j, g, y, d in zip(self.jobs, self.graphs, self.y_agg, self.dinv)]
         self.spmm = ops.SpmmBatch(entries)
+        if self.tiled_y:  # every launch of the aggregation leaves the row-major copy stale: `y` untiles lazily, once per aggregation
+            launch = self.spmm.launch
+
+            def launch_and_mark(*a, **k):
+                self._y_dirty = True
+                return launch(*a, **k)
+            self.spmm.launch = launch_and_mark
         self.n_classes = n_classes
         self.stats = ops.StatsBatch(self.graphs, self.labels, n_classes)
         self.edges = sum(g.nnz for g in self.graphs)
@@ -333,9 +341,11 @@ class SweepBatch:
     @property
     def y(self):
         """list of [n, n_feat] row-major tensors, one per job (views of the aggregation's output - or, with a tiled Y, of a
-        row-major copy refreshed by this access: stable addresses, so job tables built on them stay valid)"""
+        row-major copy: stable addresses, so job tables built on them stay valid; untiled here when an aggregation has run since
+        the last copy, i.e. once per aggregation however often the property is read)"""
         if self.tiled_y:
-            self.untile()
+            if self._y_dirty or self._y_rm is None:
+                self.untile()
             return [self._y_rm[i][:, :self.n_feat] for i in range(len(self.jobs))]
         return self._y
 
@@ -347,6 +357,7 @@ class SweepBatch:
         if self._y_rm is None:
             self._y_rm = torch.empty((j, n, g * 16), dtype=torch.float32, device=self.y_pool.device)
         self._y_rm.view(j, n, g, 16).copy_(self.y_pool.permute(0, 2, 1, 3))
+        self._y_dirty = False
 
     def tune(self, rounds=6, steps=5, confirm=24):
         """Balance the aggregation's eight segments (one per XCD) by what they really cost INSIDE the step.  The modelled cut

@@ -186,12 +186,15 @@ def similarity(features, adj, label, hard=None, LP=1, ifsum=1, idx_train=None):
         rows = (torch.nonzero(idx_train).view(-1) if idx_train.dtype == torch.bool else idx_train).to(torch.int32)
     labels_sel = labels_all if rows is None else labels_all[rows.long()]
     c = int(labels_sel.max().item()) + 1
+    lab_sel = label if rows is None else label[rows.long()]
     default_path = (LP == 1 and ifsum == 1)
+    if default_path and hard is None:
+        # the kernel's soft count takes degs_label = class size, which is `sum(label label^T, 1)` (reference :210) only for one-hot
+        # rows; any other label matrix (soft labels) gets the reference's own arithmetic on the weights instead
+        default_path = bool((((lab_sel == 0) | (lab_sel == 1)).all() & (lab_sel.sum(1) == 1).all()).item())
     cnt, n, w = ops.las(h, labels_all, c, rows=rows, want_weights=not default_path)
     if default_path:
-        # kernel counts assume one-hot `label` rows (degs_label == class size), which is what every call site passes
         return (cnt[0] if hard is None else cnt[1]).to(torch.float32) / n
-    lab_sel = label if rows is None else label[rows.long()]
     return _tails.las_from_weights(w, labels_sel, lab_sel[:, :c], hard, LP, ifsum)
 
 
