@@ -31,7 +31,9 @@ Beside the headline the N = 1 line carries (each can be switched off, see --help
   secondary           the `800` set (k = 2, 100 graphs) through the same step
   sweep_full / sweep_cold   all nine scalars of the sweep job: replayed on a resident batch / every graph visited once
   sweep_whole         the sweep the reference runs (synthetic_plot.py: 6 feature bases x 28 levels x 10 samples = 1 680 jobs, nine
-                      scalars), one pass from host arrays to rows on the host
+                      scalars), one pass from host arrays to rows on the host.  ALSO AT N > 1: the 280 adjacencies sharded over the
+                      ranks (strong scaling), rows exchanged by one all_gather, `seconds` = slowest rank, and rank 0's one-GPU pass of
+                      the same sweep in the same session -> `strong_speedup_vs_1gpu` (the north star's ">= 6 x at 8 GPUs")
   configs             BASELINE.json configs[0], [3], [4] as stated + the literal N = 4000 reading of configs[2]: per launch `us`,
                       kernel and roofline fraction (scripts/bench_configs.py holds the workloads)
   train               train + eval sweep (sweep.TrainBatch on the C3 shard): SGC-1 and GCN-2, ms per epoch (hipGraph replay),
@@ -218,7 +220,18 @@ def measure_full(args, dev):
     t0 = time.perf_counter()
     rows = sb.full_metrics()
     tail_s = time.perf_counter() - t0
-    return {"workload": f"all nine scalars of the sweep job for {len(jobs)} graphs (k={args.k}, {args.seeds} seeds): + generalized edge "
+    kr = {"kr_ridged": sb.kr_ridged, "kr_total": sb.kr_total,
+          "kr_ridged_note": "train blocks the device solver found rank deficient at fp32 rounding level and solved with a ridge (the reference: "
+                            "np.linalg.pinv, utils/homophily_plot.py:301-316); full_metrics(ridge='pinv') solves exactly those on the host"}
+    if sb.kr_ridged and args.kr_pinv_patch:  # what the reference-equal answer costs on this batch: flagged blocks gathered, pinv on host threads
+        t0 = time.perf_counter()
+        rows_p = sb.full_metrics(ridge="pinv")
+        dt_p = time.perf_counter() - t0
+        dp = (rows_p[:, 7:9] - rows[:, 7:9]).abs()
+        kr["pinv_patch"] = {"blocks": sb.kr_ridged, "seconds": dt_p, "pinv_seconds": sb.kr_pinv_seconds,
+                            "graphs_per_s_with_patch": len(jobs) / (dev_s + dt_p),
+                            "max_abs_dp": float(torch.nan_to_num(dp).max()), "median_abs_dp": float(torch.nan_to_num(dp).median())}
+    return {**kr, "workload": f"all nine scalars of the sweep job for {len(jobs)} graphs (k={args.k}, {args.seeds} seeds): + generalized edge "
                         f"homophily, KR_L and KR_NL with {args.kr_epochs} epochs each (sample_max 500: 300 train / 200 validation "
                         f"rows per regression, {sb.kr.n_jobs} regressions per batch)",
             "graphs_per_s": len(jobs) / (dev_s + tail_s), "device_ms_per_batch": dev_s * 1e3, "device_ms_slowest_replay": per_rep[-1] * 1e3,
@@ -253,7 +266,7 @@ def measure_cold(args, dev):
     out = {}
     for name, nine in (("six_scalars", False), ("nine_scalars", True)):
         phases = {"build_ms": [], "sample_ms": [], "device_ms": [], "host_tail_ms": [], "total_ms": []}
-        graphs = 0
+        graphs = ridged = total = 0
         for b, (jobs, inputs) in enumerate(shards):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -273,6 +286,7 @@ def measure_cold(args, dev):
             if b == 0:
                 continue  # warm-up shard
             graphs += len(jobs)
+            ridged, total = ridged + getattr(sb, "kr_ridged", 0), total + getattr(sb, "kr_total", 0)
             phases["build_ms"].append((t1 - t0) * 1e3)
             phases["device_ms"].append((t2 - t1) * 1e3)
             phases["host_tail_ms"].append((t3 - t2) * 1e3)
@@ -281,6 +295,7 @@ def measure_cold(args, dev):
             del sb
         total_s = sum(phases["total_ms"]) * 1e-3
         out[name] = {"graphs_per_s": graphs / total_s, **{k: sum(v) / len(v) for k, v in phases.items()},
+                     **({"kr_ridged": ridged, "kr_total": total} if nine else {}),
                      "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, rows.double().mean(0).tolist())}}
         # the same shards PIPELINED (sweep.run_shards): shard b + 1's uploads and build on a second stream while shard b's kernels
         # run; clock = first upload to the last shard's rows on the host
@@ -299,58 +314,117 @@ def measure_cold(args, dev):
     return out
 
 
-def measure_whole(args, dev):
-    """The sweep the reference actually runs (synthetic_plot.py:64-109): 6 feature bases x the homophily levels of
-    `data_synthesis/4000` x 10 samples, all nine scalars per job, every job visited ONCE - host COO arrays and host feature
-    matrices in, metric rows on the host out, everything in between inside the clock (uploads, the batched graph build - once
-    per (level, sample), shared by the six bases -, aggregation at the base's width, Grams, device-drawn node sets, regressions,
-    t-tests).  BASELINE.md: ~35 s per job on the reference's CPU path, ~17 h for the sweep."""
-    import numpy as np
-    import torch
+def whole_inputs(args, pairs_needed=None):
+    """the reference's sweep inputs as it finds them on disk (outside every clock): the (level, sample) adjacencies of
+    `data_synthesis/4000` (only those in pairs_needed when given: a rank generates its own shard) and, per feature base, one
+    feature matrix per sample"""
     from wdg_amd import sweep, synth
     levels = [h for h in synth.H_LEVELS_30 if h not in (0.05, 0.1)]  # (the levels `data_synthesis/4000` holds: SURVEY Appendix B.2)
     samples = list(range(10))
     bases = sweep.BaseSweep.REFERENCE_BASES
-    per_shard = args.whole_levels_per_shard
-    # ---- the inputs, as the reference finds them on disk (outside the clock)
-    t_in = time.perf_counter()
-    graphs = {}
-    for h in levels:
-        for s_ in samples:
-            graphs[(h, s_)] = synth.regular_graph(args.nodes, 5, 10, h, s_)
+    pairs = sweep.make_jobs(levels, samples, k=10, n_nodes=args.nodes)
+    need = pairs if pairs_needed is None else pairs_needed
+    graphs = {(j.h, j.seed): synth.regular_graph(args.nodes, 5, 10, j.h, j.seed) for j in need}
     feats = [(name, {s_: synth.features(args.nodes, width, 7000 + 100 * bi + s_) for s_ in samples}, 300 if name in ("chameleon", "film") else 500)
              for bi, (name, width) in enumerate(bases)]
-    shards = []
-    for a in range(0, len(levels), per_shard):
-        jobs = sweep.make_jobs(levels[a:a + per_shard], samples, k=10, n_nodes=args.nodes)
-        shards.append((jobs, [graphs[(j.h, j.seed)] for j in jobs]))
+    return dict(levels=levels, samples=samples, bases=bases, pairs=pairs, graphs=graphs, feats=feats)
+
+
+def measure_whole(args, dev, world=1, rank=0):
+    """The sweep the reference actually runs (synthetic_plot.py:64-109): 6 feature bases x the homophily levels of
+    `data_synthesis/4000` x 10 samples, all nine scalars per job, every job visited ONCE - host COO arrays and host feature
+    matrices in, metric rows on the host out, everything in between inside the clock (uploads, the batched graph build - once
+    per (level, sample), shared by the six bases -, aggregation at the base's width, Grams, device-drawn node sets, regressions,
+    t-tests).  BASELINE.md: ~35 s per job on the reference's CPU path, ~17 h for the sweep.
+
+    world > 1 (`bench.py --gpus N`): STRONG scaling of that sweep - the 280 adjacencies dealt to the ranks by sweep.shard_jobs,
+    every rank runs the six bases over its share (sweep.whole_sweep_rank), the [jobs, 9] rows are exchanged once
+    (sweep.exchange_rows: one all_gather), `seconds` = the slowest rank (barrier, clock, all_reduce MAX) - and rank 0 then runs the
+    WHOLE sweep alone on its GPU (the other ranks wait), so that `strong_speedup_vs_1gpu` compares two measurements of one
+    session on one box and the assembled table can be checked against the one-GPU rows bit for bit."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from wdg_amd import sweep
+    t_in = time.perf_counter()
+    from wdg_amd import synth
+    pairs_all = sweep.make_jobs([h for h in synth.H_LEVELS_30 if h not in (0.05, 0.1)], range(10), k=10, n_nodes=args.nodes)
+    pairs = sweep.broadcast_jobs(pairs_all if rank == 0 else [], dev)  # rank 0's job table, like the step's
+    mine = sweep.shard_jobs(pairs, world, rank)
+    inp = whole_inputs(args, pairs if rank == 0 else mine)  # (rank 0 also runs the one-GPU reference pass: it needs every graph)
     t_in = time.perf_counter() - t_in
-    n_jobs = sum(len(j) for j, _ in shards) * len(bases)
+    feats, bases, graphs = inp["feats"], inp["bases"], inp["graphs"]
+    n_rows = len(pairs) * len(bases)
+    per_shard = args.whole_levels_per_shard * len(inp["samples"])  # adjacencies per shard on ONE GPU (70: 16-MB Grams x 4 x 70 = 18 GB)
+
+    def graph_of(j):
+        return graphs[(j.h, j.seed)]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     # one small warm-up pass (code objects, allocator pools, scipy import) outside the clock
-    warm = [(shards[0][0][:4], shards[0][1][:4])]
-    for _ in sweep.run_bases(warm, feats, epochs=args.kr_epochs):
-        pass
-    torch.cuda.synchronize()
+    warm = pairs[:4] if rank == 0 else mine[:4]
+    if warm:
+        sweep.whole_sweep_rank(warm, graph_of, feats, 1, 0, epochs=args.kr_epochs)
     per_base = np.zeros(len(bases))
-    rows_of = {}
-    t0 = time.perf_counter()
-    t_prev = t0
-    for si, bi, rows in sweep.run_bases(shards, feats, epochs=args.kr_epochs, depth=2):
+    state = {"t": 0.0}
+
+    def progress(_si, bi, _rows):
         now = time.perf_counter()
-        per_base[bi] += now - t_prev  # (pipelined: what arrived between two fetches, attributed to the base fetched)
-        t_prev = now
-        rows_of[(si, bi)] = rows
+        per_base[bi] += now - state["t"]  # (pipelined: what arrived between two fetches, attributed to the base fetched)
+        state["t"] = now
+
+    sync_all()
+    t0 = state["t"] = time.perf_counter()
+    kr_stats = {}
+    keys, rows = sweep.whole_sweep_rank(pairs, graph_of, feats, world, rank, epochs=args.kr_epochs,
+                                        max_pairs_per_shard=per_shard if world == 1 else 80, progress=progress, stats=kr_stats)
+    torch.cuda.synchronize()
+    mine_s = time.perf_counter() - t0
+    table = sweep.exchange_rows(keys, rows, n_rows, dev)
+    sync_all()
     dt = time.perf_counter() - t0
-    allrows = torch.cat([rows_of[k] for k in sorted(rows_of)])
-    args._whole = dict(graphs=graphs, feats=feats, levels=levels, samples=samples, seconds=dt)  # (measure_projection shards the same inputs)
-    return {"workload": f"synthetic_plot.py's sweep: {len(bases)} feature bases ({', '.join(f'{n} F={w}' for n, w in bases)}) x {len(levels)} homophily "
-                        f"levels x {len(samples)} samples = {n_jobs} jobs, N={args.nodes}, k=10, all nine scalars, {args.kr_epochs} epochs per "
-                        f"classifier; {len(shards)} shards of {per_shard} levels x {len(samples)} samples, graphs built once per shard and "
-                        "shared by the six bases; host COO + host features -> rows on the host, two HIP streams",
-            "jobs": n_jobs, "seconds": dt, "graphs_per_s": n_jobs / dt, "ms_per_base": {n: 1e3 * t for (n, _w), t in zip(bases, per_base)},
-            "input_generation_s_outside_clock": t_in, "rows": list(allrows.shape), "nan_rows": int(torch.isnan(allrows).any(1).sum()),
+    rec = {}
+    kr_counts = torch.tensor([kr_stats.get("kr_ridged", 0), kr_stats.get("kr_total", 0)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(kr_counts)
+        t = torch.tensor([dt, mine_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0].item())
+        per_rank = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([mine_s, float(len(mine))], dtype=torch.float64, device=dev))
+        rec["per_rank_s"] = [round(float(x[0].item()), 4) for x in per_rank]
+        rec["adjacencies_per_rank"] = [int(x[1].item()) for x in per_rank]
+        # the one-GPU pass of the SAME sweep in the same session (rank 0 alone; everybody else waits at the barrier)
+        if rank == 0:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            k1, r1 = sweep.whole_sweep_rank(pairs, graph_of, feats, 1, 0, epochs=args.kr_epochs, max_pairs_per_shard=per_shard)
+            torch.cuda.synchronize()
+            one = time.perf_counter() - t1
+            t1gpu = torch.full((n_rows, rows.shape[1]), float("nan"), dtype=torch.float64)
+            t1gpu[k1] = r1
+            rec.update(one_gpu_s=one, strong_speedup_vs_1gpu=one / dt,
+                       rows_equal_one_gpu=bool(torch.equal(torch.nan_to_num(table, nan=-7.0), torch.nan_to_num(t1gpu, nan=-7.0))))
+        dist.barrier()
+    args._whole = dict(inp, seconds=dt)  # (measure_projection shards the same inputs)
+    shards_txt = (f"{-(-len(pairs) // per_shard)} shards of {per_shard} adjacencies" if world == 1 else
+                  f"the {len(pairs)} adjacencies dealt to {world} ranks by sweep.shard_jobs (one shard per rank), rows exchanged by one all_gather, "
+                  "`seconds` = slowest rank incl. the exchange")
+    return {"workload": f"synthetic_plot.py's sweep: {len(bases)} feature bases ({', '.join(f'{n} F={w}' for n, w in bases)}) x {len(inp['levels'])} homophily "
+                        f"levels x {len(inp['samples'])} samples = {n_rows} jobs, N={args.nodes}, k=10, all nine scalars, {args.kr_epochs} epochs per "
+                        f"classifier; {shards_txt}, graphs built once per shard and shared by the six bases; host COO + host features -> rows on "
+                        "the host, two HIP streams per rank",
+            "jobs": n_rows, "n_gpus": world, "scaling": "strong", "seconds": dt, "graphs_per_s": n_rows / dt, **rec,
+            "kr_ridged": int(kr_counts[0].item()), "kr_total": int(kr_counts[1].item()),
+            "ms_per_base_rank0": {n: 1e3 * t for (n, _w), t in zip(bases, per_base)},
+            "input_generation_s_outside_clock": t_in, "rows": list(table.shape), "nan_rows": int(torch.isnan(table).any(1).sum()),
             "reference_cpu_estimate": "~35 s per job, ~17 h for the sweep (BASELINE.md)",
-            "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, allrows.nanmean(0).tolist())}}
+            "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, table.nanmean(0).tolist())}}
 
 
 def measure_configs(args, dev):
@@ -468,23 +542,24 @@ def measure_projection(args, dev, full_ms):
     whole = getattr(args, "_whole", None)
     if whole is not None:
         # the reference's sweep sharded by (level, sample) adjacency - every rank runs the six bases over its adjacencies
-        pairs = sweep.make_jobs(whole["levels"], whole["samples"], k=10, n_nodes=args.nodes)
+        pairs = whole["pairs"]
         ws = {}
         for w in (2, 4, 8):
             secs = []
-            for r in (range(w) if w == 8 else [0]):
-                mine = sweep.shard_jobs(pairs, w, r)
-                per = len(mine) if len(mine) <= 80 else (len(mine) + 1) // 2  # (one shard per rank while its Grams stay small: fewer tables to build)
-                shards = [(mine[a:a + per], [whole["graphs"][(j.h, j.seed)] for j in mine[a:a + per]]) for a in range(0, len(mine), per)]
+            for r in range(w):  # EVERY rank's share (round 4 timed one rank at W = 2, 4: a single sample, visibly jitter-prone)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                n_rows = sum(rows.shape[0] for _si, _bi, rows in sweep.run_bases(shards, whole["feats"], epochs=args.kr_epochs, depth=2))
+                keys, _rows = sweep.whole_sweep_rank(pairs, lambda j: whole["graphs"][(j.h, j.seed)], whole["feats"], w, r,
+                                                     epochs=args.kr_epochs)
+                torch.cuda.synchronize()
                 secs.append(time.perf_counter() - t0)
-                assert n_rows == len(mine) * len(whole["feats"])
-            ws[str(w)] = {"ranks_timed": len(secs), "adjacencies_per_rank": len(sweep.shard_jobs(pairs, w, 0)), "slowest_rank_s": max(secs),
+                assert keys.shape[0] == len(sweep.shard_jobs(pairs, w, r)) * len(whole["feats"])
+            ws[str(w)] = {"ranks_timed": len(secs), "adjacencies_per_rank": [len(sweep.shard_jobs(pairs, w, r)) for r in range(w)],
+                          "per_rank_s": [round(x, 4) for x in secs], "slowest_rank_s": max(secs),
                           "projected_strong_speedup": whole["seconds"] / max(secs)}
         out["whole_sweep"] = {"jobs": len(pairs) * len(whole["feats"]), "one_gpu_s": whole["seconds"], "worlds": ws,
-                              "note": "PROJECTION: each rank's share of the 1 680-job sweep run on this GPU, one after the other"}
+                              "note": "PROJECTION: each rank's share of the 1 680-job sweep run on this GPU, one after the other (every rank of every world size "
+                                      "timed); `bench.py --gpus N` MEASURES the same split: its `sweep_whole.strong_speedup_vs_1gpu`"}
     return out
 
 
@@ -550,11 +625,13 @@ def main():
     ap.add_argument("--full-metrics", type=int, default=1, help="1: also time the whole nine-scalar sweep job batch (adds generalized edge "
                     "homophily and the kernel-regression p-values, --kr-epochs epochs) and report it as `sweep_full` (N=1 only)")
     ap.add_argument("--kr-epochs", type=int, default=100)
+    ap.add_argument("--kr-pinv-patch", type=int, default=1, help="1: when the replayed nine-scalar batch has rank-deficient train blocks, also "
+                    "time full_metrics(ridge='pinv') - those blocks solved again with np.linalg.pinv on the host - and report it in `sweep_full`")
     ap.add_argument("--cold", type=int, default=1, help="1: also time the one-pass (cold) sweep - distinct shards from host COO to "
                     "metric rows, everything inside the clock - and report it as `sweep_cold` (N=1 only)")
     ap.add_argument("--cold-shards", type=int, default=3)
     ap.add_argument("--whole", type=int, default=1, help="1: also run the reference's whole sweep (6 feature bases x 28 levels x 10 samples = 1 680 "
-                    "jobs, nine scalars, one pass) and report it as `sweep_whole` (N=1 only)")
+                    "jobs, nine scalars, one pass) and report it as `sweep_whole` (N > 1: sharded over the ranks, + rank 0's one-GPU pass -> strong_speedup_vs_1gpu)")
     ap.add_argument("--whole-levels-per-shard", type=int, default=7)
     ap.add_argument("--configs", type=int, default=1, help="1: also time BASELINE configs[0], [3], [4] as stated and the literal N = 4000 "
                     "reading of configs[2] and report them as `configs` (N=1 only)")
@@ -626,6 +703,11 @@ def main():
                             "roofline": roofline_of(args, m2)}
         del m2
     if world > 1:
+        if args.whole:  # the reference's sweep, strong-scaled over the ranks (every rank takes part; rank 0 keeps the record)
+            torch.cuda.empty_cache()
+            whole = measure_whole(args, dev, world, rank)
+            if rank == 0:
+                out["sweep_whole"] = whole
         dist.destroy_process_group()  # (before the line: RCCL writes its library path to stdout when it shuts down)
     if world == 1 and args.full_metrics:
         out["sweep_full"] = measure_full(args, dev)

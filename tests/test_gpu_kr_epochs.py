@@ -102,3 +102,80 @@ def test_ten_class_labels_fall_back_to_the_host_path():
         res[solver] = hm.classifier_based_performance_metric(x, adj, lab, 200.0, base_classifier="kernel_reg1", epochs=3, solver=solver)[0]
         assert hm.LAST_KR_ACCURACIES is None  # (no device regression ran)
     assert res["device"] == res["host"] and 0.0 <= res["host"] <= 1.0
+
+
+def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
+    """The batched sweep path (SweepBatch.prepare_full / launch_full / full_metrics) against the reference's solver on EVERY
+    regression, at the reference's epoch count: the five golden synthetic fixtures x 4 independent draws of the node sets = 20
+    jobs x 2 classifiers x 100 epochs x 2 kernels = 8 000 regressions.  Device rows (Cholesky; ridge on the blocks it flags) vs
+    `K_vt @ (np.linalg.pinv(K_tt) @ onehot)` on the host for the same blocks (SweepBatch.pinv_accuracies on ALL problems = what
+    WDG_KR_SOLVER=host computes, utils/homophily_plot.py:301-316).  Asserts the documented bounds - |d accuracy| <= 2 validation
+    rows on blocks the solver factored as they are, <= 4 on blocks it regularised; the p-value moves by no more than such a
+    perturbation of these accuracies can move it - and that ridge="pinv" reproduces the host answer on exactly the flagged
+    blocks.  The distribution (counts, median, max, by kind) is written to gpurun_out/ for profiles/."""
+    import json
+    import os
+    from _golden import SYN
+    from wdg_amd import sweep
+    from wdg_amd.utils import util_funcs as uf
+    jobs, inputs = [], []
+    for i, name in enumerate(SYN):
+        g0 = load(name)
+        n = int(g0["n_nodes"])
+        x = uf.preprocess_features(torch.from_numpy(dense_features(g0))).cpu().numpy()  # synthetic_plot.py:81-83
+        jobs.append(sweep.Job(float(name.split("_")[2]), 100 + i, 10 if "_4000_" in name else 2, n, int(g0["labels"].max()) + 1))
+        inputs.append((g0["adj_row"].astype(np.int64), g0["adj_col"].astype(np.int64), g0["labels"], x))
+    epochs, report = 100, {"fixtures": list(SYN), "draws": 4, "epochs": epochs, "per_draw": []}
+    d_rows_all, ridged_all, dp_all = [], [], []
+    for draw in range(4):
+        sb = sweep.SweepBatch(jobs, n_feat=inputs[0][3].shape[1], gcn_hidden=0, inputs=inputs)
+        sb.prepare_full(epochs=epochs, sample_max=500, base_seed=77 + draw)  # device-drawn sets, as the sweep driver does
+        sb.step()
+        sb.launch_full()
+        torch.cuda.synchronize()
+        rows_dev = sb.full_metrics(ridge="device").numpy()
+        acc_dev = sb.kr_acc.copy()                                             # [job, clf, epoch, kernel]
+        ridged = sb.kr.ridged().cpu().numpy().reshape(acc_dev.shape)
+        n_val = np.array([sb.kr_val.shape[2]] * len(jobs), np.float64)
+        acc_host = sb.pinv_accuracies(np.arange(sb.kr.n_jobs)).reshape(acc_dev.shape)
+        rows_pinv = sb.full_metrics(ridge="pinv").numpy()
+        acc_pinv = sb.kr_acc.copy()
+        # ridge="pinv": flagged blocks carry the host answer, the others the device answer
+        assert np.array_equal(acc_pinv[ridged], acc_host[ridged]) and np.array_equal(acc_pinv[~ridged], acc_dev[~ridged])
+        assert sb.kr_ridged == int(ridged.sum()) and sb.kr_total == ridged.size and (sb.kr_pinv_seconds > 0) == bool(ridged.any())
+        d_rows = np.abs(acc_dev.astype(np.float64) - acc_host) * n_val[:, None, None, None]
+        assert d_rows[~ridged].max(initial=0) <= 2.01, ("positive definite blocks", d_rows[~ridged].max())
+        assert d_rows[ridged].max(initial=0) <= 4.01, ("regularised blocks", d_rows[ridged].max())
+        p_host = sweep.welch_p_values(acc_host[..., 0], acc_host[..., 1])       # [job, clf]
+        for ji in range(len(jobs)):
+            for ci in range(2):
+                worst = 4 if ridged[ji, ci].any() else 2
+                tol = p_tolerance(acc_host[ji, ci, :, 0], acc_host[ji, ci, :, 1], float(n_val[ji]), worst, trials=100)
+                assert abs(rows_dev[ji, 7 + ci] - p_host[ji, ci]) <= tol, (draw, ji, ci, rows_dev[ji, 7 + ci], p_host[ji, ci], tol)
+                assert abs(rows_pinv[ji, 7 + ci] - p_host[ji, ci]) <= p_tolerance(acc_host[ji, ci, :, 0], acc_host[ji, ci, :, 1], float(n_val[ji]), 2, trials=100)
+        dp = np.abs(rows_dev[:, 7:9] - p_host)
+        d_rows_all.append(d_rows)
+        ridged_all.append(ridged)
+        dp_all.append(dp)
+        report["per_draw"].append({"ridged": int(ridged.sum()), "total": int(ridged.size), "max_rows": float(d_rows.max()),
+                                   "max_abs_dp": float(dp.max()), "pinv_patch_seconds": sb.kr_pinv_seconds})
+        del sb
+    d_rows, ridged, dp = np.stack(d_rows_all), np.stack(ridged_all), np.stack(dp_all)
+
+    def dist_of(v):
+        v = np.round(v).astype(int)
+        return {"n": int(v.size), "median": float(np.median(v)) if v.size else 0.0, "max": int(v.max(initial=0)),
+                "histogram_rows": {str(k): int((v == k).sum()) for k in range(int(v.max(initial=0)) + 1)}}
+
+    report.update(regressions=int(ridged.size), ridged=int(ridged.sum()),
+                  d_validation_rows_positive_definite=dist_of(d_rows[~ridged]), d_validation_rows_ridged=dist_of(d_rows[ridged]),
+                  abs_dp={"median": float(np.median(dp)), "max": float(dp.max()), "n": int(dp.size)},
+                  bound_asserted={"rows_pd": 2, "rows_ridged": 4, "p": "_golden.p_tolerance of that row bound on the host accuracies"})
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "kr_ridge_vs_pinv.json"), "w") as f:
+            json.dump(report, f, indent=1)
+    except OSError:
+        pass
+    assert report["regressions"] == 8000

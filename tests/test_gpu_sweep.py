@@ -115,12 +115,39 @@ def test_whole_sweep_over_feature_bases_equals_stand_alone_batches():
         _name, feats, sample_max = bases[bi]
         sb = sweep.SweepBatch(jobs, n_feat=next(iter(feats.values())).shape[1], gcn_hidden=0,
                               inputs=[(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, gi)])
-        sb.prepare_full(epochs=6, sample_max=sample_max, base_seed=5 + 1000 * bi + si)
+        sb.prepare_full(epochs=6, sample_max=sample_max, base_seed=5 + 1000 * bi)
         sb.step()
         sb.launch_full()
         want = sb.full_metrics()
         assert rows.shape == (len(jobs), 9)
         assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (si, bi)
+
+
+def test_whole_sweep_rows_do_not_depend_on_the_world_size():
+    """sweep.whole_sweep_rank + exchange_rows (bench.py's N-rank `sweep_whole`): the adjacencies dealt to 1, 2 and 3 "ranks" (run
+    one after the other on this GPU; a rank's rows keyed by the pair's position in the job list) assemble to the SAME [pairs x
+    bases, 9] table bit for bit - node sets are keyed by job identity, a graph's build and sum orders do not depend on its shard"""
+    from wdg_amd import sweep, synth
+    levels, samples = [0.2, 0.3, 0.5, 0.8], [0, 1]
+    pairs = sweep.make_jobs(levels, samples, k=4, n_nodes=400)
+    graphs = {(j.h, j.seed): synth.regular_graph(400, 5, 4, j.h, j.seed) for j in pairs}
+    bases = [("a", {s_: synth.features(400, 48, 10 + s_) for s_ in samples}, 500),
+             ("b", {s_: synth.features(400, 130, 20 + s_) for s_ in samples}, 300)]
+    tables = {}
+    for world in (1, 2, 3):
+        table = torch.full((len(pairs) * len(bases), 9), float("nan"), dtype=torch.float64)
+        seen = 0
+        for rank in range(world):
+            keys, rows = sweep.whole_sweep_rank(pairs, lambda j: graphs[(j.h, j.seed)], bases, world, rank, epochs=5,
+                                                max_pairs_per_shard=3 if world == 1 else 80)
+            assert rows.shape == (keys.shape[0], 9)
+            table[keys] = rows
+            seen += keys.shape[0]
+        assert seen == len(pairs) * len(bases)
+        assert not torch.isnan(table[:, :7]).any()
+        tables[world] = table
+    for world in (2, 3):
+        assert torch.equal(torch.nan_to_num(tables[world], nan=-7.0), torch.nan_to_num(tables[1], nan=-7.0)), world
 
 
 def test_batched_gemm_and_las_mixed_shapes(oracle):

@@ -133,3 +133,61 @@ def test_three_ranks_two_jobs_one_empty_shard_gloo(tmp_path):
         assert g.shape == (2, 4) and sorted(g[:, 1].tolist()) == [0.2, 0.5]
         for _seed, h, eh, _nh in g.tolist():
             assert abs(eh - 2 / int(2 / h)) < 1e-12
+
+
+def _exchange_worker(rank, world, port, out_dir, counts):
+    """keyed nine-column fp64 rows, uneven shards (counts[rank] rows, possibly none) through sweep.exchange_rows"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = sum(counts)
+    first = sum(counts[:rank])
+    # ranks own interleaved keys (as shard_jobs deals jobs: not contiguous ranges), rows = f(key) so the table can be checked
+    perm = np.random.default_rng(5).permutation(n_total)
+    keys = torch.from_numpy(np.sort(perm[first:first + counts[rank]]).astype(np.int64))
+    rows = keys.double()[:, None] * 10 + torch.arange(9, dtype=torch.float64)[None, :] / 7
+    if keys.numel():
+        rows[0, 8] = float("nan")  # (a NaN p-value travels like any other value)
+    table = sweep.exchange_rows(keys, rows, n_total + 1, torch.device("cpu"))  # (+ 1: one key nobody owns)
+    torch.save(dict(keys=keys, table=table), os.path.join(out_dir, f"x{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_exchange(tmp_path, world, counts):
+    res = [torch.load(tmp_path / f"x{r}.pt") for r in range(world)]
+    n_total = sum(counts)
+    t0 = res[0]["table"]
+    assert t0.shape == (n_total + 1, 9) and t0.dtype == torch.float64
+    for r in range(1, world):  # every rank assembles the same table
+        assert torch.equal(torch.nan_to_num(res[r]["table"], nan=-7.0), torch.nan_to_num(t0, nan=-7.0))
+    assert torch.isnan(t0[n_total]).all()  # the key nobody sent
+    firsts = {int(r["keys"][0]) for r in res if r["keys"].numel()}
+    for key in range(n_total):
+        want = key * 10 + torch.arange(9, dtype=torch.float64) / 7
+        if key in firsts:
+            assert torch.isnan(t0[key, 8]) and torch.equal(t0[key, :8], want[:8])
+        else:
+            assert torch.equal(t0[key], want), key
+    assert sorted(int(k) for r in res for k in r["keys"]) == list(range(n_total))
+
+
+def test_keyed_nine_column_rows_two_ranks_uneven_gloo(tmp_path):
+    world, port, counts = 2, _free_port(), (7, 4)
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path), counts), nprocs=world, join=True)
+    _check_exchange(tmp_path, world, counts)
+
+
+def test_keyed_nine_column_rows_three_ranks_one_empty_gloo(tmp_path):
+    world, port, counts = 3, _free_port(), (5, 0, 3)
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path), counts), nprocs=world, join=True)
+    _check_exchange(tmp_path, world, counts)
+
+
+def test_exchange_rows_single_process_and_bad_key():
+    import pytest
+    t = sweep.exchange_rows(torch.tensor([2, 0]), torch.tensor([[1.0, 2.0], [3.0, 4.0]]), 3, torch.device("cpu"))
+    assert torch.equal(t[0], torch.tensor([3.0, 4.0], dtype=torch.float64)) and torch.isnan(t[1]).all()
+    assert torch.equal(t[2], torch.tensor([1.0, 2.0], dtype=torch.float64))
+    assert sweep.exchange_rows(torch.zeros(0, dtype=torch.int64), torch.zeros((0, 9)), 0, torch.device("cpu")) is not None
+    with pytest.raises(ValueError):
+        sweep.exchange_rows(torch.tensor([5]), torch.zeros((1, 2)), 3, torch.device("cpu"))

@@ -158,6 +158,51 @@ def gather_results(local_rows, device):
     return [o[: int(c.item())] for o, c in zip(out, counts)]
 
 
+def exchange_rows(keys, rows, n_total, device):
+    """The sweep's ONE exchange step for keyed rows: every rank contributes rows [m_r, M] with global row ids keys [m_r] (m_r may
+    be 0 and differs per rank); every rank returns the assembled [n_total, M] fp64 table, row `key` = the row sent under that
+    key, rows nobody sent NaN.  One all_gather of [m_max, 1 + M] fp64 per rank (KBs; RCCL on GPUs, gloo in the CPU tests) -
+    the N-rank form of synthetic_plot.py:64-78's result arrays, which the reference fills in place in one process."""
+    keys = torch.as_tensor(keys, dtype=torch.float64).reshape(-1, 1)
+    rows = torch.as_tensor(rows, dtype=torch.float64)
+    if rows.dim() != 2 or rows.shape[0] != keys.shape[0]:
+        raise ValueError("exchange_rows: rows must be [len(keys), M] (an empty shard passes [0, M])")
+    if keys.numel() and not (0 <= int(keys.min()) and int(keys.max()) < n_total):
+        raise ValueError("exchange_rows: key outside [0, n_total)")
+    out = None
+    for part in gather_results(torch.cat([keys, rows], 1), device):
+        part = part.cpu()
+        if out is None:
+            out = torch.full((n_total, part.shape[1] - 1), float("nan"), dtype=torch.float64)
+        if part.shape[0]:
+            out[part[:, 0].long()] = part[:, 1:]
+    return out
+
+
+def whole_sweep_rank(pairs, graph_of, bases, world, rank, epochs=100, max_pairs_per_shard=80, depth=2, progress=None, stats=None):
+    """This rank's share of the reference's whole sweep (synthetic_plot.py:64-109), STRONG scaling: the (level, sample)
+    adjacencies `pairs` (a list of Job; job.seed = the sample) are dealt to the ranks by shard_jobs, every rank runs all feature
+    bases over its adjacencies through run_bases (graphs built once per shard and shared by the bases) - no data-path collective.
+    graph_of(job) -> (src, dst, labels) host arrays; bases as run_bases takes them.
+    -> (keys [m] int64, rows [m, 9] fp64): key = index of the pair in `pairs` x n_bases + base index, ready for exchange_rows.
+    A rank keeps one shard while it holds <= max_pairs_per_shard adjacencies (fewer job tables to build), else equal shards.
+    progress(shard index, base index, rows): called as every base-shard's rows arrive on the host (bench.py's per-base clock)."""
+    mine = shard_jobs(pairs, world, rank)
+    index = {j: i for i, j in enumerate(pairs)}
+    n_shards = max(1, -(-len(mine) // max_pairs_per_shard))
+    per = max(1, -(-len(mine) // n_shards))
+    shards = [(mine[a:a + per], [graph_of(j) for j in mine[a:a + per]]) for a in range(0, len(mine), per)]
+    keys, rows = [], []
+    for si, bi, r in run_bases(shards, bases, epochs=epochs, depth=depth, stats=stats):
+        keys.append(torch.tensor([index[j] * len(bases) + bi for j in shards[si][0]], dtype=torch.int64))
+        rows.append(r)
+        if progress is not None:
+            progress(si, bi, r)
+    if not keys:
+        return torch.zeros(0, dtype=torch.int64), torch.zeros((0, len(METRIC_NAMES)), dtype=torch.float64)
+    return torch.cat(keys), torch.cat(rows)
+
+
 class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
@@ -690,9 +735,70 @@ class SweepBatch:
             torch.cuda.current_stream().wait_stream(side)
         self.kr.launch()
 
-    def full_metrics(self):
+    def pinv_accuracies(self, problems, threads=None):
+        """The listed regressions solved the REFERENCE'S way (utils/homophily_plot.py:301-316, utils/homophily_metrics.py:286-297):
+        `K[val][:, train] @ (np.linalg.pinv(K[train][:, train]) @ onehot[train])` in fp32 on the host (numpy's default rcond
+        1e-15: every singular value of an fp32 block kept), arg-max, hit rate on the validation rows.  The blocks are gathered
+        from the device kernels (one gather and one copy per kernel matrix that has listed problems), the pseudo-inverses run
+        on a pool of host threads (LAPACK releases the interpreter lock).
+        problems: 1-D array of problem indices p = ((job * 2 + classifier) * epochs + epoch) * 2 + (0 aggregated | 1 raw features).
+        -> fp32 accuracies, one per listed problem.  Needs the node sets on the device (after launch_full())."""
+        from concurrent.futures import ThreadPoolExecutor
+        problems = np.asarray(problems, np.int64).reshape(-1)
+        out = np.zeros(problems.shape[0], np.float32)
+        if not problems.shape[0]:
+            return out
+        E = self.kr_epochs
+        pair, epoch, which = problems // (2 * E), (problems // 2) % E, problems % 2
+        ji, clf = pair // 2, pair % 2
+        seeds = list(self.x)
+        x_slot = {s_: len(self.jobs) + i for i, s_ in enumerate(seeds)}
+        slot = np.where(which == 0, ji, np.array([x_slot[j.seed] for j in self.jobs], np.int64)[ji])
+        sizes = [self.ops.kr_split_sizes(lab, self.kr_sample_max) for lab in self.labels_host]
+        n_tr = np.array([int(t.sum()) for _s, t in sizes], np.int64)
+        n_va = np.array([int(s_.sum() - t.sum()) for s_, t in sizes], np.int64)
+        c = self.n_classes
+        work = []  # (position in `out`, K_tt, K_vt, labels of the train rows, labels of the validation rows)
+        for key in sorted(set(zip(slot.tolist(), clf.tolist(), ji.tolist()))):
+            sl, cl, jb = key
+            sel = np.flatnonzero((slot == sl) & (clf == cl) & (ji == jb))
+            kern = (self.gram.k_linear if cl == 0 else self.gram.k_arccos)[sl]
+            rows_t = torch.from_numpy((jb * 2 + cl) * np.ones_like(sel))
+            tr = self.kr_train[rows_t, torch.from_numpy(epoch[sel])][:, :n_tr[jb]].long()  # [m, n_train] node ids
+            va = self.kr_val[rows_t, torch.from_numpy(epoch[sel])][:, :n_va[jb]].long()
+            k_tt = kern[tr[:, :, None], tr[:, None, :]].cpu().numpy()                     # [m, n_train, n_train]
+            k_vt = kern[va[:, :, None], tr[:, None, :]].cpu().numpy()
+            lab = np.asarray(self.labels_host[jb]).astype(np.int64)
+            tr_h, va_h = tr.cpu().numpy(), va.cpu().numpy()
+            for m_, pos in enumerate(sel):
+                work.append((int(pos), k_tt[m_], k_vt[m_], lab[tr_h[m_]], lab[va_h[m_]]))
+        eye = np.eye(c, dtype=np.float32)
+
+        def solve(item):
+            pos, k_tt, k_vt, lab_t, lab_v = item
+            pred = k_vt @ (np.linalg.pinv(k_tt) @ eye[lab_t])
+            return pos, np.float32(np.mean(pred.argmax(1) == lab_v))
+
+        threads = threads or int(os.environ.get("WDG_KR_PINV_THREADS", str(min(32, os.cpu_count() or 1))))
+        with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+            for pos, a in pool.map(solve, work):
+                out[pos] = a
+        return out
+
+    def full_metrics(self, ridge=None):
         """[jobs, 9] fp64: results() + ge_homo + the p-values KR_L (kernel_reg0) and KR_NL (kernel_reg1) of the Welch t-test
-        over the epochs' accuracies (scipy on the host for the t distribution, as in the reference)"""
+        over the epochs' accuracies (scipy on the host for the t distribution, as in the reference).
+        ridge: what to do with the train blocks the device solver flags as rank deficient at fp32 rounding level
+          "device" (default; WDG_SWEEP_KR_RIDGE) - keep the solver's ridge answers (a few validation rows from the reference's
+                   pseudo-inverse on such blocks; counted in kr_ridged / kr_total and announced once per shard);
+          "pinv"   - solve exactly those blocks again the reference's way (pinv_accuracies: blocks gathered from the device
+                   kernels, np.linalg.pinv on host threads) and patch their accuracies before the t-tests - what the API twin
+                   classifier_based_performance_metric does by default; its cost is kr_pinv_seconds."""
+        ridge = ridge or os.environ.get("WDG_SWEEP_KR_RIDGE", "device")
+        if ridge not in ("device", "pinv"):
+            raise ValueError(f"full_metrics: ridge={ridge!r} (device | pinv)")
+        self.kr_ridged = self.kr_total = 0
+        self.kr_pinv_seconds = 0.0
         if not self.jobs:
             return torch.zeros((0, len(METRIC_NAMES)), dtype=torch.float64)
         nj = len(self.jobs)
@@ -702,17 +808,26 @@ class SweepBatch:
                             self.kr.accuracy().to(torch.float64).reshape(-1), self.kr.ridged().sum().to(torch.float64).reshape(1)]).cpu()
         # (rank-deficient train blocks: solved with a rounding-level ridge where the reference's pinv inverts the rounding-level
         # singular values - counted and said once per shard, like utils/homophily_metrics.py does per call)
-        self.kr_ridged = int(packed[-1].item())
+        self.kr_ridged, self.kr_total = int(packed[-1].item()), int(self.kr.n_jobs)
         packed = packed[:-1]
-        if self.kr_ridged and os.environ.get("WDG_KR_QUIET", "0") in ("", "0"):
-            import warnings
-            warnings.warn(f"kernel regression: {self.kr_ridged} of {self.kr.n_jobs} train blocks of this shard were rank-deficient at fp32 "
-                          "rounding level and solved with a ridge; their accuracies can differ from the reference's pseudo-inverse by a "
-                          "few validation rows (WDG_KR_SOLVER=host runs the reference's host path per graph)", stacklevel=2)
         n_base = packed.numel() - nj - nj * 2 * self.kr_epochs * 2
         base = packed[:n_base].reshape(nj, -1)
         ge = packed[n_base:n_base + nj]
-        acc = packed[n_base + nj:].reshape(nj, 2, self.kr_epochs, 2).numpy().astype(np.float32)  # [job, classifier, epoch, (graph, features)]
+        acc = packed[n_base + nj:].numpy().astype(np.float32)  # problem order: [job, classifier, epoch, (graph, features)]
+        if self.kr_ridged and ridge == "pinv":
+            import time
+            t0 = time.perf_counter()
+            flagged = torch.nonzero(self.kr.ridged()).flatten().cpu().numpy()
+            acc[flagged] = self.pinv_accuracies(flagged)
+            self.kr_pinv_seconds = time.perf_counter() - t0
+        elif self.kr_ridged and os.environ.get("WDG_KR_QUIET", "0") in ("", "0"):
+            import warnings
+            warnings.warn(f"kernel regression: {self.kr_ridged} of {self.kr.n_jobs} train blocks of this shard were rank-deficient at fp32 "
+                          "rounding level and solved with a ridge; their accuracies can differ from the reference's pseudo-inverse by a "
+                          "few validation rows (full_metrics(ridge='pinv') / WDG_SWEEP_KR_RIDGE=pinv solves them again the reference's "
+                          "way on the host)", stacklevel=2)
+        acc = acc.reshape(nj, 2, self.kr_epochs, 2)
+        self.kr_acc = acc  # [job, classifier, epoch, (graph-aware, features only)]: diagnostics / tests
         pvals = torch.from_numpy(welch_p_values(acc[..., 0], acc[..., 1]))
         return torch.cat([base, ge[:, None], pvals], 1)
 
@@ -736,7 +851,14 @@ def welch_p_values(g_res, x_res):
     return np.where(better <= 0.5, p / 2, 1 - p / 2)
 
 
-def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symmetric=0, depth=2, first_seed=0):
+def _count_kr(stats, sb):
+    if stats is not None:
+        stats["kr_ridged"] = stats.get("kr_ridged", 0) + getattr(sb, "kr_ridged", 0)
+        stats["kr_total"] = stats.get("kr_total", 0) + getattr(sb, "kr_total", 0)
+        stats["kr_pinv_seconds"] = stats.get("kr_pinv_seconds", 0.0) + getattr(sb, "kr_pinv_seconds", 0.0)
+
+
+def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symmetric=0, depth=2, first_seed=0, stats=None):
     """The one-pass sweep over a sequence of shards (synthetic_plot.py:78-109: every graph visited once), PIPELINED: a generator
     of the shards' metric rows ([jobs, 6] fp32 / [jobs, 9] fp64 on the host), in order.
 
@@ -755,7 +877,9 @@ def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symme
     def fetch():
         sb, stream = in_flight.popleft()
         with torch.cuda.stream(stream):
-            return sb.full_metrics() if nine else sb.results().cpu()
+            rows = sb.full_metrics() if nine else sb.results().cpu()
+        _count_kr(stats if nine else None, sb)
+        return rows
 
     for b, (jobs, inputs) in enumerate(shards):
         stream = streams[b % depth]
@@ -773,7 +897,7 @@ def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symme
         yield fetch()
 
 
-def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0):
+def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, stats=None):
     """The reference's WHOLE sweep (synthetic_plot.py:64-109: 6 feature bases x 30 homophily levels x 10 samples = 1 800 jobs, nine
     scalars each), one pass, PIPELINED like run_shards: a generator of (shard index, base index, rows [jobs, 9] fp64 on the host).
 
@@ -793,7 +917,9 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0):
     def fetch():
         si, bi, sb, stream = in_flight.popleft()
         with torch.cuda.stream(stream):
-            return si, bi, sb.full_metrics()
+            rows = sb.full_metrics()
+        _count_kr(stats, sb)
+        return si, bi, rows
 
     n = 0
     for si, (jobs, graph_inputs) in enumerate(shards):
@@ -807,7 +933,9 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0):
                 sb = SweepBatch(jobs, n_feat=next(iter(feats.values())).shape[1] if feats else 0, symmetric=symmetric, gcn_hidden=0,
                                 inputs=inputs, share=first)
                 if sb.jobs:
-                    sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + 1000 * bi + si)
+                    # (the node sets are keyed by the base and the job's identity, not by where the job sits: a job draws the same
+                    # sets in whichever shard / on whichever rank it runs - the N-rank sweep computes the one-GPU sweep's rows)
+                    sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + 1000 * bi)
                 sb.step()
                 if sb.jobs:
                     sb.launch_full()
