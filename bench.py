@@ -440,6 +440,8 @@ def measure_configs(args, dev):
         r = rec["roofline"]
         return {"workload": rec["workload"], "kernel": rec["kernel"], "us": round(r["avg_launch_us"], 2), "edges_per_s": rec["edges_per_s"],
                 "roofline": {"bound": r["bound"], "frac": round(r["frac"], 4), "achieved": round(r["achieved"], 1), "peak": r["peak"], "unit": r["unit"]},
+                # the resource that really binds the launch (L2 gathers / LDS reads), beside SURVEY 8(d)'s HBM accounting above
+                **({"binding": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec["binding"].items()}} if "binding" in rec else {}),
                 **({"whole_step_us": round(rec["whole_step_us"], 1)} if "whole_step_us" in rec else {})}
 
     def model(rec):
@@ -467,6 +469,10 @@ def measure_configs(args, dev):
     out["C5 twitch agg-homophily (10 samples)"], out["C5 twitch SGC-1 (A X) W"], out["C5 twitch SGC-1 A (X W)"] = model(m[0]), model(m[1]), model(m[2])
     torch.cuda.empty_cache()
     out["C3-literal N=4000"] = agg(bc.literal("C3-literal", 4000, 10, 5, reps))
+    torch.cuda.empty_cache()
+    out["C2-literal N=800"] = agg(bc.literal("C2-literal", 800, 2, 10, reps))
+    torch.cuda.empty_cache()
+    out["C3-scaled N=2^17 F=512"] = agg(bc.scaled(reps))
     torch.cuda.empty_cache()
     return out
 

@@ -41,7 +41,30 @@ def timed(fn, reps, warm=5):
     return sum(ms) / len(ms) * 1e3, ms[len(ms) // 2] * 1e3  # mean, median in us
 
 
-def line(config, workload, kernel, alg_bytes, edges, us_mean, us_med, **extra):
+L2_PEAK_GBS = 34500.0    # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+LDS_PEAK_GBS = 150000.0  # MI355X_MICROARCH.md "LDS": ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
+
+
+def binding(kernel, edges, n_feat, elem, half_slab=False):
+    """The resource that binds the launch, next to SURVEY 8(d)'s HBM figure: the gather families (band, narrow,
+    CSR gather) fetch one source-row piece per stored entry from L2 - E x F x s bytes of L2 requests however little of it reaches
+    HBM; the LDS families (quad-row, slab) read 64 (HALF slabs: 32) bytes of the staged slab per stored entry and feature group."""
+    if "narrow" in kernel:
+        col_bytes = 16 if (n_feat <= 4 or (elem == 2 and "rw" in kernel)) else 32
+        b, res, peak = float(edges) * col_bytes, "l2-gather", L2_PEAK_GBS
+    elif "quad" in kernel or "slab" in kernel:
+        group, row = (8, 32) if half_slab else (16, 64)
+        b, res, peak = float(edges) * -(-n_feat // group) * row, "lds", LDS_PEAK_GBS
+    else:  # band / gather: E x F x s bytes gathered from L2
+        b, res, peak = float(edges) * n_feat * elem, "l2-gather", L2_PEAK_GBS
+    return {"resource": res, "bytes_per_launch": b, "peak": peak, "unit": "GB/s"}
+
+
+def line(config, workload, kernel, alg_bytes, edges, us_mean, us_med, bind=None, **extra):
+    if bind is not None:
+        bind = dict(bind, achieved=bind["bytes_per_launch"] / (us_mean * 1e-6) / 1e9)
+        bind["frac"] = bind["achieved"] / bind["peak"]
+        extra = dict(extra, binding=bind)
     rec = {"config": config, "workload": workload, "kernel": kernel, "edges_per_launch": edges,
            "edges_per_s": edges / (us_mean * 1e-6),
            "roofline": {"bound": "hbm", "achieved": alg_bytes / (us_mean * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -70,7 +93,9 @@ def single_graph(config, workload, g, x, reps, elem=4, norm=1, **extra):
     else:
         fam = ops.spmm_plan(n, g.n_cols, f, 1, 0)
         kernel = {0: "spmm_slab_kernel", 1: "spmm_gather_kernel"}.get(fam[0], str(fam))
-    return line(config, workload, kernel, alg, e, us, med, **extra)
+    kname = kernel + (" rw" if norm == 0 else "")
+    half = bool(quad and quad.get("half"))
+    return line(config, workload, kernel, alg, e, us, med, bind=binding(kname, e, f, elem, half), **extra)
 
 
 def c1(reps):
@@ -103,7 +128,7 @@ def sweep(config, k, seeds, reps):
     us_step, _ = timed(sb.step, reps)
     return line(config, f"synthetic sweep shard: 10 h-levels x {seeds} seeds = {len(jobs)} graphs in ONE launch, N=2000, k={k}, "
                 f"F=500 (+5 one-hot label columns), fp32", sb.spmm.kernel_name(), sb.spmm_algorithmic_bytes(), edges, us, med,
-                whole_step_us=us_step, graphs_per_s_step=len(jobs) / (us_step * 1e-6))
+                bind=binding(sb.spmm.kernel_name(), edges, sb.agg_feat, 4), whole_step_us=us_step, graphs_per_s_step=len(jobs) / (us_step * 1e-6))
 
 
 def c4(name, f, reps):
@@ -273,7 +298,24 @@ def literal(config, n_nodes, k, seeds, reps):
     us_step, _ = timed(sb.step, reps)
     return line(config, f"literal variant: 10 h-levels x {seeds} seeds = {len(jobs)} graphs in ONE launch, N={n_nodes} nodes, k={k}, "
                 f"F=500 (+5 one-hot label columns), fp32", sb.spmm.kernel_name(), sb.spmm_algorithmic_bytes(),
-                sum(g.nnz for g in sb.graphs), us, med, whole_step_us=us_step, graphs_per_s_step=len(jobs) / (us_step * 1e-6))
+                sum(g.nnz for g in sb.graphs), us, med,
+                bind=binding(sb.spmm.kernel_name(), sum(g.nnz for g in sb.graphs), sb.agg_feat, 4, half_slab=n_nodes > 2528),
+                whole_step_us=us_step, graphs_per_s_step=len(jobs) / (us_step * 1e-6))
+
+
+def scaled(reps, n_log2=17, f=512, deg=50):
+    """SURVEY 8(d) C3 'scaled variant': ONE graph large enough that a single aggregation exceeds L2 and the Infinity Cache (N = 2^17,
+    F = 512: X and Y are 268 MB each), uniform random columns, int(10 / 0.2) = 50 entries per row + the loop"""
+    import torch
+    from wdg_amd import ops
+    n = 1 << n_log2
+    rng = np.random.default_rng(0)
+    src = np.repeat(np.arange(n, dtype=np.int64), deg)
+    dst = rng.integers(0, n, n * deg)
+    g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS | ops.COO_BINARISE)
+    x = torch.randn(n, f, device="cuda")
+    return single_graph("C3-scaled", f"scaled single graph: N=2^{n_log2}={n}, {g.nnz} stored entries (A+I, uniform random columns, {deg} per row), "
+                        f"F={f} fp32, random-walk D^-1 (A+I) X", g, x, reps, norm=0)
 
 
 def c5(reps):
@@ -325,6 +367,7 @@ def main():
     todo = [("C1", lambda: c1(args.reps)), ("C1m", lambda: c1_models(args.reps)),
             ("C2", lambda: sweep("C2", 2, 10, args.reps)), ("C2-literal", lambda: literal("C2-literal", 800, 2, 10, args.reps)),
             ("C3", lambda: sweep("C3", 10, 5, args.reps)), ("C3-literal", lambda: literal("C3-literal", 4000, 10, 5, args.reps)),
+            ("C3-scaled", lambda: scaled(args.reps)),
             ("C4", lambda: c4("squirrel", 2089, args.reps)), ("C4", lambda: c4("chameleon", 2325, args.reps)),
             ("C4m", lambda: c4_models("squirrel", 2089, args.reps)), ("C4m", lambda: c4_models("chameleon", 2325, args.reps)),
             ("C5", lambda: c5(args.reps)), ("C5m", lambda: c5_models(args.reps)), ("C5cal", lambda: c5_calibration(args.reps))]

@@ -125,7 +125,8 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
         x = uf.preprocess_features(torch.from_numpy(dense_features(g0))).cpu().numpy()  # synthetic_plot.py:81-83
         jobs.append(sweep.Job(float(name.split("_")[2]), 100 + i, 10 if "_4000_" in name else 2, n, int(g0["labels"].max()) + 1))
         inputs.append((g0["adj_row"].astype(np.int64), g0["adj_col"].astype(np.int64), g0["labels"], x))
-    epochs, report = 100, {"fixtures": list(SYN), "draws": 4, "epochs": epochs, "per_draw": []}
+    epochs = 100
+    report = {"fixtures": list(SYN), "draws": 4, "epochs": epochs, "per_draw": []}
     d_rows_all, ridged_all, dp_all = [], [], []
     for draw in range(4):
         sb = sweep.SweepBatch(jobs, n_feat=inputs[0][3].shape[1], gcn_hidden=0, inputs=inputs)

@@ -31,25 +31,33 @@ def _arena(size):
 
 
 def test_the_advisors_example():
-    """S = 1024: P3 = [512, 768), P4 = [0, 256), P5 = [256, 512) in flight; take(512) wraps to [0, 512) and must wait for P4 AND
-    P5, although the oldest entry P3 does not overlap"""
+    """S = 1024: P3 = [512, 768), then (next lap) P4 = [0, 256), P5 = [256, 512) in flight; a request of 512 does not fit behind
+    P5's lap position 768, wraps to [0, 512) and must wait for P4 AND P5 - the oldest entry P3 does not overlap it (it is waited
+    for as well: entries complete in issue order, an older one costs nothing)"""
     ar, log, events = _arena(1024)
-    for n in (256, 256):          # P1, P2 (complete: forgotten at the next take)
-        a, _ = ar.take(n)
-        ar.issued(a, n)
+    a1, _ = ar.take(512); ar.issued(a1, 512)      # [0, 512)   lap 0
+    a3, _ = ar.take(256); ar.issued(a3, 256)      # [512, 768) lap 0  (P3)
+    events[0].done = True
+    a_skip, _ = ar.take(512); ar.issued(a_skip, 512)  # does not fit the 256-byte tail: lap 1, [0, 512) - waits for the first entry only
+    assert (a1, a3, a_skip) == (0, 512, 0) and log == [events[0]]
+    log.clear()
     for e in events:
         e.done = True
-    a3, _ = ar.take(256); ar.issued(a3, 256)      # [512, 768)
-    ar.off = 0                                    # (as after a wrap)
-    a4, _ = ar.take(256); ar.issued(a4, 256)      # [0, 256)
-    a5, _ = ar.take(256); ar.issued(a5, 256)      # [256, 512)
-    assert (a3, a4, a5) == (512, 0, 256)
-    p3, p4, p5 = events[2:5]
-    ar.off = 768
-    a, piece = ar.take(512)                       # 768 + 512 > 1024: wraps to [0, 512)
-    assert a == 0 and piece.numel() == 512
-    assert p4 in log and p5 in log and p3 not in log
-    assert [(s, e) for s, e, _ in ar.pending] == [(512, 768)]
+    ar2, log2, ev2 = _arena(1024)
+    for n in (512, 256):                          # lap 0: [0, 512) and P3 = [512, 768)
+        a, _ = ar2.take(n); ar2.issued(a, n)
+    ev2[0].done = True
+    a4, _ = ar2.take(256); ar2.issued(a4, 256)    # P4: fits the tail [768, 1024)
+    assert a4 == 768
+    a5, _ = ar2.take(256); ar2.issued(a5, 256)    # P5: lap 1 [0, 256): one lap ahead of the first entry only
+    a6, _ = ar2.take(256); ar2.issued(a6, 256)    # P6: lap 1 [256, 512)
+    assert (a5, a6) == (0, 256) and log2 == [ev2[0]]
+    log2.clear()
+    a, piece = ar2.take(512)                      # lap 1 [512, 1024): overlaps P3 and P4 of lap 0
+    assert a == 512 and piece.numel() == 512
+    assert ev2[1] in log2 and ev2[2] in log2 and ev2[3] not in log2 and ev2[4] not in log2
+    a, _ = ar2.take(512)                          # lap 2 [0, 512): overlaps P5 and P6 - neither is the head's neighbour in the buffer
+    assert a == 0 and ev2[3] in log2 and ev2[4] in log2
 
 
 def test_random_requests_never_reuse_bytes_in_flight():
@@ -72,7 +80,7 @@ def test_random_requests_never_reuse_bytes_in_flight():
         for _s, _e, ev in in_flight[:k]:
             ev.done = True
         in_flight = [x for x in in_flight if not x[2].done]
-        assert len(ar.pending) <= len(in_flight) + 1 + k  # (bounded: completed entries are forgotten)
+        assert sum(e - s_ for s_, e, _ in in_flight) <= size  # (what is in flight never exceeds one lap)
 
 
 def test_oversized_request_is_refused():

@@ -491,6 +491,7 @@ __device__ __forceinline__ unsigned philox4x32_10(unsigned c0, unsigned c1, unsi
 }
 
 constexpr int KS_THREADS = 1024, KS_MAX_CLASSES = 64;
+
 __global__ __launch_bounds__(KS_THREADS) void kr_sample_kernel(const wdg_kr_sample_job *__restrict__ jobs, int n_jobs) {
     extern __shared__ unsigned long long ks_keys[];  // [n] sort keys, then (aliased) the nodes' roles
     __shared__ int cstart[KS_MAX_CLASSES + 1], scan_t[KS_THREADS], scan_v[KS_THREADS];
@@ -580,6 +581,157 @@ __global__ __launch_bounds__(KS_THREADS) void kr_sample_kernel(const wdg_kr_samp
         if (role[i] == 2 && pv < j.val_stride) va[pv++] = i;
     }
 }
+
+// Round 5: the same sets WITHOUT sorting.  The definition above needs, per node, only whether its rank inside its class is below
+// t_c (train), below s_c (validation) or neither.  kr_select_kernel finds that by a radix SELECT: a histogram of the keys' top bits
+// per class (NB bins), a prefix over the bins to find the two bins in which the ranks t_c and s_c fall, and an exact rank only for
+// the few nodes of those two boundary bins (counted against the other members of the same class and bin, by a wave per such
+// node) - every other node is classified by its bin alone.  256 threads and ~25 KB of LDS per set instead of a 1024-thread
+// comparator network over 64-bit keys with ~90 barriers: several workgroups share a CU, so the launch also runs well BESIDE the
+// Gram kernels it is queued next to (the sort held whole CUs).  Bit for bit the sets of kr_sample_kernel (WDG_KR_SAMPLER_SORT=1
+// keeps that kernel; tests/test_gpu_batched_build.py compares the device's sets with a numpy restatement of the definition).
+constexpr int KSEL_THREADS = 256, KSEL_WAVES = KSEL_THREADS / 64, KSEL_LIST = 1024;
+__device__ __forceinline__ unsigned long long ksel_composite(unsigned cls, unsigned key, int node) {
+    return (static_cast<unsigned long long>(cls) << 56) | (static_cast<unsigned long long>(key) << 24) | static_cast<unsigned long long>(node);
+}
+constexpr int KSEL_HIST = 2048;  // histogram words: classes x bins (256 bins up to 8 classes, 128 / 64 / 32 up to 16 / 32 / 64)
+__global__ __launch_bounds__(KSEL_THREADS) void kr_select_kernel(const wdg_kr_sample_job *__restrict__ jobs, int n_jobs, int max_n_pad) {
+    extern __shared__ unsigned ksel_lds[];  // keys [max_n_pad] | hist [KSEL_HIST] | list [KSEL_LIST] | cls bytes [max_n_pad] | role bytes [max_n_pad]
+    __shared__ int bnd_bin[2][KS_MAX_CLASSES], bnd_rem[2][KS_MAX_CLASSES];  // [0]: train threshold t_c, [1]: sample threshold s_c
+    __shared__ int list_n, wave_t[KSEL_WAVES], wave_v[KSEL_WAVES];
+    int lo = 0, hi = n_jobs;
+    while (hi - lo > 1) {  // which job: first_set ascending
+        const int mid = (lo + hi) >> 1;
+        if (jobs[mid].first_set <= static_cast<int>(blockIdx.x)) lo = mid;
+        else hi = mid;
+    }
+    const wdg_kr_sample_job j = jobs[lo];
+    const int set = static_cast<int>(blockIdx.x) - j.first_set;
+    if (set >= j.n_sets) return;
+    const int n = j.n, C = j.n_classes, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb_log2 = C <= 8 ? 8 : (C <= 16 ? 7 : (C <= 32 ? 6 : 5)), NB = 1 << nb_log2, shift = 32 - nb_log2;  // C x NB <= KSEL_HIST
+    unsigned *keys = ksel_lds, *hist = keys + max_n_pad, *list = hist + KSEL_HIST;
+    unsigned char *cls = reinterpret_cast<unsigned char *>(list + KSEL_LIST), *role = cls + max_n_pad;
+    const unsigned k0 = static_cast<unsigned>(j.seed), k1 = static_cast<unsigned>(j.seed >> 32);
+    for (int b = tid; b < C * NB; b += KSEL_THREADS) hist[b] = 0;
+    if (tid == 0) list_n = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += KSEL_THREADS) {  // keys + the per-class histogram of their top bits
+        const int c = j.labels[i];
+        const bool ok = c >= 0 && c < C;
+        const unsigned key = philox4x32_10(static_cast<unsigned>(i), static_cast<unsigned>(set), k0, k1);
+        keys[i] = key;
+        cls[i] = ok ? static_cast<unsigned char>(c) : 255;  // unlabelled: never drawn
+        if (ok) atomicAdd(&hist[c * NB + (key >> shift)], 1u);
+    }
+    __syncthreads();
+    // the bins in which the ranks t_c and s_c fall: a wave per class, a lane owns NB / 64 consecutive bins (or one bin, NB <= 64)
+    for (int c = wave; c < C; c += KSEL_WAVES) {
+        const int per = NB >= 64 ? NB / 64 : 1, first = lane * per;
+        int mine = 0;
+        for (int b = 0; b < per; ++b) mine += first + b < NB ? static_cast<int>(hist[c * NB + first + b]) : 0;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const int total = __shfl(incl, 63), before = incl - mine;
+        const int want[2] = {j.train_per_class[c], j.sample_per_class[c]};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int T = want[w];
+            if (T <= 0) {  // nobody: every bin lies behind the boundary
+                if (lane == 0) bnd_bin[w][c] = -1, bnd_rem[w][c] = 0;
+            } else if (T >= total) {  // the whole class (a class smaller than its share)
+                if (lane == 0) bnd_bin[w][c] = NB, bnd_rem[w][c] = 0;
+            } else if (before < T && T <= incl) {  // exactly one lane: the rank falls into one of its bins
+                int cum = before;
+                for (int b = 0; b < per; ++b) {
+                    const int h = static_cast<int>(hist[c * NB + first + b]);
+                    if (cum < T && T <= cum + h) bnd_bin[w][c] = first + b, bnd_rem[w][c] = T - cum;
+                    cum += h;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // every node by its bin; the members of a boundary bin wait for their exact rank (role 3 + an entry in the list)
+    const int per_t = (n + KSEL_THREADS - 1) / KSEL_THREADS, a = min(n, tid * per_t), b_end = min(n, a + per_t);
+    for (int i = a; i < b_end; ++i) {
+        const int c = cls[i];
+        unsigned char r = 0;
+        if (c != 255) {
+            const int bin = static_cast<int>(keys[i] >> shift), bt = bnd_bin[0][c], bs = bnd_bin[1][c];
+            if (bin < bt) r = 1;
+            else if (bin == bt || bin == bs) {
+                r = 3;
+                const int at = atomicAdd(&list_n, 1);
+                if (at < KSEL_LIST) list[at] = static_cast<unsigned>(i);
+            } else if (bin < bs) r = 2;
+        }
+        role[i] = r;
+    }
+    __syncthreads();
+    const int listed = min(list_n, KSEL_LIST);
+    auto settle = [&](int i, int rank) {  // rank = members of i's class and bin that sort before it
+        const int c = cls[i], bin = static_cast<int>(keys[i] >> shift);
+        unsigned char r = 0;
+        if (bin == bnd_bin[0][c] && rank < bnd_rem[0][c]) r = 1;
+        else if (bin < bnd_bin[1][c] || (bin == bnd_bin[1][c] && rank < bnd_rem[1][c])) r = 2;
+        role[i] = r;
+    };
+    for (int e = wave; e < listed; e += KSEL_WAVES) {  // a wave per listed node: its rank inside its (class, bin)
+        const int i = static_cast<int>(list[e]);
+        const unsigned c = cls[i], key = keys[i], bin = key >> shift;
+        const unsigned long long me = ksel_composite(c, key, i);
+        int cnt = 0;
+        for (int q = lane; q < n; q += 64) {
+            const unsigned kq = keys[q];
+            cnt += (cls[q] == c && (kq >> shift) == bin && ksel_composite(c, kq, q) < me) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) settle(i, cnt);
+    }
+    if (list_n > KSEL_LIST) {  // (more boundary members than the list holds: the owners rank the rest themselves)
+        __syncthreads();
+        for (int i = a; i < b_end; ++i) {
+            if (role[i] != 3) continue;
+            bool in_list = false;
+            for (int e = 0; e < KSEL_LIST && !in_list; ++e) in_list = static_cast<int>(list[e]) == i;
+            if (in_list) continue;
+            const unsigned c = cls[i], key = keys[i], bin = key >> shift;
+            const unsigned long long me = ksel_composite(c, key, i);
+            int cnt = 0;
+            for (int q = 0; q < n; ++q) cnt += (cls[q] == c && (keys[q] >> shift) == bin && ksel_composite(c, keys[q], q) < me) ? 1 : 0;
+            settle(i, cnt);
+        }
+    }
+    __syncthreads();
+    // ordered compaction: a thread owns a contiguous run of node ids, so the ids come out ascending
+    int ct = 0, cv = 0;
+    for (int i = a; i < b_end; ++i) {
+        ct += role[i] == 1;
+        cv += role[i] == 2;
+    }
+    int it = ct, iv = cv;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ut = __shfl_up(it, o), uv = __shfl_up(iv, o);
+        if (lane >= o) it += ut, iv += uv;
+    }
+    if (lane == 63) wave_t[wave] = it, wave_v[wave] = iv;
+    __syncthreads();
+    int pt = it - ct, pv = iv - cv;
+    for (int w = 0; w < wave; ++w) pt += wave_t[w], pv += wave_v[w];
+    int32_t *tr = j.train_out + static_cast<int64_t>(set) * j.train_stride, *va = j.val_out + static_cast<int64_t>(set) * j.val_stride;
+    for (int i = a; i < b_end; ++i) {
+        if (role[i] == 1 && pt < j.train_stride) tr[pt++] = i;
+        if (role[i] == 2 && pv < j.val_stride) va[pv++] = i;
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------ batched kernel regression
 constexpr int KR_THREADS = 1024, KR_T = 32, KR_B = 10;  // 32 x 32 threads, 10 x 10 elements each: blocks of up to 320 x 320
@@ -1427,6 +1579,25 @@ int wdg_kr_sample_sets(const wdg_kr_sample_job *jobs_dev, int32_t n_jobs, int32_
     if (n_jobs == 0 || n_sets_total == 0 || max_n == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev != nullptr, "kr_sample_sets: null job table");
     WDG_REQUIRE(max_n <= 16000, "kr_sample_sets: graphs of more than 16 000 nodes draw their node sets on the host");
+    hipStream_t st = wdg::as_stream(stream);
+    // WDG_KR_SAMPLER_SORT=1: round 3's kernel (a 1024-thread comparator network per set); default: the radix select, same sets
+    static const bool sort_kernel = [] {
+        const char *e = getenv("WDG_KR_SAMPLER_SORT");
+        return e && atoi(e) != 0;
+    }();
+    if (!sort_kernel) {
+        const int max_n_pad = (max_n + 63) & ~63;
+        const size_t lds_sel = static_cast<size_t>(max_n_pad) * 6 + (KSEL_HIST + KSEL_LIST) * sizeof(unsigned);
+        static thread_local int sel_dev = -1;
+        if (sel_dev != wdg::current_device()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kr_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    16000 * 6 + (KSEL_HIST + KSEL_LIST) * 4 + 512) != hipSuccess)
+                return wdg::fail(WDG_ERR_LAUNCH, "kr_sample_sets: cannot raise the dynamic LDS limit");
+            sel_dev = wdg::current_device();
+        }
+        hipLaunchKernelGGL(kr_select_kernel, dim3(static_cast<unsigned>(n_sets_total)), dim3(KSEL_THREADS), lds_sel, st, jobs_dev, n_jobs, max_n_pad);
+        return wdg::check_launch("kr_select_kernel");
+    }
     const size_t lds = static_cast<size_t>(max_n) * 8 + ((static_cast<size_t>(max_n) + 15) & ~static_cast<size_t>(15));
     static thread_local int configured_dev = -1;
     if (configured_dev != wdg::current_device()) {
@@ -1435,8 +1606,7 @@ int wdg_kr_sample_sets(const wdg_kr_sample_job *jobs_dev, int32_t n_jobs, int32_
             return wdg::fail(WDG_ERR_LAUNCH, "kr_sample_sets: cannot raise the dynamic LDS limit");
         configured_dev = wdg::current_device();
     }
-    hipLaunchKernelGGL(kr_sample_kernel, dim3(static_cast<unsigned>(n_sets_total)), dim3(KS_THREADS), lds, wdg::as_stream(stream),
-                       jobs_dev, n_jobs);
+    hipLaunchKernelGGL(kr_sample_kernel, dim3(static_cast<unsigned>(n_sets_total)), dim3(KS_THREADS), lds, st, jobs_dev, n_jobs);
     return wdg::check_launch("kr_sample_kernel");
 }
 

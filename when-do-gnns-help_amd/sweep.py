@@ -544,7 +544,11 @@ class SweepBatch:
         with torch.cuda.graph(graph):
             self.step()
         self._step_graph = graph  # keep alive
-        return graph.replay
+
+        def replay():
+            self._y_dirty = True  # (a replayed aggregation leaves the row-major copy stale like a launched one)
+            graph.replay()
+        return replay
 
     def _metric_chain(self):
         if self.derive_counts:
