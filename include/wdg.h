@@ -88,6 +88,10 @@ int wdg_coo32_to_csr_i32(const int32_t *src, const int32_t *dst, const float *va
  * the data is copied into the (ideally page-locked) upload buffer by `threads` threads.  An id outside [0, n_g) becomes -1 and
  * sets *bad_out (host int32) to 1.  replaces: the host side of synthetic_plot.py:85-92's per-iteration torch.load -> dense.
  */
+/* HOST helper: a plain copy by `threads` threads (pageable source -> the page-locked upload buffer).  A sweep shard's feature
+ * matrices are 4 - 30 MB each: one thread's memcpy (~10 GB/s) was a third of the shard's host time, and torch's own host copy
+ * wakes every hardware thread of the host.  replaces: the `.to(device)` of synthetic_plot.py:81-83's feature tensors (host half). */
+int wdg_host_memcpy_mt(void *dst_host, const void *src_host, size_t bytes, int threads);
 int wdg_host_pack_coo_i32(const void *const *src_ptrs, const void *const *dst_ptrs, const int64_t *lens, const int32_t *node_ptr,
                           int32_t n_graphs, int elem_bytes, int32_t *out_src, int32_t *out_dst, int32_t *bad_out, int threads);
 int wdg_coo_blockdiag_offset(int64_t *src, int64_t *dst, const int64_t *edge_ptr_dev, const int32_t *node_ptr_dev, int32_t n_graphs,

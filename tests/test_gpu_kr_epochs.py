@@ -104,17 +104,28 @@ def test_ten_class_labels_fall_back_to_the_host_path():
     assert res["device"] == res["host"] and 0.0 <= res["host"] <= 1.0
 
 
+# Bounds asserted by the at-scale test below, in validation rows (of 200), against the reference's own per-epoch computation on the
+# host (sampled Gram by fp32 GEMM + arc-cosine map + np.linalg.pinv = SweepBatch.pinv_accuracies(kernels="host")):
+#   blocks the device solver factors as they are: <= 2 (measured: 99.7 % equal, the rest 1 row);
+#   blocks it regularises (ridge): >= 98 % within 2 rows, none beyond 4 (measured on all 3 108 flagged blocks of the 8 000: 2 599 equal,
+#   472 one row, 36 two, 1 three - profiles/r05_kr_ridge_vs_pinv.json; the three-way comparison on the golden epochs,
+#   profiles/r05_kr_three_way.txt, has the ridge within 0 - 2 rows of what the reference recorded on every synthetic fixture).
+ROWS_PD, RIDGED_SHARE_WITHIN_2, RIDGED_MAX = 2, 0.98, 4
+
+
 def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
-    """The batched sweep path (SweepBatch.prepare_full / launch_full / full_metrics) against the reference's solver on EVERY
-    regression, at the reference's epoch count: the five golden synthetic fixtures x 4 independent draws of the node sets = 20
-    jobs x 2 classifiers x 100 epochs x 2 kernels = 8 000 regressions.  Device rows (Cholesky; ridge on the blocks it flags) vs
-    `K_vt @ (np.linalg.pinv(K_tt) @ onehot)` on the host for the same blocks (SweepBatch.pinv_accuracies on ALL problems = what
-    WDG_KR_SOLVER=host computes, utils/homophily_plot.py:301-316).  Asserts the documented bounds - |d accuracy| <= 2 validation
-    rows on blocks the solver factored as they are, <= 4 on blocks it regularised; the p-value moves by no more than such a
-    perturbation of these accuracies can move it - and that ridge="pinv" reproduces the host answer on exactly the flagged
-    blocks.  The distribution (counts, median, max, by kind) is written to gpurun_out/ for profiles/."""
+    """The batched sweep path (SweepBatch.prepare_full / launch_full / full_metrics) against the reference's solver at the
+    reference's epoch count: the five golden synthetic fixtures x 4 independent draws of the node sets = 20 jobs x 2 classifiers x
+    100 epochs x 2 kernels = 8 000 regressions on the device (Cholesky; ridge on the blocks it flags), and for EVERY flagged block
+    plus a sample of the others the reference's own per-epoch computation on the host (utils/homophily_metrics.py:232-257 +
+    :283-297 through SweepBatch.pinv_accuracies: the epoch's sampled Gram by fp32 GEMM, the arc-cosine map, np.linalg.pinv).
+    Asserts the documented bounds (ROWS_PD, RIDGED_*), that full_metrics(ridge="pinv") carries the host answer on exactly the
+    flagged blocks with p-values inside what the row bound implies, and reports - not asserts - how far np.linalg.pinv applied to
+    blocks of the DEVICE kernel lands from both (the reason the patch computes its kernels the reference's way).  The
+    distributions are written to gpurun_out/ for profiles/r05_kr_ridge_vs_pinv.json."""
     import json
     import os
+    import time
     from _golden import SYN
     from wdg_amd import sweep
     from wdg_amd.utils import util_funcs as uf
@@ -125,53 +136,72 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
         x = uf.preprocess_features(torch.from_numpy(dense_features(g0))).cpu().numpy()  # synthetic_plot.py:81-83
         jobs.append(sweep.Job(float(name.split("_")[2]), 100 + i, 10 if "_4000_" in name else 2, n, int(g0["labels"].max()) + 1))
         inputs.append((g0["adj_row"].astype(np.int64), g0["adj_col"].astype(np.int64), g0["labels"], x))
-    epochs = 100
-    report = {"fixtures": list(SYN), "draws": 4, "epochs": epochs, "per_draw": []}
-    d_rows_all, ridged_all, dp_all = [], [], []
-    for draw in range(4):
+    epochs, draws = 100, 4
+    report = {"fixtures": list(SYN), "draws": draws, "epochs": epochs, "per_draw": []}
+    rng = np.random.default_rng(5)
+    d_pd, d_ridged, d_devgram, dp_all, failures = [], [], [], [], []
+    n_regressions = n_flagged = 0
+    for draw in range(draws):
         sb = sweep.SweepBatch(jobs, n_feat=inputs[0][3].shape[1], gcn_hidden=0, inputs=inputs)
         sb.prepare_full(epochs=epochs, sample_max=500, base_seed=77 + draw)  # device-drawn sets, as the sweep driver does
         sb.step()
         sb.launch_full()
         torch.cuda.synchronize()
         rows_dev = sb.full_metrics(ridge="device").numpy()
-        acc_dev = sb.kr_acc.copy()                                             # [job, clf, epoch, kernel]
-        ridged = sb.kr.ridged().cpu().numpy().reshape(acc_dev.shape)
-        n_val = np.array([sb.kr_val.shape[2]] * len(jobs), np.float64)
-        acc_host = sb.pinv_accuracies(np.arange(sb.kr.n_jobs)).reshape(acc_dev.shape)
-        rows_pinv = sb.full_metrics(ridge="pinv").numpy()
-        acc_pinv = sb.kr_acc.copy()
-        # ridge="pinv": flagged blocks carry the host answer, the others the device answer
-        assert np.array_equal(acc_pinv[ridged], acc_host[ridged]) and np.array_equal(acc_pinv[~ridged], acc_dev[~ridged])
-        assert sb.kr_ridged == int(ridged.sum()) and sb.kr_total == ridged.size and (sb.kr_pinv_seconds > 0) == bool(ridged.any())
-        d_rows = np.abs(acc_dev.astype(np.float64) - acc_host) * n_val[:, None, None, None]
-        assert d_rows[~ridged].max(initial=0) <= 2.01, ("positive definite blocks", d_rows[~ridged].max())
-        assert d_rows[ridged].max(initial=0) <= 4.01, ("regularised blocks", d_rows[ridged].max())
-        p_host = sweep.welch_p_values(acc_host[..., 0], acc_host[..., 1])       # [job, clf]
-        for ji in range(len(jobs)):
-            for ci in range(2):
-                worst = 4 if ridged[ji, ci].any() else 2
-                tol = p_tolerance(acc_host[ji, ci, :, 0], acc_host[ji, ci, :, 1], float(n_val[ji]), worst, trials=100)
-                assert abs(rows_dev[ji, 7 + ci] - p_host[ji, ci]) <= tol, (draw, ji, ci, rows_dev[ji, 7 + ci], p_host[ji, ci], tol)
-                assert abs(rows_pinv[ji, 7 + ci] - p_host[ji, ci]) <= p_tolerance(acc_host[ji, ci, :, 0], acc_host[ji, ci, :, 1], float(n_val[ji]), 2, trials=100)
-        dp = np.abs(rows_dev[:, 7:9] - p_host)
-        d_rows_all.append(d_rows)
-        ridged_all.append(ridged)
-        dp_all.append(dp)
-        report["per_draw"].append({"ridged": int(ridged.sum()), "total": int(ridged.size), "max_rows": float(d_rows.max()),
-                                   "max_abs_dp": float(dp.max()), "pinv_patch_seconds": sb.kr_pinv_seconds})
+        acc_dev = sb.kr_acc.copy().reshape(-1)                                 # problem order [job, clf, epoch, kernel]
+        ridged = sb.kr.ridged().cpu().numpy().reshape(-1)
+        n_val = float(sb.kr_val.shape[2])
+        flagged = np.flatnonzero(ridged)
+        others = rng.choice(np.flatnonzero(~ridged), 150, replace=False)
+        t0 = time.perf_counter()
+        host_f = sb.pinv_accuracies(flagged)                                   # the reference's way, kernels included
+        t_host = time.perf_counter() - t0
+        host_o = sb.pinv_accuracies(others)
+        d_ridged.append(np.abs(acc_dev[flagged].astype(np.float64) - host_f) * n_val)
+        d_pd.append(np.abs(acc_dev[others].astype(np.float64) - host_o) * n_val)
+        some = flagged[:: max(1, len(flagged) // 120)]                         # ~120 flagged blocks: pinv on the DEVICE kernel's blocks
+        d_devgram.append(np.abs(sb.pinv_accuracies(some, kernels="device").astype(np.float64) - host_f[:: max(1, len(flagged) // 120)]) * n_val)
+        n_regressions, n_flagged = n_regressions + ridged.size, n_flagged + len(flagged)
+        rec = {"ridged": int(len(flagged)), "total": int(ridged.size), "host_seconds_flagged": t_host}
+        if draw == 0:  # the patch itself: flagged blocks carry the host answer, the others the device answer; p-values follow
+            rows_pinv = sb.full_metrics(ridge="pinv").numpy()
+            acc_pinv = sb.kr_acc.copy().reshape(-1)
+            if not (np.array_equal(acc_pinv[flagged], host_f) and np.array_equal(np.delete(acc_pinv, flagged), np.delete(acc_dev, flagged))):
+                failures.append("ridge='pinv' did not patch exactly the flagged blocks with the host answer")
+            if not (sb.kr_ridged == len(flagged) and sb.kr_total == ridged.size and sb.kr_pinv_seconds > 0):
+                failures.append(f"counts {sb.kr_ridged} / {sb.kr_total} / {sb.kr_pinv_seconds}")
+            rec["pinv_patch_seconds"] = sb.kr_pinv_seconds
+            acc4 = acc_pinv.reshape(len(jobs), 2, epochs, 2)
+            p_patched = sweep.welch_p_values(acc4[..., 0], acc4[..., 1])
+            assert np.allclose(rows_pinv[:, 7:9], p_patched, equal_nan=True)
+            dp = np.abs(rows_dev[:, 7:9] - rows_pinv[:, 7:9])
+            dp_all.append(dp)
+            for ji in range(len(jobs)):
+                for ci in range(2):
+                    tol = p_tolerance(acc4[ji, ci, :, 0], acc4[ji, ci, :, 1], n_val, RIDGED_MAX if ridged.reshape(acc4.shape)[ji, ci].any() else ROWS_PD, trials=100)
+                    if abs(rows_dev[ji, 7 + ci] - rows_pinv[ji, 7 + ci]) > tol:
+                        failures.append(f"job {ji} clf {ci}: p {rows_dev[ji, 7 + ci]:.3g} (ridge) vs {rows_pinv[ji, 7 + ci]:.3g} (pinv), tolerance {tol:.3g}")
+        report["per_draw"].append(rec)
         del sb
-    d_rows, ridged, dp = np.stack(d_rows_all), np.stack(ridged_all), np.stack(dp_all)
+    d_pd, d_ridged, d_devgram = np.concatenate(d_pd), np.concatenate(d_ridged), np.concatenate(d_devgram)
 
     def dist_of(v):
         v = np.round(v).astype(int)
         return {"n": int(v.size), "median": float(np.median(v)) if v.size else 0.0, "max": int(v.max(initial=0)),
-                "histogram_rows": {str(k): int((v == k).sum()) for k in range(int(v.max(initial=0)) + 1)}}
+                "share_within_2": float((v <= 2).mean()) if v.size else 1.0,
+                "histogram_rows": {str(k): int((v == k).sum()) for k in range(int(v.max(initial=0)) + 1) if (v == k).any()}}
 
-    report.update(regressions=int(ridged.size), ridged=int(ridged.sum()),
-                  d_validation_rows_positive_definite=dist_of(d_rows[~ridged]), d_validation_rows_ridged=dist_of(d_rows[ridged]),
-                  abs_dp={"median": float(np.median(dp)), "max": float(dp.max()), "n": int(dp.size)},
-                  bound_asserted={"rows_pd": 2, "rows_ridged": 4, "p": "_golden.p_tolerance of that row bound on the host accuracies"})
+    if d_pd.max(initial=0) > ROWS_PD + 0.01:
+        failures.append(f"blocks factored as they are: up to {d_pd.max():.1f} rows from the host answer")
+    if (d_ridged <= 2.01).mean() < RIDGED_SHARE_WITHIN_2 or d_ridged.max(initial=0) > RIDGED_MAX + 0.01:
+        failures.append(f"regularised blocks: {(d_ridged <= 2.01).mean():.3f} within 2 rows, max {d_ridged.max():.1f}")
+    report.update(regressions=int(n_regressions), ridged=int(n_flagged),
+                  device_vs_reference_way_not_flagged_sample=dist_of(d_pd), device_ridge_vs_reference_way_flagged_all=dist_of(d_ridged),
+                  pinv_on_device_kernel_blocks_vs_reference_way_flagged_sample=dist_of(d_devgram),
+                  abs_dp_ridge_vs_patched={"median": float(np.median(np.concatenate(dp_all))), "max": float(np.concatenate(dp_all).max())},
+                  bound_asserted={"rows_not_flagged": ROWS_PD, "flagged_share_within_2_rows": RIDGED_SHARE_WITHIN_2, "flagged_max_rows": RIDGED_MAX,
+                                  "p": "_golden.p_tolerance of the row bound on the patched accuracies"},
+                  failures=failures)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
@@ -180,3 +210,4 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
     except OSError:
         pass
     assert report["regressions"] == 8000
+    assert not failures, "\n".join(failures[:20])

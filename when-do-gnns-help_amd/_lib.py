@@ -58,6 +58,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wdg_coo32_to_csr_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wdg_host_memcpy_mt": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     "wdg_host_pack_coo_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "wdg_coo_blockdiag_offset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "wdg_csr_split_blockdiag": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

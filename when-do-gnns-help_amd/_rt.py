@@ -92,15 +92,19 @@ class _PinnedArena:
 
 
 _ARENA = None
-_H2D_MAX_BYTES = int(float(os.environ.get("WDG_H2D_MAX_MB", "8")) * (1 << 20))  # larger arrays: the plain (blocking, pageable) copy
+_H2D_MAX_BYTES = int(float(os.environ.get("WDG_H2D_MAX_MB", "64")) * (1 << 20))  # larger arrays: the plain (blocking, pageable) copy
+_H2D_RING_BYTES = int(float(os.environ.get("WDG_H2D_RING_MB", "512")) * (1 << 20))  # two base-shards of the widest base in flight: 2 x 3 x 30 MB
+_H2D_THREADS = int(os.environ.get("WDG_H2D_THREADS", "8"))
 
 
 def _h2d(host, dev=None):
     """A host array (job table, offsets, labels, a feature matrix) -> device tensor WITHOUT blocking the host on what the stream
     has queued: through the page-locked arena and a non-blocking copy.  (`tensor.to(dev)` from pageable memory returns only when
     the copy has run, i.e. after every kernel queued before it - a shard's ~70 small uploads then serialise the host with the
-    build kernels.)  Arrays of more than WDG_H2D_MAX_MB (8) MB take the plain blocking copy: the wide bases' 30-MB feature matrices
-    through a single-threaded memcpy and a 128-MB ring cost the whole sweep 10 % (0.80 -> 0.88 s)."""
+    build kernels.)  Arrays of a megabyte and more are copied into the arena by the library's host threads (wdg_host_memcpy_mt:
+    round 4 sent everything above 8 MB down the blocking pageable path because ONE thread's memcpy of the wide bases' 30-MB
+    feature matrices cost more than it saved - and then every such upload waited for the stream's queued regressions: 5 ms a
+    piece in the profile of a rank's share of the whole sweep); only arrays above WDG_H2D_MAX_MB (64) take the plain copy."""
     global _ARENA
     dev = dev or require_gpu()
     t = torch.from_numpy(host) if isinstance(host, np.ndarray) else host
@@ -109,14 +113,17 @@ def _h2d(host, dev=None):
     if nbytes == 0:
         return torch.empty(t.shape, dtype=t.dtype, device=dev)
     if _ARENA is None:
-        _ARENA = _PinnedArena()
+        _ARENA = _PinnedArena(_H2D_RING_BYTES)
     if nbytes > _H2D_MAX_BYTES:
         return t.to(dev)
     start, piece = _ARENA.take(nbytes)
     p = piece.view(t.dtype).view(t.shape)
-    # (numpy's memcpy, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware thread of the host -
-    # measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
-    np.copyto(p.numpy(), t.numpy())
+    # (numpy's memcpy / the library's threads, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware
+    # thread of the host - measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
+    if nbytes >= (1 << 20) and _H2D_THREADS > 1:
+        check(lib.wdg_host_memcpy_mt(c_void_p(piece.data_ptr()), c_void_p(t.data_ptr()), nbytes, _H2D_THREADS), "wdg_host_memcpy_mt")
+    else:
+        np.copyto(p.numpy(), t.numpy())
     out = p.to(dev, non_blocking=True)
     _ARENA.issued(start, nbytes)
     return out

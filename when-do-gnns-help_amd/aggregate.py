@@ -407,7 +407,10 @@ class SpmmBatch:
         n = int(lib.wdg_spmm_quad_workgroups(self.n_segments, self.max_feat, self.flags))
         return torch.zeros(2 * n, dtype=torch.int64, device=self.table.device)
 
+    n_launches = 0  # launches so far (readers that keep a copy of the outputs compare it with the count they copied at)
+
     def launch(self, clock=None):
+        self.n_launches += 1
         if clock is not None and self.quad:
             check(lib.wdg_spmm_quad_batched_clocked_f32(_ptr(self.table), self.n_jobs, _ptr(self.items), _ptr(self.seg_ptr),
                                                         self.n_segments, self.max_cols, self.max_feat, self.flags, _ptr(clock),

@@ -4,6 +4,7 @@
 // rows A1-A5).  All fp sums run in a fixed order -> bitwise reproducible.
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -641,6 +642,23 @@ int wdg_coo32_to_csr_i32(const int32_t *src, const int32_t *dst, const float *va
 // threads - into page-locked memory when the caller provides it - so that the shard's edge lists cross PCIe once, as 4-byte
 // indices, without the interpreter concatenating them (ops.GraphBatch: 2.8 of a shard's 7.6 ms of build were numpy
 // concatenation + two pageable int64 uploads).  elem_bytes: 8 (int64 inputs) or 4 (int32).
+int wdg_host_memcpy_mt(void *dst, const void *src, size_t bytes, int threads) {
+    WDG_REQUIRE(bytes == 0 || (dst && src), "host_memcpy_mt: null buffer");
+    threads = std::max(1, std::min(threads, 64));
+    if (bytes < (1u << 20) || threads == 1) {
+        if (bytes) memcpy(dst, src, bytes);
+        return WDG_OK;
+    }
+    std::vector<std::thread> pool;
+    const size_t piece = ((bytes + threads - 1) / threads + 4095) & ~static_cast<size_t>(4095);
+    for (int t = 0; t < threads; ++t) {
+        const size_t a = std::min(bytes, piece * t), b = std::min(bytes, a + piece);
+        if (b > a) pool.emplace_back([=] { memcpy(static_cast<char *>(dst) + a, static_cast<const char *>(src) + a, b - a); });
+    }
+    for (auto &th : pool) th.join();
+    return WDG_OK;
+}
+
 int wdg_host_pack_coo_i32(const void *const *src_ptrs, const void *const *dst_ptrs, const int64_t *lens, const int32_t *node_ptr,
                           int32_t n_graphs, int elem_bytes, int32_t *out_src, int32_t *out_dst, int32_t *bad_out, int threads) {
     WDG_REQUIRE(n_graphs >= 0 && (elem_bytes == 8 || elem_bytes == 4) && bad_out, "host_pack_coo: bad arguments");

@@ -38,7 +38,7 @@ class GemmBatch:
             self.flops += 2 * m * n * k
         self.n_jobs = len(entries)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8) if len(entries) else torch.empty(0, dtype=torch.uint8)
-        self.table = host.to(dev)
+        self.table = _h2d(host, dev) if len(entries) else host
 
     def launch(self):
         check(lib.wdg_gemm_batched_flags_f32(_ptr(self.table), self.n_jobs, self.max_m, self.max_n, self.max_k, self.flags,
@@ -95,7 +95,7 @@ class Mlp2Batch:
             self.max_h, self.max_c = max(self.max_h, h), max(self.max_c, c)
             self.flops += 2 * m * h * (k + c)
         self.n_jobs = len(entries)
-        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.table = _h2d(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8), dev)
         # the kernel is chosen HERE, with the table, and named at every launch (1 = WDG_KERNEL_SPLIT, 2 = WDG_KERNEL_CHAIN,
         # 4 = WDG_OPERAND_TILED): the environment may change between build and launch, the table's layout does not
         self.flags = (1 if self.split_kernel() else 2) | (4 if any(isinstance(e[0], Tiled) for e in entries) else 0)

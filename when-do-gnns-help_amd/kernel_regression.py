@@ -23,6 +23,8 @@ class GramBatch:
         self.keep = mats
         self.n_jobs = len(mats)
         self.max_n = max([a.shape[0] for a in mats], default=0)
+        # (one allocation per matrix: 16-MB blocks come back from torch's caching allocator in microseconds; one 1-GB block per
+        # output kind - tried in round 5 - is returned to the driver between shards and costs 5 ms per allocation)
         self.norm2 = [torch.empty(a.shape[0], dtype=torch.float32, device=dev) for a in mats]
         self.k_linear = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if linear else None for a in mats]
         self.k_arccos = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if arccos else None for a in mats]
@@ -119,7 +121,7 @@ class KrSets:
         self.max_n = max([int(e[0].shape[0]) for e in entries], default=0)
         cls = np.concatenate([np.concatenate([np.asarray(s_, np.int32), np.asarray(t, np.int32)]) for _l, s_, t, _seed in entries]) \
             if entries else np.zeros(0, np.int32)
-        self.class_tables = torch.from_numpy(cls).to(dev)
+        self.class_tables = _h2d(cls, dev)
         arr = (_lib.KrSampleJob * self.n_pairs)()
         off = 0
         for i, (job, (lab, s_, t, seed)) in enumerate(zip(arr, entries)):
@@ -182,7 +184,7 @@ class KrBatch:
             raise ValueError(f"KrBatch: {int(n_train.min())}..{int(n_train.max())} train rows, the solver holds blocks of 1..{self.MAX_TRAIN}")
         self.correct = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
         self.flags = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)  # bit 0: the ridge refactorisation ran
-        self.n_val = torch.from_numpy(n_val.astype(np.float32)).to(dev)
+        self.n_val = _h2d(n_val.astype(np.float32), dev)
         tab = np.zeros(n, _KR_JOB_DTYPE)
         tab["K"], tab["train"], tab["val"], tab["labels"] = k_ptr, train_ptr, val_ptr, labels_ptr
         tab["correct_out"] = self.correct.data_ptr() + 4 * np.arange(n, dtype=np.int64)
@@ -192,7 +194,7 @@ class KrBatch:
         # mistaken for a result - accuracy() refuses)
         self.ablate = int(os.environ.get("WDG_KR_ABLATE", "0"))
         tab["reserved"] = self.ablate
-        self.table = torch.from_numpy(tab.view(np.uint8)).to(dev) if n else torch.empty(0, dtype=torch.uint8)
+        self.table = _h2d(tab.view(np.uint8), dev) if n else torch.empty(0, dtype=torch.uint8)
 
     def launch(self):
         check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")

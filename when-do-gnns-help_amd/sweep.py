@@ -247,7 +247,7 @@ class SweepBatch:
         build = build or os.environ.get("WDG_SWEEP_BUILD", "batched")
         feats, self.graphs, self.dinv, self.labels, self._y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
-        self.tiled_y, self._y_rm, self._untile_each_step, self._y_dirty = False, None, False, True
+        self.tiled_y, self._y_rm, self._untile_each_step, self._y_at = False, None, False, -1
         coos, labs_host = [], []
         for ji, j in enumerate(self.jobs):
             if inputs is not None:
@@ -267,7 +267,7 @@ class SweepBatch:
                 if ride:
                     xa = torch.zeros((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev)
                     xa[:, :n_feat] = x
-                    xa[torch.arange(j.n_nodes, device=dev), n_feat + torch.from_numpy(lab).to(dev)] = 1.0
+                    xa[torch.arange(j.n_nodes, device=dev), n_feat + ops._h2d(np.ascontiguousarray(lab, np.int64), dev)] = 1.0
                     x = xa
                 feats[j.seed], seed_labels[j.seed] = x, lab
             elif ride and not np.array_equal(seed_labels[j.seed], lab):
@@ -313,13 +313,9 @@ class SweepBatch:
         entries = [(g, self.x_agg[j.seed], y, d, d if symmetric else None, False)
                    for j, g, y, d in zip(self.jobs, self.graphs, self.y_agg, self.dinv)]
         self.spmm = ops.SpmmBatch(entries)
-        if self.tiled_y:  # every launch of the aggregation leaves the row-major copy stale: `y` untiles lazily, once per aggregation
-            launch = self.spmm.launch
-
-            def launch_and_mark(*a, **k):
-                self._y_dirty = True
-                return launch(*a, **k)
-            self.spmm.launch = launch_and_mark
+        # (a tiled Y: every launch of the aggregation leaves the row-major copy stale - `y` compares spmm.n_launches with the count
+        # it copied at and untiles lazily, once per aggregation.  No callback into self: a closure over self stored on self.spmm
+        # is a reference cycle, and a batch then dies in the cyclic collector - whenever that runs, e.g. inside a stream capture)
         self.n_classes = n_classes
         self.stats = ops.StatsBatch(self.graphs, self.labels, n_classes)
         self.edges = sum(g.nnz for g in self.graphs)
@@ -389,7 +385,7 @@ class SweepBatch:
         row-major copy: stable addresses, so job tables built on them stay valid; untiled here when an aggregation has run since
         the last copy, i.e. once per aggregation however often the property is read)"""
         if self.tiled_y:
-            if self._y_dirty or self._y_rm is None:
+            if self._y_at != self.spmm.n_launches or self._y_rm is None:
                 self.untile()
             return [self._y_rm[i][:, :self.n_feat] for i in range(len(self.jobs))]
         return self._y
@@ -402,7 +398,7 @@ class SweepBatch:
         if self._y_rm is None:
             self._y_rm = torch.empty((j, n, g * 16), dtype=torch.float32, device=self.y_pool.device)
         self._y_rm.view(j, n, g, 16).copy_(self.y_pool.permute(0, 2, 1, 3))
-        self._y_dirty = False
+        self._y_at = self.spmm.n_launches
 
     def tune(self, rounds=6, steps=5, confirm=24):
         """Balance the aggregation's eight segments (one per XCD) by what they really cost INSIDE the step.  The modelled cut
@@ -545,8 +541,10 @@ class SweepBatch:
             self.step()
         self._step_graph = graph  # keep alive
 
+        spmm = self.spmm
+
         def replay():
-            self._y_dirty = True  # (a replayed aggregation leaves the row-major copy stale like a launched one)
+            spmm.n_launches += 1  # (a replayed aggregation leaves the row-major copy stale like a launched one)
             graph.replay()
         return replay
 
@@ -577,7 +575,7 @@ class SweepBatch:
             host = getattr(self, "labels_host", None)
             if host is not None and len(host) == st.n_jobs:
                 cnt = np.stack([np.bincount(np.asarray(l)[(np.asarray(l) >= 0) & (np.asarray(l) < c)], minlength=c)[:c] for l in host])
-                counts = torch.from_numpy(cnt.astype(np.float32)).to(st.counters.device)
+                counts = self.ops._h2d(cnt.astype(np.float32), st.counters.device)  # (never a blocking pageable copy between launches)
             else:
                 n = st.max_rows
                 lab = torch.stack([torch.nn.functional.pad(l, (0, n - l.shape[0]), value=-1) for l in st.labels]) if st.n_jobs else torch.zeros((0, n))
@@ -686,7 +684,7 @@ class SweepBatch:
                         train_h[2 * ji + clf, e, :tr.shape[0]] = tr.numpy()
                         val_h[2 * ji + clf, e, :va.shape[0]] = va.numpy()
             torch.set_rng_state(rng_state)
-            train, val = torch.from_numpy(train_h).to(dev), torch.from_numpy(val_h).to(dev)
+            train, val = ops._h2d(train_h, dev), ops._h2d(val_h, dev)
         self.kr_train, self.kr_val = train, val
         # the problem table: p = ((job * 2 + classifier) * epochs + epoch) * 2 + (0: the aggregated features' kernel, 1: the raw
         # features' kernel), described by arithmetic on base addresses
@@ -739,12 +737,20 @@ class SweepBatch:
             torch.cuda.current_stream().wait_stream(side)
         self.kr.launch()
 
-    def pinv_accuracies(self, problems, threads=None):
-        """The listed regressions solved the REFERENCE'S way (utils/homophily_plot.py:301-316, utils/homophily_metrics.py:286-297):
-        `K[val][:, train] @ (np.linalg.pinv(K[train][:, train]) @ onehot[train])` in fp32 on the host (numpy's default rcond
-        1e-15: every singular value of an fp32 block kept), arg-max, hit rate on the validation rows.  The blocks are gathered
-        from the device kernels (one gather and one copy per kernel matrix that has listed problems), the pseudo-inverses run
-        on a pool of host threads (LAPACK releases the interpreter lock).
+    def pinv_accuracies(self, problems, threads=None, kernels="host"):
+        """The listed regressions solved the REFERENCE'S way, epoch by epoch (utils/homophily_plot.py:296-316, utils/
+        homophily_metrics.py:283-297): `K[val][:, train] @ (np.linalg.pinv(K[train][:, train]) @ onehot[train])` in fp32 on the host
+        (numpy's default rcond 1e-15: every singular value of an fp32 block kept), arg-max, hit rate on the validation rows.
+        kernels "host" (default): the epoch's kernel computed the reference's way too - the features of the epoch's sample
+                 gathered from the device, their Gram by the host's fp32 GEMM, the arc-cosine map of utils/homophily_metrics.py:
+                 232-257 in numpy - i.e. exactly what WDG_KR_SOLVER=host computes for that epoch.  This matters on rank-deficient
+                 blocks: duplicate nodes give bit-identical rows in a GEMM's Gram, so their null direction is exact and pinv's
+                 inverted rounding-level singular value multiplies an exact zero; the device Gram (products from bf16 pieces,
+                 operand roles not symmetric) leaves such rows a last bit apart, and pinv then amplifies that bit by 1e7 - measured on
+                 the golden epochs (profiles/r05_kr_three_way.txt): up to 28 validation rows from the reference on linear feature
+                 kernels with the device Gram, where the device solver's own ridge answer is within 0 - 1.
+                 "device": the blocks gathered from the device kernels (one gather and one copy per kernel matrix).
+        The pseudo-inverses run on a pool of host threads with one BLAS thread each.
         problems: 1-D array of problem indices p = ((job * 2 + classifier) * epochs + epoch) * 2 + (0 aggregated | 1 raw features).
         -> fp32 accuracies, one per listed problem.  Needs the node sets on the device (after launch_full())."""
         from concurrent.futures import ThreadPoolExecutor
@@ -752,6 +758,8 @@ class SweepBatch:
         out = np.zeros(problems.shape[0], np.float32)
         if not problems.shape[0]:
             return out
+        if kernels not in ("host", "device"):
+            raise ValueError(f"pinv_accuracies: kernels={kernels!r}")
         E = self.kr_epochs
         pair, epoch, which = problems // (2 * E), (problems // 2) % E, problems % 2
         ji, clf = pair // 2, pair % 2
@@ -762,42 +770,84 @@ class SweepBatch:
         n_tr = np.array([int(t.sum()) for _s, t in sizes], np.int64)
         n_va = np.array([int(s_.sum() - t.sum()) for s_, t in sizes], np.int64)
         c = self.n_classes
-        work = []  # (position in `out`, K_tt, K_vt, labels of the train rows, labels of the validation rows)
+        ys = self.y if kernels == "host" else None  # (row-major aggregated features; a tiled Y is copied out once)
+        work = []  # host: (position, H of the sample [train rows first], n_train, classifier, labels train, labels val); device: (position, K_tt, K_vt, ...)
         for key in sorted(set(zip(slot.tolist(), clf.tolist(), ji.tolist()))):
             sl, cl, jb = key
             sel = np.flatnonzero((slot == sl) & (clf == cl) & (ji == jb))
-            kern = (self.gram.k_linear if cl == 0 else self.gram.k_arccos)[sl]
             rows_t = torch.from_numpy((jb * 2 + cl) * np.ones_like(sel))
             tr = self.kr_train[rows_t, torch.from_numpy(epoch[sel])][:, :n_tr[jb]].long()  # [m, n_train] node ids
             va = self.kr_val[rows_t, torch.from_numpy(epoch[sel])][:, :n_va[jb]].long()
-            k_tt = kern[tr[:, :, None], tr[:, None, :]].cpu().numpy()                     # [m, n_train, n_train]
-            k_vt = kern[va[:, :, None], tr[:, None, :]].cpu().numpy()
             lab = np.asarray(self.labels_host[jb]).astype(np.int64)
             tr_h, va_h = tr.cpu().numpy(), va.cpu().numpy()
-            for m_, pos in enumerate(sel):
-                work.append((int(pos), k_tt[m_], k_vt[m_], lab[tr_h[m_]], lab[va_h[m_]]))
+            if kernels == "device":
+                kern = (self.gram.k_linear if cl == 0 else self.gram.k_arccos)[sl]
+                k_tt = kern[tr[:, :, None], tr[:, None, :]].cpu().numpy()                 # [m, n_train, n_train]
+                k_vt = kern[va[:, :, None], tr[:, None, :]].cpu().numpy()
+                for m_, pos in enumerate(sel):
+                    work.append((int(pos), k_tt[m_], k_vt[m_], None, cl, lab[tr_h[m_]], lab[va_h[m_]]))
+            else:
+                h = ys[jb] if sl < len(self.jobs) else self.x[seeds[sl - len(self.jobs)]]
+                both = torch.cat([tr, va], 1)                                            # [m, n_train + n_val]
+                step = max(1, (64 << 20) // max(1, both.shape[1] * h.shape[1] * 4))       # <= 64 MB per copy
+                for a in range(0, both.shape[0], step):
+                    hs = h[both[a:a + step].reshape(-1)].reshape(-1, both.shape[1], h.shape[1]).cpu().numpy()
+                    for m_ in range(hs.shape[0]):
+                        work.append((int(sel[a + m_]), hs[m_], None, int(n_tr[jb]), cl, lab[tr_h[a + m_]], lab[va_h[a + m_]]))
         eye = np.eye(c, dtype=np.float32)
+        eps, pi = np.float32(1e-8), np.float32(np.pi)
+
+        def sample_kernel(hs, n_layers):  # gntk_homophily_ (utils/homophily_metrics.py:232-257) for the rows of one epoch's sample
+            g = hs @ hs.T
+            if n_layers == 1:
+                d = np.sqrt(np.diag(g))
+                nrm = d[:, None] * d[None, :]
+                nrm = np.where(nrm > eps, nrm, eps).astype(np.float32)
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    ac, sq = np.arccos(g / nrm), np.sqrt(np.square(nrm) - np.square(g))
+                ac[np.isnan(ac)], sq[np.isnan(sq)] = 0, 0
+                g = (np.float32(1) / pi * (g * (pi - ac) + sq)).astype(np.float32)
+            return g / np.float32(2)
 
         def solve(item):
-            pos, k_tt, k_vt, lab_t, lab_v = item
-            pred = k_vt @ (np.linalg.pinv(k_tt) @ eye[lab_t])
+            pos, a, b, nt, cl, lab_t, lab_v = item
+            if nt is not None:
+                k = sample_kernel(a, cl)
+                a, b = k[:nt, :nt], k[nt:, :nt]
+            pred = b @ (np.linalg.pinv(a) @ eye[lab_t])
             return pos, np.float32(np.mean(pred.argmax(1) == lab_v))
 
-        threads = threads or int(os.environ.get("WDG_KR_PINV_THREADS", str(min(32, os.cpu_count() or 1))))
-        with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
-            for pos, a in pool.map(solve, work):
-                out[pos] = a
+        # (16 python threads: numpy's pinv holds the interpreter lock between its LAPACK calls - 64 threads measured SLOWER than 16 on
+        # a 128-core host; one BLAS thread per problem - left alone every pinv fans out over all cores and the threads trample
+        # each other: 37 ms per 300 x 300 block against 8 single-threaded)
+        threads = threads or int(os.environ.get("WDG_KR_PINV_THREADS", str(min(16, os.cpu_count() or 1))))
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)
+        except ImportError:  # (no threadpoolctl: correct, only slower)
+            limit = None
+        try:
+            with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+                for pos, acc_ in pool.map(solve, work):
+                    out[pos] = acc_
+        finally:
+            if limit is not None:
+                limit.restore_original_limits()
         return out
 
     def full_metrics(self, ridge=None):
         """[jobs, 9] fp64: results() + ge_homo + the p-values KR_L (kernel_reg0) and KR_NL (kernel_reg1) of the Welch t-test
         over the epochs' accuracies (scipy on the host for the t distribution, as in the reference).
         ridge: what to do with the train blocks the device solver flags as rank deficient at fp32 rounding level
-          "device" (default; WDG_SWEEP_KR_RIDGE) - keep the solver's ridge answers (a few validation rows from the reference's
-                   pseudo-inverse on such blocks; counted in kr_ridged / kr_total and announced once per shard);
-          "pinv"   - solve exactly those blocks again the reference's way (pinv_accuracies: blocks gathered from the device
-                   kernels, np.linalg.pinv on host threads) and patch their accuracies before the t-tests - what the API twin
-                   classifier_based_performance_metric does by default; its cost is kr_pinv_seconds."""
+          "device" (default; WDG_SWEEP_KR_RIDGE) - keep the solver's ridge answers (counted in kr_ridged / kr_total, announced once
+                   per shard).  Measured against what the REFERENCE computed in the same epochs (golden fixtures, profiles/
+                   r05_kr_three_way.txt): within 0 - 2 validation rows on every synthetic-sweep fixture (flagged: the raw pubmed
+                   features' kernels, which hold duplicate rows), within 4 on cora's raw-adjacency kernels;
+          "pinv"   - solve exactly those blocks again the reference's way (pinv_accuracies: the epoch's sample gathered from the
+                   device, its kernel by the host's fp32 GEMM + the arc-cosine map, np.linalg.pinv on host threads) and patch their
+                   accuracies before the t-tests: the reference-equal answer on the sweep path, at ~8 ms of one host core per flagged
+                   block (kr_pinv_seconds).  Nothing is flagged on the synthetic feature bases of bench.py (0 of 672 000); the
+                   pubmed-sample fixtures flag 39 %."""
         ridge = ridge or os.environ.get("WDG_SWEEP_KR_RIDGE", "device")
         if ridge not in ("device", "pinv"):
             raise ValueError(f"full_metrics: ridge={ridge!r} (device | pinv)")
@@ -827,9 +877,9 @@ class SweepBatch:
         elif self.kr_ridged and os.environ.get("WDG_KR_QUIET", "0") in ("", "0"):
             import warnings
             warnings.warn(f"kernel regression: {self.kr_ridged} of {self.kr.n_jobs} train blocks of this shard were rank-deficient at fp32 "
-                          "rounding level and solved with a ridge; their accuracies can differ from the reference's pseudo-inverse by a "
-                          "few validation rows (full_metrics(ridge='pinv') / WDG_SWEEP_KR_RIDGE=pinv solves them again the reference's "
-                          "way on the host)", stacklevel=2)
+                          "rounding level and keep the device solver's ridge answers: within 0 - 2 validation rows of what the reference "
+                          "computed in the same epochs on the synthetic-sweep fixtures, 4 on cora (profiles/r05_kr_three_way.txt); "
+                          "full_metrics(ridge='pinv') / WDG_SWEEP_KR_RIDGE=pinv solves them again the reference's way on the host", stacklevel=2)
         acc = acc.reshape(nj, 2, self.kr_epochs, 2)
         self.kr_acc = acc  # [job, classifier, epoch, (graph-aware, features only)]: diagnostics / tests
         pvals = torch.from_numpy(welch_p_values(acc[..., 0], acc[..., 1]))
