@@ -121,7 +121,9 @@ def _h2d(host, dev=None):
     # (numpy's memcpy / the library's threads, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware
     # thread of the host - measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
     if nbytes >= (1 << 20) and _H2D_THREADS > 1:
-        check(lib.wdg_host_memcpy_mt(c_void_p(piece.data_ptr()), c_void_p(t.data_ptr()), nbytes, _H2D_THREADS), "wdg_host_memcpy_mt")
+        # (a thread per 2 MB, at most WDG_H2D_THREADS: starting a thread costs ~30 us, a megabyte of memcpy ~100)
+        check(lib.wdg_host_memcpy_mt(c_void_p(piece.data_ptr()), c_void_p(t.data_ptr()), nbytes, max(1, min(_H2D_THREADS, nbytes >> 21))),
+              "wdg_host_memcpy_mt")
     else:
         np.copyto(p.numpy(), t.numpy())
     out = p.to(dev, non_blocking=True)

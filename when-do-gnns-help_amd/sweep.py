@@ -248,7 +248,10 @@ class SweepBatch:
         feats, self.graphs, self.dinv, self.labels, self._y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
         self.tiled_y, self._y_rm, self._untile_each_step, self._y_at = False, None, False, -1
-        coos, labs_host = [], []
+        # pass 1 (host only): every job's edge lists and labels; the graph build of the whole shard is QUEUED before the feature
+        # matrices are touched, so that the GPU builds (1.8 ms of kernels per 50-graph shard) while the host copies 20 MB of features
+        # into the upload ring - GraphBatch.finish(), the shard's one read-back, then finds its data ready
+        coos, labs_host, x_hosts = [], [], []
         for ji, j in enumerate(self.jobs):
             if inputs is not None:
                 src, dst, lab, x_host = inputs[ji]
@@ -261,7 +264,15 @@ class SweepBatch:
                 x_host = None
             coos.append((src, dst, j.n_nodes))
             labs_host.append(lab)
+            x_hosts.append(x_host)
+        mode = ops.NORM_SYM if symmetric else ops.NORM_RW
+        if share is None and build == "batched":
+            # A + I of every graph (synthetic_plot.py:92) in one build, the degrees of all of them in one launch
+            self.graph_batch = ops.GraphBatch(coos, ops.COO_ADD_SELF_LOOPS, quad=True, defer=True)
+        for ji, j in enumerate(self.jobs):
+            lab = labs_host[ji]
             if j.seed not in feats:
+                x_host = x_hosts[ji]
                 x = ops._h2d(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
                              else np.ascontiguousarray(x_host, np.float32), dev)
                 if ride:
@@ -272,12 +283,10 @@ class SweepBatch:
                 feats[j.seed], seed_labels[j.seed] = x, lab
             elif ride and not np.array_equal(seed_labels[j.seed], lab):
                 raise ValueError("SweepBatch: jobs of one seed differ in labels; set WDG_SWEEP_RIDE_LABELS=0")
-        mode = ops.NORM_SYM if symmetric else ops.NORM_RW
         if share is not None:
             self.graphs, self.dinv = list(share.graphs), list(share.dinv)
         elif build == "batched":
-            # A + I of every graph (synthetic_plot.py:92) in one build, the degrees of all of them in one launch
-            self.graph_batch = ops.GraphBatch(coos, ops.COO_ADD_SELF_LOOPS, quad=True)
+            self.graph_batch.finish()
             self.graphs = self.graph_batch.graphs
             self.dinv = [d["dinv"] for d in self.graph_batch.degree_norm(mode, ops.PREC_F32, use_values=True)]
         else:
