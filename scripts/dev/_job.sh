@@ -1,10 +1,9 @@
-python -m pytest tests/test_gpu_batched_build.py tests/test_gpu_sweep.py -x -q 2>&1 | tail -4 | cut -c1-300
-python3 scripts/dev/time_cold_build.py 2>&1 | head -12 | cut -c1-200
-python3 bench.py --steps 20 --warmup 5 --configs 0 --train 0 --secondary 0 --projection 0 --full-metrics 0 > gpurun_out/r05_bench_f.json 2> gpurun_out/r05_bench_f.err
-python3 - <<'PY'
-import json
-b=json.load(open('gpurun_out/r05_bench_f.json'))
-print(b['ms_per_step'], 'whole', b['sweep_whole']['seconds'])
-c=b['sweep_cold']
-for k in ('six_scalars','nine_scalars'): print(k, {kk:round(v,2) for kk,v in c[k].items() if isinstance(v,float)}, c[k]['pipelined']['graphs_per_s'])
-PY
+python3 scripts/dev/time_kr_batch.py 5 100 gpurun_out/kr_la.npy 2>&1 | grep -v amdgpu
+WDG_KR_KERNEL=blocked python3 scripts/dev/time_kr_batch.py 5 100 gpurun_out/kr_old.npy 2>&1 | grep -v amdgpu
+python3 -c "
+import numpy as np
+a,b=np.load('gpurun_out/kr_la.npy'),np.load('gpurun_out/kr_old.npy')
+print('hit counts equal:', np.array_equal(a,b))
+"
+export WDG_LIB_PATH=$PWD/when-do-gnns-help_amd/lib/variants/libwdg_hip_kr_prof.so
+python3 scripts/dev/time_kr_batch.py 1 20 2>&1 | grep "k2 cycles" | tail -2
