@@ -578,6 +578,27 @@ int wdg_gram_map_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32
 int wdg_gram_map_batched_flags_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, uint32_t flags, wdg_stream_t stream);
 
 /*
+ * The kernels of the AGGREGATED features without a dense product per graph (round 5): with Y = A_hat X, Y Y^T = A_hat (X X^T) A_hat^T, so
+ * K_linear(Y) = A_hat K_linear(X) A_hat^T - two aggregations with n "features" over the kernel of the raw features (which the metric
+ * computes anyway, once per feature matrix): 2 nnz n flops each instead of n^2 F.  The caller runs
+ *     T = A_hat K_linear(X)   (any aggregation entry point, n features),   wdg_transpose_batched_f32: T -> T^T,
+ *     U = A_hat T^T,          wdg_gram_finish_batched_f32
+ * wdg_gram_finish_batched_f32: job->A = U ([n, n], leading dimension lda; its LOWER triangle is taken as the half Gram G / 2, F is
+ * ignored) -> norm2 = 2 diag(U) = G_ii, K_linear = the lower triangle mirrored, K_arccos = the arc-cosine map of G = 2 U exactly
+ * as wdg_gram_map_batched_f32 maps its Gram.  K_linear may be U itself (in place).  Deterministic.
+ * replaces: the same lines as wdg_gram_map_batched_f32 (utils/homophily_metrics.py:232-243) for the aggregated features - the same
+ *           quantity by another association; entries agree with the direct product to fp32 rounding (tests: rtol 2e-5).
+ */
+typedef struct wdg_transpose_job {
+    const float *src; /* [rows, cols], leading dimension ld_src */
+    float *dst;       /* [cols, rows], leading dimension ld_dst: dst[c][r] = src[r][c] */
+    int64_t ld_src, ld_dst;
+    int32_t rows, cols;
+} wdg_transpose_job;
+int wdg_transpose_batched_f32(const wdg_transpose_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols, wdg_stream_t stream);
+int wdg_gram_finish_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream);
+
+/*
  * Generalized edge homophily from a Gram: mean over the stored non-loop entries (u, v) of cos(x_u, x_v) = 2 K_linear[u, v] /
  * sqrt(norm2[u] norm2[v]) (NaN -> 0), K_linear / norm2 = a wdg_gram_map_batched_f32 output of the feature matrix.
  * replaces: generalized_edge_homophily utils/homophily_plot.py:56-66 (utils/homophily_metrics.py:164-187, below sample_max):

@@ -1,9 +1,9 @@
-python3 scripts/dev/time_kr_batch.py 5 100 gpurun_out/kr_la.npy 2>&1 | grep -v amdgpu
-WDG_KR_KERNEL=blocked python3 scripts/dev/time_kr_batch.py 5 100 gpurun_out/kr_old.npy 2>&1 | grep -v amdgpu
-python3 -c "
-import numpy as np
-a,b=np.load('gpurun_out/kr_la.npy'),np.load('gpurun_out/kr_old.npy')
-print('hit counts equal:', np.array_equal(a,b))
-"
-export WDG_LIB_PATH=$PWD/when-do-gnns-help_amd/lib/variants/libwdg_hip_kr_prof.so
-python3 scripts/dev/time_kr_batch.py 1 20 2>&1 | grep "k2 cycles" | tail -2
+python -m pytest tests/test_gpu_kernels.py -x -q -k "propagated" 2>&1 | tail -4 | cut -c1-300
+python3 bench.py --steps 20 --warmup 5 --configs 0 --train 0 --secondary 0 --cold 0 --full-metrics 0 > gpurun_out/r05_bench_g.json 2> gpurun_out/r05_bench_g.err
+python3 - <<'PY'
+import json
+b=json.load(open('gpurun_out/r05_bench_g.json'))
+print(b['ms_per_step'], 'whole', b['sweep_whole']['seconds'], b['sweep_whole']['ms_per_base_rank0'])
+print(json.dumps(b['scaling_projection']['whole_sweep']['worlds']))
+print(b['sweep_whole']['mean_metrics'])
+PY

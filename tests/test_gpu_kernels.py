@@ -1211,6 +1211,52 @@ def test_gram_map_fused_epilogue(ops, oracle, split, monkeypatch):
     assert only.k_linear[0] is None and torch.equal(only.k_arccos[0], gb.k_arccos[0])
 
 
+@pytest.mark.parametrize("symmetric", [0, 1])
+def test_propagated_gram_equals_the_gram_of_the_aggregated_features(ops, symmetric):
+    """ops.PropagatedGram (wdg_transpose_batched_f32 + wdg_gram_finish_batched_f32 around two aggregations with n "features"):
+    K_linear(A_hat X) = A_hat K_linear(X) A_hat^T against ops.GramBatch over Y = A_hat X itself - every entry within 2e-5 of the
+    largest (fp32 rounding of two different associations), both outputs symmetric bit for bit, norm2 the Gram's own diagonal, the
+    arc-cosine map the same function of (G, norm2); graphs of two sizes that share / do not share a feature matrix, random-walk
+    and symmetric normalisation."""
+    from wdg_amd import synth
+    rng = np.random.default_rng(21 + symmetric)
+    cases = [(600, 4, 0.3, 0, 97), (600, 4, 0.5, 0, 97), (2000, 10, 0.2, 1, 700), (2000, 10, 0.8, 1, 700), (2000, 2, 0.1, 2, 700)]
+    feats, graphs, scales, ys, tw = {}, [], [], [], []
+    for n, k, h, seed, f in cases:
+        if (n, seed) not in feats:
+            feats[(n, seed)] = torch.from_numpy(synth.features(n, f, seed)).cuda()
+        src, dst, _lab = synth.regular_graph(n, 5, k, h, seed)
+        g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+        assert g.ensure_quad()
+        d = ops.degree_norm(g, ops.NORM_SYM if symmetric else ops.NORM_RW, ops.PREC_F32)["dinv"]
+        graphs.append(g)
+        scales.append(d)
+        ys.append(ops.spmm(g, feats[(n, seed)], row_scale=d, col_scale=d if symmetric else None))
+    direct = ops.GramBatch(ys)
+    direct.launch()
+    gx = ops.GramBatch(list(feats.values()))
+    gx.launch()
+    kx = dict(zip(feats, gx.k_linear))
+    prop = ops.PropagatedGram([(g, d, d if symmetric else None, kx[(c[0], c[3])]) for g, d, c in zip(graphs, scales, cases)])
+    prop.launch()
+    torch.cuda.synchronize()
+    for i in range(len(cases)):
+        a, b = _np(direct.k_linear[i]), _np(prop.k_linear[i])
+        scale = float(np.abs(a).max())
+        np.testing.assert_allclose(b, a, rtol=0, atol=2e-5 * scale, err_msg=f"K_linear {cases[i]}")
+        assert torch.equal(prop.k_linear[i], prop.k_linear[i].T) and torch.equal(prop.k_arccos[i], prop.k_arccos[i].T)
+        assert np.array_equal(_np(prop.norm2[i]), 2.0 * np.diag(b))       # G_ii from the propagated Gram's own diagonal, same bits
+        np.testing.assert_allclose(_np(prop.norm2[i]), _np(direct.norm2[i]), rtol=2e-5)
+        want = _arccos_map(2.0 * b, 1)                                    # the map on the kernel's own Gram (numpy's fp32 map)
+        np.testing.assert_allclose(_np(prop.k_arccos[i]), want, rtol=2e-5, atol=2e-6 * max(float(np.abs(want).max()), 1e-30))
+        np.testing.assert_allclose(_np(prop.k_arccos[i]), _np(direct.k_arccos[i]), rtol=0, atol=3e-4 * float(np.abs(want).max()))
+        assert np.allclose(np.diag(_np(prop.k_arccos[i])), np.diag(b), rtol=5e-4)  # K_arccos(i, i) = G_ii / 2 up to acos near 1
+    again = [k.clone() for k in prop.k_arccos]
+    prop.launch()  # the finish pass runs in place on K_linear: a relaunch recomputes everything from the raw features' kernels
+    torch.cuda.synchronize()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(again, prop.k_arccos))
+
+
 @pytest.mark.parametrize("n,nt,nv,c", [(500, 300, 200, 5), (183, 110, 73, 5), (400, 320, 80, 8), (64, 33, 31, 2), (50, 1, 49, 3)])
 def test_kernel_regression_solver_against_lapack(ops, n, nt, nv, c):
     """wdg_kernel_regress_batched_f32 on well-conditioned kernels: per problem, the number of validation rows whose arg-max

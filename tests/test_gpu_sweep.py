@@ -123,6 +123,46 @@ def test_whole_sweep_over_feature_bases_equals_stand_alone_batches():
         assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (si, bi)
 
 
+def test_nine_scalars_with_propagated_grams_match_the_direct_route(monkeypatch):
+    """SweepBatch.prepare_full with WDG_GRAM_ROUTE=propagate (the aggregated features' kernels as A_hat K(X) A_hat^T: what the
+    sweep takes for the reference's wide feature bases) against the direct route (the Gram of Y) on the golden synthetic fixtures,
+    host-drawn node sets: the seven scalars that do not depend on the kernels identical, every epoch's accuracy within 2
+    validation rows, the p-values within what that implies; and against the reference's own recorded epochs (kr_epochs.npz)
+    within the same 2 rows as the direct route is held to."""
+    from _golden import SYN, dense_features, load, load_kr, p_tolerance
+    from wdg_amd import sweep
+    from wdg_amd.utils import util_funcs as uf
+    jobs, inputs = [], []
+    for i, name in enumerate(SYN):
+        g0 = load(name)
+        n = int(g0["n_nodes"])
+        x = uf.preprocess_features(torch.from_numpy(dense_features(g0))).cpu().numpy()
+        jobs.append(sweep.Job(float(name.split("_")[2]), 100 + i, 10 if "_4000_" in name else 2, n, int(g0["labels"].max()) + 1))
+        inputs.append((g0["adj_row"].astype(np.int64), g0["adj_col"].astype(np.int64), g0["labels"], x))
+    rows, accs = {}, {}
+    for route in ("direct", "propagate"):
+        monkeypatch.setenv("WDG_GRAM_ROUTE", route)
+        sb = sweep.SweepBatch(jobs, n_feat=inputs[0][3].shape[1], gcn_hidden=0, inputs=inputs)
+        sb.prepare_full(epochs=8, sample_max=500, seed_of=lambda ji, clf: 5)
+        assert sb.gram_route == route
+        sb.step()
+        sb.launch_full()
+        torch.cuda.synchronize()
+        rows[route] = sb.full_metrics().numpy()
+        accs[route] = sb.kr_acc.copy()  # [job, clf, epoch, (graph, features)]
+    assert np.array_equal(rows["direct"][:, :7], rows["propagate"][:, :7])
+    assert np.array_equal(accs["direct"][..., 1], accs["propagate"][..., 1])  # the raw features' kernels are the same launch
+    d_rows = np.abs(accs["direct"][..., 0].astype(np.float64) - accs["propagate"][..., 0]) * 200
+    assert d_rows.max() <= 2.01, d_rows.max()
+    for ji, name in enumerate(SYN):
+        kr = load_kr(name)
+        for ci, clf in enumerate(("kernel_reg0", "kernel_reg1")):
+            g_ref, x_ref = kr[clf]["g_results"][:8], kr[clf]["x_results"][:8]
+            assert np.abs(accs["propagate"][ji, ci, :, 0] - g_ref).max() <= 2.01 / 200, (name, clf)
+            tol = p_tolerance(g_ref, x_ref, 200.0, 2)
+            assert abs(rows["propagate"][ji, 7 + ci] - rows["direct"][ji, 7 + ci]) <= 2 * tol + 1e-12, (name, clf)
+
+
 def test_whole_sweep_rows_do_not_depend_on_the_world_size():
     """sweep.whole_sweep_rank + exchange_rows (bench.py's N-rank `sweep_whole`): the adjacencies dealt to 1, 2 and 3 "ranks" (run
     one after the other on this GPU; a rank's rows keyed by the pair's position in the job list) assemble to the SAME [pairs x

@@ -127,6 +127,8 @@ SIGNATURES = {
     "wdg_las_fused_eligible": (c_int, [c_int32, c_int32, c_int32]),
     "wdg_gram_map_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "wdg_gram_map_batched_flags_f32": (c_int, [c_void_p, c_int32, c_int32, c_uint32, c_void_p]),
+    "wdg_transpose_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_gram_finish_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "wdg_kernel_regress_max_train": (c_int32, []),
     "wdg_edge_gram_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "wdg_edge_gram_mean_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
@@ -146,6 +148,11 @@ class GramJob(ctypes.Structure):
     """mirror of `wdg_gram_job` (include/wdg.h)"""
     _fields_ = [("A", c_void_p), ("norm2", c_void_p), ("K_linear", c_void_p), ("K_arccos", c_void_p), ("lda", c_int64),
                 ("ldk", c_int64), ("n", c_int32), ("F", c_int32), ("a_group_stride", c_int64)]
+
+
+class TransposeJob(ctypes.Structure):
+    """mirror of `wdg_transpose_job` (include/wdg.h)"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("ld_src", c_int64), ("ld_dst", c_int64), ("rows", c_int32), ("cols", c_int32)]
 
 
 class EdgeGramJob(ctypes.Structure):

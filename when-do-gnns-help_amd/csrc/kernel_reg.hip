@@ -401,6 +401,92 @@ __global__ __launch_bounds__(GTHREADS) void gram_split_kernel(const wdg_gram_job
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the Gram of aggregated features, propagated
+// Round 5.  The kernels of the AGGREGATED features are those of Y = A_hat X, and Y Y^T = A_hat (X X^T) A_hat^T: two aggregations
+// with n "features" over the Gram of the raw features - which the metric computes anyway, once per feature matrix - instead of a
+// dense n x n x F product per graph: 2 nnz n flops each against n^2 F.  For the reference's feature bases (F = 932 .. 3 703, n =
+// 2 000, 12 .. 67 entries per row) that is 4 .. 18 x less work, none of it on the matrix pipe's critical path, and the wide
+// aggregation Y itself is no longer needed by the metric.  The propagation runs on the quad-row aggregation kernel
+// (T = A_hat K_X, U = A_hat T^T); this file supplies the two small passes around it: the transpose between the two products and
+// the FINISH pass - the lower triangle of U is the half Gram K_linear = G / 2 of the aggregated features; it is mirrored (a
+// floating-point A_hat T^T is symmetric only to rounding) and mapped exactly as the direct kernels' epilogue maps their G.
+// gram_half_diag_kernel: norm2[i] = 2 U[i][i] = G_ii, so that the arc-cosine of a row with itself is exactly 1 here too.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const wdg_transpose_job *__restrict__ jobs) {
+    __shared__ float tile[32][33];
+    const desc_ptr<wdg_transpose_job> job = (desc_ptr<wdg_transpose_job>)(jobs + blockIdx.z);
+    const int rows = job->rows, cols = job->cols;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    if (r0 >= rows || c0 >= cols) return;
+    const global_ptr<const float> src = to_global(job->src);
+    const global_ptr<float> dst = to_global(job->dst);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int r = r0 + ty + 8 * m, c = c0 + tx;
+        tile[ty + 8 * m][tx] = (r < rows && c < cols) ? src[static_cast<int64_t>(r) * job->ld_src + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int c = c0 + ty + 8 * m, r = r0 + tx;  // dst[c][r] = src[r][c]
+        if (c < cols && r < rows) dst[static_cast<int64_t>(c) * job->ld_dst + r] = tile[tx][ty + 8 * m];
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_half_diag_kernel(const wdg_gram_job *__restrict__ jobs) {
+    const desc_ptr<wdg_gram_job> job = (desc_ptr<wdg_gram_job>)(jobs + blockIdx.y);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= job->n) return;
+    to_global(job->norm2)[i] = 2.f * to_global(job->A)[static_cast<int64_t>(i) * job->lda + i];
+}
+
+__global__ __launch_bounds__(256) void gram_finish_kernel(const wdg_gram_job *__restrict__ jobs) {
+    __shared__ float t_lin[32][33], t_arc[32][33];
+    const desc_ptr<wdg_gram_job> job = (desc_ptr<wdg_gram_job>)(jobs + blockIdx.z);
+    const int n = job->n;
+    const int ti = blockIdx.y, tj = blockIdx.x;  // tile (ti, tj) of the lower triangle: rows 32 ti .., columns 32 tj ..
+    if (tj > ti || 32 * ti >= n) return;
+    const global_ptr<const float> H = to_global(job->A), norm2 = to_global(job->norm2);
+    const global_ptr<float> Klin = to_global(job->K_linear), Karc = to_global(job->K_arccos);
+    const int64_t lda = job->lda, ldk = job->ldk;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float pi = 3.14159265358979323846f;
+    const int j = 32 * tj + tx;
+    const float dn = (Karc && j < n) ? sqrtf(norm2[j]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i = 32 * ti + ty + 8 * m;
+        float k = 0.f, kv = 0.f;
+        if (i < n && j < n) {
+            k = H[static_cast<int64_t>(max(i, j)) * lda + min(i, j)];  // (the lower triangle is the authority; only a diagonal tile has i < j)
+            const float g = k + k;
+            if (Klin) Klin[static_cast<int64_t>(i) * ldk + j] = k;
+            if (Karc) {  // the map of utils/homophily_metrics.py:236-242, as the direct kernels' epilogue computes it
+                float nu = sqrtf(norm2[i]) * dn;
+                nu = nu > 1e-8f ? nu : 1e-8f;
+                float ac = acosf(g / nu);
+                float sq = sqrtf(nu * nu - g * g);
+                ac = ac != ac ? 0.f : ac;
+                sq = sq != sq ? 0.f : sq;
+                kv = (1.f / pi) * (g * (pi - ac) + sq) * 0.5f;
+                Karc[static_cast<int64_t>(i) * ldk + j] = kv;
+            }
+        }
+        t_lin[ty + 8 * m][tx] = k;
+        t_arc[ty + 8 * m][tx] = kv;
+    }
+    if (ti == tj) return;  // (workgroup-uniform) a diagonal tile wrote both of its halves itself
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // the mirror image: entry (32 tj + ty + 8 m, 32 ti + tx) = entry (32 ti + tx, 32 tj + ty + 8 m)
+        const int r = 32 * tj + ty + 8 * m, c = 32 * ti + tx;
+        if (r < n && c < n) {
+            if (Klin) Klin[static_cast<int64_t>(r) * ldk + c] = t_lin[tx][ty + 8 * m];
+            if (Karc) Karc[static_cast<int64_t>(r) * ldk + c] = t_arc[tx][ty + 8 * m];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ mean edge cosine from a Gram
 // generalized edge homophily (utils/homophily_plot.py:56-66, utils/homophily_metrics.py:164-187) when the features' Gram is at
 // hand anyway (the kernel-regression metric computes K_linear = X X^T / 2 per feature matrix): cos(x_u, x_v) =
@@ -1556,6 +1642,26 @@ int wdg_gram_map_batched_flags_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs,
     hipLaunchKernelGGL(gram_map_kernel, dim3(wdg::ceil_div(max_n, GBM), wdg::ceil_div(max_n, GBN), n_jobs), dim3(GTHREADS), 0, st,
                        jobs_dev);
     return wdg::check_launch("gram_map_kernel");
+}
+
+int wdg_transpose_batched_f32(const wdg_transpose_job *jobs_dev, int32_t n_jobs, int32_t max_rows, int32_t max_cols, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_rows >= 0 && max_cols >= 0, "transpose_batched: negative size");
+    if (n_jobs == 0 || max_rows == 0 || max_cols == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "transpose_batched: null job table");
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(wdg::ceil_div(max_cols, 32), wdg::ceil_div(max_rows, 32), n_jobs), dim3(256), 0,
+                       wdg::as_stream(stream), jobs_dev);
+    return wdg::check_launch("transpose_batched_kernel");
+}
+
+int wdg_gram_finish_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, int32_t max_n, wdg_stream_t stream) {
+    WDG_REQUIRE(n_jobs >= 0 && max_n >= 0, "gram_finish_batched: negative size");
+    if (n_jobs == 0 || max_n == 0) return WDG_OK;
+    WDG_REQUIRE(jobs_dev != nullptr, "gram_finish_batched: null job table");
+    hipStream_t st = wdg::as_stream(stream);
+    hipLaunchKernelGGL(gram_half_diag_kernel, dim3(wdg::ceil_div(max_n, 256), n_jobs), dim3(256), 0, st, jobs_dev);
+    const unsigned tiles = static_cast<unsigned>(wdg::ceil_div(max_n, 32));
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(tiles, tiles, n_jobs), dim3(256), 0, st, jobs_dev);
+    return wdg::check_launch("gram_finish_kernel");
 }
 
 int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream) {

@@ -203,6 +203,21 @@ def whole_sweep_rank(pairs, graph_of, bases, world, rank, epochs=100, max_pairs_
     return torch.cat(keys), torch.cat(rows)
 
 
+class _GramPair:
+    """the kernels of a shard in GramBatch's slot order - [every job's aggregated features] + [every feature matrix] - when the two
+    halves come from different launches (ops.PropagatedGram over the jobs, ops.GramBatch over the raw features, which runs first)"""
+
+    def __init__(self, jobs_part, feats_part):
+        self.jobs_part, self.feats_part = jobs_part, feats_part
+        self.k_linear = list(jobs_part.k_linear) + list(feats_part.k_linear)
+        self.k_arccos = list(jobs_part.k_arccos) + list(feats_part.k_arccos)
+        self.norm2 = list(jobs_part.norm2) + list(feats_part.norm2)
+
+    def launch(self):
+        self.feats_part.launch()
+        self.jobs_part.launch()
+
+
 class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
@@ -233,6 +248,7 @@ class SweepBatch:
         self.inputs = inputs
         dev = ops.require_gpu()
         self.n_feat = n_feat
+        self.symmetric = symmetric
         n_classes = max([j.n_classes for j in self.jobs], default=0)
         # Label columns ride along: the aggregation walks X in 16-feature groups and the last group of F = 500 is three
         # quarters empty, so [X | onehot(labels) | 0] (F_agg = 512) costs the same 32 groups and the separate F = C
@@ -660,14 +676,32 @@ class SweepBatch:
         if self.n_classes > ops.KrBatch.MAX_CLASSES:
             raise ValueError(f"SweepBatch.prepare_full: {self.n_classes} classes, the device solver holds {ops.KrBatch.MAX_CLASSES}; "
                              "use utils.homophily_metrics.classifier_based_performance_metric (host path) per graph")
-        # kernels: [aggregated features of every job] + [raw features of every feature matrix], linear and arc-cosine
-        if self.tiled_y and ops.GramBatch.tiled_ok():  # the Gram kernels read the tiled aggregation output as it is
-            ys = [ya.columns(self.n_feat) for ya in self.y_agg]
-        else:  # row-major: with a tiled Y the copy, refreshed behind every aggregation from here on
-            ys = self.y
-            self._untile_each_step = self.tiled_y
-        self.gram = ops.GramBatch([ys[i] for i in range(J)] + [self.x[s] for s in seeds])
+        # kernels: [aggregated features of every job] + [raw features of every feature matrix], linear and arc-cosine.
+        # Two routes to the aggregated features' kernels (WDG_GRAM_ROUTE=direct|propagate|auto):
+        #   direct     the Gram of Y = A_hat X, one dense n x n x F product per job (ops.GramBatch over Y);
+        #   propagate  K_linear(Y) = A_hat K_linear(X) A_hat^T: two aggregations with n "features" over the raw features' half Gram
+        #              (ops.PropagatedGram) - 2 nnz n flops each instead of n^2 F; auto takes it from F = 640 on (the reference's
+        #              bases: every one but pubmed), where the dense product costs 2 - 7 x the propagation (round 5).
+        route = os.environ.get("WDG_GRAM_ROUTE", "auto")
+        if route not in ("auto", "direct", "propagate"):
+            raise ValueError(f"WDG_GRAM_ROUTE={route!r}")
+        nodes = {j.n_nodes for j in self.jobs}
+        can = len(nodes) == 1 and not ops.quad_disabled() and all(g.ensure_quad() for g in self.graphs)
+        self.gram_route = "propagate" if can and (route == "propagate" or (route == "auto" and self.n_feat >= 640)) else "direct"
         x_slot = {s: J + i for i, s in enumerate(seeds)}
+        if self.gram_route == "propagate":
+            gx = ops.GramBatch([self.x[s] for s in seeds])
+            sym = getattr(self, "symmetric", 0)
+            gy = ops.PropagatedGram([(g, d, d if sym else None, gx.k_linear[x_slot[j.seed] - J])
+                                     for j, g, d in zip(self.jobs, self.graphs, self.dinv)])
+            self.gram = _GramPair(gy, gx)
+        else:
+            if self.tiled_y and ops.GramBatch.tiled_ok():  # the Gram kernels read the tiled aggregation output as it is
+                ys = [ya.columns(self.n_feat) for ya in self.y_agg]
+            else:  # row-major: with a tiled Y the copy, refreshed behind every aggregation from here on
+                ys = self.y
+                self._untile_each_step = self.tiled_y
+            self.gram = ops.GramBatch([ys[i] for i in range(J)] + [self.x[s] for s in seeds])
         self.ge = ops.EdgeGramBatch([(g, self.gram.k_linear[x_slot[j.seed]], self.gram.norm2[x_slot[j.seed]])
                                      for j, g in zip(self.jobs, self.graphs)])
         sizes = [ops.kr_split_sizes(lab, sample_max) for lab in self.labels_host]
