@@ -24,7 +24,11 @@ pairs, graphs, feats = inp["pairs"], inp["graphs"], inp["feats"]
 graph_of = lambda j: graphs[(j.h, j.seed)]  # noqa: E731
 sweep.whole_sweep_rank(pairs[:4], graph_of, feats, 1, 0)
 torch.cuda.synchronize()
-for rep in range(2):
+import gc
+for rep in range(4):
+    if rep == 2:
+        gc.disable()
+        print("-- cyclic collector off --")
     t0 = time.perf_counter()
     keys, rows = sweep.whole_sweep_rank(pairs, graph_of, feats, world, rank)
     torch.cuda.synchronize()

@@ -103,13 +103,16 @@ def test_whole_sweep_over_feature_bases_equals_stand_alone_batches():
     graphs = {(h, s_): synth.regular_graph(600, 5, 4, h, s_) for h in levels for s_ in samples}
     bases = [("a", {s_: synth.features(600, 40, 10 + s_) for s_ in samples}, 500),
              ("b", {s_: synth.features(600, 530, 20 + s_) for s_ in samples}, 300),
-             ("c", {s_: synth.features(600, 97, 30 + s_) for s_ in samples}, 500)]
+             ("c", {s_: synth.features(600, 97, 30 + s_) for s_ in samples}, 500),
+             # (a width the sweep driver propagates: label columns only in the aggregation, K(A_hat X) = A_hat K(X) A_hat^T - the
+             # stand-alone batch below aggregates the features as well and takes the same route for the kernels)
+             ("d", {s_: synth.features(600, 656, 40 + s_) for s_ in samples}, 500)]
     shards = []
     for lv in (levels[:2], levels[2:]):
         jobs = sweep.make_jobs(lv, samples, k=4, n_nodes=600)
         shards.append((jobs, [graphs[(j.h, j.seed)] for j in jobs]))
     got = {(si, bi): rows for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=2, first_seed=5)}
-    assert sorted(got) == [(si, bi) for si in range(2) for bi in range(3)]
+    assert sorted(got) == [(si, bi) for si in range(2) for bi in range(4)]
     for (si, bi), rows in got.items():
         jobs, gi = shards[si]
         _name, feats, sample_max = bases[bi]

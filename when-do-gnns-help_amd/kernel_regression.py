@@ -58,6 +58,9 @@ class GramBatch:
               "wdg_gram_map_batched_flags_f32")
 
 
+_PROP_SCRATCH = {}  # (stream, node counts) -> (T, T^T) scratch of PropagatedGram: launches on one stream run in order
+
+
 class PropagatedGram:
     """The kernels of the AGGREGATED features of many graphs WITHOUT a dense product per graph: Y = A_hat X gives Y Y^T = A_hat (X X^T)
     A_hat^T, so K_linear(Y) = A_hat K_linear(X) A_hat^T - two batched aggregations with n "features" over the half Gram of the raw
@@ -81,8 +84,15 @@ class PropagatedGram:
         # U = A_hat T^T lands in the K_linear buffers (the finish pass works in place); T and T^T are scratch
         self.k_linear = [torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns]
         self.k_arccos = [torch.empty((n, n), dtype=torch.float32, device=dev) if arccos else None for n in ns]
-        self._t = [torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns]
-        self._tt = [torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns]
+        # T and T^T are scratch between the launches of ONE launch(): kept per (stream, shapes) across batches - a sweep builds a
+        # batch like this per feature base and shard, 2 x 70 allocations of 16 MB each time otherwise
+        key = (torch.cuda.current_stream().cuda_stream, tuple(ns))
+        if key not in _PROP_SCRATCH:
+            if len(_PROP_SCRATCH) >= 4:
+                _PROP_SCRATCH.pop(next(iter(_PROP_SCRATCH)))
+            _PROP_SCRATCH[key] = ([torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns],
+                                  [torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns])
+        self._t, self._tt = _PROP_SCRATCH[key]
         self.first = SpmmBatch([(g, kx, t, rs, cs, False) for (g, rs, cs, kx), t in zip(problems, self._t)])
         self.second = SpmmBatch([(g, tt, u, rs, cs, False) for (g, rs, cs, _kx), tt, u in zip(problems, self._tt, self.k_linear)])
         tr = (_lib.TransposeJob * self.n_jobs)()

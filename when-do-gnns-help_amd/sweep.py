@@ -222,7 +222,7 @@ class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
     def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None, share=None, feature_seed=0, tune=False,
-                 build=None):
+                 build=None, labels_only=False):
         """jobs: list of Job (graph + features come from the generator of synth.py) - or, with `inputs`, a list of the same
         length of (src, dst, labels, features [n, n_feat] fp32 numpy) tuples to run instead (real / fixture graphs; jobs that
         share a feature matrix must pass the same array object and carry the same `seed`).
@@ -234,6 +234,10 @@ class SweepBatch:
         CsrGraph.from_coo + ensure_quad per graph (~20 launches and two host syncs each), kept for A/B runs and tests.
         tune: balance the aggregation's tape cut by feedback (tune() below: ~90 extra steps) - worth it for a batch that is
         replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut.
+        labels_only: aggregate the one-hot LABEL columns only (one 16-feature group: everything the six step scalars need); the
+        feature matrices are uploaded for the kernel-regression metric, whose aggregated-feature kernels then come by propagation
+        (prepare_full: K(A_hat X) = A_hat K(X) A_hat^T) - the reference's sweep over its wide feature bases (F up to 3 703) never
+        needs A_hat X itself.  Needs gcn_hidden = 0; `y` aggregates the features on demand (the host re-solve of flagged blocks).
 
         The aggregated features are kept TILED by 16-feature groups (ops.Tiled: y_agg[i].t is [groups, n, 16]) when everything
         that reads them inside the step can - the label columns of LAS as a strided view, the fused transform through
@@ -255,11 +259,14 @@ class SweepBatch:
         # aggregation launch of the LAS metric disappears.  Needs one label vector per feature matrix (true for the
         # generator: labels = node // class size); WDG_SWEEP_RIDE_LABELS=0 keeps the separate launch.
         ride = os.environ.get("WDG_SWEEP_RIDE_LABELS", "1") != "0" and n_classes > 0
+        self.labels_only = bool(labels_only and ride and not gcn_hidden and n_classes <= 16)
+        lab_col = 0 if self.labels_only else n_feat  # first label column of [X | onehot | 0]
+        self.lab_col = lab_col
         # rows of [X | onehot | 0] and of Y are padded to whole 16-feature groups: every 64-byte row segment an item stores
         # is then 64-byte aligned (one L2 write request instead of two: 220 against 225 us per launch; ..._ALIGN=4 to compare)
         align = int(os.environ.get("WDG_SWEEP_AGG_ALIGN", "16"))
-        self.agg_feat = (n_feat + n_classes + align - 1) // align * align if ride else n_feat
-        self.alg_feat = n_feat + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
+        self.agg_feat = (lab_col + n_classes + align - 1) // align * align if ride else n_feat
+        self.alg_feat = lab_col + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
         build = build or os.environ.get("WDG_SWEEP_BUILD", "batched")
         feats, self.graphs, self.dinv, self.labels, self._y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
@@ -267,7 +274,7 @@ class SweepBatch:
         # pass 1 (host only): every job's edge lists and labels; the graph build of the whole shard is QUEUED before the feature
         # matrices are touched, so that the GPU builds (1.8 ms of kernels per 50-graph shard) while the host copies 20 MB of features
         # into the upload ring - GraphBatch.finish(), the shard's one read-back, then finds its data ready
-        coos, labs_host, x_hosts = [], [], []
+        coos, labs_host, x_hosts, x_feat = [], [], [], {}
         for ji, j in enumerate(self.jobs):
             if inputs is not None:
                 src, dst, lab, x_host = inputs[ji]
@@ -292,9 +299,19 @@ class SweepBatch:
                 x = ops._h2d(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
                              else np.ascontiguousarray(x_host, np.float32), dev)
                 if ride:
-                    xa = torch.zeros((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev)
-                    xa[:, :n_feat] = x
-                    xa[torch.arange(j.n_nodes, device=dev), n_feat + ops._h2d(np.ascontiguousarray(lab, np.int64), dev)] = 1.0
+                    # [X | onehot(labels) | 0]: the label block is laid out on the host and uploaded like any other array (an
+                    # index assignment `xa[arange, labels] = 1` on the device SYNCHRONISES the host with the stream - 3 ms a
+                    # piece behind queued regressions: a third of the whole sweep's host time in round 5's line profile)
+                    tail = np.zeros((j.n_nodes, self.agg_feat - lab_col), np.float32)
+                    ok = (lab >= 0) & (lab < self.agg_feat - lab_col)
+                    tail[np.flatnonzero(ok), lab[ok]] = 1.0
+                    if self.labels_only:
+                        x_feat[j.seed] = x
+                        xa = ops._h2d(tail, dev)
+                    else:
+                        xa = torch.empty((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev)
+                        xa[:, :n_feat] = x
+                        xa[:, lab_col:] = ops._h2d(tail, dev)
                     x = xa
                 feats[j.seed], seed_labels[j.seed] = x, lab
             elif ride and not np.array_equal(seed_labels[j.seed], lab):
@@ -322,7 +339,7 @@ class SweepBatch:
                                       and gcn_hidden <= ops.Mlp2Batch.MAX_H and n_classes <= ops.Mlp2Batch.MAX_C
                                       and 0 < n_feat <= ops.Mlp2Batch.MAX_K and n_feat % 4 == 0)
         self.tiled_y = bool(os.environ.get("WDG_SWEEP_TILED_Y", "1") != "0" and ride and self.agg_feat % 16 == 0 and len(nodes) == 1
-                            and (n_feat % 16) + n_classes <= 16 and mlp_ok and not ops.quad_disabled()
+                            and (lab_col % 16) + n_classes <= 16 and mlp_ok and not ops.quad_disabled()
                             and all(g.ensure_quad() for g in self.graphs))
         if self.tiled_y:
             n = next(iter(nodes))
@@ -332,8 +349,9 @@ class SweepBatch:
             for j in self.jobs:
                 self.y_agg.append(torch.empty((j.n_nodes, self.agg_feat), dtype=torch.float32, device=dev))
                 self._y.append(self.y_agg[-1][:, :n_feat])  # the feature part (a view: leading dimension agg_feat)
-        self.x_agg = feats                                        # what the aggregation reads: [X | onehot | 0]
-        self.x = {s: x[:, :n_feat] for s, x in feats.items()}     # the features proper (views)
+        self.x_agg = feats                                        # what the aggregation reads: [X | onehot | 0] (labels_only: [onehot | 0])
+        self.x = x_feat if self.labels_only else {s: x[:, :n_feat] for s, x in feats.items()}  # the features proper
+        self._y_lazy = None
         # A + I has unit values except a doubled pre-existing loop; the generator emits no loops -> pattern only
         entries = [(g, self.x_agg[j.seed], y, d, d if symmetric else None, False)
                    for j, g, y, d in zip(self.jobs, self.graphs, self.y_agg, self.dinv)]
@@ -352,10 +370,10 @@ class SweepBatch:
         self.h_las = []
         if ride:
             if self.tiled_y:  # the label columns lie inside one 16-feature group: [n, C] views with a row stride of 16 floats
-                g_lab, off = n_feat // 16, n_feat % 16
+                g_lab, off = lab_col // 16, lab_col % 16
                 self.h_las = [ya.t[g_lab][:, off:off + n_classes] for ya in self.y_agg]
             else:
-                self.h_las = [ya[:, n_feat:n_feat + n_classes] for ya in self.y_agg]  # written by the feature aggregation
+                self.h_las = [ya[:, lab_col:lab_col + n_classes] for ya in self.y_agg]  # written by the feature aggregation
             self.spmm_las = None
         else:
             las_entries = []
@@ -376,8 +394,8 @@ class SweepBatch:
         # GCN-2 forward (build-defined model, models.py): logits = A_hat relu((A_hat X) W0) W1, every job its own weights
         self.gcn = None
         n_streams = int(os.environ.get("WDG_SWEEP_STREAMS", "2"))  # see step_rest
-        self.side = torch.cuda.Stream() if n_streams >= 2 else None
-        self.side2 = torch.cuda.Stream() if n_streams >= 3 else None
+        self.side = _side_stream(0) if n_streams >= 2 else None
+        self.side2 = _side_stream(1) if n_streams >= 3 else None
         self._fork = torch.cuda.Event()
         if gcn_hidden:
             gen = torch.Generator(device="cpu").manual_seed(1234)
@@ -409,6 +427,11 @@ class SweepBatch:
         """list of [n, n_feat] row-major tensors, one per job (views of the aggregation's output - or, with a tiled Y, of a
         row-major copy: stable addresses, so job tables built on them stay valid; untiled here when an aggregation has run since
         the last copy, i.e. once per aggregation however often the property is read)"""
+        if self.labels_only:  # the step aggregates the label columns only: the features' aggregation on demand, once
+            if self._y_lazy is None:
+                sc = (lambda d: d) if self.symmetric else (lambda d: None)
+                self._y_lazy = [self.ops.spmm(g, self.x[j.seed], row_scale=d, col_scale=sc(d)) for j, g, d in zip(self.jobs, self.graphs, self.dinv)]
+            return self._y_lazy
         if self.tiled_y:
             if self._y_at != self.spmm.n_launches or self._y_rm is None:
                 self.untile()
@@ -687,7 +710,9 @@ class SweepBatch:
             raise ValueError(f"WDG_GRAM_ROUTE={route!r}")
         nodes = {j.n_nodes for j in self.jobs}
         can = len(nodes) == 1 and not ops.quad_disabled() and all(g.ensure_quad() for g in self.graphs)
-        self.gram_route = "propagate" if can and (route == "propagate" or (route == "auto" and self.n_feat >= 640)) else "direct"
+        self.gram_route = "propagate" if can and (route == "propagate" or (route == "auto" and self.n_feat >= 640) or self.labels_only) else "direct"
+        if self.labels_only and self.gram_route != "propagate":
+            raise ValueError("SweepBatch(labels_only=True): the aggregated features' kernels need the propagated route (graphs of one size on the quad-row kernel)")
         x_slot = {s: J + i for i, s in enumerate(seeds)}
         if self.gram_route == "propagate":
             gx = ops.GramBatch([self.x[s] for s in seeds])
@@ -704,7 +729,13 @@ class SweepBatch:
             self.gram = ops.GramBatch([ys[i] for i in range(J)] + [self.x[s] for s in seeds])
         self.ge = ops.EdgeGramBatch([(g, self.gram.k_linear[x_slot[j.seed]], self.gram.norm2[x_slot[j.seed]])
                                      for j, g in zip(self.jobs, self.graphs)])
-        sizes = [ops.kr_split_sizes(lab, sample_max) for lab in self.labels_host]
+        size_of = {}  # (the jobs of a sweep share a handful of label vectors: the per-class sizes once per distinct one)
+        sizes = []
+        for lab in self.labels_host:
+            key = np.asarray(lab).tobytes()
+            if key not in size_of:
+                size_of[key] = ops.kr_split_sizes(lab, sample_max)
+            sizes.append(size_of[key])
         if sampler == "device":
             # a (job, classifier) pair's key: the job's identity (not its position in this shard), so that the same job draws
             # the same sets on whichever rank / in whichever batch it runs, and different jobs draw independent ones
@@ -759,7 +790,7 @@ class SweepBatch:
             cur = torch.cuda.current_stream()
             if os.environ.get("WDG_SWEEP_SIDE_STREAM", "1") != "0":
                 if getattr(self, "_side_stream", None) is None:
-                    self._side_stream = torch.cuda.Stream()
+                    self._side_stream = _side_stream(2)
                 side = self._side_stream
                 side.wait_stream(cur)  # (the previous batch's regressions have read the old sets)
                 with torch.cuda.stream(side):
@@ -955,6 +986,31 @@ def _count_kr(stats, sb):
         stats["kr_pinv_seconds"] = stats.get("kr_pinv_seconds", 0.0) + getattr(sb, "kr_pinv_seconds", 0.0)
 
 
+_SIDE_STREAMS = {}  # (device, handle of the stream a batch was built on, index) -> its side stream, created once per process
+
+
+def _side_stream(index):
+    """the index-th side stream of batches built on the current stream (a stream per batch cost a hipStreamCreate - and a fresh
+    handle for everything keyed by stream - per base-shard; batches on one stream run one after the other anyway)"""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream()
+    return _SIDE_STREAMS[key]
+
+
+_PIPE_STREAMS = {}  # (device, depth) -> the pipelining streams, created once per process (stable handles: the per-stream scratch
+#                     of ops.PropagatedGram and the upload ring's events stay valid from one sweep to the next)
+
+
+def _pipe_streams(depth):
+    if depth <= 1:
+        return [torch.cuda.current_stream()]
+    key = (torch.cuda.current_device(), depth)
+    if key not in _PIPE_STREAMS:
+        _PIPE_STREAMS[key] = [torch.cuda.Stream() for _ in range(depth)]
+    return _PIPE_STREAMS[key]
+
+
 def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symmetric=0, depth=2, first_seed=0, stats=None):
     """The one-pass sweep over a sequence of shards (synthetic_plot.py:78-109: every graph visited once), PIPELINED: a generator
     of the shards' metric rows ([jobs, 6] fp32 / [jobs, 9] fp64 on the host), in order.
@@ -968,7 +1024,7 @@ def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symme
     bits either way (tests/test_gpu_sweep.py)."""
     from collections import deque
     depth = max(1, int(depth))
-    streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
+    streams = _pipe_streams(depth)
     in_flight = deque()
 
     def fetch():
@@ -994,6 +1050,15 @@ def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symme
         yield fetch()
 
 
+def propagates(n_feat, jobs):
+    """whether prepare_full takes the propagated route for the aggregated features' kernels of these jobs on its own (WDG_GRAM_ROUTE,
+    width, graphs of one size that fit the quad-row kernel's one-block slabs): the sweep driver then aggregates the label columns only"""
+    route = os.environ.get("WDG_GRAM_ROUTE", "auto")
+    one_size = len({j.n_nodes for j in jobs}) == 1 and all(j.n_nodes <= 5056 for j in jobs)
+    return bool(jobs) and one_size and os.environ.get("WDG_SPMM_NO_QUAD", "0") in ("", "0") and (
+        route == "propagate" or (route == "auto" and n_feat >= 640)) and os.environ.get("WDG_SWEEP_RIDE_LABELS", "1") != "0"
+
+
 def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, stats=None):
     """The reference's WHOLE sweep (synthetic_plot.py:64-109: 6 feature bases x 30 homophily levels x 10 samples = 1 800 jobs, nine
     scalars each), one pass, PIPELINED like run_shards: a generator of (shard index, base index, rows [jobs, 9] fp64 on the host).
@@ -1008,7 +1073,7 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
     the same inputs computes (tests/test_gpu_sweep.py)."""
     from collections import deque
     depth = max(1, int(depth))
-    streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
+    streams = _pipe_streams(depth)
     in_flight = deque()
 
     def fetch():
@@ -1027,8 +1092,9 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
                 stream.wait_stream(first_stream)  # (the shared graphs are built on the first base's stream)
             with torch.cuda.stream(stream):
                 inputs = [(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, graph_inputs)]
-                sb = SweepBatch(jobs, n_feat=next(iter(feats.values())).shape[1] if feats else 0, symmetric=symmetric, gcn_hidden=0,
-                                inputs=inputs, share=first)
+                width = next(iter(feats.values())).shape[1] if feats else 0
+                sb = SweepBatch(jobs, n_feat=width, symmetric=symmetric, gcn_hidden=0, inputs=inputs, share=first,
+                                labels_only=propagates(width, jobs))
                 if sb.jobs:
                     # (the node sets are keyed by the base and the job's identity, not by where the job sits: a job draws the same
                     # sets in whichever shard / on whichever rank it runs - the N-rank sweep computes the one-GPU sweep's rows)
