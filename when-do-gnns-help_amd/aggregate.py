@@ -210,6 +210,22 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
     for i in order:
         g, x, _y, _rs, cs = entries[i][:5]
         keys.append((x.data_ptr(), _ld(x), g.n_cols, x.shape[1], 0 if cs is None else cs.data_ptr()))
+    # (the cut depends on the graphs, on which of them share an X and on the width - not on the operands' addresses: a sweep lays the
+    # same shard's graphs out again for every feature base and for both products of the propagated kernels.  Remembered on the first
+    # graph of the table, so the memory dies with the shard's graphs)
+    runs, pos = [], 0
+    while pos < len(order):
+        end = pos + 1
+        while end < len(order) and keys[end] == keys[pos]:
+            end += 1
+        runs.append(end - pos)
+        pos = end
+    memo_key = (tuple(id(entries[i][0]) for i in order), tuple(runs), n_feat, cus, phase_ns, None if shares is None else tuple(shares),
+                os.environ.get("WDG_QUAD_SUBS"), os.environ.get("WDG_QUAD_PHASE_NS"), os.environ.get("WDG_QUAD_PHASE_ORDER"),
+                os.environ.get("WDG_QUAD_ALPHA"), os.environ.get("WDG_QUAD_WMIN"))
+    memo = entries[order[0]][0].__dict__.setdefault("_seg_memo", {}) if order else {}
+    if memo_key in memo:
+        return memo[memo_key]
     groups, costs, multi = [], [], False  # groups: (first position in `order`, n_jobs, n_units)
     unit_costs = _quad_unit_costs([entries[i][0].quad["widths"] for i in order])  # (per position in `order`)
     pos = 0
@@ -266,6 +282,9 @@ def _quad_segments(entries, order, n_feat, cus=256, phase_ns=None, shares=None):
             reordered = [items[i] for _c, i in sorted(seg_items)]
             items[first_item:first_item + len(reordered)] = reordered
         seg_ptr.append(len(items))
+    if len(memo) >= 16:
+        memo.clear()
+    memo[memo_key] = (items, seg_ptr, n_seg)
     return items, seg_ptr, n_seg
 
 

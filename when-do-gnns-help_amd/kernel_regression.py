@@ -158,6 +158,12 @@ def kr_split_sizes(labels, sample_max):
     return s_c.astype(np.int32), t_c.astype(np.int32)
 
 
+_KR_SAMPLE_DTYPE = np.dtype([("labels", "<u8"), ("sample_per_class", "<u8"), ("train_per_class", "<u8"), ("train_out", "<u8"), ("val_out", "<u8"),
+                             ("seed", "<u8"), ("n", "<i4"), ("n_classes", "<i4"), ("n_sets", "<i4"), ("first_set", "<i4"), ("train_stride", "<i4"),
+                             ("val_stride", "<i4")])
+assert _KR_SAMPLE_DTYPE.itemsize == ctypes.sizeof(_lib.KrSampleJob)
+
+
 class KrSets:
     """Job table for wdg_kr_sample_sets: the (train, validation) node sets of every epoch of many (graph, classifier) pairs,
     drawn on the device in one launch (Philox4x32-10 keyed per pair; include/wdg.h documents the generator).
@@ -169,30 +175,45 @@ class KrSets:
         dev = require_gpu()
         self.keep = entries
         self.n_pairs, self.epochs = len(entries), int(epochs)
-        self.n_train = np.array([int(np.sum(t)) for _l, _s, t, _seed in entries], np.int64)
-        self.n_val = np.array([int(np.sum(s_) - np.sum(t)) for _l, s_, t, _seed in entries], np.int64)
+        # (the table by column arithmetic: entries that share a label vector - the jobs of a sweep - share its per-class arrays)
+        n = self.n_pairs
+        sums = {}
+        for _l, s_, t, _seed in entries:
+            if id(t) not in sums:
+                sums[id(t)] = (int(np.sum(t)), int(np.sum(s_)) - int(np.sum(t)), len(s_))
+        self.n_train = np.fromiter((sums[id(e[2])][0] for e in entries), np.int64, n)
+        self.n_val = np.fromiter((sums[id(e[2])][1] for e in entries), np.int64, n)
+        n_cls = np.fromiter((sums[id(e[2])][2] for e in entries), np.int64, n)
+        if n and int(n_cls.max()) > 64:
+            raise ValueError("KrSets: more than 64 classes")
         self.train_stride, self.val_stride = int(self.n_train.max(initial=0)), int(self.n_val.max(initial=0))
-        self.train = torch.zeros((self.n_pairs, self.epochs, max(self.train_stride, 1)), dtype=torch.int32, device=dev)
-        self.val = torch.zeros((self.n_pairs, self.epochs, max(self.val_stride, 1)), dtype=torch.int32, device=dev)
+        ts, vs = max(self.train_stride, 1), max(self.val_stride, 1)
+        # (zeros only where sets are padded to a common stride: the kernel writes every entry of a set)
+        alloc = torch.zeros if (n and (int(self.n_train.min()) != ts or int(self.n_val.min()) != vs)) else torch.empty
+        self.train = alloc((n, self.epochs, ts), dtype=torch.int32, device=dev)
+        self.val = alloc((n, self.epochs, vs), dtype=torch.int32, device=dev)
         self.max_n = max([int(e[0].shape[0]) for e in entries], default=0)
-        cls = np.concatenate([np.concatenate([np.asarray(s_, np.int32), np.asarray(t, np.int32)]) for _l, s_, t, _seed in entries]) \
-            if entries else np.zeros(0, np.int32)
-        self.class_tables = _h2d(cls, dev)
-        arr = (_lib.KrSampleJob * self.n_pairs)()
-        off = 0
-        for i, (job, (lab, s_, t, seed)) in enumerate(zip(arr, entries)):
-            c = len(s_)
-            if c > 64:
-                raise ValueError("KrSets: more than 64 classes")
-            job.labels = lab.data_ptr()
-            job.sample_per_class = self.class_tables.data_ptr() + 4 * off
-            job.train_per_class = self.class_tables.data_ptr() + 4 * (off + c)
-            off += 2 * c
-            job.train_out, job.val_out = self.train[i].data_ptr(), self.val[i].data_ptr()
-            job.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-            job.n, job.n_classes, job.n_sets, job.first_set = int(lab.shape[0]), c, self.epochs, i * self.epochs
-            job.train_stride, job.val_stride = self.train.shape[2], self.val.shape[2]
-        self.table = _table(arr)
+        tables, off_of, parts, off = {}, np.zeros(n, np.int64), [], 0
+        for i, (_l, s_, t, _seed) in enumerate(entries):  # one [s_c | t_c] block per distinct pair of arrays
+            key = (id(s_), id(t))
+            if key not in tables:
+                tables[key] = off
+                parts += [np.asarray(s_, np.int32), np.asarray(t, np.int32)]
+                off += 2 * len(s_)
+            off_of[i] = tables[key]
+        self.class_tables = _h2d(np.concatenate(parts) if parts else np.zeros(0, np.int32), dev)
+        tab = np.zeros(n, _KR_SAMPLE_DTYPE)
+        idx = np.arange(n, dtype=np.int64)
+        tab["labels"] = np.fromiter((e[0].data_ptr() for e in entries), np.int64, n)
+        tab["sample_per_class"] = self.class_tables.data_ptr() + 4 * off_of
+        tab["train_per_class"] = self.class_tables.data_ptr() + 4 * (off_of + n_cls)
+        tab["train_out"] = self.train.data_ptr() + 4 * idx * self.epochs * ts
+        tab["val_out"] = self.val.data_ptr() + 4 * idx * self.epochs * vs
+        tab["seed"] = np.fromiter((int(e[3]) & 0xFFFFFFFFFFFFFFFF for e in entries), np.uint64, n)
+        tab["n"] = np.fromiter((int(e[0].shape[0]) for e in entries), np.int64, n)
+        tab["n_classes"], tab["n_sets"], tab["first_set"] = n_cls, self.epochs, idx * self.epochs
+        tab["train_stride"], tab["val_stride"] = ts, vs
+        self.table = _h2d(tab.view(np.uint8), dev) if n else torch.empty(0, dtype=torch.uint8)
 
     def launch(self):
         check(lib.wdg_kr_sample_sets(_ptr(self.table), self.n_pairs, self.n_pairs * self.epochs, self.max_n, stream_handle()),
