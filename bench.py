@@ -361,10 +361,12 @@ def measure_whole(args, dev, world=1, rank=0):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one small warm-up pass (code objects, allocator pools, scipy import) outside the clock
-    warm = pairs[:4] if rank == 0 else mine[:4]
-    if warm:
-        sweep.whole_sweep_rank(warm, graph_of, feats, 1, 0, epochs=args.kr_epochs)
+    # warm-up outside the clock (code objects, scipy import, torch's allocator pools and the per-stream scratch at the sizes the
+    # timed pass will ask for): this rank's first shard-sized piece of its share over two bases - pubmed's width, whose kernels take
+    # the dense route, and a propagated one
+    piece = (mine[:per_shard] if world == 1 else mine[:80]) or pairs[:4]
+    sweep.whole_sweep_rank(piece, graph_of, [b for b in feats if b[0] in ("pubmed", "film")] or feats[:2], 1, 0, epochs=args.kr_epochs,
+                           max_pairs_per_shard=len(piece))
     per_base = np.zeros(len(bases))
     state = {"t": 0.0}
 
