@@ -220,7 +220,7 @@ def measure_full(args, dev):
     t0 = time.perf_counter()
     rows = sb.full_metrics()
     tail_s = time.perf_counter() - t0
-    kr = {"kr_ridged": sb.kr_ridged, "kr_total": sb.kr_total,
+    kr = {"kr_ridged": sb.kr_ridged, "kr_total": sb.kr_total, "kr_sets": KR_SETS_NOTE[sb.kr_set_mode],
           "kr_ridged_note": "train blocks the device solver found rank deficient at fp32 rounding level and solved with a ridge (within 0 - 2 "
                             "validation rows of the reference's own epochs on the sweep fixtures: profiles/r05_kr_three_way.txt); "
                             "full_metrics(ridge='pinv') solves exactly those again the reference's way on the host (utils/homophily_plot.py:"
@@ -232,6 +232,14 @@ def measure_full(args, dev):
             "graphs_per_s": len(jobs) / (dev_s + tail_s), "device_ms_per_batch": dev_s * 1e3, "device_ms_slowest_replay": per_rep[-1] * 1e3,
             "replays": reps, "host_tail_ms": tail_s * 1e3,
             "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, rows.mean(0).tolist())}}
+
+
+KR_SETS_NOTE = {
+    "sample": "common random node sets per sample (WDG_SWEEP_KR_SETS=sample, the default): the homophily levels of one sample - same features, "
+              "same labels - share each epoch's (train, validation) sets, so every job's accuracies keep the distribution of the "
+              "reference's independent draws while the raw features' regression of an epoch is solved once per sample and shard instead "
+              "of once per job (kr_total counts the regressions solved); WDG_SWEEP_KR_SETS=job draws per job",
+    "job": "independent node sets per job (WDG_SWEEP_KR_SETS=job): 400 regressions per job"}
 
 
 def measure_cold(args, dev):
@@ -418,6 +426,7 @@ def measure_whole(args, dev, world=1, rank=0):
                         "the host, two HIP streams per rank",
             "jobs": n_rows, "n_gpus": world, "scaling": "strong", "seconds": dt, "graphs_per_s": n_rows / dt, **rec,
             "kr_ridged": int(kr_counts[0].item()), "kr_total": int(kr_counts[1].item()),
+            "kr_sets": KR_SETS_NOTE[os.environ.get("WDG_SWEEP_KR_SETS", "sample")],
             "ms_per_base_rank0": {n: 1e3 * t for (n, _w), t in zip(bases, per_base)},
             "input_generation_s_outside_clock": t_in, "rows": list(table.shape), "nan_rows": int(torch.isnan(table).any(1).sum()),
             "reference_cpu_estimate": "~35 s per job, ~17 h for the sweep (BASELINE.md)",

@@ -176,7 +176,8 @@ def test_nine_scalars_with_device_sampled_sets_agree_with_host_sampled_ones():
         sb.launch_full()
         torch.cuda.synchronize()
         rows[sampler] = sb.full_metrics().numpy()
-        accs[sampler] = sb.kr.accuracy().cpu().numpy().reshape(len(jobs), 2, 24, 2)
+        accs[sampler] = sb.kr_accuracy().cpu().numpy()  # [job, classifier, epoch, kernel]
+        assert accs[sampler].shape == (len(jobs), 2, 24, 2)
         assert (sb.kr_sets is not None) == (sampler == "device")
     assert np.array_equal(rows["device"][:, :7], rows["host"][:, :7])
     d, h = accs["device"].mean(2), accs["host"].mean(2)  # [job, classifier, kernel]

@@ -149,7 +149,7 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
         torch.cuda.synchronize()
         rows_dev = sb.full_metrics(ridge="device").numpy()
         acc_dev = sb.kr_acc.copy().reshape(-1)                                 # problem order [job, clf, epoch, kernel]
-        ridged = sb.kr.ridged().cpu().numpy().reshape(-1)
+        ridged = sb.kr_ridged_mask().cpu().numpy().reshape(-1)                 # (the same order: every job its own sample here)
         n_val = float(sb.kr_val.shape[2])
         flagged = np.flatnonzero(ridged)
         others = rng.choice(np.flatnonzero(~ridged), 150, replace=False)

@@ -166,6 +166,68 @@ def test_nine_scalars_with_propagated_grams_match_the_direct_route(monkeypatch):
             assert abs(rows["propagate"][ji, 7 + ci] - rows["direct"][ji, 7 + ci]) <= 2 * tol + 1e-12, (name, clf)
 
 
+def test_common_sets_per_sample_share_the_raw_feature_regressions(monkeypatch):
+    """prepare_full(sets="sample") (the default): the homophily levels of one sample draw ONE sequence of node sets, keyed by the
+    sample's identity, and the raw features' regression of an (epoch, classifier) is solved once per sample.
+      * the table holds J * 2 E regressions on the aggregated features' kernels + G * 2 E on the raw features' (G samples);
+      * the jobs of a sample read the SAME raw-feature accuracies; their graph-aware ones differ;
+      * a job computes the same nine scalars bit for bit in whichever batch it sits (alone, or with the other levels);
+      * sets="job" solves 4 E per job; both modes' mean accuracies agree within sampling noise (same distribution per job)."""
+    from wdg_amd import sweep
+    epochs = 12
+    jobs = sweep.make_jobs([0.2, 0.5, 0.9], [0, 1], k=10, n_nodes=2000)  # 2 samples x 3 levels, seed-major
+    rows, accs, totals = {}, {}, {}
+    for mode in ("sample", "job"):
+        sb = sweep.SweepBatch(jobs, n_feat=128, gcn_hidden=0)
+        sb.prepare_full(epochs=epochs, sample_max=500, base_seed=3, sets=mode)
+        sb.step()
+        sb.launch_full()
+        torch.cuda.synchronize()
+        rows[mode] = sb.full_metrics().numpy()
+        accs[mode] = sb.kr_acc.copy()  # [job, classifier, epoch, (graph-aware, features only)]
+        totals[mode] = (sb.kr.n_jobs, sb.kr_total, sb.kr_set_mode)
+        if mode == "sample":
+            assert sb.kr_group.tolist() == [0, 0, 0, 1, 1, 1] and sb.kr_rep.tolist() == [0, 3]
+            assert np.array_equal(sb.kr_accuracy().cpu().numpy(), accs[mode])
+            tr = sb.kr_train.cpu().numpy()
+            assert tr.shape[:2] == (2 * 2, epochs) and not np.array_equal(tr[0], tr[2])  # one sequence per (sample, classifier)
+    J = len(jobs)
+    assert totals["sample"] == (J * 2 * epochs + 2 * 2 * epochs, J * 2 * epochs + 2 * 2 * epochs, "sample")
+    assert totals["job"] == (J * 4 * epochs, J * 4 * epochs, "job")
+    a = accs["sample"]
+    for g in (0, 1):
+        assert np.array_equal(a[3 * g, ..., 1], a[3 * g + 1, ..., 1]) and np.array_equal(a[3 * g, ..., 1], a[3 * g + 2, ..., 1])
+        assert not np.array_equal(a[3 * g, ..., 0], a[3 * g + 2, ..., 0])
+    assert not np.array_equal(a[0, ..., 1], a[3, ..., 1])
+    assert np.array_equal(rows["sample"][:, :7], rows["job"][:, :7])
+    # same distribution per job: ~200 validation rows x 12 epochs -> sd of a mean accuracy ~ 0.01
+    assert np.abs(accs["sample"].mean(2) - accs["job"].mean(2)).max() < 0.05
+    # identity keys: a job alone in its batch draws the sets - and computes the rows - it has among the other levels
+    for ji in (1, 5):
+        sb = sweep.SweepBatch([jobs[ji]], n_feat=128, gcn_hidden=0)
+        sb.prepare_full(epochs=epochs, sample_max=500, base_seed=3)
+        sb.step()
+        sb.launch_full()
+        torch.cuda.synchronize()
+        alone = sb.full_metrics().numpy()
+        assert np.array_equal(alone[0], rows["sample"][ji], equal_nan=True), (ji, alone[0], rows["sample"][ji])
+        assert np.array_equal(sb.kr_acc[0], accs["sample"][ji])
+    # jobs of one seed whose LABEL vectors differ are different samples
+    monkeypatch.setenv("WDG_SWEEP_KR_SETS", "sample")
+    monkeypatch.setenv("WDG_SWEEP_RIDE_LABELS", "0")  # (label columns riding with the features want one label vector per seed)
+    from wdg_amd import synth
+    inputs = []
+    for j in jobs[:2]:
+        src, dst, lab = synth.regular_graph(j.n_nodes, j.n_classes, j.k, j.h, j.seed)
+        inputs.append((src, dst, lab, synth.features(j.n_nodes, 64, j.seed)))
+    flipped = inputs[1][2].copy()
+    flipped[:2] = flipped[:2][::-1].copy() if flipped[0] != flipped[1] else (flipped[:2] + 1) % jobs[0].n_classes
+    inputs[1] = (inputs[1][0], inputs[1][1], flipped, inputs[1][3])
+    sb = sweep.SweepBatch(jobs[:2], n_feat=64, gcn_hidden=0, inputs=inputs)
+    sb.prepare_full(epochs=2, sample_max=500)
+    assert sb.kr_group.tolist() == [0, 1] and sb.kr.n_jobs == 2 * 4 * 2
+
+
 def test_whole_sweep_rows_do_not_depend_on_the_world_size():
     """sweep.whole_sweep_rank + exchange_rows (bench.py's N-rank `sweep_whole`): the adjacencies dealt to 1, 2 and 3 "ranks" (run
     one after the other on this GPU; a rank's rows keyed by the pair's position in the job list) assemble to the SAME [pairs x
@@ -333,7 +395,8 @@ def test_sweep_all_nine_scalars_against_golden():
     # these epochs (tests/golden/kr_epochs.npz holds 8 epochs of the same seed: the first 4 are this run's): within 2 of the
     # 200 validation rows; the p-values within what that implies for these accuracies (_golden.p_tolerance)
     from _golden import load_kr, p_tolerance
-    acc = sb.kr.accuracy().cpu().numpy().astype(np.float64).reshape(len(jobs), 2, 4, 2)
+    acc = sb.kr_accuracy().cpu().numpy().astype(np.float64)
+    assert acc.shape == (len(jobs), 2, 4, 2)
     for ji, (name, r, g0) in enumerate(zip(names, rows, gold)):
         kr = load_kr(name)
         for ci, clf in enumerate(("kernel_reg0", "kernel_reg1")):

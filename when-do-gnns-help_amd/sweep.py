@@ -676,7 +676,7 @@ class SweepBatch:
         return torch.stack([edge, node, cls, adj, li, soft_las], 1)
 
     # -- the remaining three scalars: generalized edge homophily + the kernel-regression p-values ------
-    def prepare_full(self, epochs=100, sample_max=500, seed_of=None, sampler=None, base_seed=0):
+    def prepare_full(self, epochs=100, sample_max=500, seed_of=None, sampler=None, base_seed=0, sets=None):
         """Set up the batched kernel-regression metric for every job: the Gram / arc-cosine kernels of the aggregated features
         (per job) and of the raw features (per feature matrix) - all nodes, once -, and, per job x classifier (kernel_reg0 /
         kernel_reg1) x epoch, the train / validation node sets; both kernels of an epoch share its node sets.
@@ -684,7 +684,17 @@ class SweepBatch:
         wdg_kr_sample_sets: Philox4x32-10 keyed by base_seed, job and classifier - the reference's distribution, a documented
         generator) in launch_full(), inside the clock of a cold sweep.  sampler "host" (implied by seed_of): the reference's
         own routine on torch's CPU generator seeded with seed_of(job index, classifier index) (default 1000 job + classifier) -
-        bit for bit the reference's sets (the golden tests), ~40 ms of host time per (job, classifier) at 100 epochs."""
+        bit for bit the reference's sets (the golden tests), ~40 ms of host time per (job, classifier) at 100 epochs.
+        sets (device sampler only; WDG_SWEEP_KR_SETS): whose node sets an epoch's regressions use.
+          "sample" (default) - COMMON RANDOM SETS per sample: the jobs of a shard that share a feature matrix AND a label vector (the
+                   homophily levels of one sample, synthetic_plot.py:78-91) draw ONE sequence of sets per (sample, classifier), keyed
+                   by the sample's identity.  Every job's (X_results, G_results) pair has exactly the distribution of the reference's
+                   independent draws (both accuracies of an epoch share the epoch's sets there too, utils/homophily_metrics.py:
+                   279-297); only jobs of DIFFERENT homophily levels become correlated, which none of the reference's outputs (mean /
+                   std over the ten samples of a level, synthetic_plot.py:112-128) measures.  The raw features' regressions of such jobs
+                   are then the same problem - same kernel, same sets, same labels - and are solved ONCE per (sample, classifier,
+                   epoch) instead of once per job: 200 + 200 / (levels per shard) regressions per job instead of 400.
+          "job"    - independent sets per job, keyed by the job's identity (rounds 3 - 4)."""
         from .utils.util_funcs import kernel_regression_epoch_indices
         ops = self.ops
         dev = self.graphs[0].device if self.graphs else ops.require_gpu()
@@ -736,13 +746,40 @@ class SweepBatch:
             if key not in size_of:
                 size_of[key] = ops.kr_split_sizes(lab, sample_max)
             sizes.append(size_of[key])
+        sets = sets or os.environ.get("WDG_SWEEP_KR_SETS", "sample")
+        if sets not in ("sample", "job"):
+            raise ValueError(f"prepare_full: sets={sets!r} (sample | job)")
+        if sampler != "device":
+            sets = "job"  # (the reference's host routine draws per call)
+        self.kr_set_mode = sets
+        # group[ji]: the set sequence job ji uses; rep[g]: the first job of group g
+        if sets == "sample":
+            import zlib
+            index, group, rep, label_crc = {}, [], [], []
+            for ji, (j, lab) in enumerate(zip(self.jobs, self.labels_host)):
+                key = (j.seed, j.n_nodes, np.asarray(lab).tobytes())
+                if key not in index:
+                    index[key] = len(rep)
+                    rep.append(ji)
+                    label_crc.append(zlib.crc32(key[2]))
+                group.append(index[key])
+            group, rep = np.asarray(group, np.int64), np.asarray(rep, np.int64)
+        else:
+            group = rep = np.arange(J, dtype=np.int64)
+        G = len(rep)
+        self.kr_group, self.kr_rep = group, rep
         if sampler == "device":
-            # a (job, classifier) pair's key: the job's identity (not its position in this shard), so that the same job draws
-            # the same sets on whichever rank / in whichever batch it runs, and different jobs draw independent ones
-            self.kr_sets = ops.KrSets([(self.labels[ji], sizes[ji][0], sizes[ji][1],
-                                        _mix64(base_seed, j.seed, int(round(j.h * 1e6)), j.k, j.n_nodes, clf))
-                                       for ji, j in enumerate(self.jobs) for clf in (0, 1)], epochs)
-            train, val = self.kr_sets.train, self.kr_sets.val         # [J * 2, epochs, n_train / n_val], filled by launch_full()
+            # a (group, classifier) pair's key is an IDENTITY (not a position in this shard), so that the same job draws the same
+            # sets on whichever rank / in whichever batch it runs: the sample's (seed, size, label vector) - or, sets="job", the
+            # job's (seed, h, k, size), so that different jobs draw independent ones
+            def key_of(g, clf):
+                j = self.jobs[rep[g]]
+                if sets == "sample":
+                    return _mix64(base_seed, j.seed, j.n_nodes, label_crc[g], 0x5A3D, clf)
+                return _mix64(base_seed, j.seed, int(round(j.h * 1e6)), j.k, j.n_nodes, clf)
+            self.kr_sets = ops.KrSets([(self.labels[rep[g]], sizes[rep[g]][0], sizes[rep[g]][1], key_of(g, clf))
+                                       for g in range(G) for clf in (0, 1)], epochs)
+            train, val = self.kr_sets.train, self.kr_sets.val         # [G * 2, epochs, n_train / n_val], filled by launch_full()
         else:
             self.kr_sets = None
             seed_of = seed_of or (lambda ji, clf: 1000 * ji + clf)
@@ -759,25 +796,55 @@ class SweepBatch:
                         val_h[2 * ji + clf, e, :va.shape[0]] = va.numpy()
             torch.set_rng_state(rng_state)
             train, val = ops._h2d(train_h, dev), ops._h2d(val_h, dev)
-        self.kr_train, self.kr_val = train, val
-        # the problem table: p = ((job * 2 + classifier) * epochs + epoch) * 2 + (0: the aggregated features' kernel, 1: the raw
-        # features' kernel), described by arithmetic on base addresses
-        pair = np.repeat(np.arange(J * 2), epochs * 2)
-        ji, clf = pair // 2, pair % 2
-        epoch = np.tile(np.repeat(np.arange(epochs), 2), J * 2)
-        which = np.tile(np.arange(2), J * 2 * epochs)
+        self.kr_train, self.kr_val = train, val  # [G * 2, epochs, .]: row kr_group[job] * 2 + classifier holds a job's sets
+        # the table of the regressions that are SOLVED, described by arithmetic on base addresses:
+        #   u = (job * 2 + classifier) * epochs + epoch                      the aggregated features' kernel of every job, then
+        #   u = J * 2 * epochs + (group * 2 + classifier) * epochs + epoch   the raw features' kernel of every group (sets="job":
+        #                                                                    a group is a job)
+        # kr_index[job, classifier, epoch, (0 aggregated | 1 raw)] -> u is what kr_accuracy() / full_metrics() read through
+        e_ = np.arange(epochs, dtype=np.int64)
+        jc = np.arange(J * 2, dtype=np.int64)                        # job * 2 + classifier
+        gc = np.arange(G * 2, dtype=np.int64)                        # group * 2 + classifier
+        row_g = (group[jc // 2] * 2 + jc % 2)                        # the sets row of a (job, classifier)
+        u_job = np.repeat(jc // 2, epochs)                           # per solved problem: the job whose labels / sizes describe it,
+        u_job = np.concatenate([u_job, np.repeat(rep[gc // 2], epochs)])
+        u_clf = np.concatenate([np.repeat(jc % 2, epochs), np.repeat(gc % 2, epochs)])
+        u_row = np.concatenate([np.repeat(row_g, epochs), np.repeat(gc, epochs)])   # its sets row,
+        u_epoch = np.concatenate([np.tile(e_, J * 2), np.tile(e_, G * 2)])          # its epoch
         k_lin = np.array([k.data_ptr() for k in self.gram.k_linear], np.int64)
         k_arc = np.array([k.data_ptr() for k in self.gram.k_arccos], np.int64)
-        slot = np.where(which == 0, ji, np.array([x_slot[j.seed] for j in self.jobs], np.int64)[ji])
-        k_ptr = np.where(clf == 0, k_lin[slot], k_arc[slot])
+        xs = np.array([x_slot[j.seed] for j in self.jobs], np.int64)
+        u_slot = np.concatenate([np.repeat(jc // 2, epochs), np.repeat(xs[rep[gc // 2]], epochs)])  # and its kernel matrix
+        k_ptr = np.where(u_clf == 0, k_lin[u_slot], k_arc[u_slot])
         n_nodes = np.array([j.n_nodes for j in self.jobs], np.int64)
         n_tr = np.array([int(t.sum()) for _s, t in sizes], np.int64)
         n_va = np.array([int(s_.sum() - t.sum()) for s_, t in sizes], np.int64)
         lab_ptr = np.array([l.data_ptr() for l in self.labels], np.int64)
         self.kr = ops.KrBatch.from_arrays(
-            k_ptr, n_nodes[ji], train.data_ptr() + 4 * (pair * epochs + epoch) * train.shape[2],
-            val.data_ptr() + 4 * (pair * epochs + epoch) * val.shape[2], lab_ptr[ji], n_tr[ji], n_va[ji], self.n_classes,
+            k_ptr, n_nodes[u_job], train.data_ptr() + 4 * (u_row * epochs + u_epoch) * train.shape[2],
+            val.data_ptr() + 4 * (u_row * epochs + u_epoch) * val.shape[2], lab_ptr[u_job], n_tr[u_job], n_va[u_job], self.n_classes,
             keep=(train, val, self.gram))
+        idx = np.empty((J, 2, epochs, 2), np.int64)
+        idx[..., 0] = (jc[:, None] * epochs + e_[None, :]).reshape(J, 2, epochs)
+        idx[..., 1] = (J * 2 * epochs + row_g[:, None] * epochs + e_[None, :]).reshape(J, 2, epochs)
+        self.kr_index = idx
+        # a solved problem's name in the per-job enumeration p = ((job * 2 + classifier) * epochs + epoch) * 2 + which (what
+        # pinv_accuracies takes): the group's first job stands for a shared raw-features problem
+        self.kr_canonical = ((u_job * 2 + u_clf) * epochs + u_epoch) * 2 + (np.arange(u_job.shape[0]) >= J * 2 * epochs)
+        self._kr_index_dev = None
+
+    def kr_accuracy(self):
+        """[jobs, 2 classifiers, epochs, (graph-aware, features only)] fp32 device tensor: every job's accuracies, read through
+        kr_index from the regressions that were solved (shared raw-features problems appear once per job of their group)"""
+        if self._kr_index_dev is None:
+            self._kr_index_dev = self.ops._h2d(self.kr_index.reshape(-1), self.kr.correct.device)
+        return self.kr.accuracy()[self._kr_index_dev].reshape(self.kr_index.shape)
+
+    def kr_ridged_mask(self):
+        """[jobs, 2, epochs, 2] bool device tensor: KrBatch.ridged() through kr_index"""
+        if self._kr_index_dev is None:
+            self._kr_index_dev = self.ops._h2d(self.kr_index.reshape(-1), self.kr.correct.device)
+        return self.kr.ridged()[self._kr_index_dev].reshape(self.kr_index.shape)
 
     def launch_full(self, sample_events=None):
         """the launches of the three extra scalars (after the aggregation: they read Y): Gram + maps, edge cosines, regressions
@@ -849,7 +916,7 @@ class SweepBatch:
         for key in sorted(set(zip(slot.tolist(), clf.tolist(), ji.tolist()))):
             sl, cl, jb = key
             sel = np.flatnonzero((slot == sl) & (clf == cl) & (ji == jb))
-            rows_t = torch.from_numpy((jb * 2 + cl) * np.ones_like(sel))
+            rows_t = torch.from_numpy((int(self.kr_group[jb]) * 2 + cl) * np.ones_like(sel))  # (the sets row of (job, classifier))
             tr = self.kr_train[rows_t, torch.from_numpy(epoch[sel])][:, :n_tr[jb]].long()  # [m, n_train] node ids
             va = self.kr_val[rows_t, torch.from_numpy(epoch[sel])][:, :n_va[jb]].long()
             lab = np.asarray(self.labels_host[jb]).astype(np.int64)
@@ -936,17 +1003,18 @@ class SweepBatch:
                             self.kr.accuracy().to(torch.float64).reshape(-1), self.kr.ridged().sum().to(torch.float64).reshape(1)]).cpu()
         # (rank-deficient train blocks: solved with a rounding-level ridge where the reference's pinv inverts the rounding-level
         # singular values - counted and said once per shard, like utils/homophily_metrics.py does per call)
+        # (kr_total: the regressions that were SOLVED - with common sets per sample a shared raw-features problem counts once)
         self.kr_ridged, self.kr_total = int(packed[-1].item()), int(self.kr.n_jobs)
         packed = packed[:-1]
-        n_base = packed.numel() - nj - nj * 2 * self.kr_epochs * 2
+        n_base = packed.numel() - nj - self.kr.n_jobs
         base = packed[:n_base].reshape(nj, -1)
         ge = packed[n_base:n_base + nj]
-        acc = packed[n_base + nj:].numpy().astype(np.float32)  # problem order: [job, classifier, epoch, (graph, features)]
+        acc = packed[n_base + nj:].numpy().astype(np.float32)  # the solved problems, in table order (prepare_full)
         if self.kr_ridged and ridge == "pinv":
             import time
             t0 = time.perf_counter()
             flagged = torch.nonzero(self.kr.ridged()).flatten().cpu().numpy()
-            acc[flagged] = self.pinv_accuracies(flagged)
+            acc[flagged] = self.pinv_accuracies(self.kr_canonical[flagged])
             self.kr_pinv_seconds = time.perf_counter() - t0
         elif self.kr_ridged and os.environ.get("WDG_KR_QUIET", "0") in ("", "0"):
             import warnings
@@ -954,7 +1022,7 @@ class SweepBatch:
                           "rounding level and keep the device solver's ridge answers: within 0 - 2 validation rows of what the reference "
                           "computed in the same epochs on the synthetic-sweep fixtures, 4 on cora (profiles/r05_kr_three_way.txt); "
                           "full_metrics(ridge='pinv') / WDG_SWEEP_KR_RIDGE=pinv solves them again the reference's way on the host", stacklevel=2)
-        acc = acc.reshape(nj, 2, self.kr_epochs, 2)
+        acc = acc[self.kr_index]  # -> every job's accuracies (a shared raw-features problem is read by each job of its group)
         self.kr_acc = acc  # [job, classifier, epoch, (graph-aware, features only)]: diagnostics / tests
         pvals = torch.from_numpy(welch_p_values(acc[..., 0], acc[..., 1]))
         return torch.cat([base, ge[:, None], pvals], 1)
