@@ -628,7 +628,9 @@ int wdg_edge_gram_mean_batched_f32(const wdg_edge_gram_job *jobs_dev, int32_t n_
  *           pseudo-inverse's; when a pivot falls to rounding level (<= n eps max K_ii: rank-deficient block, duplicate nodes)
  *           the block is refactored once as K + 8 n eps max K_ii I - the pseudo-inverse's least-squares predictions to within
  *           rounding (documented deviation in the coefficients).
- * `train` / `val` index rows of K; `labels` is indexed like K's rows.
+ * `train` / `val` index rows of K; `labels` is indexed like K's rows.  Limits: ldk < 65 536 (a kernel matrix is addressed by
+ * 32-bit element offsets).  The launch is persistent - one workgroup per CU walks the problems, and a problem's predictions are
+ * made inside the next problem's factorisation (WDG_KR_PERSIST=0: one workgroup per problem) - which changes no result.
  */
 typedef struct wdg_kr_job {
     const float *K;         /* [n, n] kernel of all nodes (a wdg_gram_map_batched_f32 output), leading dimension ldk */

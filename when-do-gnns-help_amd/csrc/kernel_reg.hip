@@ -1211,7 +1211,14 @@ __device__ __forceinline__ bool k2_factor_invert(float *ld, float *lt, int li, i
 #define K2_T(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_kr_job *__restrict__ jobs) {
+// PERSISTENT form (round 5): a workgroup takes the problems blockIdx.x, blockIdx.x + gridDim.x, ... one after the other, and the
+// PREDICTIONS of a problem (its validation rows' gathers from K: a sixth of a regression's cycles when they ran after the back
+// substitution, all sixteen waves waiting on memory) are DEFERRED into the next problem's factorisation: while one wave factors
+// and inverts a diagonal block, each of the other fifteen takes one unit of four validation rows of the PREVIOUS problem
+// (alpha stays in `al` until the next back substitution; the train rows' ids are double-buffered).  What is left when the
+// factorisation ends - and the last problem of a workgroup - is flushed by all waves.  Launched with one workgroup per problem
+// (WDG_KR_PERSIST=0) every problem is a last problem: round 3's schedule.  Hit counts do not depend on the schedule.
+__global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_kr_job *__restrict__ jobs, int n_jobs) {
     __shared__ float P[(K2_NB - 1) * 32 * K2_PS];      // the step's panel L[a, kb], a > kb: [a - kb - 1][row][k], stride 36
     __shared__ float LD[K2_NB * 32 * K2_PS];           // the diagonal blocks L_kk, row-major (kept: the back substitution reads them)
     __shared__ float stash[K2_SLOTS * 32 * K2_PS];     // the factoring wave's own register blocks, while it factors
@@ -1219,30 +1226,107 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     __shared__ float zs[K2_NB * 32 * KR_MAX_C];        // right-hand sides: one-hot labels -> z = L^-1 Y (block by block)
     __shared__ float al[K2_NB * 32 * KR_MAX_C];        // alpha
     __shared__ float part[K2_WAVES][32][KR_MAX_C];     // per-wave partial sums (back substitution)
-    __shared__ int tr_idx[K2_NB * 32];
+    __shared__ int tr_idx2[2][K2_NB * 32];             // the train rows' ids: this problem's and the previous one's (its predictions)
     __shared__ signed char blk_a[K2_WAVES * K2_SLOTS], blk_b[K2_WAVES * K2_SLOTS];
-    __shared__ int deficient, correct;
+    __shared__ int deficient, pend_hits, pend_next;    // pend_*: the deferred predictions' hit count and next unit of four rows
     __shared__ float red[K2_WAVES];
 
-    const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + blockIdx.x);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li_ = lane & 31, h_ = lane >> 5;
+#ifdef K2_PROFILE
+    unsigned long long k2_prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, k2_last = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- the predictions of a finished problem `pj` (its alpha in `al`, its train ids in `tidx`): units of four validation rows,
+    //      sixteen lanes per row, the lanes of a row split the train rows (ascending columns of one row of K); a row's sum: its
+    //      lanes' partial sums added by a four-step butterfly - fixed order.  Units are dealt from an LDS counter: at most
+    //      `max_units` to the calling wave (wave-uniform call sites).
+    auto predict_units = [&](const desc_ptr<wdg_kr_job> pj, const int *tidx, int max_units) {
+        const global_ptr<const float> pK = to_global(pj->K);
+        const global_ptr<const int32_t> pval = to_global(pj->val), plabels = to_global(pj->labels);
+        const int64_t pldk = pj->ldk;
+        const int pnt = pj->n_train, pnv = pj->n_val, pC = pj->n_classes;
+        const int g = lane >> 4, gl = lane & 15;
+#ifdef WDG_KR_ABLATION
+        if (pj->reserved & 8) return;
+#endif
+        for (int u = 0; u < max_units; ++u) {
+            int unit = 0;
+            if (lane == 0) unit = atomicAdd(&pend_next, 1);
+            unit = __builtin_amdgcn_readfirstlane(unit);
+            if (4 * unit >= pnv) break;
+            const int v = 4 * unit + g, gv = pval[min(v, pnv - 1)];
+            // (one uniform base + a 32-bit element offset per gather: a register per address - these loads are issued ten at a time
+            // beside the factorisation's 48 accumulator registers; the launcher refuses kernels of 2^30 elements and more)
+            const unsigned row_off = static_cast<unsigned>(gv) * static_cast<unsigned>(pldk);
+            float p[KR_MAX_C];
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c) p[c] = 0.f;
+            // (a fixed trip count, predicated: two batches of ten gathers per lane - the K rows come from beyond the L2, and a
+            // remainder loop would pay that latency once per leftover step.  The order is pinned - ten gathers, then their ten
+            // products, alpha read from LDS as each is used: left alone the scheduler reads all of alpha first, 160 registers
+            // beside the factorisation's accumulators)
+#pragma unroll 1
+            for (int b = 0; b < 2; ++b) {
+                float kv[K2_NB];
+#pragma unroll
+                for (int k = 0; k < K2_NB; ++k) {
+                    const int t = gl + 16 * (K2_NB * b + k);
+                    const bool ok = t < pnt;
+                    kv[k] = ok ? pK[row_off + static_cast<unsigned>(tidx[ok ? t : 0])] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K2_NB; ++k) {
+                    const int t = gl + 16 * (K2_NB * b + k);
+                    const int ta = t < pnt ? t : 0;  // (kv is 0 there)
+                    const float4 a0 = *reinterpret_cast<const float4 *>(&al[ta * KR_MAX_C]), a1 = *reinterpret_cast<const float4 *>(&al[ta * KR_MAX_C + 4]);
+                    p[0] = fmaf(kv[k], a0.x, p[0]), p[1] = fmaf(kv[k], a0.y, p[1]), p[2] = fmaf(kv[k], a0.z, p[2]), p[3] = fmaf(kv[k], a0.w, p[3]);
+                    p[4] = fmaf(kv[k], a1.x, p[4]), p[5] = fmaf(kv[k], a1.y, p[5]), p[6] = fmaf(kv[k], a1.z, p[6]), p[7] = fmaf(kv[k], a1.w, p[7]);
+                    if (k & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < KR_MAX_C; ++c)
+                for (int o = 8; o > 0; o >>= 1) p[c] += __shfl_xor(p[c], o);  // (inside the row's 16 lanes: every lane ends with the sum)
+            int best = 0;
+            float bv = -3.4e38f;
+            for (int c = 0; c < pC; ++c)
+                if (p[c] > bv) {  // first maximum, like torch.argmax
+                    bv = p[c];
+                    best = c;
+                }
+            const unsigned long long hit = __ballot(gl == 0 && v < pnv && best == plabels[gv]);
+            if (lane == 0 && hit) atomicAdd(&pend_hits, __popcll(hit));
+        }
+    };
+    // the pending problem's remaining units by every wave, then its hit count goes out (all threads call this)
+    auto finish_pending = [&](const desc_ptr<wdg_kr_job> pj, const int *tidx) {
+        predict_units(pj, tidx, 1 << 30);
+        __syncthreads();
+        if (tid == 0 && pj->correct_out) *to_global(pj->correct_out) = pend_hits;
+        __syncthreads();
+    };
+
+    int pending = -1;  // (uniform) the problem whose predictions are still to be made: its alpha sits in `al`, its ids in tr_idx2[pend_buf]
+    int pend_buf = 0;
+  for (int prob = blockIdx.x; prob < n_jobs; prob += gridDim.x) {
+    const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + prob);
     const global_ptr<const float> K = to_global(job->K);
-    const global_ptr<const int32_t> train = to_global(job->train), val = to_global(job->val), labels = to_global(job->labels);
+    const global_ptr<const int32_t> train = to_global(job->train), labels = to_global(job->labels);
     const int64_t ldk = job->ldk;
-    const int nt = job->n_train, nv = job->n_val, C = job->n_classes;
+    const int nt = job->n_train, C = job->n_classes;
 #ifdef WDG_KR_ABLATION  // diagnostic build only (make EXTRA=-DWDG_KR_ABLATION; scripts/dev/time_kr_batch.py): timing-only ablations
     const int ablate = job->reserved;  // 1 no gather, 2 no factorisation, 4 no back substitution, 8 no predictions (results are wrong)
 #else
     constexpr int ablate = 0;  // (the shipped kernel ignores the descriptor's reserved word: a stray value cannot change a result)
 #endif
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li_ = lane & 31, h_ = lane >> 5;
-    if (nt <= 0 || nt > K2_NB * 32 || C <= 0 || C > KR_MAX_C) {
+    if (nt <= 0 || nt > K2_NB * 32 || C <= 0 || C > KR_MAX_C) {  // (uniform)
         if (tid == 0 && job->correct_out) *to_global(job->correct_out) = -1;
         if (tid == 0 && job->flags_out) *to_global(job->flags_out) = 0;
-        return;
+        continue;
     }
-#ifdef K2_PROFILE
-    unsigned long long k2_prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, k2_last = __builtin_amdgcn_s_memtime();
-#endif
+    int *const tr_idx = tr_idx2[pend_buf ^ 1];
+    const int *const tr_prev = tr_idx2[pend_buf];
+    const desc_ptr<wdg_kr_job> pjob = (desc_ptr<wdg_kr_job>)(jobs + (pending >= 0 ? pending : prob));
     const int nb = (nt + 31) >> 5;
     const int n_blocks = nb * (nb - 1) / 2;  // the blocks BELOW the diagonal live in registers; the diagonal blocks in LDS (LD)
     for (int i = tid; i < K2_NB * 32; i += K2_THREADS) tr_idx[i] = i < nt ? train[i] : -1;
@@ -1255,7 +1339,6 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         blk_a[tid] = static_cast<signed char>(b >= 0 ? b + 1 + idx : -1);
         blk_b[tid] = static_cast<signed char>(b);
     }
-    if (tid == 0) correct = 0;
     __syncthreads();
     // max K_ii of the train rows (the scale of the pivot test)
     float dmax = 0.f;
@@ -1283,8 +1366,8 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         for (int i = tid; i < K2_NB * 32 * KR_MAX_C; i += K2_THREADS) {
             const int row = i / KR_MAX_C, c = i % KR_MAX_C;
             zs[i] = (row < nt && labels[tr_idx[row]] == c) ? 1.f : 0.f;
-            al[i] = 0.f;
-        }
+        }  // (`al` is not touched: the back substitution writes every row it or the predictions read, and until then it holds the
+        //    PREVIOUS problem's alpha, which the deferred predictions below are reading)
         if (tid == 0) deficient = 0;
         auto gather_block = [&](int a, int b, f32x16 &t) {  // lane (i, h): A[32 a + i][32 b + jmap(h, r)] = K[tr[32 b + j]][tr[32 a + i]]
             int li = li_, h = h_;
@@ -1368,6 +1451,15 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                     d += t;
                     k2_store_block(d, &LD[(kb + 1) * 32 * K2_PS], li, h);
                 }
+                // one unit of the previous problem's predictions per step, by the waves that have no block to fetch in this step (a
+                // wave's unit takes about as long as the factoring wave's chain: two batches of gathers from beyond the L2; a wave
+                // that fetches a block AND predicts holds the step's barrier back - measured: every wave one unit 12.08 ms, every
+                // third wave 11.80, the idle waves 11.73 against 12.25 ms without deferral, 20 000 regressions)
+                bool busy = kb + 1 < nb && wave == ((first + K2_WAVES - 2) & (K2_WAVES - 1));
+#pragma unroll
+                for (int s = 0; s < K2_SLOTS; ++s) busy |= sa[s] >= 0 && sb[s] == kb + 2;
+                if (pending >= 0 && !busy)
+                    predict_units(pjob, tr_prev, 1);  // one unit of the previous problem's predictions per wave and step
             }
             K2_T(2);
             __syncthreads();
@@ -1485,6 +1577,12 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         __syncthreads();
     }
 
+    // ---- what is left of the previous problem's predictions (the back substitution below overwrites its alpha)
+    if (pending >= 0) {
+        finish_pending(pjob, tr_prev);
+        pending = -1;
+    }
+    K2_T(14);
     // ---- back substitution L^T alpha = z, block column by block column from the last (L_kk: still in LD)
     for (int kb = (ablate & 4) ? -1 : nb - 1; kb >= 0; --kb) {
         int li = li_, h = h_;  // (opaque per iteration: see the factorisation loop)
@@ -1561,46 +1659,17 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         K2_T(8);
     }
 
-    // ---- predictions: sixteen lanes per validation row (four rows per wave at a time), the lanes of a row split the train rows
-    //      (ascending columns of one row of K); a row's sum: its lanes' partial sums added by a four-step butterfly - fixed order
-    int hits = 0;
-    {
-        const int g = lane >> 4, gl = lane & 15;
-        for (int v0 = 4 * wave; v0 < ((ablate & 8) ? 0 : nv); v0 += 4 * K2_WAVES) {
-            const int v = v0 + g, gv = val[min(v, nv - 1)];
-            const global_ptr<const float> krow = K + static_cast<int64_t>(gv) * ldk;
-            float p[KR_MAX_C];
-#pragma unroll
-            for (int c = 0; c < KR_MAX_C; ++c) p[c] = 0.f;
-            // (a fixed trip count, predicated: two batches of ten gathers per lane - the K rows come from beyond the L2, and a
-            // remainder loop would pay that latency once per leftover step)
-#pragma unroll 10
-            for (int k = 0; k < K2_NB * 2; ++k) {
-                const int t = gl + 16 * k;
-                const bool ok = t < nt;
-                const float kv = ok ? krow[tr_idx[ok ? t : 0]] : 0.f;
-                const float4 a0 = *reinterpret_cast<const float4 *>(&al[(ok ? t : 0) * KR_MAX_C]), a1 = *reinterpret_cast<const float4 *>(&al[(ok ? t : 0) * KR_MAX_C + 4]);
-                p[0] = fmaf(kv, a0.x, p[0]), p[1] = fmaf(kv, a0.y, p[1]), p[2] = fmaf(kv, a0.z, p[2]), p[3] = fmaf(kv, a0.w, p[3]);
-                p[4] = fmaf(kv, a1.x, p[4]), p[5] = fmaf(kv, a1.y, p[5]), p[6] = fmaf(kv, a1.z, p[6]), p[7] = fmaf(kv, a1.w, p[7]);
-            }
-#pragma unroll
-            for (int c = 0; c < KR_MAX_C; ++c)
-                for (int o = 8; o > 0; o >>= 1) p[c] += __shfl_xor(p[c], o);  // (inside the row's 16 lanes: every lane ends with the sum)
-            int best = 0;
-            float bv = -3.4e38f;
-            for (int c = 0; c < C; ++c)
-                if (p[c] > bv) {  // first maximum, like torch.argmax
-                    bv = p[c];
-                    best = c;
-                }
-            hits += (gl == 0 && v < nv && best == labels[gv]) ? 1 : 0;
-        }
-        for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
+    // ---- this problem's predictions wait for the next problem's factorisation (or for the flush below)
+    if (tid == 0) {
+        if (job->flags_out) *to_global(job->flags_out) = ridge > 0.f ? 1 : 0;
+        pend_hits = 0;
+        pend_next = 0;
     }
-    if (lane == 0 && hits) atomicAdd(&correct, hits);
+    pending = prob;
+    pend_buf ^= 1;  // (tr_idx2[pend_buf] = the ids just used)
     __syncthreads();
-    if (tid == 0 && job->correct_out) *to_global(job->correct_out) = correct;
-    if (tid == 0 && job->flags_out) *to_global(job->flags_out) = ridge > 0.f ? 1 : 0;
+  }
+    if (pending >= 0) finish_pending((desc_ptr<wdg_kr_job>)(jobs + pending), tr_idx2[pend_buf]);
 #ifdef K2_PROFILE
     K2_T(9);
     if (blockIdx.x == 0 && tid == 0)
@@ -1673,8 +1742,21 @@ int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, w
         const char *e = getenv("WDG_KR_KERNEL");
         return e && e[0] == 'r';
     }();
+    // the blocked solver is persistent: one workgroup per CU (its 144 KB of LDS allow no second one) walks the problems and makes a
+    // problem's predictions inside the next one's factorisation; WDG_KR_PERSIST=0: one workgroup per problem (round 3's schedule)
+    static const bool persist = [] {
+        const char *e = getenv("WDG_KR_PERSIST");
+        return !(e && atoi(e) == 0 && e[0] != '\0');
+    }();
+    static thread_local int cus = 0, cus_dev = -1;
+    if (cus_dev != wdg::current_device()) {
+        int dev = wdg::current_device(), n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n, cus_dev = dev;
+    }
     if (rank1) hipLaunchKernelGGL(kr_solve_kernel, dim3(n_jobs), dim3(KR_THREADS), 0, wdg::as_stream(stream), jobs_dev);
-    else hipLaunchKernelGGL(kr_solve_blocked_kernel, dim3(n_jobs), dim3(K2_THREADS), 0, wdg::as_stream(stream), jobs_dev);
+    else hipLaunchKernelGGL(kr_solve_blocked_kernel, dim3(persist ? (n_jobs < cus ? n_jobs : cus) : n_jobs), dim3(K2_THREADS), 0,
+                            wdg::as_stream(stream), jobs_dev, n_jobs);
     return wdg::check_launch("kr_solve_kernel");
 }
 

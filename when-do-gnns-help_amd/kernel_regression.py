@@ -16,18 +16,25 @@ from ._rt import _dev, _h2d, _ld, _ptr, _table
 class GramBatch:
     """Job table for wdg_gram_map_batched_f32: K = map(A A^T) of every A of a batch (all nodes), linear and / or arc-cosine."""
 
-    def __init__(self, mats, linear=True, arccos=True):
+    def __init__(self, mats, linear=True, arccos=True, out=None):
         """mats: list of A [n, F] fp32 device tensors (unit inner stride; or ops.Tiled - 16-column groups, the sweep's aggregated
-        features - when the split-operand kernels run: `tiled_ok()`) -> self.k_linear[i], self.k_arccos[i] ([n, n] or None)"""
+        features - when the split-operand kernels run: `tiled_ok()`) -> self.k_linear[i], self.k_arccos[i] ([n, n] or None)
+        out: another GramBatch over matrices of the same row counts whose output buffers this one writes (a sweep's next feature
+        base on the same graphs: every table that holds those addresses stays valid)"""
         dev = require_gpu()
         self.keep = mats
         self.n_jobs = len(mats)
         self.max_n = max([a.shape[0] for a in mats], default=0)
-        # (one allocation per matrix: 16-MB blocks come back from torch's caching allocator in microseconds; one 1-GB block per
-        # output kind - tried in round 5 - is returned to the driver between shards and costs 5 ms per allocation)
-        self.norm2 = [torch.empty(a.shape[0], dtype=torch.float32, device=dev) for a in mats]
-        self.k_linear = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if linear else None for a in mats]
-        self.k_arccos = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if arccos else None for a in mats]
+        if out is not None:
+            if [a.shape[0] for a in mats] != [k.shape[0] for k in out.norm2] or (linear and out.k_linear[:1] == [None]) or (arccos and out.k_arccos[:1] == [None]):
+                raise ValueError("GramBatch(out=...): the other batch's outputs have other shapes")
+            self.norm2, self.k_linear, self.k_arccos = out.norm2, out.k_linear if linear else [None] * len(mats), out.k_arccos if arccos else [None] * len(mats)
+        else:
+            # (one allocation per matrix: 16-MB blocks come back from torch's caching allocator in microseconds; one 1-GB block per
+            # output kind - tried in round 5 - is returned to the driver between shards and costs 5 ms per allocation)
+            self.norm2 = [torch.empty(a.shape[0], dtype=torch.float32, device=dev) for a in mats]
+            self.k_linear = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if linear else None for a in mats]
+            self.k_arccos = [torch.empty((a.shape[0], a.shape[0]), dtype=torch.float32, device=dev) if arccos else None for a in mats]
         arr = (_lib.GramJob * self.n_jobs)()
         for job, a, n2, kl, ka in zip(arr, mats, self.norm2, self.k_linear, self.k_arccos):
             if a.dtype != torch.float32 or a.stride(1) != 1:
@@ -170,8 +177,9 @@ class KrSets:
     self.train [pairs, epochs, n_train], self.val [pairs, epochs, n_val] int32, ascending ids; pairs whose graphs differ in
     class sizes are padded to the widest (self.n_train / self.n_val hold the true lengths)."""
 
-    def __init__(self, entries, epochs):
-        """entries: list of (labels int32 device [n], s_c, t_c (kr_split_sizes), seed int)"""
+    def __init__(self, entries, epochs, out=None):
+        """entries: list of (labels int32 device [n], s_c, t_c (kr_split_sizes), seed int)
+        out: another KrSets of the same shape whose train / val tensors this one fills (other seeds for the same label vectors)"""
         dev = require_gpu()
         self.keep = entries
         self.n_pairs, self.epochs = len(entries), int(epochs)
@@ -190,8 +198,13 @@ class KrSets:
         ts, vs = max(self.train_stride, 1), max(self.val_stride, 1)
         # (zeros only where sets are padded to a common stride: the kernel writes every entry of a set)
         alloc = torch.zeros if (n and (int(self.n_train.min()) != ts or int(self.n_val.min()) != vs)) else torch.empty
-        self.train = alloc((n, self.epochs, ts), dtype=torch.int32, device=dev)
-        self.val = alloc((n, self.epochs, vs), dtype=torch.int32, device=dev)
+        if out is not None:
+            if tuple(out.train.shape) != (n, self.epochs, ts) or tuple(out.val.shape) != (n, self.epochs, vs):
+                raise ValueError("KrSets(out=...): the other table's sets have another shape")
+            self.train, self.val = out.train, out.val
+        else:
+            self.train = alloc((n, self.epochs, ts), dtype=torch.int32, device=dev)
+            self.val = alloc((n, self.epochs, vs), dtype=torch.int32, device=dev)
         self.max_n = max([int(e[0].shape[0]) for e in entries], default=0)
         tables, off_of, parts, off = {}, np.zeros(n, np.int64), [], 0
         for i, (_l, s_, t, _seed) in enumerate(entries):  # one [s_c | t_c] block per distinct pair of arrays
@@ -259,6 +272,8 @@ class KrBatch:
             raise ValueError(f"KrBatch: {n_classes} classes, the solver holds 1..{self.MAX_CLASSES}")
         if n and not (1 <= int(n_train.min()) and int(n_train.max()) <= self.MAX_TRAIN):
             raise ValueError(f"KrBatch: {int(n_train.min())}..{int(n_train.max())} train rows, the solver holds blocks of 1..{self.MAX_TRAIN}")
+        if n and int(ldk.max()) >= 65536:  # (the solver's prediction gathers address a kernel matrix by 32-bit element offsets)
+            raise ValueError(f"KrBatch: kernel matrices of leading dimension {int(ldk.max())}, the solver addresses up to 65 535")
         self.correct = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
         self.flags = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)  # bit 0: the ridge refactorisation ran
         self.n_val = _h2d(n_val.astype(np.float32), dev)

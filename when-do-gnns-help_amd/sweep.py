@@ -268,6 +268,16 @@ class SweepBatch:
         self.agg_feat = (lab_col + n_classes + align - 1) // align * align if ride else n_feat
         self.alg_feat = lab_col + n_classes if ride else n_feat  # columns that carry data (byte accounting: no padding)
         build = build or os.environ.get("WDG_SWEEP_BUILD", "batched")
+        # A STEP TWIN: with labels_only the step aggregates [onehot(labels) | 0] and nothing of the features, so its tables, its
+        # outputs and its six scalars depend on the graphs and their labels only.  A batch that shares the graphs of another
+        # labels-only batch (the feature bases of one shard, run_bases) shares that batch's whole step - job tables, Y, counters - and
+        # uploads its feature matrices for the kernel-regression metric, nothing else; its step() launches nothing (the owner's has
+        # run on a stream this one waits for).  WDG_SWEEP_STEP_TWINS=0: every batch its own step (round 4).
+        self.step_owner = None
+        if (share is not None and self.labels_only and getattr(share, "labels_only", False) and share.agg_feat == self.agg_feat
+                and share.symmetric == symmetric and len(share.jobs) == len(self.jobs) and os.environ.get("WDG_SWEEP_STEP_TWINS", "1") != "0"):
+            self._init_step_twin(share.step_owner or share, inputs, n_feat, feature_seed, dev)
+            return
         feats, self.graphs, self.dinv, self.labels, self._y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
         self.tiled_y, self._y_rm, self._untile_each_step, self._y_at = False, None, False, -1
@@ -421,6 +431,26 @@ class SweepBatch:
         if tune or os.environ.get("WDG_QUAD_TUNE", "") == "1":
             self.tune()
 
+    def _init_step_twin(self, owner, inputs, n_feat, feature_seed, dev):
+        """the rest of __init__ for a step twin (see there): the feature matrices of this base, everything else the owner's"""
+        ops = self.ops
+        self.step_owner = owner
+        for name in ("graphs", "dinv", "labels", "labels_host", "y_agg", "_y", "x_agg", "spmm", "stats", "las", "h_las", "spmm_las",
+                     "edges", "n_classes", "tiled_y", "derive_counts", "gcn", "side", "side2", "_fork", "graph_batch", "y_pool"):
+            if hasattr(owner, name):
+                setattr(self, name, getattr(owner, name))
+        self._y_rm, self._untile_each_step, self._y_at, self._y_lazy = None, False, -1, None
+        x_feat = {}
+        for ji, j in enumerate(self.jobs):
+            if j.seed in x_feat:
+                continue
+            x_host = inputs[ji][3] if inputs is not None else None
+            x_feat[j.seed] = ops._h2d(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
+                                      else np.ascontiguousarray(x_host, np.float32), dev)
+            if inputs is not None and not np.array_equal(np.asarray(inputs[ji][2]), np.asarray(owner.labels_host[ji])):
+                raise ValueError("SweepBatch(share=...): the sharing batch's labels differ from the owner's")
+        self.x = x_feat
+
     # -- the aggregated features as row-major matrices ------------------------------------------------------------
     @property
     def y(self):
@@ -524,6 +554,8 @@ class SweepBatch:
     def step(self):
         """one pass of the hot path over the batch (synthetic_plot.py:92-108 minus the kernel-regression metric):
         feature aggregation, integer edge/label pass, label aggregation + LAS, GCN-2 forward"""
+        if self.step_owner is not None:  # a step twin: the owner's step computed these outputs (same graphs, same labels)
+            return
         self.spmm.launch()        # Y = A_hat X                       (F = n_feat)   dominant kernel
         if self._untile_each_step:  # (a tiled Y and row-major readers behind the step: prepare_full's Grams, training)
             self.untile()
@@ -779,6 +811,7 @@ class SweepBatch:
                 return _mix64(base_seed, j.seed, int(round(j.h * 1e6)), j.k, j.n_nodes, clf)
             self.kr_sets = ops.KrSets([(self.labels[rep[g]], sizes[rep[g]][0], sizes[rep[g]][1], key_of(g, clf))
                                        for g in range(G) for clf in (0, 1)], epochs)
+            self._kr_rebind = (sets, [sizes[r_] for r_ in rep], label_crc if sets == "sample" else None)
             train, val = self.kr_sets.train, self.kr_sets.val         # [G * 2, epochs, n_train / n_val], filled by launch_full()
         else:
             self.kr_sets = None
@@ -832,6 +865,35 @@ class SweepBatch:
         # pinv_accuracies takes): the group's first job stands for a shared raw-features problem
         self.kr_canonical = ((u_job * 2 + u_clf) * epochs + u_epoch) * 2 + (np.arange(u_job.shape[0]) >= J * 2 * epochs)
         self._kr_index_dev = None
+
+    def rebind_features(self, feats_of_seed, n_feat, base_seed):
+        """The NEXT FEATURE BASE on a prepared labels-only batch (run_bases: synthetic_plot.py:64-65 runs six feature bases over
+        the same adjacencies): new raw feature matrices and new node-set keys, every job table kept.  The step's tables never
+        held a feature address (labels_only); the raw features' kernels are written into the SAME buffers (GramBatch(out=...)),
+        so the propagation's, the edge cosines' and the regressions' tables stay valid; the node sets are drawn into the same
+        tensors under the new base's keys.  Computes what a fresh SweepBatch + prepare_full(base_seed=...) over the same inputs
+        computes (tests/test_gpu_sweep.py).  Call only when the batch's previous results have been fetched.
+        feats_of_seed: {seed: [n, n_feat] fp32 host array}"""
+        ops = self.ops
+        if not (self.labels_only and getattr(self, "gram_route", None) == "propagate" and self.kr_sets is not None):
+            raise ValueError("rebind_features: a prepared labels-only batch on the propagated route with device-drawn sets is expected")
+        dev = self.kr.correct.device
+        seeds = list(self.x)
+        self.x = {s_: ops._h2d(np.ascontiguousarray(feats_of_seed[s_], np.float32), dev) for s_ in seeds}
+        self.n_feat = n_feat
+        self._y_lazy = None
+        gx = ops.GramBatch([self.x[s_] for s_ in seeds], out=self.gram.feats_part)
+        self.gram.feats_part = gx  # (same output tensors: the pair's k_linear / k_arccos / norm2 lists stay as they are)
+        mode, sizes_rep, label_crc = self._kr_rebind
+        rep = self.kr_rep
+
+        def key_of(g, clf):
+            j = self.jobs[rep[g]]
+            if mode == "sample":
+                return _mix64(base_seed, j.seed, j.n_nodes, label_crc[g], 0x5A3D, clf)
+            return _mix64(base_seed, j.seed, int(round(j.h * 1e6)), j.k, j.n_nodes, clf)
+        self.kr_sets = ops.KrSets([(self.labels[rep[g]], sizes_rep[g][0], sizes_rep[g][1], key_of(g, clf))
+                                   for g in range(len(rep)) for clf in (0, 1)], self.kr_epochs, out=self.kr_sets)
 
     def kr_accuracy(self):
         """[jobs, 2 classifiers, epochs, (graph-aware, features only)] fp32 device tensor: every job's accuracies, read through
@@ -1149,35 +1211,74 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
         with torch.cuda.stream(stream):
             rows = sb.full_metrics()
         _count_kr(stats, sb)
-        return si, bi, rows
+        return si, bi, rows, sb, stream
 
+    # TABLE REUSE inside a shard (round 5).  Bases on the propagated route aggregate the label columns only, so (i) they share ONE
+    # step - tables, outputs, six scalars (SweepBatch step twins) - and (ii) a base can take over the prepared batch of an earlier
+    # base with the same sample_max whose rows have been fetched: SweepBatch.rebind_features swaps the feature matrices and the
+    # node-set keys and keeps every job table (the kernels land in the same buffers).  The bases are visited in an order that puts
+    # bases of equal sample_max apart (with two base-shards in flight a batch is free again two visits later); rows carry their base
+    # index, and a batch stays on its stream.  WDG_SWEEP_REBIND=0: every base-shard builds its own tables, in the caller's order.
+    rebind_ok = os.environ.get("WDG_SWEEP_REBIND", "1") != "0"
     n = 0
     for si, (jobs, graph_inputs) in enumerate(shards):
-        first = None
-        for bi, (_name, feats, sample_max) in enumerate(bases):
+        first = first_lo = None
+        widths = [next(iter(feats.values())).shape[1] if feats else 0 for _name, feats, _sm in bases]
+        lo = [propagates(w, jobs) for w in widths]
+        order = _visit_order([(lo[bi], bases[bi][2]) if lo[bi] else ("own", bi) for bi in range(len(bases))]) if rebind_ok else list(range(len(bases)))
+        free = {}  # (sample_max, stream) -> a prepared labels-only batch whose rows have been fetched
+        for bi in order:
+            _name, feats, sample_max = bases[bi]
             stream = streams[n % depth]
             if first is not None and depth > 1:
                 stream.wait_stream(first_stream)  # (the shared graphs are built on the first base's stream)
             with torch.cuda.stream(stream):
-                inputs = [(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, graph_inputs)]
-                width = next(iter(feats.values())).shape[1] if feats else 0
-                sb = SweepBatch(jobs, n_feat=width, symmetric=symmetric, gcn_hidden=0, inputs=inputs, share=first,
-                                labels_only=propagates(width, jobs))
-                if sb.jobs:
-                    # (the node sets are keyed by the base and the job's identity, not by where the job sits: a job draws the same
-                    # sets in whichever shard / on whichever rank it runs - the N-rank sweep computes the one-GPU sweep's rows)
-                    sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + 1000 * bi)
-                sb.step()
+                width = widths[bi]
+                key = (sample_max, stream.cuda_stream)
+                sb = free.pop(key, None) if (rebind_ok and lo[bi] and jobs) else None
+                if sb is not None:
+                    sb.rebind_features(feats, width, first_seed + 1000 * bi)
+                else:
+                    inputs = [(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, graph_inputs)]
+                    sb = SweepBatch(jobs, n_feat=width, symmetric=symmetric, gcn_hidden=0, inputs=inputs,
+                                    share=(first_lo or first) if lo[bi] else first, labels_only=lo[bi])
+                    if sb.jobs:
+                        # (the node sets are keyed by the base and the job's identity, not by where the job sits: a job draws the
+                        # same sets in whichever shard / on whichever rank it runs - the N-rank sweep computes the one-GPU sweep's rows)
+                        sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + 1000 * bi)
+                    sb.step()
                 if sb.jobs:
                     sb.launch_full()
             if first is None:
                 first, first_stream = sb, stream
+            if first_lo is None and sb.labels_only:
+                first_lo = sb
             in_flight.append((si, bi, sb, stream))
             n += 1
             if len(in_flight) >= depth:
-                yield fetch()
+                done = fetch()
+                if rebind_ok and done[0] == si and done[3].labels_only and done[3].jobs and getattr(done[3], "kr_sets", None) is not None:
+                    free[(done[3].kr_sample_max, done[4].cuda_stream)] = done[3]
+                yield done[:3]
     while in_flight:
-        yield fetch()
+        yield fetch()[:3]
+
+
+def _visit_order(keys):
+    """indices of `keys` in an order that keeps equal keys apart: each time the key with the most entries left that differs from the
+    one just taken (ties: first seen) - A A A B B C -> A B A B A C"""
+    left = {}
+    for i, k in enumerate(keys):
+        left.setdefault(k, []).append(i)
+    order, prev = [], object()
+    while left:
+        cands = [k for k in left if k != prev] or list(left)
+        k = max(cands, key=lambda k_: (len(left[k_]), -left[k_][0]))
+        order.append(left[k].pop(0))
+        if not left[k]:
+            del left[k]
+        prev = k
+    return order
 
 
 class BaseSweep:
