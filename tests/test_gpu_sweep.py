@@ -126,6 +126,50 @@ def test_whole_sweep_over_feature_bases_equals_stand_alone_batches():
         assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (si, bi)
 
 
+def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkeypatch):
+    """run_bases over several WIDE feature bases (the propagated route: label columns only in the aggregation): the bases of a shard
+    share one step (step twins), a base takes over the prepared batch of an earlier base of equal sample_max (rebind_features: same
+    buffers, new features, new node-set keys) and the bases are visited out of order - every (shard, base) still gives the rows
+    of a stand-alone SweepBatch over the same inputs, bit for bit, and the same rows as the driver without any reuse
+    (WDG_SWEEP_REBIND=0 WDG_SWEEP_STEP_TWINS=0)."""
+    from wdg_amd import sweep, synth
+    levels, samples = [0.2, 0.5, 0.8], [0, 1]
+    graphs = {(h, s_): synth.regular_graph(600, 5, 4, h, s_) for h in levels for s_ in samples}
+    widths = [("p1", 656, 500), ("p2", 700, 500), ("n", 97, 500), ("p3", 720, 300), ("p4", 800, 500), ("p5", 650, 300)]
+    bases = [(name, {s_: synth.features(600, w, 10 * (i + 1) + s_) for s_ in samples}, sm) for i, (name, w, sm) in enumerate(widths)]
+    assert sweep._visit_order([(True, sm) if w >= 640 else ("own", i) for i, (_n, w, sm) in enumerate(widths)]) == [0, 3, 1, 2, 4, 5]
+    shards = []
+    for lv in (levels[:2], levels[2:]):
+        jobs = sweep.make_jobs(lv, samples, k=4, n_nodes=600)
+        shards.append((jobs, [graphs[(j.h, j.seed)] for j in jobs]))
+    rebinds, twins = [], []
+    orig_rebind, orig_twin = sweep.SweepBatch.rebind_features, sweep.SweepBatch._init_step_twin
+    monkeypatch.setattr(sweep.SweepBatch, "rebind_features", lambda self, *a: (rebinds.append(a[1]), orig_rebind(self, *a))[1])
+    monkeypatch.setattr(sweep.SweepBatch, "_init_step_twin", lambda self, *a: (twins.append(a[2]), orig_twin(self, *a))[1])
+    got = {(si, bi): rows for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=2, first_seed=5)}
+    assert sorted(got) == [(si, bi) for si in range(2) for bi in range(6)]
+    assert sorted(rebinds) == [650, 650, 700, 700, 800, 800] and sorted(twins) == [720, 720]  # per shard: p2, p4, p5 rebound; p3 a twin of p1
+    monkeypatch.setattr(sweep.SweepBatch, "rebind_features", orig_rebind)
+    monkeypatch.setattr(sweep.SweepBatch, "_init_step_twin", orig_twin)
+    for (si, bi), rows in got.items():
+        jobs, gi = shards[si]
+        _name, feats, sample_max = bases[bi]
+        sb = sweep.SweepBatch(jobs, n_feat=next(iter(feats.values())).shape[1], gcn_hidden=0,
+                              inputs=[(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, gi)])
+        sb.prepare_full(epochs=6, sample_max=sample_max, base_seed=5 + 1000 * bi)
+        sb.step()
+        sb.launch_full()
+        want = sb.full_metrics()
+        assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (si, bi)
+    monkeypatch.setenv("WDG_SWEEP_REBIND", "0")
+    monkeypatch.setenv("WDG_SWEEP_STEP_TWINS", "0")
+    order = []
+    for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=2, first_seed=5):
+        order.append((si, bi))
+        assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(got[(si, bi)], nan=-7.0)), (si, bi)
+    assert order == [(si, bi) for si in range(2) for bi in range(6)]  # (the caller's order without reuse)
+
+
 def test_nine_scalars_with_propagated_grams_match_the_direct_route(monkeypatch):
     """SweepBatch.prepare_full with WDG_GRAM_ROUTE=propagate (the aggregated features' kernels as A_hat K(X) A_hat^T: what the
     sweep takes for the reference's wide feature bases) against the direct route (the Gram of Y) on the golden synthetic fixtures,

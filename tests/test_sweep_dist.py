@@ -191,3 +191,21 @@ def test_exchange_rows_single_process_and_bad_key():
     assert sweep.exchange_rows(torch.zeros(0, dtype=torch.int64), torch.zeros((0, 9)), 0, torch.device("cpu")) is not None
     with pytest.raises(ValueError):
         sweep.exchange_rows(torch.tensor([5]), torch.zeros((1, 2)), 3, torch.device("cpu"))
+
+
+def test_visit_order_keeps_equal_keys_apart():
+    """sweep._visit_order (run_bases: the order the feature bases of a shard are visited in, so that a prepared batch is free
+    again when the next base of its kind comes up): a permutation; equal keys never adjacent while another key is left"""
+    order_of = sweep._visit_order
+    assert order_of(["a", "a", "a", "b", "b", "c"]) == [0, 3, 1, 4, 2, 5]
+    assert order_of([("p", 500), ("p", 500), ("own", 2), ("p", 300), ("p", 500), ("p", 300)]) == [0, 3, 1, 2, 4, 5]
+    assert order_of(["a", "a", "a"]) == [0, 1, 2] and order_of([]) == []
+    import random
+    rnd = random.Random(3)
+    for _ in range(200):
+        keys = [rnd.choice("abcd") for _ in range(rnd.randint(1, 9))]
+        order = order_of(keys)
+        assert sorted(order) == list(range(len(keys)))
+        for a, b, rest in zip(order, order[1:], range(len(order) - 1, 0, -1)):
+            if keys[a] == keys[b]:  # only when nothing else was left
+                assert all(keys[i] == keys[a] for i in order[order.index(b):])

@@ -222,7 +222,7 @@ class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
     def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None, share=None, feature_seed=0, tune=False,
-                 build=None, labels_only=False):
+                 build=None, labels_only=False, graph_batch=None):
         """jobs: list of Job (graph + features come from the generator of synth.py) - or, with `inputs`, a list of the same
         length of (src, dst, labels, features [n, n_feat] fp32 numpy) tuples to run instead (real / fixture graphs; jobs that
         share a feature matrix must pass the same array object and carry the same `seed`).
@@ -234,6 +234,8 @@ class SweepBatch:
         CsrGraph.from_coo + ensure_quad per graph (~20 launches and two host syncs each), kept for A/B runs and tests.
         tune: balance the aggregation's tape cut by feedback (tune() below: ~90 extra steps) - worth it for a batch that is
         replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut.
+        graph_batch: the shard's ops.GraphBatch (A + I of every job, quad=True) when the caller has queued or finished the build
+        already (run_bases builds the NEXT shard's graphs on a stream of their own while this shard's bases run).
         labels_only: aggregate the one-hot LABEL columns only (one 16-feature group: everything the six step scalars need); the
         feature matrices are uploaded for the kernel-regression metric, whose aggregated-feature kernels then come by propagation
         (prepare_full: K(A_hat X) = A_hat K(X) A_hat^T) - the reference's sweep over its wide feature bases (F up to 3 703) never
@@ -301,7 +303,7 @@ class SweepBatch:
         mode = ops.NORM_SYM if symmetric else ops.NORM_RW
         if share is None and build == "batched":
             # A + I of every graph (synthetic_plot.py:92) in one build, the degrees of all of them in one launch
-            self.graph_batch = ops.GraphBatch(coos, ops.COO_ADD_SELF_LOOPS, quad=True, defer=True)
+            self.graph_batch = graph_batch if graph_batch is not None else ops.GraphBatch(coos, ops.COO_ADD_SELF_LOOPS, quad=True, defer=True)
         for ji, j in enumerate(self.jobs):
             lab = labs_host[ji]
             if j.seed not in feats:
@@ -1220,9 +1222,33 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
     # bases of equal sample_max apart (with two base-shards in flight a batch is free again two visits later); rows carry their base
     # index, and a batch stays on its stream.  WDG_SWEEP_REBIND=0: every base-shard builds its own tables, in the caller's order.
     rebind_ok = os.environ.get("WDG_SWEEP_REBIND", "1") != "0"
+    # The NEXT shard's graphs are built ahead, on a stream of their own, as soon as this shard's first base is queued: the build's
+    # one read-back (GraphBatch.finish) then finds its data ready.  Built in place it waited behind whatever ran on the GPU at
+    # that moment - typically a regression launch that holds every CU for 5 - 9 ms - and the queue ran dry while the host stood
+    # still: a fifth of the sweep's wall clock had no kernel running.  WDG_SWEEP_PREFETCH_BUILD=0: build in place.
+    shards = list(shards)
+    prefetch = (os.environ.get("WDG_SWEEP_PREFETCH_BUILD", "1") != "0" and os.environ.get("WDG_SWEEP_BUILD", "batched") == "batched")
+    build_stream = _side_stream(3) if prefetch else None
+    queued = {}
+
+    def queue_build(si_):
+        jobs_, gi_ = shards[si_]
+        if not jobs_:
+            return None
+        from . import ops
+        with torch.cuda.stream(build_stream):
+            return ops.GraphBatch([(src, dst, j.n_nodes) for j, (src, dst, _lab) in zip(jobs_, gi_)], ops.COO_ADD_SELF_LOOPS,
+                                  quad=True, defer=True)
+
     n = 0
     for si, (jobs, graph_inputs) in enumerate(shards):
         first = first_lo = None
+        gb = None
+        if prefetch:
+            gb = queued.pop(si) if si in queued else queue_build(si)
+            if gb is not None:
+                with torch.cuda.stream(build_stream):
+                    gb.finish()
         widths = [next(iter(feats.values())).shape[1] if feats else 0 for _name, feats, _sm in bases]
         lo = [propagates(w, jobs) for w in widths]
         order = _visit_order([(lo[bi], bases[bi][2]) if lo[bi] else ("own", bi) for bi in range(len(bases))]) if rebind_ok else list(range(len(bases)))
@@ -1232,6 +1258,8 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
             stream = streams[n % depth]
             if first is not None and depth > 1:
                 stream.wait_stream(first_stream)  # (the shared graphs are built on the first base's stream)
+            elif first is None and gb is not None:
+                stream.wait_stream(build_stream)   # (... or, built ahead, on the build stream)
             with torch.cuda.stream(stream):
                 width = widths[bi]
                 key = (sample_max, stream.cuda_stream)
@@ -1241,7 +1269,8 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
                 else:
                     inputs = [(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, graph_inputs)]
                     sb = SweepBatch(jobs, n_feat=width, symmetric=symmetric, gcn_hidden=0, inputs=inputs,
-                                    share=(first_lo or first) if lo[bi] else first, labels_only=lo[bi])
+                                    share=(first_lo or first) if lo[bi] else first, labels_only=lo[bi],
+                                    graph_batch=gb if first is None else None)
                     if sb.jobs:
                         # (the node sets are keyed by the base and the job's identity, not by where the job sits: a job draws the
                         # same sets in whichever shard / on whichever rank it runs - the N-rank sweep computes the one-GPU sweep's rows)
@@ -1251,6 +1280,8 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
                     sb.launch_full()
             if first is None:
                 first, first_stream = sb, stream
+                if prefetch and si + 1 < len(shards):
+                    queued[si + 1] = queue_build(si + 1)
             if first_lo is None and sb.labels_only:
                 first_lo = sb
             in_flight.append((si, bi, sb, stream))
