@@ -48,6 +48,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# (what wdg_amd/_lib.py sets at import, here before anything can have initialised the HIP runtime: a sweep's eight concurrent streams
+# on eight hardware queues - on the default four they alias and the whole sweep takes 0.40 s instead of 0.30)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

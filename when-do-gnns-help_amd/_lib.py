@@ -8,7 +8,13 @@ and stream handles of torch tensors are then valid arguments for the kernels.
 import ctypes
 import os
 
-import torch  # noqa: F401  (loads libamdhip64 before our library needs it)
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  A
+# sweep keeps two pipelined base-shards, their side streams and the next shard's graph build in flight - 8 streams; on 4 queues the
+# reference's whole sweep took 0.40 s instead of 0.30 (round 5: the same pass ran at 0.30 in a process that had created fewer
+# streams before it).  Only a default, and only if the HIP runtime has not read it yet (it does at its first call, not at import).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402,F401  (loads libamdhip64 before our library needs it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (WDG_LIB_PATH: another build of the same library - the A/B scripts under scripts/dev/ compare kernel variants with it)
