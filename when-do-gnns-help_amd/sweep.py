@@ -70,6 +70,22 @@ def shard_jobs(jobs, world_size, rank, slack=0.02):
     fair share of the lightest, one that already holds a job of the same seed is preferred (its X is resident there: 4 MB
     saved - a tie-break, never a reason to unbalance).  Deterministic and identical on every rank; a rank may end up with
     no job when there are fewer jobs than ranks.  The shard keeps the jobs of a seed adjacent, in list order."""
+    key = (tuple(jobs), int(world_size), float(slack))
+    owner = _SHARD_MEMO.get(key)  # (a pure function of the job list: every rank of a run, and every pass of a process, asks again)
+    if owner is None:
+        owner = _shard_owner(jobs, world_size, slack)
+        if len(_SHARD_MEMO) >= 16:
+            _SHARD_MEMO.clear()
+        _SHARD_MEMO[key] = owner
+    mine = [i for i in range(len(jobs)) if owner[i] == rank]
+    return [jobs[i] for i in sorted(mine, key=lambda i: (jobs[i].seed, i))]
+
+
+_SHARD_MEMO = {}
+
+
+def _shard_owner(jobs, world_size, slack):
+    """shard_jobs' partition: the rank of every job"""
     order = sorted(range(len(jobs)), key=lambda i: (-job_cost(jobs[i]), i))
     fair = sum(job_cost(j) for j in jobs) / max(world_size, 1)
     load = [0] * world_size
@@ -118,8 +134,7 @@ def shard_jobs(jobs, world_size, rank, slack=0.02):
         owner[i] = q
         if k >= 0:
             owner[k] = hi
-    mine = [i for i in range(len(jobs)) if owner[i] == rank]
-    return [jobs[i] for i in sorted(mine, key=lambda i: (jobs[i].seed, i))]
+    return owner.tolist()
 
 
 def encode_jobs(jobs):
