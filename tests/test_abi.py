@@ -240,3 +240,15 @@ def test_every_reference_citation_resolves():
     n, bad = mod.check("/root/reference")
     assert n >= 200, n
     assert not bad, "\n".join(bad)
+
+
+def test_package_import_defaults_the_hip_hardware_queues_to_eight():
+    """wdg_amd/_lib.py sets GPU_MAX_HW_QUEUES=8 when the variable is unset (a sweep's eight concurrent streams alias on HIP's default
+    four queues: DESIGN 7) and leaves a caller's own value alone"""
+    import subprocess
+    import sys
+    code = "import os, sys; sys.path.insert(0, %r); import wdg_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1] == "8"
+    env["GPU_MAX_HW_QUEUES"] = "2"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1] == "2"

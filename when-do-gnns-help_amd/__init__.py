@@ -8,3 +8,10 @@ Layout (only what the hot path needs):
   utils/   drop-in twins of the reference's utils.util_funcs / utils.homophily_metrics / utils.homophily_plot
 """
 __version__ = "0.1.0"
+
+import os as _os_env
+
+# (see _lib.py: a sweep's eight concurrent HIP streams on eight hardware queues instead of the default four; only when unset, and only
+# effective if nothing has initialised the HIP runtime yet)
+_os_env.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+del _os_env
