@@ -131,7 +131,7 @@ def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkey
     share one step (step twins), a base takes over the prepared batch of an earlier base of equal sample_max (rebind_features: same
     buffers, new features, new node-set keys) and the bases are visited out of order - every (shard, base) still gives the rows
     of a stand-alone SweepBatch over the same inputs, bit for bit, and the same rows as the driver without any reuse
-    (WDG_SWEEP_REBIND=0 WDG_SWEEP_STEP_TWINS=0)."""
+    (WDG_SWEEP_REBIND=0 WDG_SWEEP_STEP_TWINS=0 WDG_SWEEP_PREFETCH_BUILD=0), unpipelined or with three base-shards in flight."""
     from wdg_amd import sweep, synth
     levels, samples = [0.2, 0.5, 0.8], [0, 1]
     graphs = {(h, s_): synth.regular_graph(600, 5, 4, h, s_) for h in levels for s_ in samples}
@@ -161,8 +161,12 @@ def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkey
         sb.launch_full()
         want = sb.full_metrics()
         assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (si, bi)
+    for depth in (1, 3):  # (unpipelined: a batch is free again at once; three in flight: a base may find no free batch and builds its own)
+        for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=depth, first_seed=5):
+            assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(got[(si, bi)], nan=-7.0)), (depth, si, bi)
     monkeypatch.setenv("WDG_SWEEP_REBIND", "0")
     monkeypatch.setenv("WDG_SWEEP_STEP_TWINS", "0")
+    monkeypatch.setenv("WDG_SWEEP_PREFETCH_BUILD", "0")
     order = []
     for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=2, first_seed=5):
         order.append((si, bi))
