@@ -156,6 +156,10 @@ int wdg_unpack_bits_f32(const uint32_t *words, int64_t ldw, int32_t N, int32_t F
 #define WDG_SELL16_SPLIT 1        /* wdg_spmm_job.q_flags */
 #define WDG_BAND_HUB_ON_DEVICE (-1) /* wdg_spmm_job.band_n_hub: the kernel takes the count from band_cuts[8] */
 #define WDG_SELL16_HALF 2         /* wdg_spmm_job.q_flags: offsets over 32-byte slab rows (wdg_sell16_row_bytes(n_cols) == 32) */
+#define WDG_SELL16_X_TRANSPOSED 4 /* wdg_spmm_job.q_flags (the quad-row kernel only: jobs with a SELL-16 copy): X is given TRANSPOSED,
+                                     [n_feat, n_cols] with leading dimension ldx - element (column j, feature f) at X[f ldx + j].  The
+                                     second product of a propagated kernel, U = A_hat T^T (utils/homophily_metrics.py:234-235 by
+                                     K(A_hat X) = A_hat K(X) A_hat^T), reads T where the first product wrote it */
 typedef struct wdg_spmm_job {
     const int32_t *rowptr;
     const int32_t *col;

@@ -1211,6 +1211,38 @@ def test_gram_map_fused_epilogue(ops, oracle, split, monkeypatch):
     assert only.k_linear[0] is None and torch.equal(only.k_arccos[0], gb.k_arccos[0])
 
 
+@pytest.mark.parametrize("n,k,f,col_scale", [(2000, 10, 2000, False), (600, 4, 97, True), (4000, 10, 72, False), (1500, 2, 16, True)])
+def test_quad_kernel_reads_a_transposed_source_bitwise_like_the_row_major_one(ops, n, k, f, col_scale):
+    """WDG_SELL16_X_TRANSPOSED (ops.Transposed): a batched aggregation whose X is given as [F, n] stages the same slabs as one over
+    the row-major [n, F] copy - same sums, same order: equal bit for bit (whole and ragged feature groups, full and HALF slabs, with a
+    column scale); tables of transposed sources are refused off the quad-row kernel."""
+    from wdg_amd import synth
+    rng = np.random.default_rng(n + f)
+    graphs, scales = [], []
+    for h, seed in ((0.2, 0), (0.7, 1)):
+        src, dst, _lab = synth.regular_graph(n, 5, k, h, seed)
+        g = ops.CsrGraph.from_coo(src, dst, n, None, ops.COO_ADD_SELF_LOOPS)
+        assert g.ensure_quad()
+        graphs.append(g)
+        scales.append(ops.degree_norm(g, ops.NORM_SYM if col_scale else ops.NORM_RW, ops.PREC_F32)["dinv"])
+    xt = torch.from_numpy(rng.standard_normal((f, n)).astype(np.float32)).cuda()   # [F, n]: the transposed storage
+    x = xt.t().contiguous()                                                        # [n, F]
+    ya = [torch.empty((n, f), dtype=torch.float32, device="cuda") for _ in graphs]
+    yb = [torch.empty((n, f), dtype=torch.float32, device="cuda") for _ in graphs]
+    a = ops.SpmmBatch([(g, x, y, d, d if col_scale else None, False) for g, y, d in zip(graphs, ya, scales)])
+    b = ops.SpmmBatch([(g, ops.Transposed(xt), y, d, d if col_scale else None, False) for g, y, d in zip(graphs, yb, scales)])
+    assert a.quad and b.quad
+    a.launch()
+    b.launch()
+    b.verify()  # (against the CSR kernel on the row-major copy)
+    b.launch()
+    torch.cuda.synchronize()
+    for u, v in zip(ya, yb):
+        assert torch.equal(u, v)
+    with pytest.raises(ValueError):
+        ops.SpmmBatch([(graphs[0], ops.Transposed(xt[:4]), torch.empty((n, 4), dtype=torch.float32, device="cuda"), None, None, False)])
+
+
 @pytest.mark.parametrize("symmetric", [0, 1])
 def test_propagated_gram_equals_the_gram_of_the_aggregated_features(ops, symmetric):
     """ops.PropagatedGram (wdg_transpose_batched_f32 + wdg_gram_finish_batched_f32 around two aggregations with n "features"):
@@ -1255,6 +1287,19 @@ def test_propagated_gram_equals_the_gram_of_the_aggregated_features(ops, symmetr
     prop.launch()  # the finish pass runs in place on K_linear: a relaunch recomputes everything from the raw features' kernels
     torch.cuda.synchronize()
     assert all(torch.equal(a_, b_) for a_, b_ in zip(again, prop.k_arccos))
+    # the first form of the route - a transpose pass (wdg_transpose_batched_f32) between the products instead of a second product
+    # that reads T transposed - stages the same slabs: the same kernels bit for bit
+    assert not prop.transpose_pass
+    os.environ["WDG_PROP_TRANSPOSE"] = "1"
+    try:
+        old = ops.PropagatedGram([(g, d, d if symmetric else None, kx[(c[0], c[3])]) for g, d, c in zip(graphs, scales, cases)])
+    finally:
+        del os.environ["WDG_PROP_TRANSPOSE"]
+    assert old.transpose_pass
+    old.launch()
+    torch.cuda.synchronize()
+    for i in range(len(cases)):
+        assert torch.equal(old.k_linear[i], prop.k_linear[i]) and torch.equal(old.k_arccos[i], prop.k_arccos[i]) and torch.equal(old.norm2[i], prop.norm2[i])
 
 
 @pytest.mark.parametrize("n,nt,nv,c", [(500, 300, 200, 5), (183, 110, 73, 5), (400, 320, 80, 8), (64, 33, 31, 2), (50, 1, 49, 3)])

@@ -3,7 +3,7 @@ include/wdg.h, pointer and leading-dimension helpers, and the page-locked arena 
 PyTorch is plumbing here (device memory, the current HIP stream); nothing in this package computes on the CPU or falls back."""
 __all__ = ["COO_SYMMETRISE", "COO_BINARISE", "COO_ADD_SELF_LOOPS", "COO_DROP_SELF_LOOPS", "COO_KEEP_DUPLICATES", "NORM_RW", "NORM_SYM",
            "PREC_F32", "PREC_F64", "ACT_NONE", "ACT_RELU", "SPMM_ANY_VAL", "SPMM_DMA_OK", "SPMM_SMALL_OFFSETS", "SPMM_ANY_COL_SCALE",
-           "SPMM_HALF_SLAB", "GEMM_A_VEC4", "Tiled"]  # what `from ._rt import *` hands the front-end modules: the flag values only
+           "SPMM_HALF_SLAB", "GEMM_A_VEC4", "Tiled", "Transposed"]  # what `from ._rt import *` hands the front-end modules: the flag values only
 
 import ctypes
 import os
@@ -37,7 +37,7 @@ def _dev(t, dtype, dev):
 def _ld(t):
     """Leading dimension of a row-major matrix for the C ABI.  torch / numpy report an arbitrary stride for a dimension
     of size 1 (a [1, K] view of a [K, 1] array has stride(0) == 1): with one row any value >= the row length is valid."""
-    if isinstance(t, Tiled):
+    if isinstance(t, (Tiled, Transposed)):
         return t.ld
     return t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
 
@@ -171,6 +171,27 @@ class Tiled:
     def fill_(self, v):
         self.t.fill_(v)
         return self
+
+
+class Transposed:
+    """The X operand of an aggregation given TRANSPOSED: `t` is [F, n] (fp32 / bf16, unit inner stride) and stands for the [n, F]
+    matrix t^T (WDG_SELL16_X_TRANSPOSED of include/wdg.h; the quad-row kernel only: SpmmBatch checks)."""
+
+    def __init__(self, t):
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError("Transposed: a [F, n] tensor with unit inner stride expected")
+        self.t = t
+
+    shape = property(lambda self: (int(self.t.shape[1]), int(self.t.shape[0])))
+    dtype = property(lambda self: self.t.dtype)
+    device = property(lambda self: self.t.device)
+    ld = property(lambda self: int(self.t.stride(0)) if self.t.shape[0] > 1 else max(int(self.t.stride(0)), int(self.t.shape[1])))
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def stride(self, dim):
+        return {0: 1, 1: 1}[dim]  # (what callers test is the inner stride of the stored rows)
 
 
 def _table(arr):

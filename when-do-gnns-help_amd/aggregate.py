@@ -42,7 +42,7 @@ def _fill_job(job, g, x, y, row_scale, col_scale, use_values=True, band=False):
         job.q_rows = q["rows"].data_ptr()
         job.q_val = q["val"].data_ptr() if (wants_val and q["val"] is not None) else 0
         job.q_block_cols, job.q_n_blocks = q["block_cols"], q["n_blocks"]
-        job.q_n_entries, job.q_flags = q["n_entries"], (1 if q["split"] else 0) | (2 if q["half"] else 0)
+        job.q_n_entries, job.q_flags = q["n_entries"], (1 if q["split"] else 0) | (2 if q["half"] else 0) | (4 if isinstance(x, Transposed) else 0)
     else:
         job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0
         job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
@@ -326,6 +326,8 @@ class SpmmBatch:
             order = [i for grp in groups for i in sorted(grp, key=lambda i: -entries[i][0].nnz)]
         if any(isinstance(e[2], Tiled) for e in entries) and not self.quad:
             raise ValueError("SpmmBatch: a tiled Y needs the quad-row kernel (SELL-16 copies, F >= 8)")
+        if any(isinstance(e[1], Transposed) for e in entries) and not self.quad:
+            raise ValueError("SpmmBatch: a transposed X needs the quad-row kernel (SELL-16 copies, F >= 8)")
         for job, (g, x, y, rs, cs, uv) in zip(arr, (entries[i] for i in order)):
             _fill_job(job, g, x, y, rs, cs, uv)
             any_val = any_val or bool(job.val)
@@ -361,7 +363,8 @@ class SpmmBatch:
         for i, (g, x, y, rs, cs, uv) in enumerate(self.keep):
             got = y.rowmajor() if isinstance(y, Tiled) else y.clone()
             ref = torch.empty((g.n_rows, x.shape[1]), dtype=torch.float32, device=y.device)
-            job = _fill_job(SpmmJob(), g, x, ref, rs, cs, uv)
+            xv = x.t.t().contiguous() if isinstance(x, Transposed) else x  # (the CSR kernels read row-major sources only)
+            job = _fill_job(SpmmJob(), g, xv, ref, rs, cs, uv)
             job.q_ext = job.q_col = job.q_val = job.q_perm = job.q_rows = 0  # no SELL copies: the CSR families
             job.q_block_cols = job.q_n_blocks = job.q_n_entries = job.q_flags = 0
             check(lib.wdg_spmm_csr_f32(ctypes.byref(job), stream_handle()), "wdg_spmm_csr_f32")

@@ -752,6 +752,7 @@ struct QHead {  // what a phase needs of its first job (the jobs of a phase agre
     int64_t ldx;
     int32_t n_cols, n_feat, block_cols, n_blocks, reserved;
     bool y_vec;  // every job of the launch: Y 16-byte aligned, ldy % 4 == 0 (the launcher's promise, a kernel argument)
+    bool x_t;    // WDG_SELL16_X_TRANSPOSED: X is given as [n_feat, n_cols] (element (column j, feature f) at X[f ldx + j])
 };
 typedef const wdg_spmm_job __attribute__((address_space(4))) *q_desc_ptr;
 __device__ __forceinline__ q_desc_ptr q_desc(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, int id) {
@@ -776,6 +777,7 @@ __device__ __forceinline__ QHead q_load_head(const wdg_spmm_job *jobs, const wdg
     h.ldx = j->ldx;
     h.n_cols = j->n_cols; h.n_feat = j->n_feat; h.block_cols = j->q_block_cols; h.n_blocks = j->q_n_blocks;
     h.reserved = j->reserved;
+    h.x_t = (j->q_flags & WDG_SELL16_X_TRANSPOSED) != 0;
     return h;
 }
 
@@ -816,7 +818,14 @@ __device__ __forceinline__ void q_stage(const QHead &h, int begin, int rows, int
             if (i < n_stage) {
                 const int row = begin + i / SL, f = f0 + (i % SL) * 4;
                 const global_ptr<const TIN> src = X + static_cast<int64_t>(row) * h.ldx + f;
-                if (x_vec) {
+                if (h.x_t) {  // a transposed source: four rows of X^T, 4 bytes each (sixteen slab rows x 4 bytes = one 64-byte piece per
+                    // X^T row and wave-instruction) - the second product of a propagated kernel reads T as it was written
+                    const global_ptr<const TIN> st = X + static_cast<int64_t>(f) * h.ldx + row;
+                    if (f + 0 < F) v[j].x = q_f32(st[0]);
+                    if (f + 1 < F) v[j].y = q_f32(st[h.ldx]);
+                    if (f + 2 < F) v[j].z = q_f32(st[2 * h.ldx]);
+                    if (f + 3 < F) v[j].w = q_f32(st[3 * h.ldx]);
+                } else if (x_vec) {
                     if (f < F) v[j] = load_f32x4((global_ptr<const float>)src);
                 } else {
                     if (f + 0 < F) v[j].x = q_f32(src[0]);

@@ -72,7 +72,8 @@ class PropagatedGram:
     """The kernels of the AGGREGATED features of many graphs WITHOUT a dense product per graph: Y = A_hat X gives Y Y^T = A_hat (X X^T)
     A_hat^T, so K_linear(Y) = A_hat K_linear(X) A_hat^T - two batched aggregations with n "features" over the half Gram of the raw
     features (2 nnz n flops each instead of n^2 F: 4 .. 18 x less work for the reference's feature bases, F = 932 .. 3 703), a
-    batched transpose between them and the finish pass (mirror + arc-cosine map, wdg_gram_finish_batched_f32).
+    second one reading the first one's output transposed (ops.Transposed) - and the finish pass (mirror + arc-cosine map,
+    wdg_gram_finish_batched_f32).
     Same interface as GramBatch (`k_linear[i]`, `k_arccos[i]`, `norm2[i]`, `launch()`); entries agree with GramBatch over the
     aggregated features to fp32 rounding (tests/test_gpu_kernels.py)."""
 
@@ -93,19 +94,26 @@ class PropagatedGram:
         self.k_arccos = [torch.empty((n, n), dtype=torch.float32, device=dev) if arccos else None for n in ns]
         # T and T^T are scratch between the launches of ONE launch(): kept per (stream, shapes) across batches - a sweep builds a
         # batch like this per feature base and shard, 2 x 70 allocations of 16 MB each time otherwise
-        key = (torch.cuda.current_stream().cuda_stream, tuple(ns))
+        # the second product reads T TRANSPOSED where the first wrote it (WDG_SELL16_X_TRANSPOSED: the slab staging transposes 16 rows
+        # of T at a time: 3.72 -> 3.15 ms per 70 graphs of 2000 nodes); WDG_PROP_TRANSPOSE=1: round 5's first form, a transpose pass
+        # between the products into a second scratch matrix per graph
+        self.transpose_pass = os.environ.get("WDG_PROP_TRANSPOSE", "0") == "1"
+        key = (torch.cuda.current_stream().cuda_stream, tuple(ns), self.transpose_pass)
         if key not in _PROP_SCRATCH:
             if len(_PROP_SCRATCH) >= 4:
                 _PROP_SCRATCH.pop(next(iter(_PROP_SCRATCH)))
             _PROP_SCRATCH[key] = ([torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns],
-                                  [torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns])
+                                  [torch.empty((n, n), dtype=torch.float32, device=dev) if self.transpose_pass else None for n in ns])
         self._t, self._tt = _PROP_SCRATCH[key]
         self.first = SpmmBatch([(g, kx, t, rs, cs, False) for (g, rs, cs, kx), t in zip(problems, self._t)])
-        self.second = SpmmBatch([(g, tt, u, rs, cs, False) for (g, rs, cs, _kx), tt, u in zip(problems, self._tt, self.k_linear)])
-        tr = (_lib.TransposeJob * self.n_jobs)()
-        for job, t, tt, n in zip(tr, self._t, self._tt, ns):
-            job.src, job.dst, job.ld_src, job.ld_dst, job.rows, job.cols = t.data_ptr(), tt.data_ptr(), n, n, n, n
-        self.tr_table = _table(tr)
+        self.second = SpmmBatch([(g, tt if self.transpose_pass else Transposed(t), u, rs, cs, False)
+                                 for (g, rs, cs, _kx), t, tt, u in zip(problems, self._t, self._tt, self.k_linear)])
+        self.tr_table = None
+        if self.transpose_pass:
+            tr = (_lib.TransposeJob * self.n_jobs)()
+            for job, t, tt, n in zip(tr, self._t, self._tt, ns):
+                job.src, job.dst, job.ld_src, job.ld_dst, job.rows, job.cols = t.data_ptr(), tt.data_ptr(), n, n, n, n
+            self.tr_table = _table(tr)
         fin = (_lib.GramJob * self.n_jobs)()
         for job, u, n2, ka, n in zip(fin, self.k_linear, self.norm2, self.k_arccos, ns):
             job.A, job.norm2, job.K_linear = u.data_ptr(), n2.data_ptr(), u.data_ptr()
@@ -116,7 +124,8 @@ class PropagatedGram:
 
     def launch(self):
         self.first.launch()       # T_j = A_hat_j K_linear(X)
-        check(lib.wdg_transpose_batched_f32(_ptr(self.tr_table), self.n_jobs, self.max_n, self.max_n, stream_handle()), "wdg_transpose_batched_f32")
+        if self.transpose_pass:
+            check(lib.wdg_transpose_batched_f32(_ptr(self.tr_table), self.n_jobs, self.max_n, self.max_n, stream_handle()), "wdg_transpose_batched_f32")
         self.second.launch()      # U_j = A_hat_j T_j^T
         check(lib.wdg_gram_finish_batched_f32(_ptr(self.fin_table), self.n_jobs, self.max_n, stream_handle()), "wdg_gram_finish_batched_f32")
 

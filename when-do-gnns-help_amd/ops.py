@@ -15,7 +15,7 @@ from ._lib import check, lib, require_gpu, stream_handle  # noqa: F401
 from ._rt import (  # noqa: F401
     ACT_NONE, ACT_RELU, COO_ADD_SELF_LOOPS, COO_BINARISE, COO_DROP_SELF_LOOPS, COO_KEEP_DUPLICATES, COO_SYMMETRISE,
     GEMM_A_VEC4, NORM_RW, NORM_SYM, PREC_F32, PREC_F64, SPMM_ANY_COL_SCALE, SPMM_ANY_VAL, SPMM_DMA_OK,
-    SPMM_HALF_SLAB, SPMM_SMALL_OFFSETS, Tiled, _dev, _h2d, _H2D_MAX_BYTES, _ld, _PinnedArena, _ptr, _table,
+    SPMM_HALF_SLAB, SPMM_SMALL_OFFSETS, Tiled, Transposed, _dev, _h2d, _H2D_MAX_BYTES, _ld, _PinnedArena, _ptr, _table,
 )
 from .graphs import (  # noqa: F401
     CsrGraph, degree_norm, GraphBatch, normalise_values, quad_disabled, row_l1_normalise, unpack_bits,
