@@ -133,6 +133,8 @@ def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkey
     of a stand-alone SweepBatch over the same inputs, bit for bit, and the same rows as the driver without any reuse
     (WDG_SWEEP_REBIND=0 WDG_SWEEP_STEP_TWINS=0 WDG_SWEEP_PREFETCH_BUILD=0), unpipelined or with three base-shards in flight."""
     from wdg_amd import sweep, synth
+    for name in ("WDG_SWEEP_REBIND", "WDG_SWEEP_STEP_TWINS", "WDG_SWEEP_PREFETCH_BUILD", "WDG_GRAM_ROUTE"):
+        monkeypatch.delenv(name, raising=False)  # (this test asserts WHICH bases were rebound / twinned under the defaults)
     levels, samples = [0.2, 0.5, 0.8], [0, 1]
     graphs = {(h, s_): synth.regular_graph(600, 5, 4, h, s_) for h in levels for s_ in samples}
     widths = [("p1", 656, 500), ("p2", 700, 500), ("n", 97, 500), ("p3", 720, 300), ("p4", 800, 500), ("p5", 650, 300)]
@@ -253,7 +255,7 @@ def test_common_sets_per_sample_share_the_raw_feature_regressions(monkeypatch):
     # identity keys: a job alone in its batch draws the sets - and computes the rows - it has among the other levels
     for ji in (1, 5):
         sb = sweep.SweepBatch([jobs[ji]], n_feat=128, gcn_hidden=0)
-        sb.prepare_full(epochs=epochs, sample_max=500, base_seed=3)
+        sb.prepare_full(epochs=epochs, sample_max=500, base_seed=3, sets="sample")
         sb.step()
         sb.launch_full()
         torch.cuda.synchronize()
