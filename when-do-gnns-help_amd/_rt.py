@@ -92,6 +92,7 @@ class _PinnedArena:
 
 
 _ARENA = None
+_ARENA_LOCK = __import__("threading").Lock()
 _H2D_MAX_BYTES = int(float(os.environ.get("WDG_H2D_MAX_MB", "64")) * (1 << 20))  # larger arrays: the plain (blocking, pageable) copy
 _H2D_RING_BYTES = int(float(os.environ.get("WDG_H2D_RING_MB", "512")) * (1 << 20))  # two base-shards of the widest base in flight: 2 x 3 x 30 MB
 _H2D_THREADS = int(os.environ.get("WDG_H2D_THREADS", "8"))
@@ -116,6 +117,11 @@ def _h2d(host, dev=None):
         _ARENA = _PinnedArena(_H2D_RING_BYTES)
     if nbytes > _H2D_MAX_BYTES:
         return t.to(dev)
+    with _ARENA_LOCK:  # (take .. issued is one step of the ring: sweep.run_shards uploads from a helper thread as well)
+        return _h2d_locked(t, nbytes, dev)
+
+
+def _h2d_locked(t, nbytes, dev):
     start, piece = _ARENA.take(nbytes)
     p = piece.view(t.dtype).view(t.shape)
     # (numpy's memcpy / the library's threads, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware

@@ -1181,20 +1181,62 @@ def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symme
         _count_kr(stats if nine else None, sb)
         return rows
 
-    for b, (jobs, inputs) in enumerate(shards):
-        stream = streams[b % depth]
-        with torch.cuda.stream(stream):
-            sb = SweepBatch(jobs, n_feat=n_feat, symmetric=symmetric, gcn_hidden=0, inputs=inputs)
-            if nine and sb.jobs:
-                sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + b)
-            sb.step()
-            if nine and sb.jobs:
-                sb.launch_full()
-        in_flight.append((sb, stream))
-        if len(in_flight) >= depth:
+    # The NEXT shard's graph build (host pack of the edge lists into the upload ring, upload, COO -> CSR, SELL-16 count: 2 - 3 ms of
+    # mostly GIL-free library calls) runs on a HELPER THREAD and a stream of its own while this thread builds the current shard's
+    # tables: the cold path is host-bound (6.5 ms of host work per 50-graph shard against 0.2 - 9 ms on the device), and this is
+    # the part of it that needs no interpreter.  Nine scalars only (measured, 50-graph shards: nine 2 900 -> 3 300 - 3 500 graphs/s;
+    # six scalars - 0.2 ms of device work per shard, nothing to hide a build behind - 6 100 -> 5 400 - 5 700: the helper's share of the
+    # interpreter lock costs more than it frees).  WDG_SWEEP_BUILD_THREAD=0 / depth 1: everything on this thread, in place.
+    threaded = (nine and depth > 1 and os.environ.get("WDG_SWEEP_BUILD_THREAD", "1") != "0" and os.environ.get("WDG_SWEEP_BUILD", "batched") == "batched")
+    pool = build_stream = None
+    if threaded:
+        from concurrent.futures import ThreadPoolExecutor
+        pool, build_stream = ThreadPoolExecutor(max_workers=1), _side_stream(3)
+        dev_index = torch.cuda.current_device()
+
+    def queue_build(shard):
+        from . import ops
+        torch.cuda.set_device(dev_index)
+        with torch.cuda.stream(build_stream):
+            return ops.GraphBatch([(i_[0], i_[1], j.n_nodes) for j, i_ in zip(shard[0], shard[1])], ops.COO_ADD_SELF_LOOPS, quad=True, defer=True)
+
+    def submit(shard):
+        return pool.submit(queue_build, shard) if (threaded and shard is not None and shard[0] and shard[1] is not None) else None
+
+    try:
+        it = iter(shards)
+        nxt = next(it, None)
+        fut = submit(nxt)
+        b = 0
+        while nxt is not None:
+            (jobs, inputs), cur_fut = nxt, fut
+            nxt = next(it, None)
+            stream = streams[b % depth]
+            gb = None
+            if cur_fut is not None:
+                gb = cur_fut.result()
+                fut = submit(nxt)  # (the helper packs the next shard while this thread builds this one's tables)
+                with torch.cuda.stream(build_stream):
+                    gb.finish()
+                stream.wait_stream(build_stream)
+            else:
+                fut = submit(nxt)
+            with torch.cuda.stream(stream):
+                sb = SweepBatch(jobs, n_feat=n_feat, symmetric=symmetric, gcn_hidden=0, inputs=inputs, graph_batch=gb)
+                if nine and sb.jobs:
+                    sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + b)
+                sb.step()
+                if nine and sb.jobs:
+                    sb.launch_full()
+            in_flight.append((sb, stream))
+            b += 1
+            if len(in_flight) >= depth:
+                yield fetch()
+        while in_flight:
             yield fetch()
-    while in_flight:
-        yield fetch()
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
 
 
 def propagates(n_feat, jobs):
