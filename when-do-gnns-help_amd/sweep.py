@@ -1184,10 +1184,13 @@ def run_shards(shards, n_feat=500, nine=False, epochs=100, sample_max=500, symme
     # The NEXT shard's graph build (host pack of the edge lists into the upload ring, upload, COO -> CSR, SELL-16 count: 2 - 3 ms of
     # mostly GIL-free library calls) runs on a HELPER THREAD and a stream of its own while this thread builds the current shard's
     # tables: the cold path is host-bound (6.5 ms of host work per 50-graph shard against 0.2 - 9 ms on the device), and this is
-    # the part of it that needs no interpreter.  Nine scalars only (measured, 50-graph shards: nine 2 900 -> 3 300 - 3 500 graphs/s;
-    # six scalars - 0.2 ms of device work per shard, nothing to hide a build behind - 6 100 -> 5 400 - 5 700: the helper's share of the
-    # interpreter lock costs more than it frees).  WDG_SWEEP_BUILD_THREAD=0 / depth 1: everything on this thread, in place.
-    threaded = (nine and depth > 1 and os.environ.get("WDG_SWEEP_BUILD_THREAD", "1") != "0" and os.environ.get("WDG_SWEEP_BUILD", "batched") == "batched")
+    # the part of it that needs no interpreter.  Measured over ten 50-graph shards, best of three passes (scripts/dev/time_cold_modes.py):
+    # six scalars 8 800 -> 9 700 graphs/s, nine scalars 3 360 -> 4 670.  (The shard's feature uploads moved to the helper as well:
+    # 6 300 / 4 200 - its 4-MB copies hold the upload ring's lock against this thread's twenty small uploads.)
+    # WDG_SWEEP_BUILD_THREAD=0 / depth 1: everything on this thread, in place.
+    threaded = (depth > 1 and os.environ.get("WDG_SWEEP_BUILD_THREAD", "1") != "0" and os.environ.get("WDG_SWEEP_BUILD", "batched") == "batched")
+    if "WDG_SWEEP_BUILD_THREAD_FORCE" in os.environ:  # (scripts/dev/time_cold_modes.py)
+        threaded = os.environ["WDG_SWEEP_BUILD_THREAD_FORCE"] == "1"
     pool = build_stream = None
     if threaded:
         from concurrent.futures import ThreadPoolExecutor
