@@ -35,28 +35,28 @@ def test_the_advisors_example():
     P5's lap position 768, wraps to [0, 512) and must wait for P4 AND P5 - the oldest entry P3 does not overlap it (it is waited
     for as well: entries complete in issue order, an older one costs nothing)"""
     ar, log, events = _arena(1024)
-    a1, _ = ar.take(512); ar.issued(a1, 512)      # [0, 512)   lap 0
-    a3, _ = ar.take(256); ar.issued(a3, 256)      # [512, 768) lap 0  (P3)
+    h_, a1, _ = ar.take(512); ar.issued(h_)      # [0, 512)   lap 0
+    h_, a3, _ = ar.take(256); ar.issued(h_)      # [512, 768) lap 0  (P3)
     events[0].done = True
-    a_skip, _ = ar.take(512); ar.issued(a_skip, 512)  # does not fit the 256-byte tail: lap 1, [0, 512) - waits for the first entry only
+    h_, a_skip, _ = ar.take(512); ar.issued(h_)  # does not fit the 256-byte tail: lap 1, [0, 512) - waits for the first entry only
     assert (a1, a3, a_skip) == (0, 512, 0) and log == [events[0]]
     log.clear()
     for e in events:
         e.done = True
     ar2, log2, ev2 = _arena(1024)
     for n in (512, 256):                          # lap 0: [0, 512) and P3 = [512, 768)
-        a, _ = ar2.take(n); ar2.issued(a, n)
+        h_, a, _ = ar2.take(n); ar2.issued(h_)
     ev2[0].done = True
-    a4, _ = ar2.take(256); ar2.issued(a4, 256)    # P4: fits the tail [768, 1024)
+    h_, a4, _ = ar2.take(256); ar2.issued(h_)    # P4: fits the tail [768, 1024)
     assert a4 == 768
-    a5, _ = ar2.take(256); ar2.issued(a5, 256)    # P5: lap 1 [0, 256): one lap ahead of the first entry only
-    a6, _ = ar2.take(256); ar2.issued(a6, 256)    # P6: lap 1 [256, 512)
+    h_, a5, _ = ar2.take(256); ar2.issued(h_)    # P5: lap 1 [0, 256): one lap ahead of the first entry only
+    h_, a6, _ = ar2.take(256); ar2.issued(h_)    # P6: lap 1 [256, 512)
     assert (a5, a6) == (0, 256) and log2 == [ev2[0]]
     log2.clear()
-    a, piece = ar2.take(512)                      # lap 1 [512, 1024): overlaps P3 and P4 of lap 0
+    _h, a, piece = ar2.take(512)                     # lap 1 [512, 1024): overlaps P3 and P4 of lap 0
     assert a == 512 and piece.numel() == 512
     assert ev2[1] in log2 and ev2[2] in log2 and ev2[3] not in log2 and ev2[4] not in log2
-    a, _ = ar2.take(512)                          # lap 2 [0, 512): overlaps P5 and P6 - neither is the head's neighbour in the buffer
+    _h, a, _ = ar2.take(512)                       # lap 2 [0, 512): overlaps P5 and P6 - neither is the head's neighbour in the buffer
     assert a == 0 and ev2[3] in log2 and ev2[4] in log2
 
 
@@ -67,13 +67,13 @@ def test_random_requests_never_reuse_bytes_in_flight():
     in_flight = []   # (start, end, event) of copies the "device" has not run yet
     for step in range(4000):
         n = int(rng.integers(1, size // 3))
-        a, piece = ar.take(n)
+        h_, a, piece = ar.take(n)
         b = a + ((n + 255) & ~255)
         assert b <= size and piece.numel() == n
         for s, e, ev in in_flight:
             if s < b and a < e:
                 assert ev.done, f"step {step}: [{a}, {b}) handed out while the copy of [{s}, {e}) is in flight"
-        ar.issued(a, n)
+        ar.issued(h_)
         in_flight.append((a, b, events[-1]))
         # the device completes a random prefix of the queue (copies finish in issue order)
         k = int(rng.integers(0, 3))
@@ -90,3 +90,33 @@ def test_oversized_request_is_refused():
     except ValueError:
         return
     raise AssertionError("a request larger than the ring must raise")
+
+
+def test_two_threads_may_fill_their_slices_at_the_same_time():
+    """take() enters the slice into `pending` in ring order with no event yet, issued(handle) supplies it: slices taken by two
+    threads and queued in the other order leave `pending` ascending, and a request that laps a slice whose copy has not been
+    queued yet waits until it has (and then for its event)."""
+    import threading
+    import time
+    ar, log, events = _arena(1024)
+    ha, a, _ = ar.take(256)
+    hb, b, _ = ar.take(256)
+    ar.issued(hb)              # thread B queues its copy first
+    ar.issued(ha)
+    assert (a, b) == (0, 256) and [e[0] for e in ar.pending] == [0, 256] and all(e[1] is not None for e in ar.pending)
+    hc, c, _ = ar.take(512)    # [512, 1024), taken but not queued yet
+    assert c == 512
+    got = []
+
+    def lapper():              # lap 1 [0, 768): overlaps a, b (queued) and c (not queued yet)
+        for e in events:
+            e.done = True
+        got.append(ar.take(768)[1])
+
+    t = threading.Thread(target=lapper)
+    t.start()
+    time.sleep(0.05)
+    assert t.is_alive() and not got          # waiting for c's copy to be queued
+    ar.issued(hc)
+    t.join(5)
+    assert not t.is_alive() and got == [0] and events[-1] in log

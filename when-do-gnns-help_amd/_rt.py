@@ -69,6 +69,10 @@ class _PinnedArena:
         return ev
 
     def take(self, nbytes):
+        """-> (handle, offset, the slice).  The slice's entry joins `pending` HERE, in ring order, with no event yet: `issued(handle)`
+        supplies it once the copy is queued - so two threads may fill and queue their slices at the same time (a lock around take
+        and around issued only) and `pending` still ascends.  A later request that laps an entry whose copy has not even been
+        queued waits for it (a full lap of the ring between take and issued: never in practice)."""
         n = (nbytes + 255) & ~255
         if n > self.size:
             raise ValueError(f"_PinnedArena: {nbytes} bytes do not fit the {self.size}-byte ring")
@@ -77,18 +81,22 @@ class _PinnedArena:
         va, vb = self.voff, self.voff + n
         done = 0
         while done < len(self.pending) and self.pending[done][0] + self.size < vb:
-            self.pending[done][1].synchronize()  # a lap behind the new slice's end: its bytes are about to be overwritten
+            entry = self.pending[done]
+            while entry[1] is None:  # (taken by another thread, its copy not queued yet)
+                import time
+                time.sleep(0)
+            entry[1].synchronize()  # a lap behind the new slice's end: its bytes are about to be overwritten
             done += 1
         if done:
             del self.pending[:done]
         self.voff = vb
         a = va % self.size
-        return a, self.buf[a:a + nbytes]
+        entry = [va, None]
+        self.pending.append(entry)
+        return entry, a, self.buf[a:a + nbytes]
 
-    def issued(self, start, nbytes):
-        # (the slice just handed out: its virtual start is voff minus its padded length)
-        self.pending.append((self.voff - ((nbytes + 255) & ~255), self._new_event()))
-        assert self.pending[-1][0] % self.size == start, "issued() must follow the take() it belongs to"
+    def issued(self, handle):
+        handle[1] = self._new_event()
 
 
 _ARENA = None
@@ -117,12 +125,8 @@ def _h2d(host, dev=None):
         _ARENA = _PinnedArena(_H2D_RING_BYTES)
     if nbytes > _H2D_MAX_BYTES:
         return t.to(dev)
-    with _ARENA_LOCK:  # (take .. issued is one step of the ring: sweep.run_shards uploads from a helper thread as well)
-        return _h2d_locked(t, nbytes, dev)
-
-
-def _h2d_locked(t, nbytes, dev):
-    start, piece = _ARENA.take(nbytes)
+    with _ARENA_LOCK:  # (sweep.run_shards uploads from a helper thread as well: the ring's bookkeeping under a lock, the copies not)
+        handle, _start, piece = _ARENA.take(nbytes)
     p = piece.view(t.dtype).view(t.shape)
     # (numpy's memcpy / the library's threads, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware
     # thread of the host - measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
@@ -133,7 +137,7 @@ def _h2d_locked(t, nbytes, dev):
     else:
         np.copyto(p.numpy(), t.numpy())
     out = p.to(dev, non_blocking=True)
-    _ARENA.issued(start, nbytes)
+    _ARENA.issued(handle)  # (no lock: one assignment into the slice's own entry - a take() that waits for it holds the lock)
     return out
 
 
