@@ -475,6 +475,11 @@ def measure_whole(args, dev, world=1, rank=0):
             "first_pass_seconds": t_first, "first_pass_note": "this rank's untimed first pass of the same sweep in this process (allocator pools still growing)", **rec,
             "kr_ridged": int(kr_counts[0].item()), "kr_total": int(kr_counts[1].item()),
             "kr_sets": KR_SETS_NOTE[os.environ.get("WDG_SWEEP_KR_SETS", "sample")],
+            "reuse_inside_a_shard": "what depends on less than a job is computed once (DESIGN 5): the six step scalars of the wide bases (they "
+                                    "aggregate the label columns only: graph + labels) by the first of them (WDG_SWEEP_STEP_TWINS=0: every base), "
+                                    "the job tables of a base taken over from an earlier base of equal sample_max (WDG_SWEEP_REBIND=0: built "
+                                    "per base), the raw features' regressions once per sample (kr_sets); every row equals the stand-alone "
+                                    "batch's bit for bit with or without (tests/test_gpu_sweep.py)",
             "ms_per_base_rank0": {n: 1e3 * t for (n, _w), t in zip(bases, per_base)},
             "input_generation_s_outside_clock": t_in, "rows": list(table.shape), "nan_rows": int(torch.isnan(table).any(1).sum()),
             "reference_cpu_estimate": "~35 s per job, ~17 h for the sweep (BASELINE.md)",
