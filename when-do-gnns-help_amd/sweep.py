@@ -671,7 +671,14 @@ class SweepBatch:
             st, c = self.stats, self.stats.c
             host = getattr(self, "labels_host", None)
             if host is not None and len(host) == st.n_jobs:
-                cnt = np.stack([np.bincount(np.asarray(l)[(np.asarray(l) >= 0) & (np.asarray(l) < c)], minlength=c)[:c] for l in host])
+                memo = {}  # (the jobs of a sample share their label array: counted once per distinct array)
+
+                def count(l):
+                    if id(l) not in memo:
+                        a = np.asarray(l)
+                        memo[id(l)] = np.bincount(a[(a >= 0) & (a < c)], minlength=c)[:c]
+                    return memo[id(l)]
+                cnt = np.stack([count(l) for l in host])
                 counts = self.ops._h2d(cnt.astype(np.float32), st.counters.device)  # (never a blocking pageable copy between launches)
             else:
                 n = st.max_rows
