@@ -1302,6 +1302,53 @@ def test_propagated_gram_equals_the_gram_of_the_aggregated_features(ops, symmetr
         assert torch.equal(old.k_linear[i], prop.k_linear[i]) and torch.equal(old.k_arccos[i], prop.k_arccos[i]) and torch.equal(old.norm2[i], prop.norm2[i])
 
 
+def test_persistent_solver_launch_equals_one_workgroup_per_problem_and_skips_refused_problems(ops, monkeypatch):
+    """wdg_kernel_regress_batched_f32 walks the table with one workgroup per CU and makes a problem's predictions inside the next
+    problem's factorisation: the hit counts are those of one workgroup per problem (WDG_KR_PERSIST=0 in a fresh process is the other
+    schedule; here: a table short enough for one problem per workgroup against the same problems repeated past the CU count), and a
+    problem the kernel refuses (a train count outside 1 .. 320, patched into the device table: the Python front end never builds
+    one) answers -1 without disturbing the problems around it - the deferred predictions of the problem before it included."""
+    rng = np.random.default_rng(77)
+    n, nt, nv, c = 600, 300, 200, 5
+    base = []
+    for p in range(6):
+        h = rng.standard_normal((n, 48)).astype(np.float32)
+        lab = rng.integers(0, c, n).astype(np.int32)
+        h += np.eye(c, 48, dtype=np.float32)[lab] * 2.0
+        gb = ops.GramBatch([torch.from_numpy(h).cuda()], linear=False)
+        gb.launch()
+        perm = rng.permutation(n)
+        tr, va = np.sort(perm[:nt]).astype(np.int32), np.sort(perm[nt:nt + nv]).astype(np.int32)
+        base.append((gb.k_arccos[0], torch.from_numpy(tr).cuda(), torch.from_numpy(va).cuda(), torch.from_numpy(lab).cuda()))
+    few = ops.KrBatch(base, c)                      # 6 problems: one workgroup each, every prediction by the final flush
+    few.launch()
+    torch.cuda.synchronize()
+    want = few.correct[:6].cpu().numpy()
+    assert (want > nv / c).all()
+    reps = 100                                      # 600 problems on 256 workgroups: two or three problems per workgroup, deferred predictions
+    many = ops.KrBatch(base * reps, c)
+    many.launch()
+    torch.cuda.synchronize()
+    got = many.correct[:6 * reps].cpu().numpy().reshape(reps, 6)
+    assert (got == want[None, :]).all()
+    # refuse every 7th problem
+    import ctypes
+    from wdg_amd import _lib
+    size = ctypes.sizeof(_lib.KrJob)
+    tab = many.table.cpu().numpy().copy().reshape(-1, size)
+    off = _lib.KrJob.n_train.offset
+    bad = np.arange(3, 6 * reps, 7)
+    tab[bad, off:off + 4] = np.frombuffer(np.int32(0).tobytes(), np.uint8)
+    many.table.copy_(torch.from_numpy(tab.reshape(-1)))
+    many.correct.fill_(12345)
+    many.launch()
+    torch.cuda.synchronize()
+    got = many.correct[:6 * reps].cpu().numpy()
+    ok = np.ones(6 * reps, bool)
+    ok[bad] = False
+    assert (got[bad] == -1).all() and (got[ok] == np.tile(want, reps)[ok]).all()
+
+
 @pytest.mark.parametrize("n,nt,nv,c", [(500, 300, 200, 5), (183, 110, 73, 5), (400, 320, 80, 8), (64, 33, 31, 2), (50, 1, 49, 3)])
 def test_kernel_regression_solver_against_lapack(ops, n, nt, nv, c):
     """wdg_kernel_regress_batched_f32 on well-conditioned kernels: per problem, the number of validation rows whose arg-max
