@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import dense_features, load
+from _golden import GOLDEN_DIR, dense_features, load
 
 pytestmark = pytest.mark.gpu
 
@@ -91,14 +91,64 @@ def test_cli_counterpart_matches_golden(name):
              ("class_homo", "m_class_homo", 1e-5), ("adj_homo", "m_adj_homo", 1e-5), ("label_info", "m_label_info", 1e-3),
              ("node_hom_generalized", "m_ge_homo", 1e-4)]
     for metric, key, tol in pairs:
-        got = float(cli.main(["--dataset_name", name, "--homophily_metric", metric]))
+        got = float(cli.main(["--dataset_name", name, "--data_dir", GOLDEN_DIR, "--homophily_metric", metric]))
         assert got == pytest.approx(float(g0[key]), rel=tol, abs=1e-6), metric
     for metric, key in (("agg_homo_soft", "m_agg_soft"), ("agg_homo_hard", "m_agg_hard")):
-        got = float(cli.main(["--dataset_name", name, "--homophily_metric", metric]))
+        got = float(cli.main(["--dataset_name", name, "--data_dir", GOLDEN_DIR, "--homophily_metric", metric]))
         assert abs(got - float(g0[key])) <= 2 * 1.01 / n, metric
     assert set(cli.METRIC_LIST) == {"node_homo", "edge_homo", "class_homo", "node_hom_generalized", "agg_homo_soft",
                                     "agg_homo_hard", "adj_homo", "label_info", "kernel_reg0_based_homo",
                                     "kernel_reg1_based_homo", "gnb_based_homo"}
+
+
+@pytest.mark.parametrize("symmetric", [0, 1])
+def test_cli_large_dataset_branch_against_the_oracle(oracle, tmp_path, symmetric):
+    """homophily_tests.py:87-110 - the branch the reference takes for the LINKX-scale datasets (here: node count >= 20 000):
+    fp64 scipy coefficients (sys_/row_normalized_adjacency), f.normalize on the features, and - agg_homo - a class-balanced
+    10 000-node sample per repetition.  A 20 001-node synthetic graph through the CLI against the oracle's fp64-coefficient path."""
+    from wdg_amd import homophily_tests as cli
+    from wdg_amd.utils import util_funcs as uf
+    n, c, f = cli.LARGE_NODES + 1, 3, 12
+    rng = np.random.default_rng(17 + symmetric)
+    labels = rng.integers(0, c, n)
+    # undirected, assortative-ish: 60 % of the pairs inside a class; a few self loops and duplicates as the raw files hold them
+    e = 90_000
+    src = rng.integers(0, n, e)
+    same = rng.random(e) < 0.6
+    by_class = [np.flatnonzero(labels == k) for k in range(c)]
+    dst = np.where(same, np.array([by_class[labels[u]][rng.integers(0, len(by_class[labels[u]]))] for u in src]), rng.integers(0, n, e))
+    row, col = np.concatenate([src, dst]), np.concatenate([dst, src])
+    key = np.unique(row.astype(np.int64) * n + col)   # what to_undirected + coalesce leave: a binary symmetric pattern
+    row, col = key // n, key % n
+    x = (rng.random((n, f)) < 0.3).astype(np.float32) * rng.random((n, f)).astype(np.float32)
+    path = str(tmp_path / "big.npz")
+    np.savez(path, adj_row=row, adj_col=col, labels=labels, features=x, n_nodes=n)
+    # the oracle's side: A + I, fp64 coefficients rounded to fp32 (sparse_mx_to_torch_sparse_tensor), pattern statistics
+    rowptr, ccol, val = oracle.coo_to_csr(row, col, n, None, oracle.ADD_SELF_LOOPS)
+    vhat = oracle.normalised_csr(rowptr, ccol, val, symmetric, oracle.PREC_F64)
+    adj = uf.normalized_adjacency_csr(cli.load_npz_graph(path)[0], symmetric=symmetric, prec=1)
+    assert np.array_equal(adj.rowptr.cpu().numpy(), rowptr) and np.array_equal(adj.col.cpu().numpy(), ccol)
+    np.testing.assert_allclose(adj.val.cpu().numpy(), vhat, rtol=1.2e-7, atol=0)  # <= 1 ulp of the fp64 path's fp32 rounding
+    st = oracle.edge_label_stats(rowptr, ccol, labels, c)
+    want = {"node_homo": oracle.node_homophily_sparse(st), "edge_homo": oracle.edge_homophily_sparse(st, labels_2d_classes=c),
+            "class_homo": oracle.class_homophily(st, labels), "adj_homo": oracle.adjusted_homophily(st, labels),
+            "label_info": oracle.label_informativeness(st, labels)}
+    for metric, tol in (("node_homo", 1e-6), ("edge_homo", 1e-6), ("class_homo", 1e-5), ("adj_homo", 1e-5), ("label_info", 1e-4)):
+        got = float(cli.main(["--dataset_name", path, "--symmetric", str(symmetric), "--homophily_metric", metric]))
+        assert got == pytest.approx(want[metric], rel=tol, abs=1e-6), metric
+    # aggregation homophily: raw adjacency, ten class-balanced 10 000-node samples drawn from torch's CPU generator (:124-131)
+    r2, c2, v2 = oracle.coo_to_csr(row, col, n, None, 0)
+    onehot = np.eye(c, dtype=np.float32)[labels]
+    lab_t = torch.from_numpy(labels)
+    for metric, hard in (("agg_homo_soft", None), ("agg_homo_hard", 1)):
+        torch.manual_seed(23)
+        got = float(cli.main(["--dataset_name", path, "--symmetric", str(symmetric), "--homophily_metric", metric]))
+        torch.manual_seed(23)
+        las = []
+        for _ in range(10):
+            mask, _, _ = uf.random_disassortative_splits(lab_t, lab_t.max() + 1, 10000 / n)
+            las.append(2 * oracle.similarity(onehot, r2, c2, v2, onehot, hard=hard, idx_train=mask.cpu().numpy(), f64=True) - 1)
+        assert abs(got - float(np.mean(las))) <= 2 * 1.01 / 10000, metric  # (threshold metric: one borderline node per sample, Q7)
 
 
 @pytest.mark.parametrize("kind", ["sgc", "gcn"])

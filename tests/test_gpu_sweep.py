@@ -176,6 +176,35 @@ def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkey
     assert order == [(si, bi) for si in range(2) for bi in range(6)]  # (the caller's order without reuse)
 
 
+def test_a_graph_without_sell16_copy_in_a_wide_base_shard_falls_back_instead_of_raising(monkeypatch):
+    """run_bases decided labels_only from the widths alone; one skewed graph in the shard (SELL-16 copy refused) made
+    prepare_full raise and aborted the sweep.  Now the route is decided after the build (graphs built ahead) and a labels-only
+    batch that cannot propagate falls back to the direct route over the on-demand aggregation (graphs built in place)."""
+    from wdg_amd import ops, sweep, synth
+    for name in ("WDG_SWEEP_REBIND", "WDG_SWEEP_STEP_TWINS", "WDG_SWEEP_PREFETCH_BUILD", "WDG_GRAM_ROUTE"):
+        monkeypatch.delenv(name, raising=False)
+    levels, samples = [0.2, 0.5, 0.8], [0]
+    jobs = sweep.make_jobs(levels, samples, k=4, n_nodes=600)
+    gi = [synth.regular_graph(600, 5, 4, j.h, j.seed) for j in jobs]
+    bases = [(f"w{w}", {0: synth.features(600, w, 40 + w)}, 500) for w in (656, 700)]
+    want = {bi: rows for _si, bi, rows in sweep.run_bases([(jobs, gi)], bases, epochs=4, depth=2, first_seed=3)}
+    orig = ops.GraphBatch.finish
+
+    def finish_and_refuse_one(self):
+        orig(self)
+        self.graphs[1].quad = False  # (what ensure_quad / the batched build decide for rows that would pad beyond 4 x)
+    monkeypatch.setattr(ops.GraphBatch, "finish", finish_and_refuse_one)
+    for prefetch in ("1", "0"):
+        monkeypatch.setenv("WDG_SWEEP_PREFETCH_BUILD", prefetch)
+        got = {bi: rows for _si, bi, rows in sweep.run_bases([(jobs, gi)], bases, epochs=4, depth=2, first_seed=3)}
+        assert sorted(got) == [0, 1]
+        for bi in got:
+            assert got[bi].shape == want[bi].shape and bool(torch.isfinite(got[bi][:, :7]).all())
+            # the scalars that do not depend on the kernels' route: equal to the all-quad run's to fp32 rounding
+            assert torch.allclose(got[bi][:, :7], want[bi][:, :7], rtol=2e-5, atol=1e-6), (prefetch, bi)
+            assert bool(((got[bi][:, 7:] >= 0) & (got[bi][:, 7:] <= 1)).all())
+
+
 def test_nine_scalars_with_propagated_grams_match_the_direct_route(monkeypatch):
     """SweepBatch.prepare_full with WDG_GRAM_ROUTE=propagate (the aggregated features' kernels as A_hat K(X) A_hat^T: what the
     sweep takes for the reference's wide feature bases) against the direct route (the Gram of Y) on the golden synthetic fixtures,

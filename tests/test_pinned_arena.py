@@ -120,3 +120,22 @@ def test_two_threads_may_fill_their_slices_at_the_same_time():
     ar.issued(hc)
     t.join(5)
     assert not t.is_alive() and got == [0] and events[-1] in log
+
+
+def test_an_abandoned_slice_does_not_hang_the_request_that_laps_it():
+    """the thread that took a slice raised between take() and issued() -> the entry stayed unstamped and the next
+    request a lap behind spun for ever with the ring's lock held.  abandon() stamps it; an unstamped one times out with an error."""
+    ar, log, events = _arena(1024)
+    h_bad, _a, _ = ar.take(512)
+    ar.abandon(h_bad)                               # (what _h2d does when the fill or the copy raises)
+    h_, _a, _ = ar.take(512); ar.issued(h_)
+    h_, a, _ = ar.take(512)                         # laps the abandoned slice: no event to wait for, no spin
+    assert a == 0 and log == []
+    ar.issued(h_)
+    ar2, _log2, _ev2 = _arena(1024)
+    ar2.STALL_S = 0.05
+    ar2.take(512)                                   # taken, never stamped (a bug by construction)
+    h_, _a, _ = ar2.take(512); ar2.issued(h_)
+    import pytest
+    with pytest.raises(RuntimeError, match="never queued"):
+        ar2.take(512)

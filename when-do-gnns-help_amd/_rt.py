@@ -82,10 +82,17 @@ class _PinnedArena:
         done = 0
         while done < len(self.pending) and self.pending[done][0] + self.size < vb:
             entry = self.pending[done]
-            while entry[1] is None:  # (taken by another thread, its copy not queued yet)
+            if entry[1] is None:  # (taken by another thread, its copy not queued yet)
                 import time
-                time.sleep(0)
-            entry[1].synchronize()  # a lap behind the new slice's end: its bytes are about to be overwritten
+                deadline = time.monotonic() + self.STALL_S
+                while entry[1] is None:
+                    if time.monotonic() > deadline:
+                        # a slice is only ever left unstamped by a bug (abandon() stamps it when the fill or the copy raises): fail
+                        # instead of spinning with the ring's lock held, which would hang every later upload of the process
+                        raise RuntimeError("_PinnedArena: a slice a full lap behind was taken but its copy was never queued")
+                    time.sleep(0)
+            if entry[1] is not self.ABANDONED:
+                entry[1].synchronize()  # a lap behind the new slice's end: its bytes are about to be overwritten
             done += 1
         if done:
             del self.pending[:done]
@@ -97,6 +104,13 @@ class _PinnedArena:
 
     def issued(self, handle):
         handle[1] = self._new_event()
+
+    def abandon(self, handle):
+        """the fill or the copy of a taken slice failed: no copy will read its bytes, a later lap may overwrite them at once"""
+        handle[1] = self.ABANDONED
+
+    ABANDONED = object()
+    STALL_S = 30.0
 
 
 _ARENA = None
@@ -121,23 +135,28 @@ def _h2d(host, dev=None):
     nbytes = t.numel() * t.element_size()
     if nbytes == 0:
         return torch.empty(t.shape, dtype=t.dtype, device=dev)
-    if _ARENA is None:
-        _ARENA = _PinnedArena(_H2D_RING_BYTES)
     if nbytes > _H2D_MAX_BYTES:
         return t.to(dev)
     with _ARENA_LOCK:  # (sweep.run_shards uploads from a helper thread as well: the ring's bookkeeping under a lock, the copies not)
-        handle, _start, piece = _ARENA.take(nbytes)
-    p = piece.view(t.dtype).view(t.shape)
-    # (numpy's memcpy / the library's threads, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware
-    # thread of the host - measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
-    if nbytes >= (1 << 20) and _H2D_THREADS > 1:
-        # (a thread per 2 MB, at most WDG_H2D_THREADS: starting a thread costs ~30 us, a megabyte of memcpy ~100)
-        check(lib.wdg_host_memcpy_mt(c_void_p(piece.data_ptr()), c_void_p(t.data_ptr()), nbytes, max(1, min(_H2D_THREADS, nbytes >> 21))),
-              "wdg_host_memcpy_mt")
-    else:
-        np.copyto(p.numpy(), t.numpy())
-    out = p.to(dev, non_blocking=True)
-    _ARENA.issued(handle)  # (no lock: one assignment into the slice's own entry - a take() that waits for it holds the lock)
+        if _ARENA is None:  # (created under the lock: two threads' first uploads must not pin a ring each)
+            _ARENA = _PinnedArena(_H2D_RING_BYTES)
+        arena = _ARENA
+        handle, _start, piece = arena.take(nbytes)
+    try:
+        p = piece.view(t.dtype).view(t.shape)
+        # (numpy's memcpy / the library's threads, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware
+        # thread of the host - measured 90 - 180 ms of thread wake-up on a 128-thread box for a 4-MB feature matrix)
+        if nbytes >= (1 << 20) and _H2D_THREADS > 1:
+            # (a thread per 2 MB, at most WDG_H2D_THREADS: starting a thread costs ~30 us, a megabyte of memcpy ~100)
+            check(lib.wdg_host_memcpy_mt(c_void_p(piece.data_ptr()), c_void_p(t.data_ptr()), nbytes, max(1, min(_H2D_THREADS, nbytes >> 21))),
+                  "wdg_host_memcpy_mt")
+        else:
+            np.copyto(p.numpy(), t.numpy())
+        out = p.to(dev, non_blocking=True)
+    except BaseException:
+        arena.abandon(handle)  # (an entry left unstamped would hang the request that laps it - with the lock held)
+        raise
+    arena.issued(handle)  # (no lock: one assignment into the slice's own entry - a take() that waits for it holds the lock)
     return out
 
 

@@ -1328,7 +1328,9 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
 #else
     constexpr int ablate = 0;  // (the shipped kernel ignores the descriptor's reserved word: a stray value cannot change a result)
 #endif
-    if (nt <= 0 || nt > K2_NB * 32 || C <= 0 || C > KR_MAX_C) {  // (uniform)
+    // (ldk: the deferred predictions address K by 32-bit element offsets row x ldk + column, rows and columns < ldk - a wider kernel
+    // matrix is refused HERE as well as by the Python launcher, so that a C-ABI caller gets correct_out = -1, not wrong hit counts)
+    if (nt <= 0 || nt > K2_NB * 32 || C <= 0 || C > KR_MAX_C || ldk <= 0 || ldk >= 65536) {  // (uniform)
         if (tid == 0 && job->correct_out) *to_global(job->correct_out) = -1;
         if (tid == 0 && job->flags_out) *to_global(job->flags_out) = 0;
         continue;

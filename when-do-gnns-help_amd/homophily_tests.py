@@ -12,8 +12,8 @@ What is kept from the reference script (`homophily_tests.py:46-139`):
     SURVEY Q4), ten repetitions and the `2 s - 1` map (`:126-132`), a 10 000-node class-balanced sample above
     that size.
 What differs: `class_homo` passes the edge index (the reference passes the sparse tensor and crashes, SURVEY Q1);
-data come from `.npz` graph files (`--data_dir`, default: the fixtures under tests/golden) because the
-reference's loaders / downloads are out of scope.
+data come from `.npz` / `.wdgg` graph files (`--data_dir`, default `$WDG_DATA_DIR` or `./data`, where the reference keeps
+its datasets; graph_io.py converts the reference's formats) because the reference's downloads are out of scope.
 """
 import argparse
 import os
@@ -104,11 +104,11 @@ def run(dataset_path, homophily_metric, symmetric=0, sample_max=500, base_classi
 
 
 def main(argv=None):
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter)
     p.add_argument('--no-cuda', action='store_true', default=False, help='accepted for compatibility; ignored')
     p.add_argument('--dataset_name', type=str, required=True, help='name of <data_dir>/real_<name>.npz, or a path to an .npz / .wdgg (graph_io container) graph')
-    p.add_argument('--data_dir', type=str, default=os.path.join(here, "tests", "golden"))
+    p.add_argument('--data_dir', type=str, default=os.environ.get("WDG_DATA_DIR", "./data"),
+                   help='directory holding real_<name>.npz graph files (default: $WDG_DATA_DIR or ./data, the reference\'s data directory)')
     p.add_argument('--symmetric', type=float, default=0, help='1 for symmetric renormalized adj, 0 for random walk renormalized adj')
     p.add_argument('--sample_max', type=float, default=500, help='maxinum number of samples used in gntk')
     p.add_argument('--base_classifier', type=str, default='kernel_reg1', choices=BASE_CLASSIFIERS)

@@ -98,10 +98,15 @@ class PropagatedGram:
         # of T at a time: 3.72 -> 3.15 ms per 70 graphs of 2000 nodes); WDG_PROP_TRANSPOSE=1: round 5's first form, a transpose pass
         # between the products into a second scratch matrix per graph
         self.transpose_pass = os.environ.get("WDG_PROP_TRANSPOSE", "0") == "1"
-        key = (torch.cuda.current_stream().cuda_stream, tuple(ns), self.transpose_pass)
-        if key not in _PROP_SCRATCH:
+        # (the job tables below hold T's addresses, so the scratch belongs to the stream current HERE: launch() checks that it runs on
+        # that stream - two batches of equal shapes built on one stream and launched on two would race on T without an error)
+        self.owner_stream = torch.cuda.current_stream().cuda_stream
+        key = (self.owner_stream, tuple(ns), self.transpose_pass)
+        if key in _PROP_SCRATCH:
+            _PROP_SCRATCH[key] = _PROP_SCRATCH.pop(key)  # (most recently used last: the dict is the LRU order)
+        else:
             if len(_PROP_SCRATCH) >= 4:
-                _PROP_SCRATCH.pop(next(iter(_PROP_SCRATCH)))
+                _PROP_SCRATCH.pop(next(iter(_PROP_SCRATCH)))  # the least recently used key
             _PROP_SCRATCH[key] = ([torch.empty((n, n), dtype=torch.float32, device=dev) for n in ns],
                                   [torch.empty((n, n), dtype=torch.float32, device=dev) if self.transpose_pass else None for n in ns])
         self._t, self._tt = _PROP_SCRATCH[key]
@@ -123,6 +128,9 @@ class PropagatedGram:
         self.linear = linear  # (K_linear is produced either way: it is the propagated quantity)
 
     def launch(self):
+        if torch.cuda.current_stream().cuda_stream != self.owner_stream:
+            raise _lib.WdgError("PropagatedGram.launch: launched on another stream than the one it was built on (its T scratch is shared, "
+                           "in stream order, with the other batches of that stream)")
         self.first.launch()       # T_j = A_hat_j K_linear(X)
         if self.transpose_pass:
             check(lib.wdg_transpose_batched_f32(_ptr(self.tr_table), self.n_jobs, self.max_n, self.max_n, stream_handle()), "wdg_transpose_batched_f32")

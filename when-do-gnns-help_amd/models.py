@@ -126,6 +126,8 @@ def graphed_inference(model, adj, x, **forward_kwargs):
             model(adj, x, **forward_kwargs)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        if getattr(model, "_cache", None) is not None:
+            model._cache = None  # (SGC1: the captured forward aggregates; a replay is a whole forward pass, not the head alone)
         with torch.cuda.graph(graph):
             logits = model(adj, x, **forward_kwargs)
     return graph.replay, logits  # (the bound method keeps the graph alive)

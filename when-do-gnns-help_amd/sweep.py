@@ -777,8 +777,9 @@ class SweepBatch:
         nodes = {j.n_nodes for j in self.jobs}
         can = len(nodes) == 1 and not ops.quad_disabled() and all(g.ensure_quad() for g in self.graphs)
         self.gram_route = "propagate" if can and (route == "propagate" or (route == "auto" and self.n_feat >= 640) or self.labels_only) else "direct"
-        if self.labels_only and self.gram_route != "propagate":
-            raise ValueError("SweepBatch(labels_only=True): the aggregated features' kernels need the propagated route (graphs of one size on the quad-row kernel)")
+        # (a labels-only batch whose graphs cannot take the propagated route - one graph of the shard without a SELL-16 copy: padding
+        # beyond 4 x, graphs.py ensure_quad - falls back to the direct route over `y`, the features' aggregation made on demand graph by
+        # graph: slower, same rows; round 5 raised here and a single hub-heavy graph aborted the whole sweep - ADVICE r05)
         x_slot = {s: J + i for i, s in enumerate(seeds)}
         if self.gram_route == "propagate":
             gx = ops.GramBatch([self.x[s] for s in seeds])
@@ -787,7 +788,9 @@ class SweepBatch:
                                      for j, g, d in zip(self.jobs, self.graphs, self.dinv)])
             self.gram = _GramPair(gy, gx)
         else:
-            if self.tiled_y and ops.GramBatch.tiled_ok():  # the Gram kernels read the tiled aggregation output as it is
+            if self.labels_only:
+                ys = self.y  # (aggregated on demand, row-major; the step's tables hold the label columns only)
+            elif self.tiled_y and ops.GramBatch.tiled_ok():  # the Gram kernels read the tiled aggregation output as it is
                 ys = [ya.columns(self.n_feat) for ya in self.y_agg]
             else:  # row-major: with a tiled Y the copy, refreshed behind every aggregation from here on
                 ys = self.y
@@ -813,7 +816,8 @@ class SweepBatch:
             import zlib
             index, group, rep, label_crc = {}, [], [], []
             for ji, (j, lab) in enumerate(zip(self.jobs, self.labels_host)):
-                key = (j.seed, j.n_nodes, np.asarray(lab).tobytes())
+                # (one dtype before the bytes are hashed: the same job given int32 or int64 labels draws the same sets - ADVICE r05)
+                key = (j.seed, j.n_nodes, np.ascontiguousarray(lab, dtype=np.int64).tobytes())
                 if key not in index:
                     index[key] = len(rep)
                     rep.append(ji)
@@ -1317,7 +1321,10 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
                 with torch.cuda.stream(build_stream):
                     gb.finish()
         widths = [next(iter(feats.values())).shape[1] if feats else 0 for _name, feats, _sm in bases]
-        lo = [propagates(w, jobs) for w in widths]
+        # (decided AFTER the graphs are built when they are built ahead: a graph without a SELL-16 copy rules the propagated route out
+        # for the whole shard - its bases then aggregate at full width and take the dense Gram, as round 4 did)
+        quad_ok = gb is None or all(g.quad for g in gb.graphs)
+        lo = [quad_ok and propagates(w, jobs) for w in widths]
         order = _visit_order([(lo[bi], bases[bi][2]) if lo[bi] else ("own", bi) for bi in range(len(bases))]) if rebind_ok else list(range(len(bases)))
         free = {}  # (sample_max, stream) -> a prepared labels-only batch whose rows have been fetched
         for bi in order:
@@ -1355,7 +1362,8 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
             n += 1
             if len(in_flight) >= depth:
                 done = fetch()
-                if rebind_ok and done[0] == si and done[3].labels_only and done[3].jobs and getattr(done[3], "kr_sets", None) is not None:
+                if (rebind_ok and done[0] == si and done[3].labels_only and done[3].jobs and getattr(done[3], "kr_sets", None) is not None
+                        and getattr(done[3], "gram_route", None) == "propagate"):
                     free[(done[3].kr_sample_max, done[4].cuda_stream)] = done[3]
                 yield done[:3]
     while in_flight:
