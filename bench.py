@@ -286,7 +286,7 @@ def measure_full(args, dev):
                             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": gram_flop / (gram_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                             "note": f"K = map(A A^T) of {n_gram} matrices of {n_nodes} x {args.feat}, fp32-equivalent flops of the computed triangle; "
                                     "split-bf16 products (six piece products per fp32 product): issue-bound (DESIGN 4.7)"}}
-    kr = {**rl, "kr_ridged": sb.kr_ridged, "kr_total": sb.kr_total, "kr_sets": KR_SETS_NOTE[sb.kr_set_mode],
+    kr = {**rl, "kr_ridged": sb.kr_ridged, "kr_deflated": sb.kr_deflated, "kr_total": sb.kr_total, "kr_sets": KR_SETS_NOTE[sb.kr_set_mode],
           "kr_ridged_note": "train blocks the device solver found rank deficient at fp32 rounding level and solved with a ridge (within 0 - 2 "
                             "validation rows of the reference's own epochs on the sweep fixtures: profiles/r05_kr_three_way.txt); "
                             "full_metrics(ridge='pinv') solves exactly those again the reference's way on the host (utils/homophily_plot.py:"
@@ -336,7 +336,7 @@ def measure_cold(args, dev):
     out = {}
     for name, nine in (("six_scalars", False), ("nine_scalars", True)):
         phases = {"build_ms": [], "sample_ms": [], "device_ms": [], "host_tail_ms": [], "total_ms": []}
-        graphs = ridged = total = 0
+        graphs = ridged = total = deflated_n = 0
         for b, (jobs, inputs) in enumerate(shards):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -357,6 +357,7 @@ def measure_cold(args, dev):
                 continue  # warm-up shard
             graphs += len(jobs)
             ridged, total = ridged + getattr(sb, "kr_ridged", 0), total + getattr(sb, "kr_total", 0)
+            deflated_n += getattr(sb, "kr_deflated", 0)
             phases["build_ms"].append((t1 - t0) * 1e3)
             phases["device_ms"].append((t2 - t1) * 1e3)
             phases["host_tail_ms"].append((t3 - t2) * 1e3)
@@ -365,7 +366,7 @@ def measure_cold(args, dev):
             del sb
         total_s = sum(phases["total_ms"]) * 1e-3
         out[name] = {"graphs_per_s": graphs / total_s, **{k: sum(v) / len(v) for k, v in phases.items()},
-                     **({"kr_ridged": ridged, "kr_total": total} if nine else {}),
+                     **({"kr_ridged": ridged, "kr_deflated": deflated_n, "kr_total": total} if nine else {}),
                      "mean_metrics": {n: float(v) for n, v in zip(sweep.METRIC_NAMES, rows.double().mean(0).tolist())}}
         # the same shards PIPELINED (sweep.run_shards): shard b + 1's uploads and build - on a helper thread and a stream of their own -
         # while shard b's tables are built and its kernels run; clock = first upload to the last shard's rows on the host
@@ -476,7 +477,7 @@ def measure_whole(args, dev, world=1, rank=0):
     sync_all()
     dt = time.perf_counter() - t0
     rec = {}
-    kr_counts = torch.tensor([kr_stats.get("kr_ridged", 0), kr_stats.get("kr_total", 0)], dtype=torch.int64, device=dev)
+    kr_counts = torch.tensor([kr_stats.get("kr_ridged", 0), kr_stats.get("kr_total", 0), kr_stats.get("kr_deflated", 0)], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(kr_counts)
         t = torch.tensor([dt, mine_s], dtype=torch.float64, device=dev)
@@ -508,7 +509,8 @@ def measure_whole(args, dev, world=1, rank=0):
                         "the host, two HIP streams per rank",
             "jobs": n_rows, "n_gpus": world, "scaling": "strong", "seconds": dt, "graphs_per_s": n_rows / dt,
             "first_pass_seconds": t_first, "first_pass_note": "this rank's untimed first pass of the same sweep in this process (allocator pools still growing)", **rec,
-            "kr_ridged": int(kr_counts[0].item()), "kr_total": int(kr_counts[1].item()),
+            "kr_ridged": int(kr_counts[0].item()), "kr_total": int(kr_counts[1].item()), "kr_deflated": int(kr_counts[2].item()),
+            "feature_duplicates": args.dup_frac,
             "kr_sets": KR_SETS_NOTE[os.environ.get("WDG_SWEEP_KR_SETS", "sample")],
             "reuse_inside_a_shard": "what depends on less than a job is computed once (DESIGN 5): the six step scalars of the wide bases (they "
                                     "aggregate the label columns only: graph + labels) by the first of them (WDG_SWEEP_STEP_TWINS=0: every base), "
@@ -768,7 +770,7 @@ def compact_line(out, detail_path=None):
         line["sweep_full"] = {"graphs_per_s": _num(sf.get("graphs_per_s")), "device_ms_per_batch": _num(sf.get("device_ms_per_batch")),
                               "solver_ms": _num(sf.get("roofline_solver", {}).get("ms_per_launch")),
                               "solver_frac_mfma": _num(sf.get("roofline_solver", {}).get("frac")),
-                              "kr_total": sf.get("kr_total"), "kr_ridged": sf.get("kr_ridged")}
+                              "kr_total": sf.get("kr_total"), "kr_ridged": sf.get("kr_ridged"), "kr_deflated": sf.get("kr_deflated")}
     sc = out.get("sweep_cold")
     if sc:
         line["sweep_cold"] = {name: _num(sc[name].get("pipelined", {}).get("graphs_per_s", sc[name].get("graphs_per_s")))
@@ -840,6 +842,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: --seeds seeds PER RANK (per-GPU work fixed); "
                     "strong: --seeds seeds in all (configs[2] literally: 50 jobs), sharded over the ranks")
     ap.add_argument("--timeout", type=float, default=1500.0, help="self-launched workers (--gpus N > 1) are stopped after this many seconds")
+    ap.add_argument("--dup-frac", type=float, default=0.033, help="share of the synthetic feature rows that copy another row of their class - the "
+                    "reference's features are real nodes' rows sampled per class with replacement (pubmed sample: 3.3 %%): such rows make "
+                    "kernel-regression train blocks exactly singular, which the solver deflates (0: no duplicates, rounds 1 - 5)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -848,6 +853,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from wdg_amd import synth as _synth
+    _synth.DUPLICATE_FRACTION = args.dup_frac  # (every feature matrix of every block below)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

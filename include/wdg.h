@@ -623,6 +623,32 @@ int wdg_edge_gram_mean_batched_f32(const wdg_edge_gram_job *jobs_dev, int32_t n_
                                    size_t workspace_bytes, wdg_stream_t stream);
 
 /*
+ * Row representatives: rep_out[i] = the smallest row index j <= i whose row is BIT-IDENTICAL to row i (+0 == -0; a NaN equals nothing),
+ * of a dense fp32 matrix (WDG_ROW_REP_DENSE: A [n, F], row-major or tiled like wdg_gram_job.A) or of a scaled CSR pattern
+ * (WDG_ROW_REP_CSR: rows equal in length, columns, stored order, values - NULL: unit - and row_scale; identical rows of A_hat give
+ * identical rows of A_hat X whatever X holds).  A 64-bit row hash, then every candidate verified element by element.  Deterministic.
+ * replaces: the part of `np.linalg.pinv(K_train_train)` (utils/homophily_metrics.py:283-297, utils/homophily_plot.py:296-310) that
+ *           answers EXACTLY singular train blocks: duplicate nodes give bit-identical rows of the reference's Gram (utils/
+ *           homophily_metrics.py:232-247), the pseudo-inverse's minimum-norm answer is the solution of the system deflated to one
+ *           representative per duplicate class with the class's mean one-hot label - which wdg_kernel_regress_batched_f32 solves
+ *           when a job carries these maps (wdg_kr_job.rep).
+ */
+#define WDG_ROW_REP_DENSE 0
+#define WDG_ROW_REP_CSR 1
+typedef struct wdg_row_rep_job {
+    const float *A;           /* DENSE: [n, F] */
+    const int32_t *rowptr;    /* CSR: [n + 1] */
+    const int32_t *col;       /* CSR: [nnz] */
+    const float *val;         /* CSR: [nnz] or NULL (unit values) */
+    const float *row_scale;   /* CSR: [n] or NULL */
+    int32_t *rep_out;         /* [n] */
+    void *hash_ws;            /* [n] 8-byte scratch */
+    int64_t lda, a_group_stride; /* DENSE: as wdg_gram_job */
+    int32_t n, F;
+} wdg_row_rep_job;
+int wdg_row_rep_batched(const wdg_row_rep_job *jobs_dev, int32_t n_jobs, int32_t max_n, int32_t source, wdg_stream_t stream);
+
+/*
  * Batched kernel regression: for every job, alpha = K[train, train]^-1 onehot(labels[train]) by a register-resident Cholesky
  * factorisation (n_train <= wdg_kernel_regress_max_train() = 320, n_classes <= 8), predictions K[val, train] alpha, and
  * *correct_out = #{v in val : argmax_c prediction == labels[v]} (first maximum, like torch.argmax); -1 for shapes out of range.
@@ -632,6 +658,14 @@ int wdg_edge_gram_mean_batched_f32(const wdg_edge_gram_job *jobs_dev, int32_t n_
  *           pseudo-inverse's; when a pivot falls to rounding level (<= n eps max K_ii: rank-deficient block, duplicate nodes)
  *           the block is refactored once as K + 8 n eps max K_ii I - the pseudo-inverse's least-squares predictions to within
  *           rounding (documented deviation in the coefficients).
+ *           wdg_kernel_regress_deflated_batched_f32 - `rep` (wdg_row_rep_batched of the matrix the kernel was computed from) and a
+ *           workspace `ws` per job - does not leave EXACT duplicates to the ridge: every train / validation id is read at its representative
+ *           (duplicate rows of K are then identical by construction), the train rows are deflated to one row per duplicate class with
+ *           the class's mean one-hot label - the pseudo-inverse's minimum-norm answer, by a positive definite factorisation; flags bit 1 reports it.  Rows
+ *           below the block's fp32 resolution (K_ii <= n eps max K_ii: all-zero rows, the arc-cosine kernel of an all-zero feature
+ *           row) are dropped like exact zeros - an fp32 SVD cannot resolve their singular value either.  The deflated block is
+ *           scaled by the square roots of the class sizes (pinv(P K_u P^T) = Q pinv(S K_u S) Q^T, Q = P S^-1), so that a block that is
+ *           rank deficient beyond its duplicates is regularised in the full system's metric.  wdg_kernel_regress_batched_f32 itself ignores both fields.
  * `train` / `val` index rows of K; `labels` is indexed like K's rows.  Limits: ldk < 65 536 (a kernel matrix is addressed by
  * 32-bit element offsets).  The launch is persistent - one workgroup per CU walks the problems, and a problem's predictions are
  * made inside the next problem's factorisation (WDG_KR_PERSIST=0: one workgroup per problem) - which changes no result.
@@ -642,10 +676,22 @@ typedef struct wdg_kr_job {
     const int32_t *val;     /* [n_val] */
     const int32_t *labels;  /* [n] */
     int32_t *correct_out;   /* [1]: validation rows predicted right; -1 = problem refused (shape outside the limits) */
-    int32_t *flags_out;     /* [1] or NULL: bit 0 = a pivot fell to rounding level and the block was refactored with the ridge */
+    int32_t *flags_out;     /* [1] or NULL: bit 0 = a pivot fell to rounding level and the block was refactored with the ridge;
+                               bit 1 = the train rows were deflated (duplicates merged / zero rows dropped) */
     int64_t ldk;
     int32_t n_train, n_val, n_classes, reserved;
+    const int32_t *rep;     /* [n] or NULL: row representatives of the matrix K was computed from (wdg_row_rep_batched) */
+    void *ws;               /* NULL, or wdg_kr_deflate_workspace_bytes(n_val) bytes (16-byte aligned) of the problem's own
+                               (wdg_kernel_regress_deflated_batched_f32) */
 } wdg_kr_job;
+/* The same regression for a table whose EVERY job carries a workspace `ws` (and, where the matrix has them, the row representatives
+ * `rep`; NULL = every node its own): a pre-pass writes per problem the train rows to solve (one representative per class of duplicate
+ * nodes, rows with K_ii == 0 dropped), their labels / right-hand sides and the validation rows' representatives and labels into ws,
+ * the solver reads them and tests its pivots per row.  Two launches, one call.
+ * replaces: the same lines as wdg_kernel_regress_batched_f32 - np.linalg.pinv's answer on exactly singular blocks included
+ *           (utils/homophily_metrics.py:291-297). */
+size_t wdg_kr_deflate_workspace_bytes(int32_t n_val);
+int wdg_kernel_regress_deflated_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream);
 int32_t wdg_kernel_regress_max_train(void);
 
 /*

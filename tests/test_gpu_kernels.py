@@ -1708,3 +1708,106 @@ def test_spmm_narrow_batched_table(ops, oracle, f, ld):
     first = [e[2].clone() for e in entries]
     batch.launch()
     assert all(torch.equal(a, e[2]) for a, e in zip(first, entries))
+
+
+# ------------------------------------------------------------------------------------------- row representatives / deflation
+def _rep_numpy(rows_bytes):
+    first, rep = {}, []
+    for i, b in enumerate(rows_bytes):
+        rep.append(first.setdefault(b, i))
+    return np.asarray(rep, np.int32)
+
+
+def test_row_representatives_of_dense_tiled_and_csr_rows():
+    """wdg_row_rep_batched: rep[i] = the smallest row bit-identical to row i (+0 == -0, a NaN row equals nothing), for row-major and
+    tiled dense matrices and for the rows of a scaled CSR pattern - against a dictionary over the rows' bytes"""
+    from wdg_amd import ops
+    rng = np.random.default_rng(11)
+    n, f = 700, 53
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    x[rng.random((n, f)) < 0.5] = 0.0
+    for i in rng.choice(n, 200, replace=False):  # planted duplicates (chains too: a duplicate of a duplicate)
+        x[i] = x[rng.integers(0, n)]
+    x[5] = x[3]
+    x[5, 7] = -0.0 if x[3, 7] == 0 else x[5, 7]       # +0 / -0: equal
+    x[40] = 0.0
+    x[41] = -0.0                                       # an all-zero row in both signs
+    x[60, 2] = np.nan
+    x[61] = x[60]                                      # NaN rows: never equal, not even to themselves' copies
+    canon = x.copy()
+    canon[canon == 0] = 0.0
+    want = _rep_numpy([r.tobytes() if not np.isnan(r).any() else (b"nan", i) for i, r in enumerate(canon)])
+    xd = torch.from_numpy(x).cuda()
+    pad = torch.zeros((n, f + 3), device="cuda")
+    pad[:, :f] = xd
+    f16 = (f + 15) // 16 * 16
+    full = torch.zeros((n, f16), device="cuda")
+    full[:, :f] = xd
+    tiled = full.reshape(n, f16 // 16, 16).permute(1, 0, 2).contiguous()   # element (r, c) at [c // 16, r, c % 16]
+    rb = ops.RowRepBatch(dense=[xd, pad[:, :f], ops.Tiled(tiled, f)])
+    rb.launch()
+    for r in rb.rep:
+        np.testing.assert_array_equal(r.cpu().numpy(), want)
+    assert (want != np.arange(n)).sum() >= 150
+    # CSR rows: equal length, columns, order and row scale
+    m = 500
+    deg = rng.integers(1, 6, m)
+    cols = [np.sort(rng.choice(m, d, replace=False)) for d in deg]
+    for i in rng.choice(m, 120, replace=False):
+        cols[i] = cols[rng.integers(0, m)]
+    src = np.concatenate([np.full(len(c), i) for i, c in enumerate(cols)])
+    g = ops.CsrGraph.from_coo(src, np.concatenate(cols), m, None, 0)
+    scale = rng.choice(np.array([0.5, 0.25, 1.0], np.float32), m)
+    sd = torch.from_numpy(scale).cuda()
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    want_p = _rep_numpy([col[rowptr[i]:rowptr[i + 1]].tobytes() for i in range(m)])
+    want_s = _rep_numpy([col[rowptr[i]:rowptr[i + 1]].tobytes() + scale[i].tobytes() for i in range(m)])
+    rb = ops.RowRepBatch(csr=[(g, None, False), (g, sd, False)])
+    rb.launch()
+    np.testing.assert_array_equal(rb.rep[0].cpu().numpy(), want_p)
+    np.testing.assert_array_equal(rb.rep[1].cpu().numpy(), want_s)
+    assert (want_p != np.arange(m)).sum() >= 80 and (want_s != want_p).any()
+
+
+@pytest.mark.parametrize("kernel", ["linear", "arccos"])
+def test_deflated_regression_equals_the_pseudo_inverse_on_duplicate_and_zero_rows(kernel):
+    """wdg_kernel_regress_deflated_batched_f32: features with duplicate rows (some classes of duplicates with DIFFERENT labels) and
+    all-zero rows - exactly singular train blocks.  The reference's `K_vt @ (pinv(K_tt) @ onehot)` (utils/homophily_metrics.py:
+    291-297), evaluated in fp64 on the kernel read at representatives (where the pseudo-inverse is exact), against the device: no
+    block is left to the ridge, hit counts within two validation rows of 200."""
+    from wdg_amd import ops
+    rng = np.random.default_rng(3 if kernel == "linear" else 4)
+    n, f, c = 600, 320, 4   # (more features than train rows: without the duplicates the linear kernel's train block has full rank)
+    lab = rng.integers(0, c, n)
+    means = 2.0 * (rng.random((c, f)) < 0.1)            # a clear class signal: few predictions sit on a tie
+    x = (rng.standard_normal((n, f)) + means[lab]).astype(np.float32)
+    dup = rng.choice(n, 240, replace=False)
+    src_of = rng.integers(0, n, 240)
+    x[dup] = x[src_of]                                  # ~ a third of the nodes duplicate another one,
+    lab[dup[30:]] = lab[src_of[30:]]                    # its label too - except thirty: duplicate classes with MIXED labels
+    x[rng.choice(n, 12, replace=False)] = 0.0           # all-zero feature rows
+    xd = torch.from_numpy(x).cuda()
+    gb = ops.GramBatch([xd], linear=kernel == "linear", arccos=kernel == "arccos")
+    gb.launch()
+    kmat = (gb.k_linear if kernel == "linear" else gb.k_arccos)[0]
+    rep = gb.rep[0]
+    labd = torch.from_numpy(lab).cuda().to(torch.int32)
+    problems, sets = [], []
+    for _ in range(24):
+        perm = rng.permutation(n)
+        tr, va = np.sort(perm[:260]), np.sort(perm[260:460])
+        sets.append((tr, va))
+        problems.append((kmat, torch.from_numpy(tr).cuda().to(torch.int32), torch.from_numpy(va).cuda().to(torch.int32), labd, rep))
+    kb = ops.KrBatch(problems, c)
+    kb.launch()
+    torch.cuda.synchronize()
+    hits = kb.correct[:len(problems)].cpu().numpy()
+    assert not bool(kb.ridged().any()) and bool(kb.deflated().all())
+    k64 = kmat.cpu().numpy().astype(np.float64)
+    r_h = rep.cpu().numpy()
+    eye = np.eye(c)
+    for (tr, va), got in zip(sets, hits):
+        k_tt, k_vt = k64[np.ix_(r_h[tr], r_h[tr])], k64[np.ix_(r_h[va], r_h[tr])]
+        pred = k_vt @ (np.linalg.pinv(k_tt, rcond=1e-8) @ eye[lab[tr]])  # (the exact null directions cut - and the arc-cosine kernel's 1.6e-9 rows of all-zero features, below what an fp32 SVD resolves)
+        want = int((pred.argmax(1) == lab[va]).sum())
+        assert abs(int(got) - want) <= 2, (got, want)  # (fp32 factorisation against the fp64 pseudo-inverse: a near-tie or two of 200)

@@ -9,14 +9,19 @@ from _golden import KR_FIXTURES, dense_features, load, load_kr, p_tolerance, wel
 
 pytestmark = pytest.mark.gpu
 
-# validation rows (of 196 - 200; texas 73) by which an epoch's accuracy may differ from the reference's.  Positive definite
-# train blocks (no ridge: KrBatch.ridged() false): 2 everywhere.  Blocks the solver had to regularise (the feature kernels of
-# the pubmed sample hold duplicate rows): 3 - there the reference's own answer carries the noise of its inverted
-# rounding-level singular values.  The raw-adjacency kernels of the real graphs are rank deficient
-# (isolated and duplicate nodes: exactly singular train blocks); the reference's pinv keeps their rounding-level singular
-# values (rcond 1e-15), which no other factorisation reproduces - the device solver answers with a ridge at n eps max K_ii / 8
-# (csrc/kernel_reg.hip): measured deviation <= 2 rows on texas, <= 4 on cora (fp32 emulation: 0 - 2, one epoch 4).
-ROWS_OFF = {"real_texas": 2, "real_cora": 4, "real_cora_s200": 4}
+# validation rows (of 196 - 200; texas 73) by which an epoch's accuracy may differ from what the REFERENCE recorded in that epoch.
+# Round 6 (row representatives + the deflating solver, csrc/row_rep.hip, csrc/kernel_reg.hip): the synthetic-sweep fixtures - whose
+# pubmed-sample features hold duplicate rows: 39 % of their train blocks were regularised in round 5, 0 - 2 rows off - are
+# reproduced EXACTLY, every epoch, both kernels; cora (duplicate aggregated rows under the raw adjacency: every block deflated, one
+# still regularised) within 1 row where round 5 needed 4; texas' raw-adjacency kernels (rank deficient beyond their duplicates:
+# aggregated rows that are sums of other rows - the deflated block is regularised in the full system's metric) within 1 row.
+# One structural exception: a class of DUPLICATE nodes (texas: the leaves of one hub aggregate to the same row) whose train members'
+# labels TIE for the majority.  The regression interpolates its train rows, so every validation member of the class is predicted
+# the class's mean label - two equal entries, an arg-max decided by rounding for all of them at once (texas, arc-cosine kernel,
+# epoch 6: 24 of 73 validation rows; an fp64 pseudo-inverse of the device kernel and one of the host's GEMM kernel disagree there
+# as well).  Such an epoch may differ by the number of validation rows in tied classes on top of the bound.
+ROWS_OFF = {"real_texas": 1, "real_cora": 1, "real_cora_s200": 0}
+ROWS_SYN = 0
 
 
 def _device_inputs(name):
@@ -43,13 +48,25 @@ def test_device_solver_per_epoch_against_the_reference(name):
     h, x, lab = _device_inputs(name)
     gb = ops.GramBatch([h, x])
     gb.launch()
-    rows = ROWS_OFF.get(name, 2)
+    rows = ROWS_OFF.get(name, ROWS_SYN)
+    lab_h = lab.cpu().numpy()
+
+    def tied_validation_rows(rep_h, tr, va):
+        """validation rows whose duplicate class has train members with a tied majority label"""
+        n_tied = 0
+        for u in np.unique(rep_h[va]):
+            members = tr[rep_h[tr] == u]
+            if members.size >= 2:
+                cnt = np.sort(np.bincount(lab_h[members]))[::-1]
+                if cnt.size >= 2 and cnt[0] == cnt[1]:
+                    n_tied += int((rep_h[va] == u).sum())
+        return n_tied
     for clf, kern in (("kernel_reg0", gb.k_linear), ("kernel_reg1", gb.k_arccos)):
         rec = kr[clf]
         problems = []
         for tr, va in rec["node_sets"]:
             tr, va = torch.from_numpy(tr).cuda().to(torch.int32), torch.from_numpy(va).cuda().to(torch.int32)
-            problems += [(kern[0], tr, va, lab), (kern[1], tr, va, lab)]
+            problems += [(kern[0], tr, va, lab, gb.rep[0]), (kern[1], tr, va, lab, gb.rep[1])]
         kb = ops.KrBatch(problems, int(lab.max().item()) + 1)
         kb.launch()
         torch.cuda.synchronize()
@@ -57,11 +74,17 @@ def test_device_solver_per_epoch_against_the_reference(name):
         n_val = np.array([len(v) for _, v in rec["node_sets"]], np.float64)
         off_g, off_x = (acc[:, 0] - rec["g_results"]) * n_val, (acc[:, 1] - rec["x_results"]) * n_val
         ridged = kb.ridged().cpu().numpy().reshape(-1, 2)
-        lim = np.where(ridged, max(rows, 3), rows) + 0.01  # [epoch, (graph-aware, features only)]
+        print(f"[kr epochs] {name} {clf}: rows off (graph) max {np.abs(off_g).max():.0f} mean {np.abs(off_g).mean():.2f}, (features) max "
+              f"{np.abs(off_x).max():.0f} mean {np.abs(off_x).mean():.2f}; ridged {ridged.sum(0).tolist()} deflated "
+              f"{kb.deflated().cpu().numpy().reshape(-1, 2).sum(0).tolist()} of {len(rec['node_sets'])}")
+        lim = np.full(ridged.shape, rows + 0.01)  # [epoch, (graph-aware, features only)]
+        if gb.rep[0] is not None:  # (validation members of a duplicate class with a tied mean label share ONE fragile arg-max: see above)
+            lim[:, 0] += np.array([tied_validation_rows(gb.rep[0].cpu().numpy(), tr, va) for tr, va in rec["node_sets"]])
+            lim[:, 1] += np.array([tied_validation_rows(gb.rep[1].cpu().numpy(), tr, va) for tr, va in rec["node_sets"]])
         assert (np.abs(off_g) <= lim[:, 0]).all() and (np.abs(off_x) <= lim[:, 1]).all(), (name, clf, np.round(off_g), np.round(off_x), ridged.T)
-        rows = int(lim.max())
-        # the p-value: within what that accuracy bound implies for these accuracies (no fixed 0.15)
-        tol = p_tolerance(rec["g_results"], rec["x_results"], float(n_val.min()), rows)
+        assert (np.abs(off_g) > rows + 0.01).sum() + (np.abs(off_x) > rows + 0.01).sum() <= 1  # (at most one such epoch per fixture and classifier)
+        # the p-value: within what the accuracy bound implies for these accuracies (no fixed 0.15)
+        tol = p_tolerance(rec["g_results"], rec["x_results"], float(n_val.min()), max(int(np.abs(off_g).max().round()), int(np.abs(off_x).max().round()), 1))
         assert abs(welch_p(acc[:, 0], acc[:, 1]) - rec["p"]) <= tol, (name, clf, welch_p(acc[:, 0], acc[:, 1]), rec["p"], tol)
 
 
@@ -111,6 +134,10 @@ def test_ten_class_labels_fall_back_to_the_host_path():
 #   472 one row, 36 two, 1 three - profiles/r05_kr_ridge_vs_pinv.json; the three-way comparison on the golden epochs,
 #   profiles/r05_kr_three_way.txt, has the ridge within 0 - 2 rows of what the reference recorded on every synthetic fixture).
 ROWS_PD, RIDGED_SHARE_WITHIN_2, RIDGED_MAX = 2, 0.98, 4
+# Round 6: blocks with duplicate nodes in the train rows are DEFLATED on the device (row representatives, csrc/row_rep.hip + the
+# solver's pre-pass) - the pseudo-inverse's answer by a positive definite factorisation; they are held to the bound of the blocks
+# factored as they are, and nothing of this test's 8 000 regressions is left to the ridge.
+DEFLATED_EQUAL_SHARE = 0.99
 
 
 def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
@@ -139,8 +166,8 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
     epochs, draws = 100, 4
     report = {"fixtures": list(SYN), "draws": draws, "epochs": epochs, "per_draw": []}
     rng = np.random.default_rng(5)
-    d_pd, d_ridged, d_devgram, dp_all, failures = [], [], [], [], []
-    n_regressions = n_flagged = 0
+    d_pd, d_ridged, d_devgram, d_defl, dp_all, failures = [], [], [], [], [], []
+    n_regressions = n_flagged = n_deflated = 0
     for draw in range(draws):
         sb = sweep.SweepBatch(jobs, n_feat=inputs[0][3].shape[1], gcn_hidden=0, inputs=inputs)
         sb.prepare_full(epochs=epochs, sample_max=500, base_seed=77 + draw)  # device-drawn sets, as the sweep driver does
@@ -150,17 +177,23 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
         rows_dev = sb.full_metrics(ridge="device").numpy()
         acc_dev = sb.kr_acc.copy().reshape(-1)                                 # problem order [job, clf, epoch, kernel]
         ridged = sb.kr_ridged_mask().cpu().numpy().reshape(-1)                 # (the same order: every job its own sample here)
+        deflated = sb.kr_deflated_mask().cpu().numpy().reshape(-1) & ~ridged
         n_val = float(sb.kr_val.shape[2])
         flagged = np.flatnonzero(ridged)
-        others = rng.choice(np.flatnonzero(~ridged), 150, replace=False)
+        others = rng.choice(np.flatnonzero(~ridged & ~deflated), 150, replace=False)
+        defl = np.flatnonzero(deflated)
+        host_d = sb.pinv_accuracies(defl)                                      # EVERY deflated block the reference's way
+        d_defl.append(np.abs(acc_dev[defl].astype(np.float64) - host_d) * n_val)
+        n_deflated += len(defl)
         t0 = time.perf_counter()
         host_f = sb.pinv_accuracies(flagged)                                   # the reference's way, kernels included
         t_host = time.perf_counter() - t0
         host_o = sb.pinv_accuracies(others)
         d_ridged.append(np.abs(acc_dev[flagged].astype(np.float64) - host_f) * n_val)
         d_pd.append(np.abs(acc_dev[others].astype(np.float64) - host_o) * n_val)
-        some = flagged[:: max(1, len(flagged) // 120)]                         # ~120 flagged blocks: pinv on the DEVICE kernel's blocks
-        d_devgram.append(np.abs(sb.pinv_accuracies(some, kernels="device").astype(np.float64) - host_f[:: max(1, len(flagged) // 120)]) * n_val)
+        src_, host_ = (flagged, host_f) if len(flagged) else (defl, host_d)    # ~120 singular blocks: pinv on the DEVICE kernel's blocks
+        some = src_[:: max(1, len(src_) // 120)]
+        d_devgram.append(np.abs(sb.pinv_accuracies(some, kernels="device").astype(np.float64) - host_[:: max(1, len(src_) // 120)]) * n_val)
         n_regressions, n_flagged = n_regressions + ridged.size, n_flagged + len(flagged)
         rec = {"ridged": int(len(flagged)), "total": int(ridged.size), "host_seconds_flagged": t_host}
         if draw == 0:  # the patch itself: flagged blocks carry the host answer, the others the device answer; p-values follow
@@ -168,7 +201,8 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
             acc_pinv = sb.kr_acc.copy().reshape(-1)
             if not (np.array_equal(acc_pinv[flagged], host_f) and np.array_equal(np.delete(acc_pinv, flagged), np.delete(acc_dev, flagged))):
                 failures.append("ridge='pinv' did not patch exactly the flagged blocks with the host answer")
-            if not (sb.kr_ridged == len(flagged) and sb.kr_total == ridged.size and sb.kr_pinv_seconds > 0):
+            if not (sb.kr_ridged == len(flagged) and sb.kr_total == ridged.size and (sb.kr_pinv_seconds > 0 or not len(flagged))
+                    and sb.kr_deflated == int(sb.kr.deflated().sum())):
                 failures.append(f"counts {sb.kr_ridged} / {sb.kr_total} / {sb.kr_pinv_seconds}")
             rec["pinv_patch_seconds"] = sb.kr_pinv_seconds
             acc4 = acc_pinv.reshape(len(jobs), 2, epochs, 2)
@@ -183,7 +217,7 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
                         failures.append(f"job {ji} clf {ci}: p {rows_dev[ji, 7 + ci]:.3g} (ridge) vs {rows_pinv[ji, 7 + ci]:.3g} (pinv), tolerance {tol:.3g}")
         report["per_draw"].append(rec)
         del sb
-    d_pd, d_ridged, d_devgram = np.concatenate(d_pd), np.concatenate(d_ridged), np.concatenate(d_devgram)
+    d_pd, d_ridged, d_devgram, d_defl = np.concatenate(d_pd), np.concatenate(d_ridged), np.concatenate(d_devgram), np.concatenate(d_defl)
 
     def dist_of(v):
         v = np.round(v).astype(int)
@@ -193,9 +227,14 @@ def test_batched_sweep_ridge_against_the_pseudo_inverse_at_scale():
 
     if d_pd.max(initial=0) > ROWS_PD + 0.01:
         failures.append(f"blocks factored as they are: up to {d_pd.max():.1f} rows from the host answer")
-    if (d_ridged <= 2.01).mean() < RIDGED_SHARE_WITHIN_2 or d_ridged.max(initial=0) > RIDGED_MAX + 0.01:
+    if d_ridged.size and ((d_ridged <= 2.01).mean() < RIDGED_SHARE_WITHIN_2 or d_ridged.max(initial=0) > RIDGED_MAX + 0.01):
         failures.append(f"regularised blocks: {(d_ridged <= 2.01).mean():.3f} within 2 rows, max {d_ridged.max():.1f}")
-    report.update(regressions=int(n_regressions), ridged=int(n_flagged),
+    if d_defl.size and ((d_defl < 0.5).mean() < DEFLATED_EQUAL_SHARE or d_defl.max(initial=0) > ROWS_PD + 0.01):
+        failures.append(f"deflated blocks: {(d_defl < 0.5).mean():.4f} equal to the host answer, max {d_defl.max():.1f} rows")
+    if n_deflated < 2000 or n_flagged > 0:  # (the pubmed-sample features hold duplicate rows: ~39 % of these blocks; none may need the ridge)
+        failures.append(f"{n_deflated} deflated / {n_flagged} regularised blocks of {n_regressions}")
+    report.update(regressions=int(n_regressions), ridged=int(n_flagged), deflated=int(n_deflated),
+                  device_deflated_vs_reference_way_all=dist_of(d_defl),
                   device_vs_reference_way_not_flagged_sample=dist_of(d_pd), device_ridge_vs_reference_way_flagged_all=dist_of(d_ridged),
                   pinv_on_device_kernel_blocks_vs_reference_way_flagged_sample=dist_of(d_devgram),
                   abs_dp_ridge_vs_patched={"median": float(np.median(np.concatenate(dp_all))), "max": float(np.concatenate(dp_all).max())},

@@ -1094,6 +1094,15 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
 //            validation rows.
 // Rank-deficient blocks: as in kr_solve_kernel (pivot test at n eps max K_ii / 64, one restart on K + n eps max K_ii / 8 I).
 constexpr int K2_THREADS = 1024, K2_WAVES = 16, K2_NB = 10, K2_SLOTS = 3, K2_PS = 36;
+// the deflation workspace of a problem (wdg_kr_job.ws, filled by kr_deflate_kernel, read by the solver), as int32 words:
+//   [KRW_NT] rows to solve, [KRW_DEFLATED] != 0 when fewer than n_train, [KRW_TRAIN ..] their representatives (padded with -1),
+//   [KRW_VAL ..] n_val validation representatives, then n_val labels, then (mixed classes only) fp32 right-hand sides [row][KR_MAX_C]
+//   compact form: [KRW_LAB ..] a solved row's label when all members of its duplicate class carry the same one (right-hand side = its
+//   one-hot row), and only for a problem with a MIXED class ([KRW_MIXED] != 0) the fp32 right-hand sides behind the validation arrays
+//   [KRW_SCALE ..] sqrt(members) of a solved row's duplicate class (fp32 bits): the solver factors M = S K S, S = diag of these
+constexpr int KRW_NT = 0, KRW_DEFLATED = 1, KRW_MIXED = 2, KRW_TRAIN = 4, KRW_LAB = KRW_TRAIN + K2_NB * 32, KRW_SCALE = KRW_LAB + K2_NB * 32,
+              KRW_VAL = KRW_SCALE + K2_NB * 32;
+constexpr int KRW_RHS_WORDS = K2_NB * 32 * 8;  // (at KRW_VAL + 2 n_val)
 static_assert(K2_NB * (K2_NB - 1) / 2 <= K2_WAVES * K2_SLOTS, "every block below the diagonal needs a register slot");
 
 __device__ __forceinline__ int k2_jmap(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -1198,6 +1207,132 @@ __device__ __forceinline__ bool k2_factor_invert(float *ld, float *lt, int li, i
     return low_any;
 }
 
+// Deflation pre-pass (one workgroup per problem): with the row representatives of the matrix K was computed from (wdg_kr_job.rep,
+// csrc/row_rep.hip) every id is taken at its representative - duplicate rows of K are then identical by construction -, the train
+// rows are DEFLATED to one row per duplicate class with the class's mean one-hot label as right-hand side, and rows whose K_ii is
+// exactly 0 (all-zero feature rows under the linear kernel) are dropped.  That is the answer of the reference's
+// `np.linalg.pinv(K_train_train) @ label_onehot[idx_train]` (utils/homophily_metrics.py:291-297) on an exactly singular block: the
+// minimum-norm solution shares a class's weight among its members, K[v, members] sums it up again.  With P the members-to-class
+// incidence matrix and D = P^T P (the class sizes), K_tt = P K_u P^T = Q (D^1/2 K_u D^1/2) Q^T with Q = P D^-1/2 orthonormal, so
+// pinv(K_tt) = Q pinv(M) Q^T, M = S K_u S, S = D^1/2: the solver factors the SCALED block M with right-hand sides S^-1 P^T Y (a
+// class's label counts over sqrt(size)) and multiplies the solution by S - for a regular K_u the same as K_u^-1 (mean label), and
+// for a K_u that is rank deficient beyond its duplicates (texas: aggregated rows that are sums of others) the regularised answer
+// keeps the full system's metric (the unscaled form was up to 26 validation rows from the reference there).  The solver reads the
+// result from the problem's workspace and factors a positive definite block where round 5 added a rounding-level ridge.
+constexpr int KD_THREADS = 320;
+static_assert(KD_THREADS == K2_NB * 32, "one thread per train row");
+__global__ __launch_bounds__(KD_THREADS) void kr_deflate_kernel(const wdg_kr_job *__restrict__ jobs) {
+    __shared__ int d_raw[KD_THREADS], d_lab[KD_THREADS], d_first[KD_THREADS], d_slot[KD_THREADS], d_mult[KD_THREADS];
+    __shared__ float rhs[KD_THREADS * KR_MAX_C];
+    __shared__ int n_keep, any_mixed;
+    const desc_ptr<wdg_kr_job> job = (desc_ptr<wdg_kr_job>)(jobs + blockIdx.x);
+    if (job->ws == nullptr) return;  // (uniform)
+    const int tid = threadIdx.x, nt_in = job->n_train, nv = job->n_val;
+    const global_ptr<int32_t> ws = to_global(static_cast<int32_t *>(job->ws));
+    if (nt_in <= 0 || nt_in > KD_THREADS) {  // (the solver refuses the problem by its own test; the workspace must still be sane)
+        if (tid == 0) ws[KRW_NT] = -1, ws[KRW_DEFLATED] = 0;
+        return;
+    }
+    const global_ptr<const float> K = to_global(job->K);
+    const global_ptr<const int32_t> train = to_global(job->train), val = to_global(job->val), labels = to_global(job->labels),
+                                    rep = to_global(job->rep);
+    const bool has_rep = job->rep != nullptr;  // (without the maps every node is its own representative: zero rows are still dropped)
+    const int64_t ldk = job->ldk;
+    if (tid == 0) n_keep = 0, any_mixed = 0;
+    int r = -1, lb = -1;
+    float diag = 0.f;
+    if (tid < nt_in) {
+        const int g = train[tid];
+        r = has_rep ? rep[g] : g, lb = labels[g];
+        diag = K[static_cast<int64_t>(r) * ldk + r];
+    }
+    // rows BELOW THE BLOCK'S fp32 RESOLUTION are dropped (weight 0): K_ii <= n eps max K_ii - an all-zero row of K (an isolated node's
+    // aggregated features, an all-zero feature row under the linear kernel: an exact zero singular value, which the pseudo-inverse
+    // cuts), and the arc-cosine kernel's row of such a node (every entry 1.6e-9: a singular value 1e-12 of the largest, which an
+    // fp32 SVD cannot resolve - the reference's pinv leaves it no weight either: measured on texas, where factoring that row
+    // exactly, as an fp64 pseudo-inverse would, moved an epoch 24 validation rows away from the reference's)
+    float dmax = diag == diag ? diag : 0.f;
+    for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+    if ((tid & 63) == 0) rhs[tid >> 6] = dmax;  // (rhs doubles as the waves' maxima; zeroed below)
+    __syncthreads();
+    dmax = 0.f;
+    for (int w = 0; w < KD_THREADS / 64; ++w) dmax = fmaxf(dmax, rhs[w]);
+    if (tid < nt_in && !(diag > static_cast<float>(nt_in) * 1.1920929e-7f * dmax)) r = -2;
+    __syncthreads();
+    d_raw[tid] = r, d_lab[tid] = lb, d_mult[tid] = 0;
+    for (int i = tid; i < KD_THREADS * KR_MAX_C; i += KD_THREADS) rhs[i] = 0.f;
+    __syncthreads();
+    int first = r < 0 ? -1 : tid;  // the first train row with this representative
+    if (r >= 0)  // (eight ids per step, tested together: a one-at-a-time loop with an early exit waits for every LDS read)
+        for (int j0 = 0; j0 < tid && first == tid; j0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = d_raw[min(j0 + e, KD_THREADS - 1)];
+#pragma unroll
+            for (int e = 7; e >= 0; --e)
+                if (v[e] == r && j0 + e < tid) first = j0 + e;  // (descending: the smallest match stays)
+        }
+    d_first[tid] = first;
+    // a kept row's slot = the kept rows before it (train ids ascend: so do the slots' rows): ballot prefix inside a wave + the
+    // earlier waves' counts
+    const bool keep = first == tid;
+    const unsigned long long kmask = __ballot(keep);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) d_mult[wv] = __popcll(kmask);  // (d_mult doubles as the per-wave counts until the barrier; zeroed again below)
+    __syncthreads();
+    int slot = -1;
+    if (keep) {
+        slot = __popcll(kmask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; ++w) slot += d_mult[w];
+        d_slot[tid] = slot;
+    }
+    if (tid == 0) {
+        int total = 0;
+        for (int w = 0; w < KD_THREADS / 64; ++w) total += d_mult[w];
+        n_keep = total;
+    }
+    __syncthreads();
+    if (tid < KD_THREADS / 64) d_mult[tid] = 0;
+    __syncthreads();
+    if (first >= 0 && first != tid) slot = d_slot[first];
+    if (first == tid) d_first[slot] = r;  // (d_first is free now: the kept representatives, compact)
+    if (slot >= 0) {  // (counts of small integers: exact in any order)
+        atomicAdd(&d_mult[slot], 1);
+        if (lb >= 0 && lb < KR_MAX_C) atomicAdd(&rhs[slot * KR_MAX_C + lb], 1.f);
+    }
+    __syncthreads();
+    const int kept = n_keep;
+    ws[KRW_TRAIN + tid] = tid < kept ? d_first[tid] : -1;
+    // slot `tid`: pure (every member one label -> that label; members without a label in range -> -1: a zero row) or mixed
+    int pure = -1;
+    bool mixed = false;
+    if (tid < kept) {
+        const float m = static_cast<float>(d_mult[tid]);
+        int nz = 0;
+        for (int c = 0; c < KR_MAX_C; ++c) {
+            const float cnt = rhs[tid * KR_MAX_C + c];
+            if (cnt != 0.f) ++nz, pure = c;
+            if (cnt != 0.f && cnt != m) mixed = true;
+        }
+        mixed |= nz > 1;
+        if (mixed) any_mixed = 1, pure = -2;
+    }
+    ws[KRW_LAB + tid] = pure;
+    ws[KRW_SCALE + tid] = __builtin_bit_cast(int, tid < kept ? sqrtf(static_cast<float>(d_mult[tid])) : 1.f);
+    for (int v = tid; v < nv; v += KD_THREADS) {
+        const int g = val[v];
+        ws[KRW_VAL + v] = has_rep ? rep[g] : g;
+        ws[KRW_VAL + nv + v] = labels[g];
+    }
+    __syncthreads();
+    if (any_mixed)  // (uniform; rare: duplicate nodes with different labels) the fp32 right-hand sides, behind the validation arrays
+        for (int i = tid; i < KD_THREADS * KR_MAX_C; i += KD_THREADS) {
+            const int m = d_mult[i / KR_MAX_C];
+            ws[KRW_VAL + 2 * nv + i] = __builtin_bit_cast(int, m > 1 ? rhs[i] / sqrtf(static_cast<float>(m)) : rhs[i]);
+        }
+    if (tid == 0) ws[KRW_NT] = kept, ws[KRW_DEFLATED] = kept != nt_in, ws[KRW_MIXED] = any_mixed;
+}
+
 #ifdef K2_PROFILE  // diagnostic build (make EXTRA=-DK2_PROFILE): thread 0 of workgroup 0 sums the shader clocks spent per phase
 #define K2_T(k)                                                                   \
     do {                                                                          \
@@ -1218,6 +1353,9 @@ __device__ __forceinline__ bool k2_factor_invert(float *ld, float *lt, int li, i
 // (alpha stays in `al` until the next back substitution; the train rows' ids are double-buffered).  What is left when the
 // factorisation ends - and the last problem of a workgroup - is flushed by all waves.  Launched with one workgroup per problem
 // (WDG_KR_PERSIST=0) every problem is a last problem: round 3's schedule.  Hit counts do not depend on the schedule.
+// WS: every job of the table carries a deflation workspace (kr_deflate_kernel has run): the train rows to solve, their labels /
+// right-hand sides and the validation rows' representatives and labels are read from it, and the pivot test is per row.
+template <bool WS>
 __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_kr_job *__restrict__ jobs, int n_jobs) {
     __shared__ float P[(K2_NB - 1) * 32 * K2_PS];      // the step's panel L[a, kb], a > kb: [a - kb - 1][row][k], stride 36
     __shared__ float LD[K2_NB * 32 * K2_PS];           // the diagonal blocks L_kk, row-major (kept: the back substitution reads them)
@@ -1228,6 +1366,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     __shared__ float part[K2_WAVES][32][KR_MAX_C];     // per-wave partial sums (back substitution)
     __shared__ int tr_idx2[2][K2_NB * 32];             // the train rows' ids: this problem's and the previous one's (its predictions)
     __shared__ signed char blk_a[K2_WAVES * K2_SLOTS], blk_b[K2_WAVES * K2_SLOTS];
+    __shared__ float sc[WS ? K2_NB * 32 : 1];            // (WS) sqrt(size) of a solved row's duplicate class: the block factored is S K S
     __shared__ int deficient, pend_hits, pend_next;    // pend_*: the deferred predictions' hit count and next unit of four rows
     __shared__ float red[K2_WAVES];
 
@@ -1239,11 +1378,17 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     //      sixteen lanes per row, the lanes of a row split the train rows (ascending columns of one row of K); a row's sum: its
     //      lanes' partial sums added by a four-step butterfly - fixed order.  Units are dealt from an LDS counter: at most
     //      `max_units` to the calling wave (wave-uniform call sites).
+    int pend_nt = 0;  // (uniform) the pending problem's train rows as solved (fewer than n_train after deflation)
     auto predict_units = [&](const desc_ptr<wdg_kr_job> pj, const int *tidx, int max_units) {
         const global_ptr<const float> pK = to_global(pj->K);
-        const global_ptr<const int32_t> pval = to_global(pj->val), plabels = to_global(pj->labels);
+        const int pnv = pj->n_val, pC = pj->n_classes;
+        // with a deflation workspace (wdg_kr_deflate_batched) a validation row's kernel row (its representative) and its label come
+        // from two arrays indexed by v - no id -> label chain; without: val[v] and labels[val[v]]
+        constexpr bool pws = WS;
+        const global_ptr<const int32_t> pval = pws ? to_global(static_cast<const int32_t *>(pj->ws)) + KRW_VAL : to_global(pj->val);
+        const global_ptr<const int32_t> plabels = pws ? pval + pnv : to_global(pj->labels);
         const int64_t pldk = pj->ldk;
-        const int pnt = pj->n_train, pnv = pj->n_val, pC = pj->n_classes;
+        const int pnt = pend_nt;
         const int g = lane >> 4, gl = lane & 15;
 #ifdef WDG_KR_ABLATION
         if (pj->reserved & 8) return;
@@ -1294,7 +1439,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                     bv = p[c];
                     best = c;
                 }
-            const unsigned long long hit = __ballot(gl == 0 && v < pnv && best == plabels[gv]);
+            const unsigned long long hit = __ballot(gl == 0 && v < pnv && best == plabels[pws ? min(v, pnv - 1) : gv]);
             if (lane == 0 && hit) atomicAdd(&pend_hits, __popcll(hit));
         }
     };
@@ -1322,7 +1467,15 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     const global_ptr<const float> K = to_global(job->K);
     const global_ptr<const int32_t> train = to_global(job->train), labels = to_global(job->labels);
     const int64_t ldk = job->ldk;
-    const int nt = job->n_train, C = job->n_classes;
+    const int nt_in = job->n_train, C = job->n_classes;
+    // a deflation workspace (wdg_kr_deflate_batched has run on this table): the train rows to solve - one representative per class of
+    // duplicate nodes, rows with K_ii == 0 dropped -, their right-hand sides (a class's mean one-hot label) and the validation rows'
+    // representatives / labels are read from it; the reference's pseudo-inverse answers exactly singular blocks that way
+    const global_ptr<const int32_t> ws = to_global(static_cast<const int32_t *>(job->ws));
+    constexpr bool has_ws = WS;
+    const int nt = has_ws ? ws[KRW_NT] : nt_in;
+    const bool deflated = has_ws && ws[KRW_DEFLATED] != 0;
+    const bool mixed = has_ws && ws[KRW_MIXED] != 0;  // (uniform) fp32 right-hand sides in the workspace (duplicates with different labels)
 #ifdef WDG_KR_ABLATION  // diagnostic build only (make EXTRA=-DWDG_KR_ABLATION; scripts/dev/time_kr_batch.py): timing-only ablations
     const int ablate = job->reserved;  // 1 no gather, 2 no factorisation, 4 no back substitution, 8 no predictions (results are wrong)
 #else
@@ -1330,7 +1483,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
 #endif
     // (ldk: the deferred predictions address K by 32-bit element offsets row x ldk + column, rows and columns < ldk - a wider kernel
     // matrix is refused HERE as well as by the Python launcher, so that a C-ABI caller gets correct_out = -1, not wrong hit counts)
-    if (nt <= 0 || nt > K2_NB * 32 || C <= 0 || C > KR_MAX_C || ldk <= 0 || ldk >= 65536) {  // (uniform)
+    if (nt_in <= 0 || nt_in > K2_NB * 32 || nt < 0 || nt > nt_in || C <= 0 || C > KR_MAX_C || ldk <= 0 || ldk >= 65536) {  // (uniform)
         if (tid == 0 && job->correct_out) *to_global(job->correct_out) = -1;
         if (tid == 0 && job->flags_out) *to_global(job->flags_out) = 0;
         continue;
@@ -1340,7 +1493,10 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     const desc_ptr<wdg_kr_job> pjob = (desc_ptr<wdg_kr_job>)(jobs + (pending >= 0 ? pending : prob));
     const int nb = (nt + 31) >> 5;
     const int n_blocks = nb * (nb - 1) / 2;  // the blocks BELOW the diagonal live in registers; the diagonal blocks in LDS (LD)
-    for (int i = tid; i < K2_NB * 32; i += K2_THREADS) tr_idx[i] = i < nt ? train[i] : -1;
+    for (int i = tid; i < K2_NB * 32; i += K2_THREADS) {
+        tr_idx[i] = i < nt ? (has_ws ? ws[KRW_TRAIN + i] : train[i]) : -1;
+        if (has_ws) sc[i] = i < nt ? __builtin_bit_cast(float, ws[KRW_SCALE + i]) : 1.f;
+    }
     if (tid < K2_WAVES * K2_SLOTS) {  // block `tid` of the enumeration: columns nb-2 .. 0, rows b+1 .. nb-1 inside a column
         int idx = tid, b = nb - 2;
         while (b >= 0 && idx >= nb - 1 - b) {
@@ -1353,7 +1509,11 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     __syncthreads();
     // max K_ii of the train rows (the scale of the pivot test)
     float dmax = 0.f;
-    for (int t = tid; t < nt; t += K2_THREADS) dmax = fmaxf(dmax, K[static_cast<int64_t>(tr_idx[t]) * ldk + tr_idx[t]]);
+    for (int t = tid; t < nt; t += K2_THREADS) {
+        float d = K[static_cast<int64_t>(tr_idx[t]) * ldk + tr_idx[t]];
+        if (has_ws) d *= sc[t] * sc[t];
+        dmax = fmaxf(dmax, d);
+    }
     for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
     if (lane == 0) red[wave] = dmax;
     __syncthreads();
@@ -1376,7 +1536,8 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         // ---- right-hand sides and the gather
         for (int i = tid; i < K2_NB * 32 * KR_MAX_C; i += K2_THREADS) {
             const int row = i / KR_MAX_C, c = i % KR_MAX_C;
-            zs[i] = (row < nt && labels[tr_idx[row]] == c) ? 1.f : 0.f;
+            zs[i] = row >= nt ? 0.f : !has_ws ? (labels[tr_idx[row]] == c ? 1.f : 0.f)
+                    : mixed ? __builtin_bit_cast(float, ws[KRW_VAL + 2 * job->n_val + i]) : (ws[KRW_LAB + row] == c ? sc[row] : 0.f);
         }  // (`al` is not touched: the back substitution writes every row it or the predictions read, and until then it holds the
         //    PREVIOUS problem's alpha, which the deferred predictions below are reading)
         if (tid == 0) deficient = 0;
@@ -1389,6 +1550,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
                 const int j = k2_jmap(h, r), gj = tr_idx[32 * b + j];
                 const bool diag = a == b && li == j;
                 float v = (gi >= 0 && gj >= 0 && !(ablate & 1)) ? K[static_cast<int64_t>(gj) * ldk + gi] : (diag ? 1.f : 0.f);
+                if (has_ws) v *= sc[32 * a + li] * sc[32 * b + j];  // (1 for rows without duplicates: exact)
                 if (diag && gi >= 0) v += ridge;
                 t[r] = v;
             }
@@ -1593,6 +1755,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         finish_pending(pjob, tr_prev);
         pending = -1;
     }
+    if (nt == 0 && tid < KR_MAX_C) al[tid] = 0.f;  // (every train row dropped: no back substitution writes alpha; the predictions' masked reads hit row 0)
     K2_T(14);
     // ---- back substitution L^T alpha = z, block column by block column from the last (L_kk: still in LD)
     for (int kb = (ablate & 4) ? -1 : nb - 1; kb >= 0; --kb) {
@@ -1670,13 +1833,19 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         K2_T(8);
     }
 
+    // (WS) a class's weight as the predictions apply it: sqrt(size) x the scaled system's solution - once the back substitution, which
+    // reads alpha's later blocks, is through (the loop's last barrier has passed)
+    if (has_ws && deflated) {
+        for (int i = tid; i < nt * KR_MAX_C; i += K2_THREADS) al[i] *= sc[i / KR_MAX_C];
+    }
     // ---- this problem's predictions wait for the next problem's factorisation (or for the flush below)
     if (tid == 0) {
-        if (job->flags_out) *to_global(job->flags_out) = ridge > 0.f ? 1 : 0;
+        if (job->flags_out) *to_global(job->flags_out) = (ridge > 0.f ? 1 : 0) | (deflated ? 2 : 0);
         pend_hits = 0;
         pend_next = 0;
     }
     pending = prob;
+    pend_nt = nt;
     pend_buf ^= 1;  // (tr_idx2[pend_buf] = the ids just used)
     __syncthreads();
   }
@@ -1744,7 +1913,11 @@ int wdg_gram_finish_batched_f32(const wdg_gram_job *jobs_dev, int32_t n_jobs, in
     return wdg::check_launch("gram_finish_kernel");
 }
 
-int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream) {
+}  // extern "C"
+
+namespace {
+
+int kernel_regress_launch(const wdg_kr_job *jobs_dev, int32_t n_jobs, bool deflated, wdg_stream_t stream) {
     WDG_REQUIRE(n_jobs >= 0, "kernel_regress_batched: negative size");
     if (n_jobs == 0) return WDG_OK;
     WDG_REQUIRE(jobs_dev != nullptr, "kernel_regress_batched: null job table");
@@ -1765,13 +1938,33 @@ int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, w
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus = n, cus_dev = dev;
     }
-    if (rank1) hipLaunchKernelGGL(kr_solve_kernel, dim3(n_jobs), dim3(KR_THREADS), 0, wdg::as_stream(stream), jobs_dev);
-    else hipLaunchKernelGGL(kr_solve_blocked_kernel, dim3(persist ? (n_jobs < cus ? n_jobs : cus) : n_jobs), dim3(K2_THREADS), 0,
-                            wdg::as_stream(stream), jobs_dev, n_jobs);
+    if (rank1 && !deflated) hipLaunchKernelGGL(kr_solve_kernel, dim3(n_jobs), dim3(KR_THREADS), 0, wdg::as_stream(stream), jobs_dev);
+    else if (deflated) {
+        hipLaunchKernelGGL(kr_deflate_kernel, dim3(static_cast<unsigned>(n_jobs)), dim3(KD_THREADS), 0, wdg::as_stream(stream), jobs_dev);
+        hipLaunchKernelGGL(kr_solve_blocked_kernel<true>, dim3(persist ? (n_jobs < cus ? n_jobs : cus) : n_jobs), dim3(K2_THREADS), 0,
+                           wdg::as_stream(stream), jobs_dev, n_jobs);
+    } else hipLaunchKernelGGL(kr_solve_blocked_kernel<false>, dim3(persist ? (n_jobs < cus ? n_jobs : cus) : n_jobs), dim3(K2_THREADS), 0,
+                              wdg::as_stream(stream), jobs_dev, n_jobs);
     return wdg::check_launch("kr_solve_kernel");
 }
 
+}  // namespace
+
+extern "C" {
+
+int wdg_kernel_regress_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream) {
+    return kernel_regress_launch(jobs_dev, n_jobs, false, stream);
+}
+
+int wdg_kernel_regress_deflated_batched_f32(const wdg_kr_job *jobs_dev, int32_t n_jobs, wdg_stream_t stream) {
+    return kernel_regress_launch(jobs_dev, n_jobs, true, stream);
+}
+
 int32_t wdg_kernel_regress_max_train(void) { return KR_MAX_N; }
+
+size_t wdg_kr_deflate_workspace_bytes(int32_t n_val) {
+    return (static_cast<size_t>(KRW_VAL + 2 * (n_val > 0 ? n_val : 0) + KRW_RHS_WORDS) * 4 + 255) & ~static_cast<size_t>(255);
+}
 
 int wdg_kr_sample_sets(const wdg_kr_sample_job *jobs_dev, int32_t n_jobs, int32_t n_sets_total, int32_t max_n, wdg_stream_t stream) {
     WDG_REQUIRE(n_jobs >= 0 && n_sets_total >= 0 && max_n >= 0, "kr_sample_sets: negative size");

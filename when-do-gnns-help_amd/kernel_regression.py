@@ -13,6 +13,54 @@ from ._rt import _dev, _h2d, _ld, _ptr, _table
 
 
 # ------------------------------------------------------------------------------------------- kernel-regression metric
+def deflation_enabled():
+    """WDG_KR_DEFLATE=0: no row representatives - the solver answers exactly singular train blocks with its ridge (round 5)"""
+    return os.environ.get("WDG_KR_DEFLATE", "1") not in ("0", "")
+
+
+class RowRepBatch:
+    """Job table for wdg_row_rep_batched: per matrix the map row -> smallest bit-identical row (`rep[i]`, int32 [n]) - what the
+    kernel-regression solver deflates duplicate nodes with (KrBatch(rep=...); csrc/row_rep.hip)."""
+
+    def __init__(self, dense=None, csr=None, out=None):
+        """dense: list of A [n, F] fp32 device tensors (or ops.Tiled) - or csr: list of (CsrGraph, row_scale | None, use_values)
+        out: another RowRepBatch over matrices of the same row counts whose `rep` tensors this one fills"""
+        dev = require_gpu()
+        if (dense is None) == (csr is None):
+            raise ValueError("RowRepBatch: dense or csr")
+        self.source = 0 if dense is not None else 1
+        items = dense if dense is not None else csr
+        self.keep = items
+        ns = [int(a.shape[0]) for a in dense] if dense is not None else [int(g.n_rows) for g, _rs, _uv in csr]
+        self.n_jobs, self.max_n = len(ns), max(ns, default=0)
+        off = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+        if out is not None:
+            if [int(r.shape[0]) for r in out.rep] != ns:
+                raise ValueError("RowRepBatch(out=...): the other batch's maps have other lengths")
+            self.rep = out.rep
+        else:
+            pool = torch.empty(int(off[-1]), dtype=torch.int32, device=dev)
+            self.rep = [pool[int(off[i]):int(off[i + 1])] for i in range(len(ns))]
+        self.hash_ws = torch.empty(max(int(off[-1]), 1), dtype=torch.int64, device=dev)
+        arr = (_lib.RowRepJob * self.n_jobs)()
+        for i, (job, it) in enumerate(zip(arr, items)):
+            job.rep_out, job.hash_ws, job.n = self.rep[i].data_ptr(), self.hash_ws.data_ptr() + 8 * int(off[i]), ns[i]
+            if dense is not None:
+                if it.dtype != torch.float32 or it.stride(1) != 1:
+                    raise ValueError("RowRepBatch: A must be fp32 with unit inner stride")
+                job.A, job.lda, job.F = it.data_ptr(), _ld(it), int(it.shape[1])
+                job.a_group_stride = it.group_stride if isinstance(it, Tiled) else 0
+            else:
+                g, rs, use_values = it
+                job.rowptr, job.col = g.rowptr.data_ptr(), g.col.data_ptr()
+                job.val = g.val.data_ptr() if (use_values and g.val is not None and not getattr(g, "unit_values", False)) else 0
+                job.row_scale = 0 if rs is None else rs.data_ptr()
+        self.table = _table(arr)
+
+    def launch(self):
+        check(lib.wdg_row_rep_batched(_ptr(self.table), self.n_jobs, self.max_n, self.source, stream_handle()), "wdg_row_rep_batched")
+
+
 class GramBatch:
     """Job table for wdg_gram_map_batched_f32: K = map(A A^T) of every A of a batch (all nodes), linear and / or arc-cosine."""
 
@@ -50,6 +98,9 @@ class GramBatch:
         # the kernel family is chosen with the table and named at every launch (1 = WDG_KERNEL_SPLIT, 2 = WDG_KERNEL_CHAIN,
         # 4 = WDG_OPERAND_TILED): see Mlp2Batch
         self.flags = (1 if self.tiled_ok() else 2) | (4 if any(isinstance(a, Tiled) for a in mats) else 0)
+        # rep[i]: row -> smallest bit-identical row of A_i (launch() fills it beside the Gram): the solver's deflation maps
+        self.row_rep = (RowRepBatch(dense=mats, out=getattr(out, "row_rep", None)) if (deflation_enabled() and mats) else None)
+        self.rep = self.row_rep.rep if self.row_rep is not None else [None] * len(mats)
 
     @staticmethod
     def tiled_ok():
@@ -63,6 +114,8 @@ class GramBatch:
     def launch(self):
         check(lib.wdg_gram_map_batched_flags_f32(_ptr(self.table), self.n_jobs, self.max_n, self.flags, stream_handle()),
               "wdg_gram_map_batched_flags_f32")
+        if self.row_rep is not None:
+            self.row_rep.launch()
 
 
 _PROP_SCRATCH = {}  # (stream, node counts) -> (T, T^T) scratch of PropagatedGram: launches on one stream run in order
@@ -126,6 +179,12 @@ class PropagatedGram:
             job.lda, job.ldk, job.n, job.F, job.a_group_stride = n, n, n, n, 0
         self.fin_table = _table(fin)
         self.linear = linear  # (K_linear is produced either way: it is the propagated quantity)
+        # duplicate rows of Y = A_hat X without Y: identical rows of A_hat (columns, order, values, row scale) - bit-identical rows of
+        # the reference's A_hat X whatever X holds.  (Rows that coincide only through duplicate FEATURE rows are not found here: such a
+        # train block falls to the solver's ridge and is counted as ridged.)
+        self.row_rep = (RowRepBatch(csr=[(g, rs, False) for g, rs, _cs, _kx in problems])  # (pattern + scales: what the products read)
+                        if (deflation_enabled() and problems) else None)
+        self.rep = self.row_rep.rep if self.row_rep is not None else [None] * len(problems)
 
     def launch(self):
         if torch.cuda.current_stream().cuda_stream != self.owner_stream:
@@ -136,6 +195,8 @@ class PropagatedGram:
             check(lib.wdg_transpose_batched_f32(_ptr(self.tr_table), self.n_jobs, self.max_n, self.max_n, stream_handle()), "wdg_transpose_batched_f32")
         self.second.launch()      # U_j = A_hat_j T_j^T
         check(lib.wdg_gram_finish_batched_f32(_ptr(self.fin_table), self.n_jobs, self.max_n, stream_handle()), "wdg_gram_finish_batched_f32")
+        if self.row_rep is not None:
+            self.row_rep.launch()
 
 
 class EdgeGramBatch:
@@ -251,7 +312,7 @@ class KrSets:
 
 
 _KR_JOB_DTYPE = np.dtype([("K", "<u8"), ("train", "<u8"), ("val", "<u8"), ("labels", "<u8"), ("correct_out", "<u8"), ("flags_out", "<u8"),
-                          ("ldk", "<i8"), ("n_train", "<i4"), ("n_val", "<i4"), ("n_classes", "<i4"), ("reserved", "<i4")])
+                          ("ldk", "<i8"), ("n_train", "<i4"), ("n_val", "<i4"), ("n_classes", "<i4"), ("reserved", "<i4"), ("rep", "<u8"), ("ws", "<u8")])
 assert _KR_JOB_DTYPE.itemsize == ctypes.sizeof(_lib.KrJob)
 
 
@@ -262,7 +323,9 @@ class KrBatch:
     MAX_CLASSES = 8  # KR_MAX_C of csrc/kernel_reg.hip: the right-hand sides a problem's workgroup carries
 
     def __init__(self, problems, n_classes):
-        """problems: list of (K [n, n] fp32 device, train int32 device [nt], val int32 device [nv], labels int32 device [n])
+        """problems: list of (K [n, n] fp32 device, train int32 device [nt], val int32 device [nv], labels int32 device [n]
+        [, rep int32 device [n] | None: the row representatives of the matrix K was computed from - GramBatch.rep[i]; the solver
+        then deflates duplicate nodes instead of regularising the block])
         -> self.correct [n_problems] int32 after launch().  Shapes the solver does not hold (more than 8 classes, more than
         320 or fewer than 1 train rows) raise here: the kernel would answer them with the sentinel -1, and an accuracy of
         -1 / n_val fed to the t-test is a silently wrong p-value (callers with such label sets take the host path)."""
@@ -271,18 +334,20 @@ class KrBatch:
         col = lambda f: np.fromiter((f(p_) for p_ in problems), np.int64, n)  # noqa: E731
         self._build(col(lambda p_: p_[0].data_ptr()), col(lambda p_: _ld(p_[0])), col(lambda p_: p_[1].data_ptr()),
                     col(lambda p_: p_[2].data_ptr()), col(lambda p_: p_[3].data_ptr()), col(lambda p_: p_[1].shape[0]),
-                    col(lambda p_: p_[2].shape[0]), n_classes)
+                    col(lambda p_: p_[2].shape[0]), n_classes,
+                    col(lambda p_: p_[4].data_ptr() if len(p_) > 4 and p_[4] is not None else 0))
 
     @classmethod
-    def from_arrays(cls, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes, keep=None):
+    def from_arrays(cls, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes, keep=None, rep_ptr=None):
         """the same table from per-problem numpy columns (device addresses and sizes): a sweep shard's 20 000 problems are
         described by arithmetic on a few base pointers, not by 20 000 tensor objects"""
         self = cls.__new__(cls)
         self.keep = keep
-        self._build(*(np.asarray(a, np.int64) for a in (k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val)), n_classes)
+        self._build(*(np.asarray(a, np.int64) for a in (k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val)), n_classes,
+                    None if rep_ptr is None else np.asarray(rep_ptr, np.int64))
         return self
 
-    def _build(self, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes):
+    def _build(self, k_ptr, ldk, train_ptr, val_ptr, labels_ptr, n_train, n_val, n_classes, rep_ptr=None):
         dev = require_gpu()
         n = self.n_jobs = int(k_ptr.shape[0])
         if n and not 1 <= int(n_classes) <= self.MAX_CLASSES:
@@ -299,6 +364,13 @@ class KrBatch:
         tab["correct_out"] = self.correct.data_ptr() + 4 * np.arange(n, dtype=np.int64)
         tab["flags_out"] = self.flags.data_ptr() + 4 * np.arange(n, dtype=np.int64)
         tab["ldk"], tab["n_train"], tab["n_val"], tab["n_classes"] = ldk, n_train, n_val, int(n_classes)
+        # row representatives -> the deflating entry point: a workspace for EVERY problem of the table (problems without maps: identity)
+        self.ws = None
+        tab["rep"] = 0 if rep_ptr is None else rep_ptr
+        if n and bool((tab["rep"] != 0).any()):
+            per = int(lib.wdg_kr_deflate_workspace_bytes(int(n_val.max())))
+            self.ws = torch.empty(n * per, dtype=torch.uint8, device=dev)
+            tab["ws"] = self.ws.data_ptr() + per * np.arange(n, dtype=np.int64)
         # (timing-only diagnostics of the blocked solver: honoured only by a library built with -DWDG_KR_ABLATION, and never
         # mistaken for a result - accuracy() refuses)
         self.ablate = int(os.environ.get("WDG_KR_ABLATE", "0"))
@@ -306,11 +378,18 @@ class KrBatch:
         self.table = _h2d(tab.view(np.uint8), dev) if n else torch.empty(0, dtype=torch.uint8)
 
     def launch(self):
-        check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")
+        if self.ws is not None:
+            check(lib.wdg_kernel_regress_deflated_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_deflated_batched_f32")
+        else:
+            check(lib.wdg_kernel_regress_batched_f32(_ptr(self.table), self.n_jobs, stream_handle()), "wdg_kernel_regress_batched_f32")
 
     def ridged(self):
         """[n_problems] bool: the train block was rank deficient in fp32 and was solved with the rounding-level ridge"""
         return (self.flags[:self.n_jobs] & 1).bool()
+
+    def deflated(self):
+        """[n_problems] bool: duplicate train rows were merged / zero rows dropped before the factorisation (row representatives)"""
+        return (self.flags[:self.n_jobs] & 2).bool()
 
     def accuracy(self):
         """[n_problems] fp32 hit rate on the validation rows; raises when the kernel refused a problem (sentinel -1)"""

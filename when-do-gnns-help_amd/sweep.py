@@ -227,6 +227,7 @@ class _GramPair:
         self.k_linear = list(jobs_part.k_linear) + list(feats_part.k_linear)
         self.k_arccos = list(jobs_part.k_arccos) + list(feats_part.k_arccos)
         self.norm2 = list(jobs_part.norm2) + list(feats_part.norm2)
+        self.rep = list(jobs_part.rep) + list(feats_part.rep)  # (row representatives: the solver's deflation maps, or None)
 
     def launch(self):
         self.feats_part.launch()
@@ -881,10 +882,12 @@ class SweepBatch:
         n_tr = np.array([int(t.sum()) for _s, t in sizes], np.int64)
         n_va = np.array([int(s_.sum() - t.sum()) for s_, t in sizes], np.int64)
         lab_ptr = np.array([l.data_ptr() for l in self.labels], np.int64)
+        # (the row representatives of the matrix a kernel was computed from: duplicate nodes are deflated, not regularised - DESIGN 4.8)
+        rep_of_slot = np.array([0 if r is None else r.data_ptr() for r in self.gram.rep], np.int64)
         self.kr = ops.KrBatch.from_arrays(
             k_ptr, n_nodes[u_job], train.data_ptr() + 4 * (u_row * epochs + u_epoch) * train.shape[2],
             val.data_ptr() + 4 * (u_row * epochs + u_epoch) * val.shape[2], lab_ptr[u_job], n_tr[u_job], n_va[u_job], self.n_classes,
-            keep=(train, val, self.gram))
+            keep=(train, val, self.gram), rep_ptr=rep_of_slot[u_slot])
         idx = np.empty((J, 2, epochs, 2), np.int64)
         idx[..., 0] = (jc[:, None] * epochs + e_[None, :]).reshape(J, 2, epochs)
         idx[..., 1] = (J * 2 * epochs + row_g[:, None] * epochs + e_[None, :]).reshape(J, 2, epochs)
@@ -935,6 +938,12 @@ class SweepBatch:
         if self._kr_index_dev is None:
             self._kr_index_dev = self.ops._h2d(self.kr_index.reshape(-1), self.kr.correct.device)
         return self.kr.ridged()[self._kr_index_dev].reshape(self.kr_index.shape)
+
+    def kr_deflated_mask(self):
+        """[jobs, 2, epochs, 2] bool device tensor: KrBatch.deflated() (duplicate train rows merged / zero rows dropped) through kr_index"""
+        if self._kr_index_dev is None:
+            self._kr_index_dev = self.ops._h2d(self.kr_index.reshape(-1), self.kr.correct.device)
+        return self.kr.deflated()[self._kr_index_dev].reshape(self.kr_index.shape)
 
     def launch_full(self, sample_events=None):
         """the launches of the three extra scalars (after the aggregation: they read Y): Gram + maps, edge cosines, regressions
@@ -1082,7 +1091,7 @@ class SweepBatch:
         ridge = ridge or os.environ.get("WDG_SWEEP_KR_RIDGE", "device")
         if ridge not in ("device", "pinv"):
             raise ValueError(f"full_metrics: ridge={ridge!r} (device | pinv)")
-        self.kr_ridged = self.kr_total = 0
+        self.kr_ridged = self.kr_deflated = self.kr_total = 0
         self.kr_pinv_seconds = 0.0
         if not self.jobs:
             return torch.zeros((0, len(METRIC_NAMES)), dtype=torch.float64)
@@ -1090,12 +1099,13 @@ class SweepBatch:
         # one copy back: the step's scalars, the edge cosine means, the 4 x epochs accuracies of every job and the count of
         # train blocks the solver had to regularise
         packed = torch.cat([self.results().to(torch.float64).reshape(-1), self.ge.mean[:nj].to(torch.float64).reshape(-1),
-                            self.kr.accuracy().to(torch.float64).reshape(-1), self.kr.ridged().sum().to(torch.float64).reshape(1)]).cpu()
+                            self.kr.accuracy().to(torch.float64).reshape(-1), self.kr.deflated().sum().to(torch.float64).reshape(1),
+                            self.kr.ridged().sum().to(torch.float64).reshape(1)]).cpu()
         # (rank-deficient train blocks: solved with a rounding-level ridge where the reference's pinv inverts the rounding-level
         # singular values - counted and said once per shard, like utils/homophily_metrics.py does per call)
         # (kr_total: the regressions that were SOLVED - with common sets per sample a shared raw-features problem counts once)
-        self.kr_ridged, self.kr_total = int(packed[-1].item()), int(self.kr.n_jobs)
-        packed = packed[:-1]
+        self.kr_ridged, self.kr_deflated, self.kr_total = int(packed[-1].item()), int(packed[-2].item()), int(self.kr.n_jobs)
+        packed = packed[:-2]
         n_base = packed.numel() - nj - self.kr.n_jobs
         base = packed[:n_base].reshape(nj, -1)
         ge = packed[n_base:n_base + nj]
@@ -1141,6 +1151,7 @@ def _count_kr(stats, sb):
     if stats is not None:
         stats["kr_ridged"] = stats.get("kr_ridged", 0) + getattr(sb, "kr_ridged", 0)
         stats["kr_total"] = stats.get("kr_total", 0) + getattr(sb, "kr_total", 0)
+        stats["kr_deflated"] = stats.get("kr_deflated", 0) + getattr(sb, "kr_deflated", 0)
         stats["kr_pinv_seconds"] = stats.get("kr_pinv_seconds", 0.0) + getattr(sb, "kr_pinv_seconds", 0.0)
 
 

@@ -202,9 +202,15 @@ def similarity(features, adj, label, hard=None, LP=1, ifsum=1, idx_train=None):
 def _gram_kernel(a, n_layers):
     """K / 2 of utils/homophily_metrics.py:234-257 for the rows of `a`: the Gram on the matrix pipe with the arc-cosine map
     (n_layers == 1) or the halving (n_layers == 0) fused as the launch's epilogue (wdg_gram_map_batched_f32)."""
+    return _gram_kernel_rep(a, n_layers)[0]
+
+
+def _gram_kernel_rep(a, n_layers):
+    """(_gram_kernel's K, the row representatives of `a` - row -> smallest bit-identical row, or None with WDG_KR_DEFLATE=0 -: what
+    the solver deflates duplicate nodes with, csrc/row_rep.hip)"""
     gb = ops.GramBatch([a.contiguous()], linear=n_layers != 1, arccos=n_layers == 1)
     gb.launch()
-    return gb.k_arccos[0] if n_layers == 1 else gb.k_linear[0]
+    return (gb.k_arccos[0] if n_layers == 1 else gb.k_linear[0]), gb.rep[0]
 
 
 def _as_index(idx, dev):
@@ -259,17 +265,17 @@ def _kernel_regression_on_device(features, adj, labels, sample_max, base_classif
     h_agg = ops.spmm(g, features)
     problems = []
     if labels.shape[0] <= FULL_KERNEL_MAX_NODES:
-        k_g, k_x = _gram_kernel(h_agg, n_layers), _gram_kernel(features, n_layers)
+        (k_g, rep_g), (k_x, rep_x) = _gram_kernel_rep(h_agg, n_layers), _gram_kernel_rep(features, n_layers)
         for tr, va in node_sets:
             tr, va = tr.to(dev, torch.int32), va.to(dev, torch.int32)
-            problems += [(k_g, tr, va, lab32), (k_x, tr, va, lab32)]
+            problems += [(k_g, tr, va, lab32, rep_g), (k_x, tr, va, lab32, rep_x)]
     else:  # kernels of each epoch's sample only (rows: train first, then validation)
         for tr, va in node_sets:
             rows = torch.cat([tr, va]).to(dev)
-            k_g, k_x = _gram_kernel(h_agg[rows], n_layers), _gram_kernel(features[rows], n_layers)
+            (k_g, rep_g), (k_x, rep_x) = _gram_kernel_rep(h_agg[rows], n_layers), _gram_kernel_rep(features[rows], n_layers)
             lt = torch.arange(tr.shape[0], dtype=torch.int32, device=dev)
             lv = torch.arange(tr.shape[0], rows.shape[0], dtype=torch.int32, device=dev)
-            problems += [(k_g, lt, lv, lab32[rows]), (k_x, lt, lv, lab32[rows])]
+            problems += [(k_g, lt, lv, lab32[rows], rep_g), (k_x, lt, lv, lab32[rows], rep_x)]
     kb = ops.KrBatch(problems, n_cls)
     kb.launch()
     acc = kb.accuracy().cpu().reshape(-1)
@@ -287,7 +293,7 @@ def _kernel_regression_on_device(features, adj, labels, sample_max, base_classif
     if on_host:
         lab_cpu = labels.cpu()
         for i in torch.nonzero(ridged).flatten().tolist():
-            kern, tr, va, lab_p = problems[i]
+            kern, tr, va, lab_p = problems[i][:4]
             tr_l, va_l = tr.long(), va.long()
             k_tt = kern[tr_l][:, tr_l].cpu()
             k_vt = kern[va_l][:, tr_l].cpu()
