@@ -574,6 +574,64 @@ def test_sell16_bank_aware_order_reduces_conflicts(ops, oracle, monkeypatch, ord
     assert tot_c / tot_s < bound
 
 
+@pytest.mark.parametrize("order,bound", [("2", 1.40), ("1", 1.56)])
+def test_sell16_half_slab_order_reduces_conflicts(ops, oracle, monkeypatch, order, bound):
+    """HALF slabs (2529 .. 5056 columns: 32-byte slab rows, ds_read_b64): an LDS service group is 32 lanes = the EIGHT rows of
+    slots 0 - 7 / 8 - 15, a row's bank window is 8 (column mod 8) .. + 7 - a step costs one cycle when the eight rows read lie in
+    eight different windows (equal addresses broadcast), one more per extra distinct row in a window.  Round 4's greedy order
+    (WDG_SELL_ORDER=1): 1.50 cycles per step on the N = 4000 sweep graphs (31 % of the sweep's LDS cycles were conflicts,
+    profiles/r05_c3lit_pmc_summary.txt); the edge-coloured order (default) - the OPTIMUM for a slice's rows and steps: conflicts
+    only where a window class holds more entries than the slice has steps - 1.37.  The floor is set by the slack, not by the
+    order: a slice is swept for exactly as many steps as its longest row has entries (rounded up to 4), and eight rows' entries
+    split over eight windows fluctuate by +- sqrt(L): 1.2 - 1.8 cycles per step whatever the order (scripts/dev/half_slab_floor.py
+    simulates regrouping and extra steps: another 10 - 25 %).  On the kernel's clock the order is worth 1 % (254 against 257 us for
+    the literal N = 4000 shard): the HALF loop is bound by its instruction stream, not by the bank conflicts."""
+    from wdg_amd import synth
+    monkeypatch.setenv("WDG_SELL_ORDER", order)
+    tot_c = tot_s = 0
+    for h in (0.15, 0.3, 0.9):
+        src, dst, _ = synth.regular_graph(4000, 5, 10, h, 0)
+        g = ops.CsrGraph.from_coo(src, dst, 4000, None, ops.COO_ADD_SELF_LOOPS)
+        assert g.ensure_quad() and g.quad["half"]
+        q = g.quad
+        ext, qc = _np(q["ext"]).reshape(-1, 2), _np(q["col"])
+        rowptr, col = _np(g.rowptr), _np(g.col)
+        perm = _np(q["perm"])
+        cycles = steps = 0
+        sl = 0
+        while sl < q["n_entries"]:
+            c0, word = ext[sl]
+            assert not word & CONT
+            swept, nxt = 0, sl
+            while True:  # the slice's pieces
+                swept += -(-(ext[nxt][1] & 0xffff) // 4) * 4
+                nxt += 1
+                if nxt >= q["n_entries"] or not ext[nxt][1] & CONT or (ext[nxt][1] & 0xffff) == 0:
+                    break
+            while nxt < q["n_entries"] and ext[nxt][1] & CONT:  # ghosts
+                nxt += 1
+            n_chunks = -(-swept // 16)
+            blk = qc[c0 * 256:(c0 + n_chunks) * 256].reshape(n_chunks, 16, 16).transpose(1, 0, 2).reshape(16, -1)[:, :swept]
+            assert (blk % 32 == 0).all()
+            rows_blk = _np(q["rows"]).reshape(-1, 16)[sl]
+            for r16 in range(16):  # the slot holds exactly its row's entries (in whatever order) + zero-row padding
+                cr = col[rowptr[rows_blk[r16]]:rowptr[rows_blk[r16] + 1]]
+                got = blk[r16] // 32
+                np.testing.assert_array_equal(np.sort(got[got < 4000]), cr)
+                assert ((got >= 4000) & (got < 4004)).sum() == swept - len(cr)
+            for grp in (range(0, 8), range(8, 16)):
+                for e in range(swept):
+                    rows_read = np.unique(blk[list(grp), e] // 32)
+                    cycles += np.bincount(rows_read & 7, minlength=8).max()
+                    steps += 1
+            sl = nxt
+        print(f"[half slab order {order}] h={h}: {cycles / steps:.3f}")
+        assert cycles / steps < bound, (h, cycles / steps)
+        tot_c, tot_s = tot_c + cycles, tot_s + steps
+    print(f"[half slab order {order}] LDS cycles per group and step: {tot_c / tot_s:.3f}")
+    assert tot_c / tot_s < bound
+
+
 QUAD_SHAPES = [(2000, 2000, 512, 60000), (2000, 2000, 500, 20000), (2708, 2708, 1433, 13264), (100, 100, 8, 300),
                (1, 1, 16, 1), (17, 33, 40, 200), (3000, 2528, 64, 20000), (3000, 2529, 36, 20000), (5201, 5201, 130, 100000),
                (700, 9000, 24, 30000), (4000, 4000, 100, 100000), (2048, 2048, 10, 2048), (1500, 1500, 9, 9000),

@@ -1096,13 +1096,13 @@ __global__ __launch_bounds__(KR_THREADS) void kr_solve_kernel(const wdg_kr_job *
 constexpr int K2_THREADS = 1024, K2_WAVES = 16, K2_NB = 10, K2_SLOTS = 3, K2_PS = 36;
 // the deflation workspace of a problem (wdg_kr_job.ws, filled by kr_deflate_kernel, read by the solver), as int32 words:
 //   [KRW_NT] rows to solve, [KRW_DEFLATED] != 0 when fewer than n_train, [KRW_TRAIN ..] their representatives (padded with -1),
-//   [KRW_VAL ..] n_val validation representatives, then n_val labels, then (mixed classes only) fp32 right-hand sides [row][KR_MAX_C]
-//   compact form: [KRW_LAB ..] a solved row's label when all members of its duplicate class carry the same one (right-hand side = its
-//   one-hot row), and only for a problem with a MIXED class ([KRW_MIXED] != 0) the fp32 right-hand sides behind the validation arrays
-//   [KRW_SCALE ..] sqrt(members) of a solved row's duplicate class (fp32 bits): the solver factors M = S K S, S = diag of these
+//   [KRW_VAL ..] n_val validation representatives, then n_val labels
+//   [KRW_LAB ..] a solved row's label when all members of its duplicate class carry the same one (right-hand side: sqrt(size) in that
+//   column), -2 for a class with MIXED labels, whose non-zero right-hand-side entries are listed in [KRW_MIX ..]: [KRW_MIXED] words
+//   (row << 16 | label << 12 | members with that label); [KRW_SCALE ..] sqrt(members) of a solved row's duplicate class (fp32 bits):
+//   the solver factors M = S K S, S = diag of these
 constexpr int KRW_NT = 0, KRW_DEFLATED = 1, KRW_MIXED = 2, KRW_TRAIN = 4, KRW_LAB = KRW_TRAIN + K2_NB * 32, KRW_SCALE = KRW_LAB + K2_NB * 32,
-              KRW_VAL = KRW_SCALE + K2_NB * 32;
-constexpr int KRW_RHS_WORDS = K2_NB * 32 * 8;  // (at KRW_VAL + 2 n_val)
+              KRW_MIX = KRW_SCALE + K2_NB * 32, KRW_VAL = KRW_MIX + K2_NB * 32;
 static_assert(K2_NB * (K2_NB - 1) / 2 <= K2_WAVES * K2_SLOTS, "every block below the diagonal needs a register slot");
 
 __device__ __forceinline__ int k2_jmap(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -1315,7 +1315,13 @@ __global__ __launch_bounds__(KD_THREADS) void kr_deflate_kernel(const wdg_kr_job
             if (cnt != 0.f && cnt != m) mixed = true;
         }
         mixed |= nz > 1;
-        if (mixed) any_mixed = 1, pure = -2;
+        if (mixed) {  // (a (row, label) pair per train row at most: the list never outgrows its K2_NB * 32 words)
+            pure = -2;
+            for (int c = 0; c < KR_MAX_C; ++c) {
+                const int cnt = static_cast<int>(rhs[tid * KR_MAX_C + c]);
+                if (cnt > 0) ws[KRW_MIX + atomicAdd(&any_mixed, 1)] = (tid << 16) | (c << 12) | cnt;
+            }
+        }
     }
     ws[KRW_LAB + tid] = pure;
     ws[KRW_SCALE + tid] = __builtin_bit_cast(int, tid < kept ? sqrtf(static_cast<float>(d_mult[tid])) : 1.f);
@@ -1325,11 +1331,6 @@ __global__ __launch_bounds__(KD_THREADS) void kr_deflate_kernel(const wdg_kr_job
         ws[KRW_VAL + nv + v] = labels[g];
     }
     __syncthreads();
-    if (any_mixed)  // (uniform; rare: duplicate nodes with different labels) the fp32 right-hand sides, behind the validation arrays
-        for (int i = tid; i < KD_THREADS * KR_MAX_C; i += KD_THREADS) {
-            const int m = d_mult[i / KR_MAX_C];
-            ws[KRW_VAL + 2 * nv + i] = __builtin_bit_cast(int, m > 1 ? rhs[i] / sqrtf(static_cast<float>(m)) : rhs[i]);
-        }
     if (tid == 0) ws[KRW_NT] = kept, ws[KRW_DEFLATED] = kept != nt_in, ws[KRW_MIXED] = any_mixed;
 }
 
@@ -1475,7 +1476,7 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     constexpr bool has_ws = WS;
     const int nt = has_ws ? ws[KRW_NT] : nt_in;
     const bool deflated = has_ws && ws[KRW_DEFLATED] != 0;
-    const bool mixed = has_ws && ws[KRW_MIXED] != 0;  // (uniform) fp32 right-hand sides in the workspace (duplicates with different labels)
+    const int n_mixed = has_ws ? ws[KRW_MIXED] : 0;  // (uniform) listed right-hand-side entries (duplicates with different labels)
 #ifdef WDG_KR_ABLATION  // diagnostic build only (make EXTRA=-DWDG_KR_ABLATION; scripts/dev/time_kr_batch.py): timing-only ablations
     const int ablate = job->reserved;  // 1 no gather, 2 no factorisation, 4 no back substitution, 8 no predictions (results are wrong)
 #else
@@ -1536,8 +1537,17 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
         // ---- right-hand sides and the gather
         for (int i = tid; i < K2_NB * 32 * KR_MAX_C; i += K2_THREADS) {
             const int row = i / KR_MAX_C, c = i % KR_MAX_C;
-            zs[i] = row >= nt ? 0.f : !has_ws ? (labels[tr_idx[row]] == c ? 1.f : 0.f)
-                    : mixed ? __builtin_bit_cast(float, ws[KRW_VAL + 2 * job->n_val + i]) : (ws[KRW_LAB + row] == c ? sc[row] : 0.f);
+            float v = 0.f;
+            if (row < nt) {
+                const int lb = has_ws ? ws[KRW_LAB + row] : labels[tr_idx[row]];
+                v = lb == c ? (has_ws ? sc[row] : 1.f) : 0.f;
+                if (has_ws && lb == -2)  // (rare) a class of duplicates with different labels: its label counts over sqrt(size)
+                    for (int e = 0; e < n_mixed; ++e) {
+                        const int w = ws[KRW_MIX + e];
+                        if ((w >> 12) == ((row << 4) | c)) v = static_cast<float>(w & 0xfff) / sc[row];
+                    }
+            }
+            zs[i] = v;
         }  // (`al` is not touched: the back substitution writes every row it or the predictions read, and until then it holds the
         //    PREVIOUS problem's alpha, which the deferred predictions below are reading)
         if (tid == 0) deficient = 0;
@@ -1963,7 +1973,7 @@ int wdg_kernel_regress_deflated_batched_f32(const wdg_kr_job *jobs_dev, int32_t 
 int32_t wdg_kernel_regress_max_train(void) { return KR_MAX_N; }
 
 size_t wdg_kr_deflate_workspace_bytes(int32_t n_val) {
-    return (static_cast<size_t>(KRW_VAL + 2 * (n_val > 0 ? n_val : 0) + KRW_RHS_WORDS) * 4 + 255) & ~static_cast<size_t>(255);
+    return (static_cast<size_t>(KRW_VAL + 2 * (n_val > 0 ? n_val : 0)) * 4 + 255) & ~static_cast<size_t>(255);
 }
 
 int wdg_kr_sample_sets(const wdg_kr_sample_job *jobs_dev, int32_t n_jobs, int32_t n_sets_total, int32_t max_n, wdg_stream_t stream) {

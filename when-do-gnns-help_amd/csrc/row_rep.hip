@@ -14,8 +14,8 @@
 // Two sources of rows: a dense fp32 matrix (row-major or tiled by 16-column groups: X, or Y = A_hat X where it is materialised) and
 // the rows of a scaled CSR pattern (identical rows of A_hat give identical rows of A_hat X whatever X is: what the propagated-Gram
 // route uses, which never forms Y).  Both: a 64-bit hash per row (order-independent combination of position-keyed lane hashes:
-// deterministic), then per row a scan over the earlier rows for an equal hash, every candidate VERIFIED element by element (a hash
-// collision can never merge two different nodes).  +0 and -0 compare equal (they give the same products), NaNs never do.
+// deterministic), then per row a scan over the earlier rows for an equal hash, the candidate VERIFIED element by element by a wave (a
+// hash collision can never merge two different nodes).  +0 and -0 compare equal (they give the same products), NaNs never do.
 #include "wdg_common.h"
 
 namespace {
@@ -83,31 +83,9 @@ __global__ __launch_bounds__(256) void csr_row_hash_kernel(const wdg_row_rep_job
     to_global(static_cast<unsigned long long *>(job->hash_ws))[row] = h;
 }
 
-__device__ __forceinline__ bool dense_rows_equal(const desc_ptr<wdg_row_rep_job> job, int i, int j) {
-    const global_ptr<const float> A = to_global(job->A);
-    const int64_t lda = job->lda, gs = job->a_group_stride;
-    const int F = job->F;
-    for (int k = 0; k < F; ++k) {
-        const float a = dense_at(A, lda, gs, i, k), b = dense_at(A, lda, gs, j, k);
-        if (a != a || b != b || canon_bits(a) != canon_bits(b)) return false;
-    }
-    return true;
-}
-__device__ __forceinline__ bool csr_rows_equal(const desc_ptr<wdg_row_rep_job> job, int i, int j) {
-    const global_ptr<const int32_t> rowptr = to_global(job->rowptr), col = to_global(job->col);
-    const global_ptr<const float> val = to_global(job->val), rs = to_global(job->row_scale);
-    const int ai = rowptr[i], aj = rowptr[j], len = rowptr[i + 1] - ai;
-    if (rowptr[j + 1] - aj != len) return false;
-    if (rs && (rs[i] != rs[i] || canon_bits(rs[i]) != canon_bits(rs[j]))) return false;
-    for (int e = 0; e < len; ++e) {
-        if (col[ai + e] != col[aj + e]) return false;
-        if (val && (val[ai + e] != val[ai + e] || canon_bits(val[ai + e]) != canon_bits(val[aj + e]))) return false;
-    }
-    return true;
-}
-
-// rep[i] = min { j <= i : row j == row i }: thread i scans the hashes of the rows before it, tile by tile through LDS
-template <bool CSR>
+// rep[i] = min { j <= i : hash j == hash i }: thread i scans the hashes of the rows before it, tile by tile through LDS
+// (eight hashes per step, tested together: a one-at-a-time loop with its early exit waits for every LDS read - 260 cycles per row
+// compared, 250 us for the 55 matrices of a shard)
 __global__ __launch_bounds__(256) void row_rep_kernel(const wdg_row_rep_job *__restrict__ jobs) {
     __shared__ unsigned long long tile[256];
     const desc_ptr<wdg_row_rep_job> job = (desc_ptr<wdg_row_rep_job>)(jobs + blockIdx.y);
@@ -126,27 +104,51 @@ __global__ __launch_bounds__(256) void row_rep_kernel(const wdg_row_rep_job *__r
         __syncthreads();
         if (found) continue;
         const int lim = min(256, i - base);  // rows before i only
-        // (eight hashes per step, tested together: a one-at-a-time loop with its early exit waits for every LDS read - 260 cycles
-        // per row compared, 250 us for the 55 matrices of a shard; a match - rare - takes the slow path)
         for (int t0 = 0; t0 < lim && !found; t0 += 8) {
             unsigned long long v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = tile[(t0 + e) & 255];
-            bool any = false;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) any |= v[e] == mine;
-            if (!any) continue;
-            for (int e = 0; e < 8 && t0 + e < lim; ++e) {
-                if (v[e] != mine) continue;
-                if (CSR ? csr_rows_equal(job, i, base + t0 + e) : dense_rows_equal(job, i, base + t0 + e)) {
-                    rep = base + t0 + e;
-                    found = true;
-                    break;
-                }
-            }
+            for (int e = 7; e >= 0; --e)
+                if (v[e] == mine && t0 + e < lim) rep = base + t0 + e, found = true;  // (descending: the smallest match stays)
         }
     }
     if (i < n) to_global(job->rep_out)[i] = rep;
+}
+
+// every candidate VERIFIED, a wave per row: row i against row rep[i], element by element (the first row with a hash is its own
+// representative, so rep[rep[i]] == rep[i]).  A mismatch - a 64-bit hash collision - makes the row its own representative (a
+// later true duplicate of it is then not found either: such a train block falls to the solver's ridge).
+template <bool CSR>
+__global__ __launch_bounds__(256) void row_rep_verify_kernel(const wdg_row_rep_job *__restrict__ jobs) {
+    const desc_ptr<wdg_row_rep_job> job = (desc_ptr<wdg_row_rep_job>)(jobs + blockIdx.y);
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= job->n) return;
+    const global_ptr<int32_t> rep = to_global(job->rep_out);
+    const int j = rep[i];
+    if (j == i) return;  // (wave-uniform)
+    bool same = true;
+    if (CSR) {
+        const global_ptr<const int32_t> rowptr = to_global(job->rowptr), col = to_global(job->col);
+        const global_ptr<const float> val = to_global(job->val), rs = to_global(job->row_scale);
+        const int ai = rowptr[i], aj = rowptr[j], len = rowptr[i + 1] - ai;
+        same = rowptr[j + 1] - aj == len;
+        if (same && rs) same = rs[i] == rs[i] && canon_bits(rs[i]) == canon_bits(rs[j]);
+        if (same)
+            for (int e = lane; e < len; e += 64) {
+                same = same && col[ai + e] == col[aj + e];
+                if (val) same = same && val[ai + e] == val[ai + e] && canon_bits(val[ai + e]) == canon_bits(val[aj + e]);
+            }
+    } else {
+        const global_ptr<const float> A = to_global(job->A);
+        const int64_t lda = job->lda, gs = job->a_group_stride;
+        const int F = job->F;
+        for (int k = lane; k < F; k += 64) {
+            const float a = dense_at(A, lda, gs, i, k), b = dense_at(A, lda, gs, j, k);
+            same = same && a == a && b == b && canon_bits(a) == canon_bits(b);
+        }
+    }
+    if (!__all(same) && lane == 0) rep[i] = i;
 }
 
 }  // namespace
@@ -158,12 +160,11 @@ extern "C" int wdg_row_rep_batched(const wdg_row_rep_job *jobs_dev, int32_t n_jo
     WDG_REQUIRE(jobs_dev != nullptr, "row_rep_batched: null job table");
     hipStream_t st = wdg::as_stream(stream);
     const unsigned blocks = static_cast<unsigned>(wdg::ceil_div(max_n, 256));
-    if (source == WDG_ROW_REP_DENSE) {
-        hipLaunchKernelGGL(dense_row_hash_kernel, dim3(static_cast<unsigned>(wdg::ceil_div(max_n, 4)), n_jobs), dim3(256), 0, st, jobs_dev);
-        hipLaunchKernelGGL(row_rep_kernel<false>, dim3(blocks, n_jobs), dim3(256), 0, st, jobs_dev);
-    } else {
-        hipLaunchKernelGGL(csr_row_hash_kernel, dim3(blocks, n_jobs), dim3(256), 0, st, jobs_dev);
-        hipLaunchKernelGGL(row_rep_kernel<true>, dim3(blocks, n_jobs), dim3(256), 0, st, jobs_dev);
-    }
+    const unsigned rows4 = static_cast<unsigned>(wdg::ceil_div(max_n, 4));
+    if (source == WDG_ROW_REP_DENSE) hipLaunchKernelGGL(dense_row_hash_kernel, dim3(rows4, n_jobs), dim3(256), 0, st, jobs_dev);
+    else hipLaunchKernelGGL(csr_row_hash_kernel, dim3(blocks, n_jobs), dim3(256), 0, st, jobs_dev);
+    hipLaunchKernelGGL(row_rep_kernel, dim3(blocks, n_jobs), dim3(256), 0, st, jobs_dev);
+    if (source == WDG_ROW_REP_DENSE) hipLaunchKernelGGL(row_rep_verify_kernel<false>, dim3(rows4, n_jobs), dim3(256), 0, st, jobs_dev);
+    else hipLaunchKernelGGL(row_rep_verify_kernel<true>, dim3(rows4, n_jobs), dim3(256), 0, st, jobs_dev);
     return wdg::check_launch("row_rep_kernel");
 }

@@ -532,6 +532,173 @@ __device__ __forceinline__ bool sell16_fill_balanced(QbShared &sh, int entry, co
     return true;
 }
 
+// ---- HALF slabs (32-byte slab rows, ds_read_b64): an LDS service group is 32 lanes = EIGHT rows (slots 0 - 7 / 8 - 15 of the
+// slice), a row's bank window is 8 (column mod 8) .. + 7: a step is conflict-free when the eight columns read differ mod 8.  Round 4's
+// greedy order (below: every row in turn takes a class nobody took yet in this step) left 31 % of the sweep's LDS cycles to conflicts
+// on the N = 4000 shard (profiles/r05_c3lit_pmc_summary.txt).  The schedule is an EDGE COLOURING of the bipartite multigraph
+// rows x classes (an edge per stored entry, a colour = a step): by Koenig's theorem max(longest row, fullest class) colours
+// suffice, i.e. every step is conflict-free whenever no class holds more entries (over the group's eight rows) than the slice has
+// steps - and the few entries beyond that (a class total above the step count: ~1 - 3 % on the sweep's graphs) double up.  One
+// lane per group colours its edges one by one: a step free at the row and at the class if there is one, else the a / b Kempe
+// chain from the class is flipped (a free at the row, b free at the class).  Padding (a row shorter than the schedule) reads one
+// of the four zero rows - the one whose window no row of the group reads in that step, when there is one.
+struct QhShared {
+    unsigned char cls[Q_ROWS][QB_MAXW];       // class (local column mod 8) of entry j of slot r, column order
+    unsigned char at_row[Q_ROWS][QB_MAXW];    // per slot and step: the class read (0xff: padding)
+    unsigned char at_cls[2][8][QB_MAXW];      // per group, class and step: the slot (0 .. 7) that reads the class's window (0xff: none)
+    unsigned long long free_row[Q_ROWS][2], free_cls[2][8][2];  // steps still free (bit s of word s / 64)
+    unsigned char need[Q_ROWS][8];            // entries per slot and class
+};
+union QfShared {
+    QbShared b;
+    QhShared h;
+};
+__device__ __forceinline__ int qh_first(unsigned long long lo, unsigned long long hi) {
+    return lo ? __ffsll(static_cast<long long>(lo)) - 1 : 64 + __ffsll(static_cast<long long>(hi)) - 1;
+}
+// -> true when the slice was laid out here (else the caller's greedy order runs)
+__device__ __forceinline__ bool sell16_fill_half_coloured(QhShared &sh, int entry, const int32_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                          const int32_t *rows, int32_t block_cols, const int32_t *__restrict__ ext,
+                                                          int32_t *__restrict__ q_col, float *__restrict__ q_val) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q4 = lane >> 4;
+    const int chunk0 = ext[2 * entry];
+    const int row = rows[entry * Q_ROWS + r];
+    const int row_next = __shfl(row, (lane & 48) + min(r + 1, 15));
+    if (__any(r < 15 && row == row_next)) return false;  // padding slots (duplicate rows): the greedy order keeps them equal
+    const int a = rowptr[row], len = rowptr[row + 1] - a;
+    int width = len;
+    for (int o = 8; o > 0; o >>= 1) width = max(width, __shfl_xor(width, o));
+    const int n_chunks = (width + Q_CHUNK - 1) / Q_CHUNK, S = n_chunks * Q_CHUNK;
+    if (S > QB_MAXW || width == 0) return false;
+    // the steps the kernel SWEEPS (split form: 32 per full piece + the last piece rounded up to whole quads): no entry may lie beyond
+    const int pieces = (width + Q_SPLIT_WIDTH - 1) / Q_SPLIT_WIDTH;
+    const int T = Q_SPLIT_WIDTH * (pieces - 1) + ((width - Q_SPLIT_WIDTH * (pieces - 1) + 3) & ~3);
+    // ---- classes into LDS (quarter q4 of the wave takes entries q4, q4 + 4, ..), per-slot class counts
+    if (q4 == 0)
+        for (int c = 0; c < 8; ++c) sh.need[r][c] = 0;
+    for (int j = q4; j < len; j += 4) sh.cls[r][j] = static_cast<unsigned char>(col[a + j] & 7);
+    for (int s_ = q4; s_ < S; s_ += 4) sh.at_row[r][s_] = 0xff;
+    for (int i = lane; i < 2 * 8 * QB_MAXW; i += 64) (&sh.at_cls[0][0][0])[i] = 0xff;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < Q_ROWS)
+        for (int j = 0; j < len; ++j) ++sh.need[r][sh.cls[r][j]];
+    __builtin_amdgcn_wave_barrier();
+    // ---- one lane per group of eight slots colours the group's edges
+    if (lane == 0 || lane == 8) {
+        const int g = lane >> 3, r0 = 8 * g;
+        int tot[8], lmax = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tot[c] = 0;
+        for (int i = 0; i < 8; ++i) {
+            int l = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tot[c] += sh.need[r0 + i][c], l += sh.need[r0 + i][c];
+            lmax = max(lmax, l);
+        }
+        int tmax = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tmax = max(tmax, tot[c]);
+        const int steps = min(T, max(lmax, tmax));  // colours in use: padding only where a slot is shorter than the schedule
+        const unsigned long long lo = steps >= 64 ? ~0ull : ((1ull << steps) - 1ull), hi = steps <= 64 ? 0ull : (steps >= 128 ? ~0ull : ((1ull << (steps - 64)) - 1ull));
+        for (int i = 0; i < 8; ++i) {
+            sh.free_row[r0 + i][0] = lo, sh.free_row[r0 + i][1] = hi;
+            sh.free_cls[g][i][0] = lo, sh.free_cls[g][i][1] = hi;
+        }
+        auto take = [&](unsigned long long *m, int s_) { m[s_ >> 6] &= ~(1ull << (s_ & 63)); };
+        auto give = [&](unsigned long long *m, int s_) { m[s_ >> 6] |= 1ull << (s_ & 63); };
+        int reg[8];  // entries of a class coloured so far: at most `steps` of them can have a step of their own
+#pragma unroll
+        for (int c = 0; c < 8; ++c) reg[c] = 0;
+        for (int i = 0; i < 8; ++i) {
+            const int rr = r0 + i;
+            for (int c = 0; c < 8; ++c) {
+                int n_reg = min(static_cast<int>(sh.need[rr][c]), steps - reg[c]);
+                reg[c] += n_reg;
+                sh.need[rr][c] -= static_cast<unsigned char>(n_reg);  // (what is left: the entries that double up, placed below)
+                for (; n_reg > 0; --n_reg) {
+                    unsigned long long *fr = sh.free_row[rr], *fc = sh.free_cls[g][c];
+                    const unsigned long long c0 = fr[0] & fc[0], c1 = fr[1] & fc[1];
+                    int s_;
+                    if (c0 | c1) {
+                        s_ = qh_first(c0, c1);
+                    } else {  // a: free at the slot (taken at the class), b: free at the class (taken at the slot)
+                        const int ca = qh_first(fr[0], fr[1]), cb = qh_first(fc[0], fc[1]);
+                        int x = c, r1 = sh.at_cls[g][c][ca];  // the edge (r1, x) leaves colour a ..
+                        sh.at_cls[g][c][ca] = 0xff;
+                        sh.at_row[r0 + r1][ca] = 0xff;
+                        take(fc, cb);  // (c: b taken from now on; a goes to the new edge)
+                        for (;;) {     // .. and takes b; what it displaces takes a; and so on along the chain
+                            const int c1_ = sh.at_row[r0 + r1][cb];
+                            sh.at_cls[g][x][cb] = static_cast<unsigned char>(r1);
+                            sh.at_row[r0 + r1][cb] = static_cast<unsigned char>(x);
+                            if (c1_ == 0xff) {
+                                give(sh.free_row[r0 + r1], ca), take(sh.free_row[r0 + r1], cb);
+                                break;
+                            }
+                            sh.at_cls[g][c1_][cb] = 0xff;
+                            const int r2 = sh.at_cls[g][c1_][ca];
+                            sh.at_row[r0 + r1][ca] = static_cast<unsigned char>(c1_);
+                            sh.at_cls[g][c1_][ca] = static_cast<unsigned char>(r1);
+                            if (r2 == 0xff) {
+                                give(sh.free_cls[g][c1_], cb), take(sh.free_cls[g][c1_], ca);
+                                break;
+                            }
+                            sh.at_row[r0 + r2][ca] = 0xff;
+                            x = c1_, r1 = r2;
+                        }
+                        s_ = ca;
+                    }
+                    sh.at_row[rr][s_] = static_cast<unsigned char>(c);
+                    sh.at_cls[g][c][s_] = static_cast<unsigned char>(i);
+                    take(fr, s_), take(fc, s_);
+                }
+            }
+        }
+        // the entries beyond a class's steps: any step the slot still has (they share the class's window with another slot)
+        for (int i = 0; i < 8; ++i)
+            for (int c = 0; c < 8; ++c)
+                for (int k = sh.need[r0 + i][c]; k > 0; --k) {
+                    unsigned long long *fr = sh.free_row[r0 + i];
+                    const int s_ = qh_first(fr[0], fr[1]);
+                    sh.at_row[r0 + i][s_] = static_cast<unsigned char>(c);
+                    take(fr, s_);
+                }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- emit: lane s < 16 writes the row in slot s: per step the next entry (column order) of the scheduled class
+    if (lane < Q_ROWS) {
+        int32_t *dst = q_col + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + r * Q_CHUNK;
+        float *dstv = q_val ? q_val + static_cast<int64_t>(chunk0) * Q_CHUNK_INTS + r * Q_CHUNK : nullptr;
+        int cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int g = r >> 3;
+        for (int e = 0; e < S; ++e) {
+            const int at = (e / Q_CHUNK) * Q_CHUNK_INTS + (e % Q_CHUNK);
+            const int c = sh.at_row[r][e];
+            int off;
+            float v = 0.f;
+            if (c != 0xff) {
+                int j = 0;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) j = cc == c ? cur[cc] : j;
+                while (sh.cls[r][j] != c) ++j;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) cur[cc] = cc == c ? j + 1 : cur[cc];
+                off = col[a + j] * 32;
+                v = val ? val[a + j] : 1.f;
+            } else {  // padding: the zero row (four of them behind the block: windows block_cols mod 8 .. + 3) nobody's window collides with
+                int k = 0;
+                for (int t = 3; t >= 0; --t) k = sh.at_cls[g][(block_cols + t) & 7][e] == 0xff ? t : k;
+                off = (block_cols + k) * 32;
+            }
+            dst[at] = off;
+            if (dstv) dstv[at] = v;
+        }
+    }
+    return true;
+}
+
 // One wave per (column block, entry that starts a slice); lane r < 16 orders row r's segment.  Bank-aware order (reorder != 0):
 // the sweep reads, for entry e of all 16 rows, the 64-byte LDS row of each row's column; the four rows of a service group
 // collide when their columns agree mod 4 (64-byte rows: a row's bank window is 16 (column mod 4) .. + 15).  The order of a
@@ -541,7 +708,7 @@ __device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__rest
                                                  const float *__restrict__ val, int32_t *rows,
                                                  int32_t n_entries, int32_t n_blocks, int32_t block_cols,
                                                  const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
-                                                 float *__restrict__ q_val, int reorder, QbShared *qb) {
+                                                 float *__restrict__ q_val, int reorder, QfShared *qb) {
     const int lane = threadIdx.x & 63;
     if (task >= n_entries * n_blocks) return;  // (whole waves: a task is a wave)
     const int blk = task / n_entries, entry = task % n_entries;
@@ -549,7 +716,10 @@ __device__ __forceinline__ void sell16_fill_body(int task, const int32_t *__rest
     // split form (one column block, <= 128 entries per row): the conflict-free order (reorder 2: WDG_SELL_ORDER=1 keeps round 2's greedy one)
     const int rb = (n_blocks == 1 && block_cols > Q_MAX_BLOCK_COLS) ? 32 : 64;  // bytes of a slab row (HALF slabs: 8 features)
     if (reorder == 2 && rb == 64 && n_blocks == 1 && (ext[2 * n_entries + 1] & Q_CONT) &&
-        sell16_fill_balanced(*qb, entry, rowptr, col, val, rows, n_entries, block_cols, ext, q_col, q_val))
+        sell16_fill_balanced(qb->b, entry, rowptr, col, val, rows, n_entries, block_cols, ext, q_col, q_val))
+        return;
+    // HALF slabs: the edge-coloured order (reorder 2; WDG_SELL_ORDER=1 keeps round 4's greedy one)
+    if (reorder == 2 && rb == 32 && n_blocks == 1 && (ext[2 * n_entries + 1] & Q_CONT) && sell16_fill_half_coloured(qb->h, entry, rowptr, col, val, rows, block_cols, ext, q_col, q_val))
         return;
     const int chunk0 = ext[2 * task];
     const int r = lane & 15;
@@ -630,7 +800,7 @@ __global__ __launch_bounds__(256) void sell16_fill(const int32_t *__restrict__ r
                                                    int32_t n_entries, int32_t n_blocks, int32_t block_cols,
                                                    const int32_t *__restrict__ ext, int32_t *__restrict__ q_col,
                                                    float *__restrict__ q_val, int reorder) {
-    __shared__ QbShared qb[4];  // one per wave
+    __shared__ QfShared qb[4];  // one per wave
     sell16_fill_body((blockIdx.x * 256 + threadIdx.x) >> 6, rowptr, col, val, rows, n_entries, n_blocks, block_cols, ext, q_col, q_val,
                      reorder, &qb[threadIdx.x >> 6]);
 }
@@ -730,7 +900,7 @@ __global__ __launch_bounds__(256) void sell16_fill_batched(const wdg_sell16_job 
     if (j.n_rows <= 0 || !j.q_col) return;  // (no SELL-16 copy wanted for this graph: decided by the caller after the count)
     const Sell16Shape sh = sell16_shape(j.n_rows, j.n_cols);
     const int32_t n_entries = j.q_ext[2 * sh.n_blocks * sh.max_entries + 1] & 0x3fffffff;
-    __shared__ QbShared qb[4];  // one per wave
+    __shared__ QfShared qb[4];  // one per wave
     sell16_fill_body((blockIdx.x * 256 + threadIdx.x) >> 6, j.rowptr, j.col, j.val, j.q_rows, n_entries, sh.n_blocks, sh.block_cols,
                      j.q_ext, j.q_col, j.q_val, reorder, &qb[threadIdx.x >> 6]);
 }
