@@ -413,6 +413,16 @@ int wdg_sweep_scalars_f32(const int64_t *totals, const int32_t *rows, const int6
                           const int64_t *las_counts, const float *las_n, const float *class_prop, int32_t n_jobs, int32_t max_rows,
                           int32_t n_classes, float *out, wdg_stream_t stream);
 
+/*
+ * A nine-scalar shard's device results gathered into ONE fp64 vector (one launch, then one copy to the host):
+ *   out = [scalars (n_scalars fp32, widened) | ge_mean (n_ge fp64) | kr_correct[i] / kr_n_val[i] (the fp32 quotient, widened; n_kr) |
+ *          #problems with flags bit 1 (deflated), #with bit 0 (ridged), #with correct < 0 (refused)]      (n_scalars + n_ge + n_kr + 3)
+ * replaces: the result bookkeeping of the sweep loop - `X_results[j] = accuracy(...)`, `G_results[j] = ...` utils/homophily_metrics.py:
+ *           293-297 and the scalar appends of synthetic_plot.py:94-109 - as one device pass instead of a dozen library launches.
+ */
+int wdg_sweep_pack_f64(const float *scalars, int32_t n_scalars, const double *ge_mean, int32_t n_ge, const int32_t *kr_correct,
+                       const int32_t *kr_flags, const float *kr_n_val, int32_t n_kr, double *out, wdg_stream_t stream);
+
 /* ------------------------------------------------------------------ per-edge cosine (SDDMM) */
 /*
  * out[i] = cos(x_u, x_v) for stored entry e_i = (u, v) (e_i = entries[i], or i when entries == NULL); NaN -> 0;

@@ -88,11 +88,11 @@ def test_cli_counterpart_matches_golden(name):
     g0 = load("real_" + name)
     n = int(g0["n_nodes"])
     pairs = [("node_homo", "m_node_homo", 1e-6), ("edge_homo", "m_edge_homo_onehot_quirk", 1e-6),
-             ("class_homo", "m_class_homo", 1e-5), ("adj_homo", "m_adj_homo", 1e-5), ("label_info", "m_label_info", 1e-3),
+             ("class_homo", "m_class_homo", 1e-5), ("adj_homo", "m_adj_homo", 1e-5), ("label_info", "m_label_info", 1e-5),
              ("node_hom_generalized", "m_ge_homo", 1e-4)]
     for metric, key, tol in pairs:
         got = float(cli.main(["--dataset_name", name, "--data_dir", GOLDEN_DIR, "--homophily_metric", metric]))
-        assert got == pytest.approx(float(g0[key]), rel=tol, abs=1e-6), metric
+        assert got == pytest.approx(float(g0[key]), rel=tol, abs=4e-6 if metric == "label_info" else 1e-6), metric  # (LI: formed near 2 in fp32)
     for metric, key in (("agg_homo_soft", "m_agg_soft"), ("agg_homo_hard", "m_agg_hard")):
         got = float(cli.main(["--dataset_name", name, "--data_dir", GOLDEN_DIR, "--homophily_metric", metric]))
         assert abs(got - float(g0[key])) <= 2 * 1.01 / n, metric
@@ -133,9 +133,9 @@ def test_cli_large_dataset_branch_against_the_oracle(oracle, tmp_path, symmetric
     want = {"node_homo": oracle.node_homophily_sparse(st), "edge_homo": oracle.edge_homophily_sparse(st, labels_2d_classes=c),
             "class_homo": oracle.class_homophily(st, labels), "adj_homo": oracle.adjusted_homophily(st, labels),
             "label_info": oracle.label_informativeness(st, labels)}
-    for metric, tol in (("node_homo", 1e-6), ("edge_homo", 1e-6), ("class_homo", 1e-5), ("adj_homo", 1e-5), ("label_info", 1e-4)):
+    for metric, tol in (("node_homo", 1e-6), ("edge_homo", 1e-6), ("class_homo", 1e-5), ("adj_homo", 1e-5), ("label_info", 1e-5)):
         got = float(cli.main(["--dataset_name", path, "--symmetric", str(symmetric), "--homophily_metric", metric]))
-        assert got == pytest.approx(want[metric], rel=tol, abs=1e-6), metric
+        assert got == pytest.approx(want[metric], rel=tol, abs=4e-6 if metric == "label_info" else 1e-6), metric
     # aggregation homophily: raw adjacency, ten class-balanced 10 000-node samples drawn from torch's CPU generator (:124-131)
     r2, c2, v2 = oracle.coo_to_csr(row, col, n, None, 0)
     onehot = np.eye(c, dtype=np.float32)[labels]

@@ -467,7 +467,9 @@ def test_sweep_all_nine_scalars_against_golden():
         assert r[1] == pytest.approx(float(g0["m_node_homo"]), rel=1e-6)
         assert r[2] == pytest.approx(float(g0["m_class_homo"]), rel=1e-5, abs=1e-7)
         assert r[3] == pytest.approx(float(g0["m_adj_homo"]), rel=1e-4, abs=2e-7)
-        assert r[4] == pytest.approx(float(g0["m_label_info"]), rel=2e-3, abs=2e-6)
+        # (label informativeness = 2 - sum pc ln pc / sum p ln p, formed near 2 in fp32 by the reference and here: each side carries
+        # ~2e-6 of absolute rounding whatever the value - 3.6e-5 on syn_4000_0.2 - so the bound is absolute; round 5 allowed rel 2e-3)
+        assert r[4] == pytest.approx(float(g0["m_label_info"]), rel=1e-5, abs=4e-6)
         assert abs(r[5] - float(g0["m_soft_las"])) <= 2.01 / j.n_nodes
         assert r[6] == pytest.approx(float(g0["m_ge_homo"]), rel=2e-5)
     # the accuracies behind the p-values, per (job, classifier, epoch, kernel), against what the reference computed in each of

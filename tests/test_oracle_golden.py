@@ -195,10 +195,9 @@ def test_gntk_kernels(oracle, name, nl):
     x = dense_features(g)
     rowptr, col, val = oracle.coo_to_csr(g["adj_row"], g["adj_col"], n, g["adj_val"])
     kg, kx = oracle.gntk_kernels(x, rowptr, col, val, g["gntk_sample"], nl)
-    s = np.abs(g[f"gntk_KG_l{nl}"]).max()
-    np.testing.assert_allclose(kg, g[f"gntk_KG_l{nl}"], rtol=2e-4, atol=2e-6 * s)
-    s = np.abs(g[f"gntk_KX_l{nl}"]).max()
-    np.testing.assert_allclose(kx, g[f"gntk_KX_l{nl}"], rtol=2e-4, atol=2e-6 * s)
+    from _golden import assert_gntk_close
+    assert_gntk_close(kg, g[f"gntk_KG_l{nl}"], g["gntk_KG_l0"], nl)
+    assert_gntk_close(kx, g[f"gntk_KX_l{nl}"], g["gntk_KX_l0"], nl)
 
 
 # --------------------------------------------------------------------------- plain helpers

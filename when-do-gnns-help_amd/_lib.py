@@ -140,6 +140,7 @@ SIGNATURES = {
     "wdg_edge_gram_mean_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "wdg_kernel_regress_batched_f32": (c_int, [c_void_p, c_int32, c_void_p]),
     "wdg_row_rep_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_sweep_pack_f64": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "wdg_kr_deflate_workspace_bytes": (c_size_t, [c_int32]),
     "wdg_kernel_regress_deflated_batched_f32": (c_int, [c_void_p, c_int32, c_void_p]),
     "wdg_kr_sample_sets": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -197,6 +197,32 @@ __global__ __launch_bounds__(SC_THREADS) void sweep_scalars_kernel(const int64_t
     o[5] = static_cast<float>(las_counts[2 * j]) / las_n[j];
 }
 
+// A nine-scalar shard's device results -> ONE fp64 vector for ONE copy to the host (one workgroup: a few tens of thousands of
+// elements): [scalars | edge-cosine means | accuracies correct / n_val (the fp32 quotient, widened) | #deflated, #ridged, #refused].
+// Replaces ~12 library launches per base-shard (compare, any, copy, divide, and, sum, cat ...), each of which - a few microseconds
+// of work - queued behind the persistent regression launch that holds every CU.
+__global__ __launch_bounds__(1024) void sweep_pack_kernel(const float *__restrict__ scalars, int n_scalars, const double *__restrict__ ge_mean,
+                                                          int n_ge, const int32_t *__restrict__ kr_correct, const int32_t *__restrict__ kr_flags,
+                                                          const float *__restrict__ kr_n_val, int n_kr, double *__restrict__ out) {
+    __shared__ int cnt[3];
+    const int tid = threadIdx.x;
+    if (tid < 3) cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n_scalars; i += 1024) out[i] = static_cast<double>(scalars[i]);
+    for (int i = tid; i < n_ge; i += 1024) out[n_scalars + i] = ge_mean[i];
+    int defl = 0, ridged = 0, refused = 0;
+    for (int i = tid; i < n_kr; i += 1024) {
+        const int c = kr_correct[i], f = kr_flags[i];
+        out[n_scalars + n_ge + i] = static_cast<double>(static_cast<float>(c) / kr_n_val[i]);
+        defl += (f >> 1) & 1, ridged += f & 1, refused += c < 0;
+    }
+    if (defl) atomicAdd(&cnt[0], defl);
+    if (ridged) atomicAdd(&cnt[1], ridged);
+    if (refused) atomicAdd(&cnt[2], refused);
+    __syncthreads();
+    if (tid < 3) out[n_scalars + n_ge + n_kr + tid] = static_cast<double>(cnt[tid]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -241,6 +267,16 @@ int wdg_sweep_scalars_f32(const int64_t *totals, const int32_t *rows, const int6
     hipLaunchKernelGGL(sweep_scalars_kernel, dim3(static_cast<unsigned>(n_jobs)), dim3(SC_THREADS), 0, as_stream(stream), totals, rows, compat,
                        classdeg, las_counts, las_n, class_prop, max_rows, n_classes, out);
     return check_launch("sweep_scalars_kernel");
+}
+
+int wdg_sweep_pack_f64(const float *scalars, int32_t n_scalars, const double *ge_mean, int32_t n_ge, const int32_t *kr_correct,
+                       const int32_t *kr_flags, const float *kr_n_val, int32_t n_kr, double *out, wdg_stream_t stream) {
+    WDG_REQUIRE(n_scalars >= 0 && n_ge >= 0 && n_kr >= 0, "sweep_pack: negative size");
+    WDG_REQUIRE(out && (n_scalars == 0 || scalars) && (n_ge == 0 || ge_mean) && (n_kr == 0 || (kr_correct && kr_flags && kr_n_val)),
+                "sweep_pack: null array");
+    hipLaunchKernelGGL(sweep_pack_kernel, dim3(1), dim3(1024), 0, as_stream(stream), scalars, n_scalars, ge_mean, n_ge, kr_correct, kr_flags,
+                       kr_n_val, n_kr, out);
+    return check_launch("sweep_pack_kernel");
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import synth
+from ._lib import WdgError
 
 # the nine scalars of a sweep job (synthetic_plot.py:94-109).  results() returns the first six (one integer pass + LAS: what
 # a bench step computes); full_metrics() adds generalized edge homophily and the two kernel-regression p-values
@@ -1098,14 +1099,24 @@ class SweepBatch:
         nj = len(self.jobs)
         # one copy back: the step's scalars, the edge cosine means, the 4 x epochs accuracies of every job and the count of
         # train blocks the solver had to regularise
-        packed = torch.cat([self.results().to(torch.float64).reshape(-1), self.ge.mean[:nj].to(torch.float64).reshape(-1),
-                            self.kr.accuracy().to(torch.float64).reshape(-1), self.kr.deflated().sum().to(torch.float64).reshape(1),
-                            self.kr.ridged().sum().to(torch.float64).reshape(1)]).cpu()
+        # (one launch - wdg_sweep_pack_f64 - instead of a dozen library launches queued behind the regressions, then the one copy)
+        res = self.results().contiguous()
+        n_kr = int(self.kr.n_jobs)
+        packed_dev = torch.empty(res.numel() + nj + n_kr + 3, dtype=torch.float64, device=res.device)
+        ops = self.ops
+        ops.check(ops.lib.wdg_sweep_pack_f64(res.data_ptr(), res.numel(), self.ge.mean.data_ptr(), nj, self.kr.correct.data_ptr(),
+                                             self.kr.flags.data_ptr(), self.kr.n_val.data_ptr(), n_kr, packed_dev.data_ptr(),
+                                             ops.stream_handle()), "wdg_sweep_pack_f64")
+        packed = packed_dev.cpu()
+        if getattr(self.kr, "ablate", 0):
+            raise WdgError("KrBatch: WDG_KR_ABLATE is set - the launch was a timing-only ablation, its accuracies mean nothing")
+        if int(packed[-1].item()):
+            raise WdgError("wdg_kernel_regress_batched_f32 refused a problem (shape outside the solver's limits)")
         # (rank-deficient train blocks: solved with a rounding-level ridge where the reference's pinv inverts the rounding-level
         # singular values - counted and said once per shard, like utils/homophily_metrics.py does per call)
         # (kr_total: the regressions that were SOLVED - with common sets per sample a shared raw-features problem counts once)
-        self.kr_ridged, self.kr_deflated, self.kr_total = int(packed[-1].item()), int(packed[-2].item()), int(self.kr.n_jobs)
-        packed = packed[:-2]
+        self.kr_ridged, self.kr_deflated, self.kr_total = int(packed[-2].item()), int(packed[-3].item()), n_kr
+        packed = packed[:-3]
         n_base = packed.numel() - nj - self.kr.n_jobs
         base = packed[:n_base].reshape(nj, -1)
         ge = packed[n_base:n_base + nj]
