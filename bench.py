@@ -413,7 +413,7 @@ def measure_whole(args, dev, world=1, rank=0):
     per (level, sample), shared by the six bases -, aggregation at the base's width, Grams, device-drawn node sets, regressions,
     t-tests).  BASELINE.md: ~35 s per job on the reference's CPU path, ~17 h for the sweep.
 
-    world > 1 (`bench.py --gpus N`): STRONG scaling of that sweep - the 280 adjacencies dealt to the ranks by sweep.shard_jobs,
+    world > 1 (`bench.py --gpus N`): STRONG scaling of that sweep - the 280 adjacencies dealt to the ranks by sweep.shard_pairs (contiguous, sample-aware),
     every rank runs the six bases over its share (sweep.whole_sweep_rank), the [jobs, 9] rows are exchanged once
     (sweep.exchange_rows: one all_gather), `seconds` = the slowest rank (barrier, clock, all_reduce MAX) - and rank 0 then runs the
     WHOLE sweep alone on its GPU (the other ranks wait), so that `strong_speedup_vs_1gpu` compares two measurements of one
@@ -426,7 +426,7 @@ def measure_whole(args, dev, world=1, rank=0):
     from wdg_amd import synth
     pairs_all = sweep.make_jobs([h for h in synth.H_LEVELS_30 if h not in (0.05, 0.1)], range(10), k=10, n_nodes=args.nodes)
     pairs = sweep.broadcast_jobs(pairs_all if rank == 0 else [], dev)  # rank 0's job table, like the step's
-    mine = sweep.shard_jobs(pairs, world, rank)
+    mine = sweep.pairs_of_rank(pairs, world, rank)
     inp = whole_inputs(args, pairs if rank == 0 else mine)  # (rank 0 also runs the one-GPU reference pass: it needs every graph)
     t_in = time.perf_counter() - t_in
     feats, bases, graphs = inp["feats"], inp["bases"], inp["graphs"]
@@ -501,7 +501,7 @@ def measure_whole(args, dev, world=1, rank=0):
         dist.barrier()
     args._whole = dict(inp, seconds=dt)  # (measure_projection shards the same inputs)
     shards_txt = (f"{-(-len(pairs) // per_shard)} shards of {per_shard} adjacencies" if world == 1 else
-                  f"the {len(pairs)} adjacencies dealt to {world} ranks by sweep.shard_jobs (one shard per rank), rows exchanged by one all_gather, "
+                  f"the {len(pairs)} adjacencies dealt to {world} ranks by sweep.shard_pairs (one shard per rank), rows exchanged by one all_gather, "
                   "`seconds` = slowest rank incl. the exchange")
     return {"workload": f"synthetic_plot.py's sweep: {len(bases)} feature bases ({', '.join(f'{n} F={w}' for n, w in bases)}) x {len(inp['levels'])} homophily "
                         f"levels x {len(inp['samples'])} samples = {n_rows} jobs, N={args.nodes}, k=10, all nine scalars, {args.kr_epochs} epochs per "
@@ -660,8 +660,8 @@ def measure_projection(args, dev, full_ms):
                     dt_ = time.perf_counter() - t0
                     best = dt_ if best is None else min(best, dt_)
                 secs.append(best)
-                assert keys.shape[0] == len(sweep.shard_jobs(pairs, w, r)) * len(whole["feats"])
-            ws[str(w)] = {"ranks_timed": len(secs), "adjacencies_per_rank": [len(sweep.shard_jobs(pairs, w, r)) for r in range(w)],
+                assert keys.shape[0] == len(sweep.pairs_of_rank(pairs, w, r)) * len(whole["feats"])
+            ws[str(w)] = {"ranks_timed": len(secs), "adjacencies_per_rank": [len(sweep.pairs_of_rank(pairs, w, r)) for r in range(w)],
                           "per_rank_s": [round(x, 4) for x in secs], "slowest_rank_s": max(secs),
                           "projected_strong_speedup": whole["seconds"] / max(secs)}
         out["whole_sweep"] = {"jobs": len(pairs) * len(whole["feats"]), "one_gpu_s": whole["seconds"], "worlds": ws,

@@ -46,12 +46,15 @@ def tracer(frame, event, arg):
     return local
 
 
+W, R = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 0)
+sweep.whole_sweep_rank(pairs, graph_of, feats, W, R)
+torch.cuda.synchronize()
 sys.settrace(tracer)
 t0 = time.perf_counter()
-sweep.whole_sweep_rank(pairs, graph_of, feats, 1, 0)
+sweep.whole_sweep_rank(pairs, graph_of, feats, W, R)
 torch.cuda.synchronize()
 sys.settrace(None)
 print(f"traced pass: {(time.perf_counter() - t0) * 1e3:.0f} ms")
 src = open(sweep.__file__).read().splitlines()
-for (code, line), t in sorted(acc.items(), key=lambda kv: -kv[1])[:25]:
+for (code, line), t in sorted(acc.items(), key=lambda kv: -kv[1])[:40]:
     print(f"{t * 1e3:8.1f} ms  {code}:{line}  {src[line - 1].strip()[:110]}")

@@ -42,3 +42,7 @@ pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(45)
 st.sort_stats("tottime").print_stats(30)
+if os.environ.get("WDG_PROF_CALLEES"):
+    st.sort_stats("cumulative")
+    for pat in ("prepare_full", "sweep.py:.*(__init__)", "rebind_features", "kernel_regression.py:.*(__init__)", "aggregate.py:.*(__init__)"):
+        st.print_callees(pat)

@@ -133,7 +133,7 @@ def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkey
     of a stand-alone SweepBatch over the same inputs, bit for bit, and the same rows as the driver without any reuse
     (WDG_SWEEP_REBIND=0 WDG_SWEEP_STEP_TWINS=0 WDG_SWEEP_PREFETCH_BUILD=0), unpipelined or with three base-shards in flight."""
     from wdg_amd import sweep, synth
-    for name in ("WDG_SWEEP_REBIND", "WDG_SWEEP_STEP_TWINS", "WDG_SWEEP_PREFETCH_BUILD", "WDG_GRAM_ROUTE"):
+    for name in ("WDG_SWEEP_REBIND", "WDG_SWEEP_STEP_TWINS", "WDG_SWEEP_PREFETCH_BUILD", "WDG_GRAM_ROUTE", "WDG_SWEEP_PROLOGUE"):
         monkeypatch.delenv(name, raising=False)  # (this test asserts WHICH bases were rebound / twinned under the defaults)
     levels, samples = [0.2, 0.5, 0.8], [0, 1]
     graphs = {(h, s_): synth.regular_graph(600, 5, 4, h, s_) for h in levels for s_ in samples}
@@ -146,8 +146,8 @@ def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkey
         shards.append((jobs, [graphs[(j.h, j.seed)] for j in jobs]))
     rebinds, twins = [], []
     orig_rebind, orig_twin = sweep.SweepBatch.rebind_features, sweep.SweepBatch._init_step_twin
-    monkeypatch.setattr(sweep.SweepBatch, "rebind_features", lambda self, *a: (rebinds.append(a[1]), orig_rebind(self, *a))[1])
-    monkeypatch.setattr(sweep.SweepBatch, "_init_step_twin", lambda self, *a: (twins.append(a[2]), orig_twin(self, *a))[1])
+    monkeypatch.setattr(sweep.SweepBatch, "rebind_features", lambda self, *a, **k: (rebinds.append(a[1]), orig_rebind(self, *a, **k))[1])
+    monkeypatch.setattr(sweep.SweepBatch, "_init_step_twin", lambda self, *a, **k: (twins.append(a[2]), orig_twin(self, *a, **k))[1])
     got = {(si, bi): rows for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=2, first_seed=5)}
     assert sorted(got) == [(si, bi) for si in range(2) for bi in range(6)]
     assert sorted(rebinds) == [650, 650, 700, 700, 800, 800] and sorted(twins) == [720, 720]  # per shard: p2, p4, p5 rebound; p3 a twin of p1
@@ -166,6 +166,10 @@ def test_table_reuse_across_wide_feature_bases_equals_stand_alone_batches(monkey
     for depth in (1, 3):  # (unpipelined: a batch is free again at once; three in flight: a base may find no free batch and builds its own)
         for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=depth, first_seed=5):
             assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(got[(si, bi)], nan=-7.0)), (depth, si, bi)
+    monkeypatch.setenv("WDG_SWEEP_PROLOGUE", "1")  # (round 6's feature prologue - a helper thread uploads the wide bases' features and
+    for si, bi, rows in sweep.run_bases(shards, bases, epochs=6, depth=2, first_seed=5):  # launches their Grams ahead - : the same rows)
+        assert torch.equal(torch.nan_to_num(rows, nan=-7.0), torch.nan_to_num(got[(si, bi)], nan=-7.0)), ("prologue", si, bi)
+    monkeypatch.delenv("WDG_SWEEP_PROLOGUE")
     monkeypatch.setenv("WDG_SWEEP_REBIND", "0")
     monkeypatch.setenv("WDG_SWEEP_STEP_TWINS", "0")
     monkeypatch.setenv("WDG_SWEEP_PREFETCH_BUILD", "0")

@@ -40,6 +40,30 @@ def test_shard_jobs_north_star_split():
     assert max(edges) / min(edges) <= 1.25  # (the cost has a per-row part: stored entries alone balance less tightly)
 
 
+def test_shard_pairs_is_a_contiguous_sample_aware_partition():
+    """the nine-scalar sweep's partition (whole_sweep_rank): every adjacency exactly once, contiguous in sample-major order, as few
+    samples per rank as the split allows (the reference's 280 adjacencies on 8 ranks: two each - shard_jobs' LPT dealt up to three),
+    modelled costs within 3 % of each other, deterministic; more ranks than adjacencies: the spare ranks get nothing"""
+    levels = [h for h in synth.H_LEVELS_30 if h not in (0.05, 0.1)]
+    pairs = sweep.make_jobs(levels, range(10), k=10, n_nodes=2000)
+    key = lambda j: (j.seed, levels.index(j.h))  # noqa: E731
+    for ws in (1, 2, 3, 4, 5, 8, 16):
+        shards = [sweep.shard_pairs(pairs, ws, r) for r in range(ws)]
+        assert sum(shards, []) == sorted(pairs, key=key)  # contiguous ranges of the sample-major list, in order
+        assert shards == [sweep.shard_pairs(list(pairs), ws, r) for r in range(ws)]
+        cost = [sum(sweep.PAIR_COST_US + sweep.PAIR_COST_PER_ENTRY_US * j.nnz for j in m) + sweep.SAMPLE_COST_US * len({j.seed for j in m})
+                for m in shards]
+        assert max(cost) <= 1.03 * min(cost) or ws > 8, (ws, cost)
+        if ws == 8:
+            assert all(len({j.seed for j in m}) == 2 for m in shards)
+            lpt = [sweep.shard_jobs(pairs, 8, r) for r in range(8)]
+            assert sum(len({j.seed for j in m}) for m in lpt) > 16  # (what the sample-aware split saves)
+    few = pairs[:3]
+    got = [sweep.shard_pairs(few, 5, r) for r in range(5)]
+    assert sum(got, []) == few and sum(1 for m in got if m) == 3
+    assert sweep.shard_pairs([], 4, 1) == []
+
+
 def test_shard_jobs_fewer_jobs_than_ranks():
     jobs = sweep.make_jobs([0.2, 0.5], [0], k=2, n_nodes=200)
     shards = [sweep.shard_jobs(jobs, 3, r) for r in range(3)]

@@ -84,6 +84,49 @@ def shard_jobs(jobs, world_size, rank, slack=0.02):
 
 _SHARD_MEMO = {}
 
+# What an adjacency costs in the NINE-scalar sweep, in microseconds per feature base (round 6, one MI355X: 200 regressions at 0.58 us
+# each - the metric's share does not depend on the graph - + the propagated kernels' two aggregations and the edge cosines, which grow
+# with the stored entries), and what a SAMPLE costs the rank that touches it (its feature matrices' uploads, Grams, row hashes and the
+# 200 raw-feature regressions per base, shared by the sample's levels)
+PAIR_COST_US, PAIR_COST_PER_ENTRY_US, SAMPLE_COST_US = 145.0, 0.045 / 59000 * 1000, 2200.0
+
+
+def shard_pairs(pairs, world_size, rank):
+    """Partition of the (homophily level, sample) adjacencies of the nine-scalar sweep (whole_sweep_rank), SAMPLE-AWARE: the list is
+    cut into `world_size` CONTIGUOUS ranges of its sample-major order, so a rank touches as few samples as the split allows (two, where
+    shard_jobs' LPT over single jobs dealt the reference's 280 adjacencies to 8 ranks with up to three samples each: a third
+    sample is a third set of feature uploads, Grams and raw-feature regressions per base - 6 ms of a rank's 50).  The cuts balance
+    the modelled cost (PAIR_COST_*: the regressions' flat share + the stored entries' + SAMPLE_COST_US per sample a range touches):
+    every cut is moved, in turn, to where the heavier of its two ranges is lightest, until nothing moves.  Deterministic, identical
+    on every rank; ranks beyond the list get nothing."""
+    order = sorted(range(len(pairs)), key=lambda i: (pairs[i].seed, i))
+    n, w = len(order), int(world_size)
+    if n == 0 or w <= 1:
+        return [pairs[i] for i in order] if rank == 0 else []
+    cost = np.array([PAIR_COST_US + PAIR_COST_PER_ENTRY_US * pairs[i].nnz for i in order])
+    seed = np.array([pairs[i].seed for i in order])
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    new_sample = np.concatenate([[1], (seed[1:] != seed[:-1]).astype(np.int64)])
+    cum_new = np.concatenate([[0], np.cumsum(new_sample)])  # distinct samples that START before position p
+
+    def range_cost(a, b):
+        if b <= a:
+            return 0.0
+        return cum[b] - cum[a] + SAMPLE_COST_US * (1 + cum_new[b] - cum_new[a + 1])
+
+    cuts = [int(np.searchsorted(cum, cum[-1] * r / w)) for r in range(w + 1)]
+    cuts[0], cuts[-1] = 0, n
+    for _ in range(64):
+        moved = False
+        for c in range(1, w):
+            lo, hi = cuts[c - 1], cuts[c + 1]
+            best = min(range(lo, hi + 1), key=lambda p_: (max(range_cost(lo, p_), range_cost(p_, hi)), abs(p_ - cuts[c])))
+            if best != cuts[c]:
+                cuts[c], moved = best, True
+        if not moved:
+            break
+    return [pairs[i] for i in order[cuts[rank]:cuts[rank + 1]]]
+
 
 def _shard_owner(jobs, world_size, slack):
     """shard_jobs' partition: the rank of every job"""
@@ -195,15 +238,21 @@ def exchange_rows(keys, rows, n_total, device):
     return out
 
 
+def pairs_of_rank(pairs, world, rank):
+    """the adjacencies whole_sweep_rank gives `rank`: shard_pairs (sample-aware; WDG_SWEEP_SHARD=lpt: round 5's shard_jobs)"""
+    return shard_pairs(pairs, world, rank) if os.environ.get("WDG_SWEEP_SHARD", "sample") != "lpt" else shard_jobs(pairs, world, rank)
+
+
 def whole_sweep_rank(pairs, graph_of, bases, world, rank, epochs=100, max_pairs_per_shard=80, depth=2, progress=None, stats=None):
     """This rank's share of the reference's whole sweep (synthetic_plot.py:64-109), STRONG scaling: the (level, sample)
-    adjacencies `pairs` (a list of Job; job.seed = the sample) are dealt to the ranks by shard_jobs, every rank runs all feature
+    adjacencies `pairs` (a list of Job; job.seed = the sample) are dealt to the ranks by shard_pairs (contiguous ranges of the
+    sample-major list, balanced by modelled cost; WDG_SWEEP_SHARD=lpt: round 5's shard_jobs), every rank runs all feature
     bases over its adjacencies through run_bases (graphs built once per shard and shared by the bases) - no data-path collective.
     graph_of(job) -> (src, dst, labels) host arrays; bases as run_bases takes them.
     -> (keys [m] int64, rows [m, 9] fp64): key = index of the pair in `pairs` x n_bases + base index, ready for exchange_rows.
     A rank keeps one shard while it holds <= max_pairs_per_shard adjacencies (fewer job tables to build), else equal shards.
     progress(shard index, base index, rows): called as every base-shard's rows arrive on the host (bench.py's per-base clock)."""
-    mine = shard_jobs(pairs, world, rank)
+    mine = pairs_of_rank(pairs, world, rank)
     index = {j: i for i, j in enumerate(pairs)}
     n_shards = max(1, -(-len(mine) // max_pairs_per_shard))
     per = max(1, -(-len(mine) // n_shards))
@@ -217,6 +266,90 @@ def whole_sweep_rank(pairs, graph_of, bases, world, rank, epochs=100, max_pairs_
     if not keys:
         return torch.zeros(0, dtype=torch.int64), torch.zeros((0, len(METRIC_NAMES)), dtype=torch.float64)
     return torch.cat(keys), torch.cat(rows)
+
+
+class _PrelaunchedGram:
+    """A GramBatch that has been LAUNCHED already on another stream (run_bases' feature prologue: a shard's raw-feature uploads and
+    Grams are queued before its graphs exist): the first launch() only waits for that launch's event, later ones (a replayed batch)
+    launch the table again.  Outputs as GramBatch's."""
+
+    def __init__(self, gx, event):
+        self.gx, self.event = gx, event
+        self.k_linear, self.k_arccos, self.norm2, self.rep, self.row_rep = gx.k_linear, gx.k_arccos, gx.norm2, gx.rep, gx.row_rep
+
+    def launch(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+        else:
+            self.gx.launch()
+
+
+class _CopiedGram:
+    """The raw-feature kernels of a prepared batch (whose job tables hold these buffers' addresses: SweepBatch.rebind_features) filled
+    by COPY from a GramBatch launched elsewhere (the feature prologue): 64 MB device to device per base and two samples instead of the
+    Gram itself on this stream.  Outputs: the batch's own buffers."""
+
+    def __init__(self, dst, src, event):
+        self.dst, self.src, self.event = dst, src, event
+        self.k_linear, self.k_arccos, self.norm2, self.rep, self.row_rep = dst.k_linear, dst.k_arccos, dst.norm2, dst.rep, dst.row_rep
+
+    def launch(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+        else:
+            self.src.launch()  # (a replay: the source table again, on this stream, then the copies)
+        for name in ("k_linear", "k_arccos", "norm2", "rep"):
+            for d, s_ in zip(getattr(self.dst, name), getattr(self.src, name)):
+                if d is not None and s_ is not None:
+                    d.copy_(s_, non_blocking=True)
+
+
+class FeaturePrologue:
+    """The raw-feature side of a shard's wide bases - the feature matrices' uploads, their Grams / arc-cosine kernels and row
+    representatives - queued on a stream of its own BEFORE the shard's graphs exist: none of it depends on a graph, and a rank's
+    share of the sweep otherwise starts with ~13 ms of host work (graph build, the first base's tables) during which the GPU has
+    nothing to do (a quarter of a rank's 51 ms at 8 ranks; scripts/dev/rank_phases.py).  items[base index] = (x {seed: device
+    tensor}, GramBatch, event) through get()."""
+
+    _POOL = None  # one helper thread per process: the uploads' host copies (150 MB per rank and pass) run beside the main thread
+
+    def __init__(self, bases, which, seeds, stream):
+        """which: the base indices, in the order they will be asked for.  The work runs on a helper thread (the copies into the page-
+        locked ring - library threads, the interpreter lock released - took 19 ms of a rank's start-up when the main thread made
+        them); get(bi) waits until base bi has been QUEUED."""
+        from concurrent.futures import ThreadPoolExecutor
+        from . import ops
+        dev = ops.require_gpu()
+        if FeaturePrologue._POOL is None:
+            FeaturePrologue._POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="wdg-prologue")
+        device_index = torch.cuda.current_device()
+
+        def one(bi):
+            torch.cuda.set_device(device_index)
+            with torch.cuda.stream(stream):
+                _name, feats, _sm = bases[bi]
+                x = {s_: ops._h2d(np.ascontiguousarray(feats[s_], np.float32), dev) for s_ in seeds}
+                gx = ops.GramBatch([x[s_] for s_ in seeds])
+                gx.launch()
+                ev = torch.cuda.Event()
+                ev.record()
+                return x, gx, ev
+
+        self.futures = {bi: FeaturePrologue._POOL.submit(one, bi) for bi in which}
+
+    def get(self, bi):
+        f = self.futures.get(bi)
+        return None if f is None else f.result()
+
+    def drain(self):
+        """(a consumer that skipped bases - an exception, a route decided otherwise - must not leave uploads running into freed state)"""
+        for f in self.futures.values():
+            try:
+                f.result()
+            except Exception:  # noqa: BLE001  (reported where the base is asked for; here only the thread is joined)
+                pass
 
 
 class _GramPair:
@@ -239,7 +372,7 @@ class SweepBatch:
     """All jobs of this rank, resident in HBM, with prebuilt job tables (one launch per stage per step)."""
 
     def __init__(self, jobs, n_feat=500, symmetric=0, gcn_hidden=64, inputs=None, share=None, feature_seed=0, tune=False,
-                 build=None, labels_only=False, graph_batch=None):
+                 build=None, labels_only=False, graph_batch=None, x_dev=None):
         """jobs: list of Job (graph + features come from the generator of synth.py) - or, with `inputs`, a list of the same
         length of (src, dst, labels, features [n, n_feat] fp32 numpy) tuples to run instead (real / fixture graphs; jobs that
         share a feature matrix must pass the same array object and carry the same `seed`).
@@ -253,6 +386,7 @@ class SweepBatch:
         replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut.
         graph_batch: the shard's ops.GraphBatch (A + I of every job, quad=True) when the caller has queued or finished the build
         already (run_bases builds the NEXT shard's graphs on a stream of their own while this shard's bases run).
+        x_dev: {seed: [n, n_feat] fp32 device tensor} - the feature matrices, uploaded already (run_bases' feature prologue).
         labels_only: aggregate the one-hot LABEL columns only (one 16-feature group: everything the six step scalars need); the
         feature matrices are uploaded for the kernel-regression metric, whose aggregated-feature kernels then come by propagation
         (prepare_full: K(A_hat X) = A_hat K(X) A_hat^T) - the reference's sweep over its wide feature bases (F up to 3 703) never
@@ -295,7 +429,7 @@ class SweepBatch:
         self.step_owner = None
         if (share is not None and self.labels_only and getattr(share, "labels_only", False) and share.agg_feat == self.agg_feat
                 and share.symmetric == symmetric and len(share.jobs) == len(self.jobs) and os.environ.get("WDG_SWEEP_STEP_TWINS", "1") != "0"):
-            self._init_step_twin(share.step_owner or share, inputs, n_feat, feature_seed, dev)
+            self._init_step_twin(share.step_owner or share, inputs, n_feat, feature_seed, dev, x_dev)
             return
         feats, self.graphs, self.dinv, self.labels, self._y = {}, [], [], [], []
         self.y_agg, seed_labels = [], {}
@@ -325,8 +459,8 @@ class SweepBatch:
             lab = labs_host[ji]
             if j.seed not in feats:
                 x_host = x_hosts[ji]
-                x = ops._h2d(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
-                             else np.ascontiguousarray(x_host, np.float32), dev)
+                x = x_dev[j.seed] if x_dev is not None else ops._h2d(
+                    synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None else np.ascontiguousarray(x_host, np.float32), dev)
                 if ride:
                     # [X | onehot(labels) | 0]: the label block is laid out on the host and uploaded like any other array (an
                     # index assignment `xa[arange, labels] = 1` on the device SYNCHRONISES the host with the stream - 3 ms a
@@ -450,7 +584,7 @@ class SweepBatch:
         if tune or os.environ.get("WDG_QUAD_TUNE", "") == "1":
             self.tune()
 
-    def _init_step_twin(self, owner, inputs, n_feat, feature_seed, dev):
+    def _init_step_twin(self, owner, inputs, n_feat, feature_seed, dev, x_dev=None):
         """the rest of __init__ for a step twin (see there): the feature matrices of this base, everything else the owner's"""
         ops = self.ops
         self.step_owner = owner
@@ -464,8 +598,8 @@ class SweepBatch:
             if j.seed in x_feat:
                 continue
             x_host = inputs[ji][3] if inputs is not None else None
-            x_feat[j.seed] = ops._h2d(synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None
-                                      else np.ascontiguousarray(x_host, np.float32), dev)
+            x_feat[j.seed] = x_dev[j.seed] if x_dev is not None else ops._h2d(
+                synth.features(j.n_nodes, n_feat, j.seed + feature_seed) if x_host is None else np.ascontiguousarray(x_host, np.float32), dev)
             if inputs is not None and not np.array_equal(np.asarray(inputs[ji][2]), np.asarray(owner.labels_host[ji])):
                 raise ValueError("SweepBatch(share=...): the sharing batch's labels differ from the owner's")
         self.x = x_feat
@@ -734,7 +868,7 @@ class SweepBatch:
         return torch.stack([edge, node, cls, adj, li, soft_las], 1)
 
     # -- the remaining three scalars: generalized edge homophily + the kernel-regression p-values ------
-    def prepare_full(self, epochs=100, sample_max=500, seed_of=None, sampler=None, base_seed=0, sets=None):
+    def prepare_full(self, epochs=100, sample_max=500, seed_of=None, sampler=None, base_seed=0, sets=None, gx=None):
         """Set up the batched kernel-regression metric for every job: the Gram / arc-cosine kernels of the aggregated features
         (per job) and of the raw features (per feature matrix) - all nodes, once -, and, per job x classifier (kernel_reg0 /
         kernel_reg1) x epoch, the train / validation node sets; both kernels of an epoch share its node sets.
@@ -784,7 +918,8 @@ class SweepBatch:
         # graph: slower, same rows; round 5 raised here and a single hub-heavy graph aborted the whole sweep - ADVICE r05)
         x_slot = {s: J + i for i, s in enumerate(seeds)}
         if self.gram_route == "propagate":
-            gx = ops.GramBatch([self.x[s] for s in seeds])
+            # (gx: (GramBatch over self.x in seed order, event) launched already - run_bases' feature prologue)
+            gx = ops.GramBatch([self.x[s] for s in seeds]) if gx is None else _PrelaunchedGram(*gx)
             sym = getattr(self, "symmetric", 0)
             gy = ops.PropagatedGram([(g, d, d if sym else None, gx.k_linear[x_slot[j.seed] - J])
                                      for j, g, d in zip(self.jobs, self.graphs, self.dinv)])
@@ -898,7 +1033,7 @@ class SweepBatch:
         self.kr_canonical = ((u_job * 2 + u_clf) * epochs + u_epoch) * 2 + (np.arange(u_job.shape[0]) >= J * 2 * epochs)
         self._kr_index_dev = None
 
-    def rebind_features(self, feats_of_seed, n_feat, base_seed):
+    def rebind_features(self, feats_of_seed, n_feat, base_seed, pre=None):
         """The NEXT FEATURE BASE on a prepared labels-only batch (run_bases: synthetic_plot.py:64-65 runs six feature bases over
         the same adjacencies): new raw feature matrices and new node-set keys, every job table kept.  The step's tables never
         held a feature address (labels_only); the raw features' kernels are written into the SAME buffers (GramBatch(out=...)),
@@ -911,11 +1046,17 @@ class SweepBatch:
             raise ValueError("rebind_features: a prepared labels-only batch on the propagated route with device-drawn sets is expected")
         dev = self.kr.correct.device
         seeds = list(self.x)
-        self.x = {s_: ops._h2d(np.ascontiguousarray(feats_of_seed[s_], np.float32), dev) for s_ in seeds}
         self.n_feat = n_feat
         self._y_lazy = None
-        gx = ops.GramBatch([self.x[s_] for s_ in seeds], out=self.gram.feats_part)
-        self.gram.feats_part = gx  # (same output tensors: the pair's k_linear / k_arccos / norm2 lists stay as they are)
+        if pre is not None:  # (x {seed: device tensor}, GramBatch, event): uploaded and launched by the feature prologue - copied in
+            self.x = {s_: pre[0][s_] for s_ in seeds}
+            old = self.gram.feats_part
+            self.gram.feats_part = _CopiedGram(old.dst if isinstance(old, _CopiedGram) else old, pre[1], pre[2])
+        else:
+            self.x = {s_: ops._h2d(np.ascontiguousarray(feats_of_seed[s_], np.float32), dev) for s_ in seeds}
+            old = self.gram.feats_part
+            gx = ops.GramBatch([self.x[s_] for s_ in seeds], out=old.dst if isinstance(old, _CopiedGram) else old)
+            self.gram.feats_part = gx  # (same output tensors: the pair's k_linear / k_arccos / norm2 lists stay as they are)
         mode, sizes_rep, label_crc = self._kr_rebind
         rep = self.kr_rep
 
@@ -1333,16 +1474,34 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
             return ops.GraphBatch([(src, dst, j.n_nodes) for j, (src, dst, _lab) in zip(jobs_, gi_)], ops.COO_ADD_SELF_LOOPS,
                                   quad=True, defer=True)
 
+    # The FEATURE PROLOGUE (round 6, WDG_SWEEP_PROLOGUE=1; OFF by default): the wide bases' feature uploads, raw-feature Grams and row
+    # representatives depend on no graph - queued, by a helper thread and on a stream of their own, before the shard's graph build is
+    # waited for, they give the GPU work during the ~13 ms in which the host builds a rank's graphs and its first base's tables.
+    # Measured at 8 ranks (scripts/dev/rank_phases.py): the device span of a rank's pass shrinks from 37.4 to 33.2 ms, but the first
+    # base's launches are queued 4 ms later (the helper's table and upload work competes with the main thread for the interpreter)
+    # - 51.0 ms per pass either way; made by the main thread itself the prologue costs 19 ms of host copies up front (65 ms).  The
+    # start-up is host-bound table building, not missing device work: kept as a switch, rows identical (tests/test_gpu_sweep.py).
+    prologue_on = os.environ.get("WDG_SWEEP_PROLOGUE", "0") not in ("0", "")
+    pro_stream = _side_stream(4) if prologue_on else None
+    widths = [next(iter(feats.values())).shape[1] if feats else 0 for _name, feats, _sm in bases]
     n = 0
     for si, (jobs, graph_inputs) in enumerate(shards):
         first = first_lo = None
         gb = None
         if prefetch:
             gb = queued.pop(si) if si in queued else queue_build(si)
-            if gb is not None:
-                with torch.cuda.stream(build_stream):
-                    gb.finish()
-        widths = [next(iter(feats.values())).shape[1] if feats else 0 for _name, feats, _sm in bases]
+        pro = None
+        if prologue_on and jobs:
+            lo_guess = [propagates(w, jobs) for w in widths]  # (what `lo` below becomes when every graph has its SELL-16 copy)
+            guess = (_visit_order([(lo_guess[bi], bases[bi][2]) if lo_guess[bi] else ("own", bi) for bi in range(len(bases))])
+                     if rebind_ok else list(range(len(bases))))
+            wide = [bi for bi in guess if lo_guess[bi]]
+            if wide:
+                pro_stream.wait_stream(torch.cuda.current_stream())
+                pro = FeaturePrologue(bases, wide, sorted({j.seed for j in jobs}), pro_stream)
+        if prefetch and gb is not None:
+            with torch.cuda.stream(build_stream):
+                gb.finish()
         # (decided AFTER the graphs are built when they are built ahead: a graph without a SELL-16 copy rules the propagated route out
         # for the whole shard - its bases then aggregate at full width and take the dense Gram, as round 4 did)
         quad_ok = gb is None or all(g.quad for g in gb.graphs)
@@ -1360,17 +1519,19 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
                 width = widths[bi]
                 key = (sample_max, stream.cuda_stream)
                 sb = free.pop(key, None) if (rebind_ok and lo[bi] and jobs) else None
+                pre = pro.get(bi) if (pro is not None and lo[bi]) else None  # (x, GramBatch, event) of the prologue
                 if sb is not None:
-                    sb.rebind_features(feats, width, first_seed + 1000 * bi)
+                    sb.rebind_features(feats, width, first_seed + 1000 * bi, pre=pre)
                 else:
                     inputs = [(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, graph_inputs)]
                     sb = SweepBatch(jobs, n_feat=width, symmetric=symmetric, gcn_hidden=0, inputs=inputs,
                                     share=(first_lo or first) if lo[bi] else first, labels_only=lo[bi],
-                                    graph_batch=gb if first is None else None)
+                                    graph_batch=gb if first is None else None, x_dev=pre[0] if pre else None)
                     if sb.jobs:
                         # (the node sets are keyed by the base and the job's identity, not by where the job sits: a job draws the
                         # same sets in whichever shard / on whichever rank it runs - the N-rank sweep computes the one-GPU sweep's rows)
-                        sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + 1000 * bi)
+                        sb.prepare_full(epochs=epochs, sample_max=sample_max, base_seed=first_seed + 1000 * bi,
+                                        gx=(pre[1], pre[2]) if pre else None)
                     sb.step()
                 if sb.jobs:
                     sb.launch_full()
@@ -1388,6 +1549,8 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
                         and getattr(done[3], "gram_route", None) == "propagate"):
                     free[(done[3].kr_sample_max, done[4].cuda_stream)] = done[3]
                 yield done[:3]
+        if pro is not None:
+            pro.drain()
     while in_flight:
         yield fetch()[:3]
 
