@@ -650,7 +650,9 @@ def measure_projection(args, dev, full_ms):
             secs = []
             for r in range(w):  # EVERY rank's share (round 4 timed one rank at W = 2, 4: a single sample, visibly jitter-prone)
                 best = None
-                for _rep in range(2):  # (the faster of two passes: a rank of a real node has run its share's shapes in its warm-up pass,
+                for _rep in range(3):  # (the fastest of three passes: a rank of a real node has run its share's shapes in its warm-up
+                    #                     passes - measure_whole makes two before its clock - while here every rank brings new shapes to the
+                    #                     allocator (round 6: the first rank timed was 5 ms slower than the seven after it with two passes);
                     #                     and one stall of this shared host's enqueueing thread - 0.14 s seen - is not a rank's time)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()

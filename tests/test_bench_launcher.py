@@ -83,3 +83,54 @@ def test_single_gpu_and_torchrun_paths_do_not_relaunch():
     """--gpus 1, or WORLD_SIZE already set by torch.distributed.run: bench.py is the worker itself"""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"WORLD_SIZE" not in os.environ and args.gpus > 1' in src
+
+
+def test_eight_worker_dry_run_of_the_strong_scaled_sweep(tmp_path):
+    """`python bench.py --gpus 8` with stand-in workers (no GPU here): the launcher's eight processes run what bench.py's
+    measure_whole runs around the device work - rank 0's job table broadcast (sweep.broadcast_jobs), the sample-aware partition
+    (sweep.pairs_of_rank), one exchange of keyed rows (sweep.exchange_rows), MAX over the ranks' clocks - over gloo on 127.0.0.1, while
+    EVERY worker burns a host core for its share's duration (eight enqueueing interpreters at once, as on an 8-GPU node).  Asserts
+    the assembled table (every key once, from the rank that owns it), that no rank's host section took more than 3 x the quietest
+    rank's (host contention in the enqueue path would show here), and that only rank 0's line reaches stdout."""
+    res = _run(tmp_path, """
+        import json, os, sys, time
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        from wdg_amd import sweep, synth
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cpu")
+        levels = [h for h in synth.H_LEVELS_30 if h not in (0.05, 0.1)]
+        pairs = sweep.make_jobs(levels, range(10), k=10, n_nodes=2000) if rank == 0 else []
+        pairs = sweep.broadcast_jobs(pairs, dev)
+        mine = sweep.pairs_of_rank(pairs, world, rank)
+        index = {j: i for i, j in enumerate(pairs)}
+        n_bases = 6
+        dist.barrier()
+        t0 = time.perf_counter()
+        # the host section of a rank's pass: interpreter-bound table building - here a pure-Python loop of the same order of work
+        # (~50 ms), on every rank at once
+        acc, t_cpu = 0, time.process_time()
+        while time.process_time() - t_cpu < 0.05:
+            acc += sum(i * i for i in range(2000))
+        host_s = time.perf_counter() - t0
+        keys = torch.tensor([index[j] * n_bases + b for j in mine for b in range(n_bases)], dtype=torch.int64)
+        rows = torch.stack([keys.double() * 9 + c for c in range(9)], 1) if len(keys) else torch.zeros((0, 9), dtype=torch.float64)
+        table = sweep.exchange_rows(keys, rows, len(pairs) * n_bases, dev)
+        t = torch.tensor([time.perf_counter() - t0, host_s], dtype=torch.float64)
+        both = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = bool(torch.equal(table, torch.arange(len(pairs) * n_bases, dtype=torch.float64)[:, None] * 9 + torch.arange(9, dtype=torch.float64)[None, :]))
+        dist.barrier()
+        dist.destroy_process_group()
+        print(json.dumps({"metric": "dry run", "rank": rank, "rows_ok": ok, "adjacencies": len(mine), "seconds": float(t[0]),
+                          "host_s": [float(b[1]) for b in both]}))
+        """ % ROOT, gpus=8)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["rank"] == 0 and rec["rows_ok"] and 34 <= rec["adjacencies"] <= 36
+    host = rec["host_s"]
+    assert len(host) == 8 and max(host) <= 3.0 * min(host) + 0.05, host  # (8 vCPUs here: every worker has a core; a serialised section would show 8 x)

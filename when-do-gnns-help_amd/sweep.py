@@ -103,6 +103,10 @@ def shard_pairs(pairs, world_size, rank):
     n, w = len(order), int(world_size)
     if n == 0 or w <= 1:
         return [pairs[i] for i in order] if rank == 0 else []
+    memo_key = (tuple(pairs), w)  # (a pure function of the list: every pass of a process asks again - 4 ms of search each time)
+    if memo_key in _PAIRS_MEMO:
+        cuts = _PAIRS_MEMO[memo_key]
+        return [pairs[i] for i in order[cuts[rank]:cuts[rank + 1]]]
     cost = np.array([PAIR_COST_US + PAIR_COST_PER_ENTRY_US * pairs[i].nnz for i in order])
     seed = np.array([pairs[i].seed for i in order])
     cum = np.concatenate([[0.0], np.cumsum(cost)])
@@ -125,7 +129,13 @@ def shard_pairs(pairs, world_size, rank):
                 cuts[c], moved = best, True
         if not moved:
             break
+    if len(_PAIRS_MEMO) >= 16:
+        _PAIRS_MEMO.clear()
+    _PAIRS_MEMO[memo_key] = cuts
     return [pairs[i] for i in order[cuts[rank]:cuts[rank + 1]]]
+
+
+_PAIRS_MEMO = {}
 
 
 def _shard_owner(jobs, world_size, slack):
@@ -935,13 +945,20 @@ class SweepBatch:
             self.gram = ops.GramBatch([ys[i] for i in range(J)] + [self.x[s] for s in seeds])
         self.ge = ops.EdgeGramBatch([(g, self.gram.k_linear[x_slot[j.seed]], self.gram.norm2[x_slot[j.seed]])
                                      for j, g in zip(self.jobs, self.graphs)])
-        size_of = {}  # (the jobs of a sweep share a handful of label vectors: the per-class sizes once per distinct one)
-        sizes = []
+        # (the jobs of a sweep share a handful of label vectors - a sample's levels carry equal labels in separate arrays: a job's
+        # vector is first compared with the distinct ones met so far (np.array_equal: 2 us) and its bytes taken only for a new one -
+        # 35 x 2 `tobytes` of 16 KB were 1 ms of a rank's start-up)
+        distinct = []  # (array as int64, its bytes, per-class sizes)
+        which = []
         for lab in self.labels_host:
-            key = np.asarray(lab).tobytes()
-            if key not in size_of:
-                size_of[key] = ops.kr_split_sizes(lab, sample_max)
-            sizes.append(size_of[key])
+            la = np.asarray(lab)
+            k = next((i for i, (a, _b, _s) in enumerate(distinct) if a.shape == la.shape and np.array_equal(a, la)), -1)
+            if k < 0:
+                a64 = np.ascontiguousarray(la, dtype=np.int64)
+                distinct.append((a64, a64.tobytes(), ops.kr_split_sizes(la, sample_max)))
+                k = len(distinct) - 1
+            which.append(k)
+        sizes = [distinct[k][2] for k in which]
         sets = sets or os.environ.get("WDG_SWEEP_KR_SETS", "sample")
         if sets not in ("sample", "job"):
             raise ValueError(f"prepare_full: sets={sets!r} (sample | job)")
@@ -952,13 +969,14 @@ class SweepBatch:
         if sets == "sample":
             import zlib
             index, group, rep, label_crc = {}, [], [], []
-            for ji, (j, lab) in enumerate(zip(self.jobs, self.labels_host)):
-                # (one dtype before the bytes are hashed: the same job given int32 or int64 labels draws the same sets - ADVICE r05)
-                key = (j.seed, j.n_nodes, np.ascontiguousarray(lab, dtype=np.int64).tobytes())
+            for ji, j in enumerate(self.jobs):
+                # (the label vector enters by VALUE - its int64 bytes' CRC -: the same job given int32 or int64 labels, or equal labels in
+                # another array, draws the same sets - ADVICE r05)
+                key = (j.seed, j.n_nodes, which[ji])
                 if key not in index:
                     index[key] = len(rep)
                     rep.append(ji)
-                    label_crc.append(zlib.crc32(key[2]))
+                    label_crc.append(zlib.crc32(distinct[which[ji]][1]))
                 group.append(index[key])
             group, rep = np.asarray(group, np.int64), np.asarray(rep, np.int64)
         else:
