@@ -46,12 +46,12 @@ for a, b, _ in part:
         end = b
 by, lib = {}, 0
 for a, b, n in part:
-    k = n.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:40]
+    k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0][:40]
     by[k] = by.get(k, 0) + (b - a)
     if "at::native" in n or "rocclr" in n:
         lib += b - a
 tot = sum(b - a for a, b, _ in part)
-print(f"kernels of the timed pass: {len(part)}; span {1e-6 * (t1 - t0):.1f} ms; some kernel running {1e-6 * busy:.1f} ms ({100 * busy / (t1 - t0):.1f} %); sum of kernel durations {1e-6 * tot:.1f} ms (streams overlap); library kernels (torch + rocclr copies) {1e-6 * lib:.1f} ms = {100 * lib / tot:.1f} % of that sum")
+print(f"kernels after the largest gap of the trace (bench.py's whole-sweep passes: warm-up piece, first pass, timed pass): {len(part)}; span {1e-6 * (t1 - t0):.1f} ms; some kernel running {1e-6 * busy:.1f} ms ({100 * busy / (t1 - t0):.1f} %); sum of kernel durations {1e-6 * tot:.1f} ms (streams overlap); library kernels (torch + rocclr copies) {1e-6 * lib:.1f} ms = {100 * lib / tot:.1f} % of that sum")
 for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:14]:
     print(f"  {k:42s} {1e-6 * v:8.1f} ms")
 PY

@@ -1508,15 +1508,22 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
         gb = None
         if prefetch:
             gb = queued.pop(si) if si in queued else queue_build(si)
-        pro = None
-        if prologue_on and jobs:
+        pro, early = None, None
+        if jobs and (prologue_on or (prefetch and gb is not None)):
             lo_guess = [propagates(w, jobs) for w in widths]  # (what `lo` below becomes when every graph has its SELL-16 copy)
             guess = (_visit_order([(lo_guess[bi], bases[bi][2]) if lo_guess[bi] else ("own", bi) for bi in range(len(bases))])
                      if rebind_ok else list(range(len(bases))))
             wide = [bi for bi in guess if lo_guess[bi]]
-            if wide:
+            if prologue_on and wide:
                 pro_stream.wait_stream(torch.cuda.current_stream())
                 pro = FeaturePrologue(bases, wide, sorted({j.seed for j in jobs}), pro_stream)
+            elif lo_guess[guess[0]]:
+                # the FIRST base's feature matrices go into the upload ring while the GPU builds the shard's graphs: the copies (1.2 ms
+                # of library threads for cora's two 11-MB matrices) otherwise sit between the build's read-back and the first launch
+                from . import ops
+                with torch.cuda.stream(streams[n % depth]):
+                    early = (guess[0], {s_: ops._h2d(np.ascontiguousarray(bases[guess[0]][1][s_], np.float32), ops.require_gpu())
+                                        for s_ in sorted({j.seed for j in jobs})})
         if prefetch and gb is not None:
             with torch.cuda.stream(build_stream):
                 gb.finish()
@@ -1538,13 +1545,14 @@ def run_bases(shards, bases, epochs=100, symmetric=0, depth=2, first_seed=0, sta
                 key = (sample_max, stream.cuda_stream)
                 sb = free.pop(key, None) if (rebind_ok and lo[bi] and jobs) else None
                 pre = pro.get(bi) if (pro is not None and lo[bi]) else None  # (x, GramBatch, event) of the prologue
+                x_early = early[1] if (early is not None and early[0] == bi and lo[bi] and first is None) else None  # (uploaded on this stream)
                 if sb is not None:
                     sb.rebind_features(feats, width, first_seed + 1000 * bi, pre=pre)
                 else:
                     inputs = [(src, dst, lab, feats[j.seed]) for j, (src, dst, lab) in zip(jobs, graph_inputs)]
                     sb = SweepBatch(jobs, n_feat=width, symmetric=symmetric, gcn_hidden=0, inputs=inputs,
                                     share=(first_lo or first) if lo[bi] else first, labels_only=lo[bi],
-                                    graph_batch=gb if first is None else None, x_dev=pre[0] if pre else None)
+                                    graph_batch=gb if first is None else None, x_dev=pre[0] if pre else x_early)
                     if sb.jobs:
                         # (the node sets are keyed by the base and the job's identity, not by where the job sits: a job draws the
                         # same sets in whichever shard / on whichever rank it runs - the N-rank sweep computes the one-GPU sweep's rows)
