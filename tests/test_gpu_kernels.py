@@ -1869,3 +1869,53 @@ def test_deflated_regression_equals_the_pseudo_inverse_on_duplicate_and_zero_row
         pred = k_vt @ (np.linalg.pinv(k_tt, rcond=1e-8) @ eye[lab[tr]])  # (the exact null directions cut - and the arc-cosine kernel's 1.6e-9 rows of all-zero features, below what an fp32 SVD resolves)
         want = int((pred.argmax(1) == lab[va]).sum())
         assert abs(int(got) - want) <= 2, (got, want)  # (fp32 factorisation against the fp64 pseudo-inverse: a near-tie or two of 200)
+
+
+def test_deflating_entry_without_representatives_equals_the_plain_solver():
+    """wdg_kernel_regress_deflated_batched_f32 on a table in which only SOME problems carry row representatives: the others go through
+    the pre-pass with every node its own representative and must give the plain entry point's hit counts bit for bit (a regular
+    kernel: nothing to deflate, nothing below the block's resolution); empty validation sets and one-row train sets included."""
+    from wdg_amd import ops
+    rng = np.random.default_rng(21)
+    n, f, c = 500, 400, 5
+    lab = rng.integers(0, c, n)
+    x = (rng.standard_normal((n, f)) + 2.0 * (rng.random((c, f)) < 0.1)[lab]).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    gb = ops.GramBatch([xd])
+    gb.launch()
+    assert int((gb.rep[0].cpu() != torch.arange(n)).sum()) == 0  # no duplicate rows
+    labd = torch.from_numpy(lab).cuda().to(torch.int32)
+    plain, mixed = [], []
+    for i in range(12):
+        perm = rng.permutation(n)
+        nt = [250, 1, 320, 33][i % 4]
+        tr = torch.from_numpy(np.sort(perm[:nt])).cuda().to(torch.int32)
+        va = torch.from_numpy(np.sort(perm[320:320 + (0 if i == 5 else 150)])).cuda().to(torch.int32)
+        k = gb.k_linear[0] if i % 2 else gb.k_arccos[0]
+        plain.append((k, tr, va, labd))
+        mixed.append((k, tr, va, labd, gb.rep[0] if i % 3 == 0 else None))
+    a, b = ops.KrBatch(plain, c), ops.KrBatch(mixed, c)
+    assert a.ws is None and b.ws is not None
+    a.launch()
+    b.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(a.correct[:12], b.correct[:12]) and not bool(b.deflated().any()) and torch.equal(a.ridged(), b.ridged())
+
+
+def test_sweep_pack_gathers_a_shards_results_into_one_vector():
+    """wdg_sweep_pack_f64 against the torch expressions it replaced (SweepBatch.full_metrics, round 5)"""
+    from wdg_amd import ops
+    rng = np.random.default_rng(8)
+    n_s, n_ge, n_kr = 47 * 6, 47, 3001
+    scal = torch.from_numpy(rng.standard_normal(n_s).astype(np.float32)).cuda()
+    ge = torch.from_numpy(rng.standard_normal(n_ge)).cuda()
+    correct = torch.from_numpy(rng.integers(0, 200, n_kr).astype(np.int32)).cuda()
+    correct[17] = -1
+    flags = torch.from_numpy(rng.integers(0, 4, n_kr).astype(np.int32)).cuda()
+    n_val = torch.from_numpy(rng.integers(100, 201, n_kr).astype(np.float32)).cuda()
+    out = torch.empty(n_s + n_ge + n_kr + 3, dtype=torch.float64, device="cuda")
+    ops.check(ops.lib.wdg_sweep_pack_f64(scal.data_ptr(), n_s, ge.data_ptr(), n_ge, correct.data_ptr(), flags.data_ptr(), n_val.data_ptr(),
+                                         n_kr, out.data_ptr(), ops.stream_handle()), "wdg_sweep_pack_f64")
+    want = torch.cat([scal.double(), ge, (correct.float() / n_val).double(),
+                      torch.tensor([float(((flags >> 1) & 1).sum()), float((flags & 1).sum()), 1.0], dtype=torch.float64, device="cuda")])
+    assert torch.equal(out, want)
