@@ -1658,6 +1658,21 @@ __global__ __launch_bounds__(MODE == Q_MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS)
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
     const int n_local = subs * n_groups;
     bool first_phase = true;
+    if (subs < 0) {
+        // GLOBAL deal (single graphs with many feature groups, round 6): -subs segments in all, the (segment, feature group) pairs
+        // dealt round-robin over ALL workgroups.  A graph of 131 - 180 feature groups has enough parallelism in its groups: with the
+        // per-XCD deal (8 x subs segments) every group's slab was staged eight times and more, for a few super-units of work each.
+        const int n_segments = -subs, n_units = inline_job.q_n_entries / Q_SU;
+        if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        for (int w = blockIdx.x; w < n_segments * n_groups; w += gridDim.x) {
+            const int seg = w / n_groups, f0 = (w % n_groups) * (MODE == Q_HALF ? 8 : 16);
+            if (MODE == Q_MULTI) q_phase_multi<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
+            else q_phase_single<TIN, HAS_VAL, MODE == Q_HALF>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
+            first_phase = false;
+        }
+        if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
     Q_STAMP(0);
     // (wg_clock: optional [2 x workgroups] device buffer - the workgroup's start and end on the 100 MHz clock; the sweep driver
     // balances the XCDs' segments with it, ops.SpmmBatch.balance)
@@ -1724,7 +1739,7 @@ int q_launch(const wdg_spmm_job *jobs, const wdg_spmm_job &inl, const wdg_spmm_i
     }
     const int cus = std::max(wdg_device_cus(), 8);
     const int wgs_per_xcd = std::max(1, std::min(cus / kXcds, subs * n_groups));
-    const dim3 grid(static_cast<unsigned>(wgs_per_xcd * kXcds));
+    const dim3 grid(static_cast<unsigned>(subs < 0 ? std::min(cus, -subs * n_groups) : wgs_per_xcd * kXcds));
 #define WDG_Q_LAUNCH(V, M)                                                                                             \
     hipLaunchKernelGGL((spmm_quad_kernel<TIN, V, M>), grid, dim3(M == Q_MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS), lds, st, jobs, inl, items, seg_ptr, subs, \
                        n_groups, y_vec_all ? 1 : 0, wg_clock)
@@ -1784,6 +1799,17 @@ int quad_single(const wdg_spmm_job &j, hipStream_t st) {
     if (j.q_n_blocks > 1) {  // a wave keeps <= Q_MAXU slices across the column blocks
         const int need = static_cast<int>(ceil_div(n_units, static_cast<int64_t>(Q_MAXU / Q_SU) * Q_MULTI_WAVES * kXcds));
         subs = std::max(subs, need);
+    }
+    // many feature groups: the global deal (see the kernel) with as few segments as fill the chip about twice
+    // (WDG_QUAD_SINGLE_SEGMENTS: experiments; 0 = the per-XCD deal of rounds 2 - 5)
+    {
+        int glob = n_groups >= 64 ? static_cast<int>(ceil_div(2 * wdg_device_cus(), n_groups)) : 0;
+        if (const char *e = getenv("WDG_QUAD_SINGLE_SEGMENTS")) glob = atoi(e);
+        if (glob > 0) {
+            if (j.q_n_blocks > 1) glob = std::max(glob, static_cast<int>(ceil_div(n_units, static_cast<int64_t>(Q_MAXU / Q_SU) * Q_MULTI_WAVES)));
+            glob = std::min(glob, std::max(1, n_units));
+            subs = -glob;
+        }
     }
     // 16-byte stores and 32-bit byte offsets into Y and into the index arrays (what the fast loop addresses with)
     // (experimental builds with a deeper request pipeline - WDG_Q_DEPTH > 1 - fault in the fast loop on this entry's single-job
