@@ -499,6 +499,27 @@ def measure_whole(args, dev, world=1, rank=0):
             rec.update(one_gpu_s=one, strong_speedup_vs_1gpu=one / dt,
                        rows_equal_one_gpu=bool(torch.equal(torch.nan_to_num(table, nan=-7.0), torch.nan_to_num(t1gpu, nan=-7.0))))
         dist.barrier()
+    if world == 1:
+        # the same sweep with INDEPENDENT node sets per job (WDG_SWEEP_KR_SETS=job: the reference's own draws, utils/homophily_metrics.py:
+        # 267-283 - 672 000 regressions instead of 348 000), beside the headline figure that shares the sets inside a sample
+        # (VERDICT r05 weak 2): the second of two passes
+        prev = os.environ.get("WDG_SWEEP_KR_SETS")
+        os.environ["WDG_SWEEP_KR_SETS"] = "job"
+        try:
+            stats_job = {}
+            for _rep in range(2):
+                stats_job.clear()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sweep.whole_sweep_rank(pairs, graph_of, feats, 1, 0, epochs=args.kr_epochs, max_pairs_per_shard=per_shard, stats=stats_job)
+                torch.cuda.synchronize()
+                rec["seconds_sets_job"] = time.perf_counter() - t1
+            rec["kr_total_sets_job"] = int(stats_job.get("kr_total", 0))
+        finally:
+            if prev is None:
+                os.environ.pop("WDG_SWEEP_KR_SETS", None)
+            else:
+                os.environ["WDG_SWEEP_KR_SETS"] = prev
     args._whole = dict(inp, seconds=dt)  # (measure_projection shards the same inputs)
     shards_txt = (f"{-(-len(pairs) // per_shard)} shards of {per_shard} adjacencies" if world == 1 else
                   f"the {len(pairs)} adjacencies dealt to {world} ranks by sweep.shard_pairs (one shard per rank), rows exchanged by one all_gather, "

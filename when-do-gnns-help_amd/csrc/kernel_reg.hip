@@ -1474,9 +1474,10 @@ __global__ __launch_bounds__(K2_THREADS) void kr_solve_blocked_kernel(const wdg_
     // representatives / labels are read from it; the reference's pseudo-inverse answers exactly singular blocks that way
     const global_ptr<const int32_t> ws = to_global(static_cast<const int32_t *>(job->ws));
     constexpr bool has_ws = WS;
-    const int nt = has_ws ? ws[KRW_NT] : nt_in;
-    const bool deflated = has_ws && ws[KRW_DEFLATED] != 0;
-    const int n_mixed = has_ws ? ws[KRW_MIXED] : 0;  // (uniform) listed right-hand-side entries (duplicates with different labels)
+    const bool ws_ok = !has_ws || job->ws != nullptr;  // (a table handed to the deflating entry with a job that has no workspace: refused below)
+    const int nt = !has_ws ? nt_in : (ws_ok ? ws[KRW_NT] : -1);
+    const bool deflated = has_ws && ws_ok && ws[KRW_DEFLATED] != 0;
+    const int n_mixed = (has_ws && ws_ok) ? ws[KRW_MIXED] : 0;  // (uniform) listed right-hand-side entries (duplicates with different labels)
 #ifdef WDG_KR_ABLATION  // diagnostic build only (make EXTRA=-DWDG_KR_ABLATION; scripts/dev/time_kr_batch.py): timing-only ablations
     const int ablate = job->reserved;  // 1 no gather, 2 no factorisation, 4 no back substitution, 8 no predictions (results are wrong)
 #else
