@@ -283,14 +283,17 @@ class _PrelaunchedGram:
     Grams are queued before its graphs exist): the first launch() only waits for that launch's event, later ones (a replayed batch)
     launch the table again.  Outputs as GramBatch's."""
 
-    def __init__(self, gx, event):
-        self.gx, self.event = gx, event
+    def __init__(self, gx, event=None):
+        """event: recorded behind the launch on the stream it ran on; None: it ran on the stream the batch launches on"""
+        self.gx, self.event, self.pending = gx, event, True
         self.k_linear, self.k_arccos, self.norm2, self.rep, self.row_rep = gx.k_linear, gx.k_arccos, gx.norm2, gx.rep, gx.row_rep
 
     def launch(self):
-        if self.event is not None:
-            torch.cuda.current_stream().wait_event(self.event)
-            self.event = None
+        if self.pending:
+            self.pending = False
+            if self.event is not None:
+                torch.cuda.current_stream().wait_event(self.event)
+                self.event = None
         else:
             self.gx.launch()
 
@@ -929,7 +932,16 @@ class SweepBatch:
         x_slot = {s: J + i for i, s in enumerate(seeds)}
         if self.gram_route == "propagate":
             # (gx: (GramBatch over self.x in seed order, event) launched already - run_bases' feature prologue)
-            gx = ops.GramBatch([self.x[s] for s in seeds]) if gx is None else _PrelaunchedGram(*gx)
+            if gx is None:
+                # the raw features' kernels are launched HERE, while the host goes on building the propagation's and the regressions'
+                # tables: they depend on nothing else of the batch (1.7 ms of device work for cora's two matrices that a rank's
+                # start-up otherwise leaves the GPU waiting for)
+                gx = ops.GramBatch([self.x[s] for s in seeds])
+                if os.environ.get("WDG_SWEEP_EARLY_GRAM", "1") != "0":
+                    gx.launch()
+                    gx = _PrelaunchedGram(gx)
+            else:
+                gx = _PrelaunchedGram(*gx)
             sym = getattr(self, "symmetric", 0)
             gy = ops.PropagatedGram([(g, d, d if sym else None, gx.k_linear[x_slot[j.seed] - J])
                                      for j, g, d in zip(self.jobs, self.graphs, self.dinv)])
