@@ -198,7 +198,8 @@ typedef struct wdg_spmm_job {
     const int32_t *band_perm; /* [wdg_csr_band_perm_len(n_rows)] rows by length, longest first; the first band_n_hub are the hub rows */
     const int32_t *band_cuts; /* [24] cost cuts of the hub rows [0..8] and of the other rows [9..17]; [18], [19] = rows of more than
                                  2048 / 128 entries (the narrow kernel's row classes); the rest 0                                  */
-    int32_t band_n_hub;       /* hub rows = rows of more than 256 entries (each is swept by a team of waves), a prefix of band_perm:
+    int32_t band_n_hub;       /* hub rows = rows of more than the plan's hub_len entries (256 unless wdg_csr_band_plan_hub named another;
+                                 each is swept by a team of waves), a prefix of band_perm:
                                  the count, or WDG_BAND_HUB_ON_DEVICE = "read band_cuts[8]" for callers that never fetched it      */
     int32_t band_reserved;    /* 0 */
     int64_t y_group_stride;   /* 0: Y is row-major, element (row, f) at Y[row ldy + f].  > 0 (the quad-row kernel only: jobs with a
@@ -297,7 +298,7 @@ int wdg_csr_to_sell16_fill_batched(const wdg_sell16_job *jobs_dev, int32_t n_job
  * wdg_spmm_csr_f32 run that kernel for fp32 X of >= 16 features when the job carries the plan and no SELL-16 copy in split
  * form): band_perm = the rows by length, longest first (<= 16 384 rows: ties by row index; more: rows of equal length in no
  * particular order - the order only schedules, every row's sum has a fixed order), wdg_csr_band_perm_len(N) ints;
- * band_cuts = 24 ints (layout: wdg_spmm_job.band_cuts); the number of hub rows - rows with more than 256 entries, a prefix of
+ * band_cuts = 24 ints (layout: wdg_spmm_job.band_cuts); the number of hub rows - rows with more than 256 entries (wdg_csr_band_plan_hub: hub_len entries), a prefix of
  * band_perm - is band_cuts[8] and STAYS ON THE DEVICE (round 5: the call used to read it back and synchronise the stream; now it
  * only enqueues, like every other entry point): a job passes band_n_hub = WDG_BAND_HUB_ON_DEVICE and the kernel reads the word,
  * or the caller copies band_cuts[8] back whenever it wants the number.  One-time per graph; nothing depends on the feature width.
@@ -308,6 +309,14 @@ size_t wdg_csr_band_plan_workspace_bytes(int32_t N);
 int32_t wdg_csr_band_perm_len(int32_t N);
 int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, void *workspace,
                       size_t workspace_bytes, wdg_stream_t stream);
+/* The same plan with the HUB THRESHOLD named by the caller (0: the default, 256): rows longer than hub_len are swept by the four waves of
+ * a workgroup, the others by one wave each.  A launch ends with its longest single-wave row, so a graph of short rows with a few
+ * long ones is better off with a lower threshold (Cora, mean 4.9 entries per row, longest 169: 22 -> 17.5 us at 32); the Python side
+ * passes 6 x the mean row length clamped to 32 .. 256.  Any threshold computes every row's sum in a fixed order (a hub row: its four
+ * pieces in piece order).
+ * replaces: the same `torch.spmm(adj, features)` call sites as wdg_csr_band_plan (utils/homophily_metrics.py:199-200,234-235). */
+int wdg_csr_band_plan_hub(const int32_t *rowptr, int32_t N, int32_t hub_len, int32_t *band_perm, int32_t *band_cuts, void *workspace,
+                          size_t workspace_bytes, wdg_stream_t stream);
 
 /*
  * The aggregation for ONE graph with at most 8 features (csrc/spmm_narrow.hip; config C5: twitch-gamers scale with 7 bf16

@@ -160,7 +160,8 @@ def test_quad_row_fast_loop_keeps_its_memory_operations_to_itself(tmp_path):
         for n_asm, own in with_asm:
             assert not own, f"{variant}: compiler-emitted memory operations beside {n_asm} asm ones: {own[:3]}"
         res = chk.check_kernel(text, variant)
-        assert res["depth"] == 1 and res["in_flight"] == 4 and res["loops"] == 2, res  # the shipped pipeline: requests one super-unit ahead
+        assert res["depth"] == 1 and res["in_flight"] == 4 and res["loops"] == 3, res  # the shipped pipeline: requests one super-unit ahead
+            # (three inlined copies of the loop: batched jobs, a single graph dealt per XCD, a single graph dealt over all workgroups - round 6)
         assert not res["violations"], f"{variant}: compiler instructions touch registers of loads in flight: {res['violations'][:5]}"
         checked += 1
     assert checked == 4

@@ -1610,7 +1610,7 @@ def test_spmm_band_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, hub
                      col_scale=None if cs is None else torch.from_numpy(cs).cuda(), use_values=use_values,
                      out=None if out is None else out[:, 2:2 + f])
         assert g.band and g.quad is None, "the call must have gone to the band kernel"
-        assert g.band["n_hub"] == int((deg > 256).sum())
+        assert g.band["n_hub"] == int((deg > g.band["hub_len"]).sum())
         if out is not None:
             assert float(out[:, :2].min()) == 7.0 and float(out[:, 2 + f:].min()) == 7.0  # nothing written beside Y
         v = val.copy() if use_values else np.ones_like(val)
@@ -1632,8 +1632,8 @@ def test_spmm_band_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, hub
 
 
 def test_spmm_band_plan_orders_rows_and_cuts_by_cost(ops):
-    """wdg_csr_band_plan: band_perm is a permutation with non-increasing row lengths whose first n_hub rows are exactly the
-    rows of more than 256 entries; the cuts of both row classes are monotone, start at 0, end at the class size, and split
+    """wdg_csr_band_plan_hub: band_perm is a permutation with non-increasing row lengths whose first n_hub rows are exactly the
+    rows of more than hub_len entries (6 x the mean row length, 32 .. 256), cuts[19] counts the rows of more than 128; the cuts of both row classes are monotone, start at 0, end at the class size, and split
     the class's cost (entries + 8 per row) into eighths within one row's cost"""
     rng = np.random.default_rng(5)
     for n, m, e, hubs, hub_len in ((3000, 3000, 40000, 30, 900), (30000, 30000, 200000, 9, 2000), (10, 10, 30, 0, 0)):
@@ -1644,7 +1644,9 @@ def test_spmm_band_plan_orders_rows_and_cuts_by_cost(ops):
         perm, cuts, n_hub = _np(g.band["perm"])[:n], _np(g.band["cuts"]), g.band["n_hub"]
         assert sorted(perm.tolist()) == list(range(n))
         assert (np.diff(deg[perm]) <= 0).all()
-        assert n_hub == int((deg > 256).sum())
+        hub_len = min(256, max(32, 6 * int(deg.sum()) // n))
+        assert g.band["hub_len"] == hub_len and n_hub == int((deg > hub_len).sum())
+        assert g.band["n_long"] == int((deg > 128).sum()) == int(cuts[19])
         for cls, (first, count) in enumerate(((0, n_hub), (n_hub, n - n_hub))):
             c = cuts[9 * cls:9 * cls + 9]
             assert c[0] == 0 and c[8] == count and (np.diff(c) >= 0).all()
@@ -1666,13 +1668,14 @@ def test_spmm_band_is_deterministic_and_sums_in_csr_order(ops, monkeypatch):
     monkeypatch.setenv("WDG_SPMM_BAND", "1")
     a = ops.spmm(g, x).clone()
     b = ops.spmm(g, x)
-    assert g.band and g.band["n_hub"] == 4
+    hub_len = g.band["hub_len"]
+    assert g.band and 32 <= hub_len <= 256 and g.band["n_hub"] == int((np.diff(rowptr) > hub_len).sum()) >= 4
     assert torch.equal(a, b)
     # (np.cumsum adds sequentially in fp32, np.sum would add pairwise)
     xh, ah = _np(x), _np(a)
     for r in range(n):
         s, e = rowptr[r], rowptr[r + 1]
-        if 0 < e - s <= 256:
+        if 0 < e - s <= hub_len:
             np.testing.assert_array_equal(ah[r], np.cumsum(xh[col[s:e]], axis=0, dtype=np.float32)[-1], err_msg=f"row {r}")
         elif e == s:
             assert not ah[r].any()

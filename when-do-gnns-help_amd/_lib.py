@@ -94,6 +94,7 @@ SIGNATURES = {
     "wdg_csr_band_plan_workspace_bytes": (c_size_t, [c_int32]),
     "wdg_csr_band_perm_len": (c_int32, [c_int32]),
     "wdg_csr_band_plan": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wdg_csr_band_plan_hub": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wdg_spmm_narrow_col_bytes": (c_int32, [c_int32, c_int32, c_int32]),
     "wdg_spmm_narrow_parts": (c_int32, [c_int32, c_int32]),
     "wdg_spmm_narrow_workspace_bytes": (c_size_t, [c_int32, c_int32]),

@@ -36,7 +36,8 @@ constexpr int B_WAVES = B_THREADS / kWave;
 constexpr int B_NB = WDG_BAND_NB;  // source rows per batch; two batches are requested before the first is consumed
 constexpr int B_TEAM = 4;        // waves that sweep a hub row together
 constexpr int B_TEAMS = B_WAVES / B_TEAM;
-constexpr int B_HUB_LEN = 256;   // rows longer than this are hub rows (the plan's default; WDG_BAND_HUB overrides, experiments)
+constexpr int B_HUB_LEN = 256;   // rows longer than this are hub rows (wdg_csr_band_plan's default; wdg_csr_band_plan_hub names it,
+                                 // WDG_BAND_HUB overrides both: experiments)
 constexpr int B_ROW_COST = 8;    // fixed cost of a (row, band) item in entries (descriptor loads, the store)
 constexpr int B_BUCKETS = 4096;  // length buckets of the large-graph row sort
 
@@ -475,7 +476,12 @@ int32_t wdg_csr_band_perm_len(int32_t N) { return (N + 15) / 16 * 16; }
 
 int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int32_t *band_cuts, void *workspace,
                       size_t workspace_bytes, wdg_stream_t stream) {
-    WDG_REQUIRE(N >= 0 && band_cuts && (N == 0 || (rowptr && band_perm)), "csr_band_plan: bad arguments");
+    return wdg_csr_band_plan_hub(rowptr, N, 0, band_perm, band_cuts, workspace, workspace_bytes, stream);
+}
+
+int wdg_csr_band_plan_hub(const int32_t *rowptr, int32_t N, int32_t hub_len_arg, int32_t *band_perm, int32_t *band_cuts, void *workspace,
+                          size_t workspace_bytes, wdg_stream_t stream) {
+    WDG_REQUIRE(N >= 0 && hub_len_arg >= 0 && band_cuts && (N == 0 || (rowptr && band_perm)), "csr_band_plan: bad arguments");
     if (!workspace || workspace_bytes < wdg_csr_band_plan_workspace_bytes(N)) return wdg::fail(WDG_ERR_WORKSPACE, "csr_band_plan: workspace too small");
     hipStream_t st = wdg::as_stream(stream);
     char *ws = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
@@ -491,8 +497,9 @@ int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int3
         if (int e = wdg::exclusive_scan_i32(hist, B_BUCKETS, cursor, nullptr, scan_ws, st)) return e;
         hipLaunchKernelGGL(band_scatter, dim3(wdg::ceil_div(N, B_SORT_THREADS * B_SORT_ROWS)), dim3(B_SORT_THREADS), 0, st, rowptr, N, cursor, band_perm);
     }
-    int hub_len = B_HUB_LEN;
-    if (const char *h = getenv("WDG_BAND_HUB")) hub_len = std::max(8, atoi(h));
+    int hub_len = hub_len_arg > 0 ? std::max(8, static_cast<int>(hub_len_arg)) : B_HUB_LEN;
+    if (const char *h = getenv("WDG_BAND_HUB"))
+        if (atoi(h) > 0) hub_len = std::max(8, atoi(h));
     const int n_wgs = std::max(1, std::min(CUT_MAX_WGS, static_cast<int>(wdg::ceil_div(N, CUT_THREADS))));
     CutPartial *partials = reinterpret_cast<CutPartial *>(hist);     // (the bucket sort is done with both arrays by now)
     CutTargets *targets = reinterpret_cast<CutTargets *>(cursor);

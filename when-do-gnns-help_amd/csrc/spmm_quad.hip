@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(MODE == Q_MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS)
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wgs_per_xcd = gridDim.x / kXcds;
     const int n_local = subs * n_groups;
     bool first_phase = true;
-    if (subs < 0) {
+    if (MODE != Q_MULTI && subs < 0) {  // (not the several-block variant: a second inlined phase there parks 4 more registers)
         // GLOBAL deal (single graphs with many feature groups, round 6): -subs segments in all, the (segment, feature group) pairs
         // dealt round-robin over ALL workgroups.  A graph of 131 - 180 feature groups has enough parallelism in its groups: with the
         // per-XCD deal (8 x subs segments) every group's slab was staged eight times and more, for a few super-units of work each.
@@ -1666,8 +1666,8 @@ __global__ __launch_bounds__(MODE == Q_MULTI ? Q_MULTI_THREADS : Q_FAST_THREADS)
         if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         for (int w = blockIdx.x; w < n_segments * n_groups; w += gridDim.x) {
             const int seg = w / n_groups, f0 = (w % n_groups) * (MODE == Q_HALF ? 8 : 16);
-            if (MODE == Q_MULTI) q_phase_multi<TIN, HAS_VAL>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, first_phase, y_vec_all != 0);
-            else q_phase_single<TIN, HAS_VAL, MODE == Q_HALF>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
+            if constexpr (MODE != Q_MULTI)
+                q_phase_single<TIN, HAS_VAL, MODE == Q_HALF>(nullptr, inline_job, 0, 1, seg, n_units, n_segments, f0, q_lds, next_unit, first_phase, y_vec_all != 0);
             first_phase = false;
         }
         if (wg_clock && threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1805,8 +1805,8 @@ int quad_single(const wdg_spmm_job &j, hipStream_t st) {
     {
         int glob = n_groups >= 64 ? static_cast<int>(ceil_div(2 * wdg_device_cus(), n_groups)) : 0;
         if (const char *e = getenv("WDG_QUAD_SINGLE_SEGMENTS")) glob = atoi(e);
+        if (j.q_n_blocks > 1) glob = 0;  // (several column blocks: the per-XCD deal; such graphs go to the band kernel anyway)
         if (glob > 0) {
-            if (j.q_n_blocks > 1) glob = std::max(glob, static_cast<int>(ceil_div(n_units, static_cast<int64_t>(Q_MAXU / Q_SU) * Q_MULTI_WAVES)));
             glob = std::min(glob, std::max(1, n_units));
             subs = -glob;
         }

@@ -23,9 +23,10 @@ class _BandPlan(dict):
     `CsrGraph.prefers_band` on a graph of <= 2 528 columns) - the launches themselves pass WDG_BAND_HUB_ON_DEVICE until then"""
 
     def __missing__(self, key):
-        if key != "n_hub":
+        if key not in ("n_hub", "n_long"):
             raise KeyError(key)
-        self[key] = int(self["cuts"][8].item())
+        both = self["cuts"][[8, 19]].tolist()  # (one read-back: the hub rows and the rows of more than 128 entries)
+        self["n_hub"], self["n_long"] = int(both[0]), int(both[1])
         return self[key]
 
 
@@ -69,9 +70,12 @@ class CsrGraph:
         cuts = torch.empty(24, dtype=torch.int32, device=dev)
         ws_bytes = lib.wdg_csr_band_plan_workspace_bytes(self.n_rows)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        check(lib.wdg_csr_band_plan(_ptr(self.rowptr), self.n_rows, _ptr(perm), _ptr(cuts), _ptr(ws), ws_bytes, stream_handle()),
-              "wdg_csr_band_plan")
-        self.band = _BandPlan(perm=perm, cuts=cuts, ws=ws)  # (ws: alive until the plan's kernels have run)
+        # hub threshold: rows longer than this are swept by four waves.  A launch ends with its longest single-wave row: 6 x the mean
+        # row length, 32 .. 256 (Cora - mean 4.9, longest 169 - 22.4 -> 17.5 us; chameleon and squirrel keep ~ the default's 256)
+        hub_len = int(min(256, max(32, 6 * self.nnz // max(self.n_rows, 1))))
+        check(lib.wdg_csr_band_plan_hub(_ptr(self.rowptr), self.n_rows, hub_len, _ptr(perm), _ptr(cuts), _ptr(ws), ws_bytes, stream_handle()),
+              "wdg_csr_band_plan_hub")
+        self.band = _BandPlan(perm=perm, cuts=cuts, ws=ws, hub_len=hub_len)  # (ws: alive until the plan's kernels have run)
         return True
 
     def prefers_band(self, n_feat):
@@ -87,7 +91,7 @@ class CsrGraph:
             return True
         # (2 529 .. 5 056 columns fit one block of 32-byte rows since round 4, but ONE graph there is still the band kernel's: Cora
         # 21 us against 105, a 4000-node sweep graph 17 against 42 - a slab per feature group is worth staging for a batch)
-        return n_feat >= 64 and (self.n_cols > self.QUAD_SLAB_COLS or self.band["n_hub"] > 0)
+        return n_feat >= 64 and (self.n_cols > self.QUAD_SLAB_COLS or self.band["n_long"] > 0)  # (n_long: rows of more than 128 entries)
 
     QUAD_MAX_BLOCKS = 4  # column blocks of <= 2528 columns the quad-row kernel sweeps (csrc/spmm_quad.hip)
 
