@@ -301,11 +301,11 @@ def measure_full(args, dev):
 
 
 KR_SETS_NOTE = {
-    "sample": "common random node sets per sample (WDG_SWEEP_KR_SETS=sample, the default): the homophily levels of one sample - same features, "
+    "sample": "common random node sets per sample (WDG_SWEEP_KR_SETS=sample, opt-in): the homophily levels of one sample - same features, "
               "same labels - share each epoch's (train, validation) sets, so every job's accuracies keep the distribution of the "
               "reference's independent draws while the raw features' regression of an epoch is solved once per sample and shard instead "
-              "of once per job (kr_total counts the regressions solved); WDG_SWEEP_KR_SETS=job draws per job",
-    "job": "independent node sets per job (WDG_SWEEP_KR_SETS=job): 400 regressions per job"}
+              "of once per job (kr_total counts the regressions solved); the default draws per job",
+    "job": "independent node sets per job (the default, the reference's own draws: utils/homophily_metrics.py:267-283): 400 regressions per job"}
 
 
 def measure_cold(args, dev):
@@ -499,22 +499,25 @@ def measure_whole(args, dev, world=1, rank=0):
             rec.update(one_gpu_s=one, strong_speedup_vs_1gpu=one / dt,
                        rows_equal_one_gpu=bool(torch.equal(torch.nan_to_num(table, nan=-7.0), torch.nan_to_num(t1gpu, nan=-7.0))))
         dist.barrier()
+    mode = os.environ.get("WDG_SWEEP_KR_SETS", "job")
     if world == 1:
-        # the same sweep with INDEPENDENT node sets per job (WDG_SWEEP_KR_SETS=job: the reference's own draws, utils/homophily_metrics.py:
-        # 267-283 - 672 000 regressions instead of 348 000), beside the headline figure that shares the sets inside a sample
-        # (VERDICT r05 weak 2): the second of two passes
+        # the same sweep in the OTHER node-set mode, beside the headline figure (the second of two passes).  Default: independent node
+        # sets per job - the reference's own draws, utils/homophily_metrics.py:267-283, 672 000 regressions -; the other mode
+        # (WDG_SWEEP_KR_SETS=sample) shares the sets inside a sample and solves 348 000 (an optimisation with a changed estimator:
+        # opt-in since round 6)
+        other = "sample" if mode == "job" else "job"
         prev = os.environ.get("WDG_SWEEP_KR_SETS")
-        os.environ["WDG_SWEEP_KR_SETS"] = "job"
+        os.environ["WDG_SWEEP_KR_SETS"] = other
         try:
-            stats_job = {}
+            stats_other = {}
             for _rep in range(2):
-                stats_job.clear()
+                stats_other.clear()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                sweep.whole_sweep_rank(pairs, graph_of, feats, 1, 0, epochs=args.kr_epochs, max_pairs_per_shard=per_shard, stats=stats_job)
+                sweep.whole_sweep_rank(pairs, graph_of, feats, 1, 0, epochs=args.kr_epochs, max_pairs_per_shard=per_shard, stats=stats_other)
                 torch.cuda.synchronize()
-                rec["seconds_sets_job"] = time.perf_counter() - t1
-            rec["kr_total_sets_job"] = int(stats_job.get("kr_total", 0))
+                rec[f"seconds_sets_{other}"] = time.perf_counter() - t1
+            rec[f"kr_total_sets_{other}"] = int(stats_other.get("kr_total", 0))
         finally:
             if prev is None:
                 os.environ.pop("WDG_SWEEP_KR_SETS", None)
@@ -532,7 +535,7 @@ def measure_whole(args, dev, world=1, rank=0):
             "first_pass_seconds": t_first, "first_pass_note": "this rank's untimed first pass of the same sweep in this process (allocator pools still growing)", **rec,
             "kr_ridged": int(kr_counts[0].item()), "kr_total": int(kr_counts[1].item()), "kr_deflated": int(kr_counts[2].item()),
             "feature_duplicates": args.dup_frac,
-            "kr_sets": KR_SETS_NOTE[os.environ.get("WDG_SWEEP_KR_SETS", "sample")],
+            "kr_sets_mode": mode, "kr_sets": KR_SETS_NOTE[mode],
             "reuse_inside_a_shard": "what depends on less than a job is computed once (DESIGN 5): the six step scalars of the wide bases (they "
                                     "aggregate the label columns only: graph + labels) by the first of them (WDG_SWEEP_STEP_TWINS=0: every base), "
                                     "the job tables of a base taken over from an earlier base of equal sample_max (WDG_SWEEP_REBIND=0: built "
@@ -785,7 +788,7 @@ def compact_line(out, detail_path=None):
                              "spmm_us": _num(sec.get("roofline", {}).get("avg_launch_us")), "frac": _num(sec.get("roofline", {}).get("frac"))}
     sw = out.get("sweep_whole")
     if sw:
-        line["sweep_whole"] = {k: _num(sw.get(k)) for k in ("jobs", "n_gpus", "scaling", "seconds", "first_pass_seconds", "seconds_sets_job",
+        line["sweep_whole"] = {k: _num(sw.get(k)) for k in ("jobs", "n_gpus", "scaling", "seconds", "first_pass_seconds", "kr_sets_mode", "seconds_sets_job", "seconds_sets_sample",
                                                             "kr_total", "kr_ridged", "kr_deflated", "one_gpu_s", "strong_speedup_vs_1gpu",
                                                             "rows_equal_one_gpu", "per_rank_s") if k in sw}
     sf = out.get("sweep_full")

@@ -250,7 +250,7 @@ def test_nine_scalars_with_propagated_grams_match_the_direct_route(monkeypatch):
 
 
 def test_common_sets_per_sample_share_the_raw_feature_regressions(monkeypatch):
-    """prepare_full(sets="sample") (the default): the homophily levels of one sample draw ONE sequence of node sets, keyed by the
+    """prepare_full(sets="sample") (opt-in; the default draws per job like the reference): the homophily levels of one sample draw ONE sequence of node sets, keyed by the
     sample's identity, and the raw features' regression of an (epoch, classifier) is solved once per sample.
       * the table holds J * 2 E regressions on the aggregated features' kernels + G * 2 E on the raw features' (G samples);
       * the jobs of a sample read the SAME raw-feature accuracies; their graph-aware ones differ;

@@ -891,15 +891,17 @@ class SweepBatch:
         own routine on torch's CPU generator seeded with seed_of(job index, classifier index) (default 1000 job + classifier) -
         bit for bit the reference's sets (the golden tests), ~40 ms of host time per (job, classifier) at 100 epochs.
         sets (device sampler only; WDG_SWEEP_KR_SETS): whose node sets an epoch's regressions use.
-          "sample" (default) - COMMON RANDOM SETS per sample: the jobs of a shard that share a feature matrix AND a label vector (the
+          "job" (default, the reference's own draws: utils/homophily_metrics.py:267-283 draws per call) - independent sets per job, keyed
+                   by the job's identity: 400 regressions per job at 100 epochs.
+          "sample" - COMMON RANDOM SETS per sample (an optimisation, opt-in since round 6: a CHANGED ESTIMATOR is not a default): the jobs of a shard that share a feature matrix AND a label vector (the
                    homophily levels of one sample, synthetic_plot.py:78-91) draw ONE sequence of sets per (sample, classifier), keyed
                    by the sample's identity.  Every job's (X_results, G_results) pair has exactly the distribution of the reference's
                    independent draws (both accuracies of an epoch share the epoch's sets there too, utils/homophily_metrics.py:
                    279-297); only jobs of DIFFERENT homophily levels become correlated, which none of the reference's outputs (mean /
                    std over the ten samples of a level, synthetic_plot.py:112-128) measures.  The raw features' regressions of such jobs
                    are then the same problem - same kernel, same sets, same labels - and are solved ONCE per (sample, classifier,
-                   epoch) instead of once per job: 200 + 200 / (levels per shard) regressions per job instead of 400.
-          "job"    - independent sets per job, keyed by the job's identity (rounds 3 - 4)."""
+                   epoch) instead of once per job: 200 + 200 / (levels per shard) regressions per job instead of 400 (the whole sweep:
+                   348 000 instead of 672 000, 0.30 instead of 0.47 s on one GPU)."""
         from .utils.util_funcs import kernel_regression_epoch_indices
         ops = self.ops
         dev = self.graphs[0].device if self.graphs else ops.require_gpu()
@@ -971,7 +973,7 @@ class SweepBatch:
                 k = len(distinct) - 1
             which.append(k)
         sizes = [distinct[k][2] for k in which]
-        sets = sets or os.environ.get("WDG_SWEEP_KR_SETS", "sample")
+        sets = sets or os.environ.get("WDG_SWEEP_KR_SETS", "job")
         if sets not in ("sample", "job"):
             raise ValueError(f"prepare_full: sets={sets!r} (sample | job)")
         if sampler != "device":
