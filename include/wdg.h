@@ -312,7 +312,7 @@ int wdg_csr_band_plan(const int32_t *rowptr, int32_t N, int32_t *band_perm, int3
 /* The same plan with the HUB THRESHOLD named by the caller (0: the default, 256): rows longer than hub_len are swept by the four waves of
  * a workgroup, the others by one wave each.  A launch ends with its longest single-wave row, so a graph of short rows with a few
  * long ones is better off with a lower threshold (Cora, mean 4.9 entries per row, longest 169: 22 -> 17.5 us at 32); the Python side
- * passes 6 x the mean row length clamped to 32 .. 256.  Any threshold computes every row's sum in a fixed order (a hub row: its four
+ * passes 6 x the mean row length clamped to 32 .. 192 (squirrel: 186 -> 176 us at 192).  Any threshold computes every row's sum in a fixed order (a hub row: its four
  * pieces in piece order).
  * replaces: the same `torch.spmm(adj, features)` call sites as wdg_csr_band_plan (utils/homophily_metrics.py:199-200,234-235). */
 int wdg_csr_band_plan_hub(const int32_t *rowptr, int32_t N, int32_t hub_len, int32_t *band_perm, int32_t *band_cuts, void *workspace,

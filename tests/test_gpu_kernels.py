@@ -1633,7 +1633,7 @@ def test_spmm_band_family_shapes(ops, oracle, monkeypatch, n, m, f, e, hubs, hub
 
 def test_spmm_band_plan_orders_rows_and_cuts_by_cost(ops):
     """wdg_csr_band_plan_hub: band_perm is a permutation with non-increasing row lengths whose first n_hub rows are exactly the
-    rows of more than hub_len entries (6 x the mean row length, 32 .. 256), cuts[19] counts the rows of more than 128; the cuts of both row classes are monotone, start at 0, end at the class size, and split
+    rows of more than hub_len entries (6 x the mean row length, 32 .. 192), cuts[19] counts the rows of more than 128; the cuts of both row classes are monotone, start at 0, end at the class size, and split
     the class's cost (entries + 8 per row) into eighths within one row's cost"""
     rng = np.random.default_rng(5)
     for n, m, e, hubs, hub_len in ((3000, 3000, 40000, 30, 900), (30000, 30000, 200000, 9, 2000), (10, 10, 30, 0, 0)):
@@ -1644,7 +1644,7 @@ def test_spmm_band_plan_orders_rows_and_cuts_by_cost(ops):
         perm, cuts, n_hub = _np(g.band["perm"])[:n], _np(g.band["cuts"]), g.band["n_hub"]
         assert sorted(perm.tolist()) == list(range(n))
         assert (np.diff(deg[perm]) <= 0).all()
-        hub_len = min(256, max(32, 6 * int(deg.sum()) // n))
+        hub_len = min(192, max(32, 6 * int(deg.sum()) // n))
         assert g.band["hub_len"] == hub_len and n_hub == int((deg > hub_len).sum())
         assert g.band["n_long"] == int((deg > 128).sum()) == int(cuts[19])
         for cls, (first, count) in enumerate(((0, n_hub), (n_hub, n - n_hub))):
@@ -1669,7 +1669,7 @@ def test_spmm_band_is_deterministic_and_sums_in_csr_order(ops, monkeypatch):
     a = ops.spmm(g, x).clone()
     b = ops.spmm(g, x)
     hub_len = g.band["hub_len"]
-    assert g.band and 32 <= hub_len <= 256 and g.band["n_hub"] == int((np.diff(rowptr) > hub_len).sum()) >= 4
+    assert g.band and 32 <= hub_len <= 192 and g.band["n_hub"] == int((np.diff(rowptr) > hub_len).sum()) >= 4
     assert torch.equal(a, b)
     # (np.cumsum adds sequentially in fp32, np.sum would add pairwise)
     xh, ah = _np(x), _np(a)

@@ -71,8 +71,9 @@ class CsrGraph:
         ws_bytes = lib.wdg_csr_band_plan_workspace_bytes(self.n_rows)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         # hub threshold: rows longer than this are swept by four waves.  A launch ends with its longest single-wave row: 6 x the mean
-        # row length, 32 .. 256 (Cora - mean 4.9, longest 169 - 22.4 -> 17.5 us; chameleon and squirrel keep ~ the default's 256)
-        hub_len = int(min(256, max(32, 6 * self.nnz // max(self.n_rows, 1))))
+        # row length, 32 .. 192 (Cora - mean 4.9, longest 169 - 22.4 -> 17.5 us at 32; squirrel 186 -> 176 us at 192, non-monotone between:
+        # 144: 181, 160: 190, 224: 184, 256: 185, 320: 192; chameleon 44 - 45 us from 128 to 192, 47 - 49 above)
+        hub_len = int(min(192, max(32, 6 * self.nnz // max(self.n_rows, 1))))
         check(lib.wdg_csr_band_plan_hub(_ptr(self.rowptr), self.n_rows, hub_len, _ptr(perm), _ptr(cuts), _ptr(ws), ws_bytes, stream_handle()),
               "wdg_csr_band_plan_hub")
         self.band = _BandPlan(perm=perm, cuts=cuts, ws=ws, hub_len=hub_len)  # (ws: alive until the plan's kernels have run)
