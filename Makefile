@@ -7,6 +7,8 @@ SRCS     := $(wildcard $(CSRC)/*.hip)
 # per-file flags: the 32 steps of kernel_reg.hip's in-wave substitution must unroll completely (their register indices and
 # branch conditions are compile-time only then) - with the default budget the compiler peels 11 steps and rolls the rest
 FLAGS_kernel_reg := -mllvm -pragma-unroll-threshold=200000
+# gnb.hip reproduces numpy's fp32 sums bit for bit: no multiply-add may be fused (its source says so as well: #pragma clang fp contract(off))
+FLAGS_gnb := -ffp-contract=off
 OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 LIB      := $(PKG)/lib/libwdg_hip.so
 

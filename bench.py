@@ -502,7 +502,7 @@ def measure_whole(args, dev, world=1, rank=0):
     mode = os.environ.get("WDG_SWEEP_KR_SETS", "job")
     if world == 1:
         # the same sweep in the OTHER node-set mode, beside the headline figure (the second of two passes).  Default: independent node
-        # sets per job - the reference's own draws, utils/homophily_metrics.py:267-283, 672 000 regressions -; the other mode
+        # sets per job - the reference's own draws, utils/homophily_metrics.py:267-283 (672 000 regressions) -; the other mode
         # (WDG_SWEEP_KR_SETS=sample) shares the sets inside a sample and solves 348 000 (an optimisation with a changed estimator:
         # opt-in since round 6)
         other = "sample" if mode == "job" else "job"
@@ -620,6 +620,47 @@ def measure_train(args, dev):
                      "mean_test_acc": float(r["test_acc"].mean())}
         del tb
         torch.cuda.empty_cache()
+    return out
+
+
+def measure_gnb(args, dev):
+    """The GNB classifier-based metric (homophily_tests.py:133-137 with `gnb_based_homo`; utils/homophily_metrics.py:296-312) on a
+    Cora-sized input - 2 709 nodes, 1 433 row-normalised features, 7 classes, sample_max 500, 100 epochs = 200 fits + 200 predictions:
+    the device call (node sets on torch's CPU generator like the reference, aggregation, ONE wdg_gnb_batched_f32 call, t-test) beside the
+    reference's own route for the same call - scikit-learn on the host, epoch by epoch (WDG_GNB_SOLVER=host; same sets, same p-value)."""
+    import numpy as np
+    import torch
+    from wdg_amd import synth
+    from wdg_amd.utils import homophily_metrics as hm
+    n, f, c, epochs = 2709, 1433, 7, 100  # (7 x 387 nodes: the generator's classes are contiguous blocks of equal size)
+    src, dst, lab = synth.regular_graph(n, c, 4, 0.8, 3)
+    x = synth.features(n, f, 11, labels=lab, n_classes=c)
+    x = np.abs(x)
+    x /= np.maximum(x.sum(1, keepdims=True), 1e-12)
+    idx = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    adj = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (n, n)).coalesce()
+    feats, labels = torch.from_numpy(x.astype(np.float32)), torch.from_numpy(np.asarray(lab, np.int64))
+    out = {"workload": f"classifier_based_performance_metric(base_classifier='gnb'): N={n}, F={f}, C={c}, sample_max 500, {epochs} epochs"}
+    prev = os.environ.get("WDG_GNB_SOLVER")
+    try:
+        for mode, reps in (("device", 3), ("host", 1)):
+            os.environ["WDG_GNB_SOLVER"] = mode
+            best = None
+            for _ in range(reps):
+                torch.manual_seed(3)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                p, _secs = hm.classifier_based_performance_metric(feats, adj, labels, 500.0, base_classifier="gnb", epochs=epochs)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out[f"{mode}_ms"], out[f"p_{mode}"] = best * 1e3, float(p)
+    finally:
+        if prev is None:
+            os.environ.pop("WDG_GNB_SOLVER", None)
+        else:
+            os.environ["WDG_GNB_SOLVER"] = prev
+    out["p_equal"] = bool(abs(out["p_device"] - out["p_host"]) <= 1e-12)
     return out
 
 
@@ -805,6 +846,9 @@ def compact_line(out, detail_path=None):
     if tr:
         line["train"] = {name: _num(tr[name]["ms_per_epoch"]) for name in ("SGC-1", "GCN-2") if name in tr}
         line["train"]["unit"] = "ms/epoch"
+    gn = out.get("gnb")
+    if gn:  # the GNB metric of one Cora-sized call: [device ms, scikit-learn on the host ms, p-values equal]
+        line["gnb_metric_ms"] = [_num(gn.get("device_ms"), 4), _num(gn.get("host_ms"), 4), gn.get("p_equal")]
     cf = out.get("configs")
     if cf:  # per aggregation config: [launch us, HBM fraction by SURVEY 8(d) bytes]
         line["configs"] = {name: [_num(rec["us"], 4), _num(rec["roofline"]["frac"], 3)] for name, rec in cf.items() if "us" in rec and "roofline" in rec}
@@ -816,7 +860,7 @@ def compact_line(out, detail_path=None):
         line["detail"] = detail_path
     text = json.dumps(line, allow_nan=False)
     if len(text) > LINE_LIMIT:  # never let a side block cost the headline: drop them in this order
-        for k in ("configs", "sweep_cold", "sweep_full", "projection_8", "train", "secondary", "sweep_whole"):
+        for k in ("gnb_metric_ms", "configs", "sweep_cold", "sweep_full", "projection_8", "train", "secondary", "sweep_whole"):
             line.pop(k, None)
             text = json.dumps(line, allow_nan=False)
             if len(text) <= LINE_LIMIT:
@@ -862,6 +906,7 @@ def main():
     ap.add_argument("--config-reps", type=int, default=10)
     ap.add_argument("--train", type=int, default=1, help="1: also time the train + eval sweep (SGC-1, GCN-2) on the shard and report it as `train` (N=1 only)")
     ap.add_argument("--train-epochs", type=int, default=30)
+    ap.add_argument("--gnb", type=int, default=1, help="1: also time the GNB classifier-based metric on a Cora-sized input, device call beside scikit-learn on the host (N=1 only)")
     ap.add_argument("--projection", type=int, default=1, help="1: also step every rank's shard of the 50-job sweep for world sizes 2 / 4 / 8 on "
                     "this GPU and report the projected strong scaling as `scaling_projection` (N=1 only)")
     ap.add_argument("--projection-steps", type=int, default=100)
@@ -952,6 +997,9 @@ def main():
     if world == 1 and args.train:
         torch.cuda.empty_cache()
         out["train"] = measure_train(args, dev)
+    if world == 1 and args.gnb:
+        torch.cuda.empty_cache()
+        out["gnb"] = measure_gnb(args, dev)
     if world == 1 and args.projection:
         torch.cuda.empty_cache()
         out["scaling_projection"] = measure_projection(args, dev, out["ms_per_step"])

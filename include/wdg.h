@@ -432,6 +432,35 @@ int wdg_sweep_scalars_f32(const int64_t *totals, const int32_t *rows, const int6
 int wdg_sweep_pack_f64(const float *scalars, int32_t n_scalars, const double *ge_mean, int32_t n_ge, const int32_t *kr_correct,
                        const int32_t *kr_flags, const float *kr_n_val, int32_t n_kr, double *out, wdg_stream_t stream);
 
+/*
+ * Batched Gaussian naive Bayes: per problem, fit on the train rows of a feature matrix and predict its validation rows - the GNB branch
+ * of the classifier-based performance metric, every (epoch, feature matrix) problem of a call in one call here (three launches).
+ * The statistics are scikit-learn's on a float32 matrix, bit for bit: per class present among the train rows the fp32 mean and
+ * population variance of every feature by SEQUENTIAL fp32 sums over the train rows IN THE ORDER OF `train` (the reference indexes with
+ * boolean masks: ascending node ids), epsilon = float32(1e-9) x the largest fp32 variance of all train rows; the joint log likelihood
+ * in fp64, first maximum over the present classes (csrc/gnb.hip: what can differ from numpy is the rounding of two fp64 sums over the
+ * features).  correct_out = validation rows whose predicted class is their label; pred (optional) = the predicted class per validation
+ * row.  Classes 0 .. n_classes - 1, n_classes <= 16; labels outside are the caller's error.  A problem with n_train < 1 predicts nothing
+ * (correct 0, pred untouched).  ws: wdg_gnb_workspace_bytes(F, n_classes) bytes per problem, 256-byte aligned.
+ * replaces: `GaussianNB().fit(X[idx_train], labels_sample[idx_train])` / `.predict(X[idx_val])` for X and X_agg and the two accuracies
+ *           (utils/homophily_metrics.py:296-312, utils/homophily_plot.py:317-333) inside the epoch loop of
+ *           classifier_based_performance_metric (utils/homophily_metrics.py:260-349).
+ */
+typedef struct {
+    const float *X;          /* [n, F] fp32 row-major, leading dimension ldx */
+    const int32_t *train;    /* [n_train] row ids, in the order the statistics are summed in */
+    const int32_t *val;      /* [n_val] row ids */
+    const int32_t *labels;   /* [n] class of every row */
+    void *ws;                /* wdg_gnb_workspace_bytes(F, n_classes) bytes */
+    int32_t *correct;        /* out: hits among the validation rows (NULL: not wanted) */
+    int32_t *pred;           /* out [n_val]: predicted class (NULL: not wanted) */
+    int64_t ldx;
+    int32_t n_train, n_val, F, n_classes;
+} wdg_gnb_job;
+size_t wdg_gnb_workspace_bytes(int32_t n_feat, int32_t n_classes);
+int wdg_gnb_batched_f32(const wdg_gnb_job *jobs_dev, int32_t n_jobs, int32_t max_feat, int32_t max_val, int32_t max_classes,
+                        wdg_stream_t stream);
+
 /* ------------------------------------------------------------------ per-edge cosine (SDDMM) */
 /*
  * out[i] = cos(x_u, x_v) for stored entry e_i = (u, v) (e_i = entries[i], or i when entries == NULL); NaN -> 0;

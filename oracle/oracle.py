@@ -380,3 +380,79 @@ def welch_p_value(g_results, x_results):
     g, x = np.asarray(g_results, np.float32), np.asarray(x_results, np.float32)
     _, p = ttest_ind(x, g, axis=0, equal_var=False, nan_policy="propagate")
     return float(p / 2 if np.mean((g > x).astype(np.float32)) <= 0.5 else 1 - p / 2)
+
+
+def _seq_sum_f32(rows):
+    """fp32 sum of the rows of a [n, F] array, row after row (what `np.add.reduce(axis=0)` does on a C-contiguous float32 matrix)"""
+    acc = np.zeros(rows.shape[1], np.float32)
+    for r in rows:
+        acc = (acc + r).astype(np.float32)
+    return acc
+
+
+def gnb_fit(x_train, y_train):
+    """Gaussian naive Bayes, fit: the algorithm of `sklearn.naive_bayes.GaussianNB().fit(X, y)` as the reference calls it
+    (utils/homophily_metrics.py:296-303, utils/homophily_plot.py:317-324: default priors, var_smoothing = 1e-9) - scikit-learn is a
+    third-party dependency that is not part of the reference checkout; the build container holds 1.7.2 on numpy 2.2, which
+    produced the golden p-values (tests/golden/make_golden.py).  Restated from its published source (`_partial_fit`,
+    `_update_mean_variance`) with the arithmetic made explicit:
+      * float32 inputs stay float32: per present class c (ascending) theta_c = fp32 mean, var_c = fp32 population variance of the
+        class's rows in their order, both by SEQUENTIAL fp32 sums over the rows (np.mean / np.var, axis 0);
+      * epsilon = float32(1e-9) * max_f fp32-var(all rows)[f] in fp32 (numpy 2: a Python float is weak beside a float32 scalar);
+      * theta, var are stored as float64; var += epsilon in float64; prior_c = count_c / n.
+    -> dict(classes [k], theta [k, F] f64, var [k, F] f64, prior [k] f64, epsilon f32).  Pinned against sklearn itself by
+    tests/test_oracle_golden.py (attributes bit for bit)."""
+    x = np.ascontiguousarray(x_train, np.float32)
+    y = np.asarray(y_train)
+    n = x.shape[0]
+
+    def mean_var(rows):
+        cnt = np.float32(rows.shape[0])
+        mean = (_seq_sum_f32(rows) / cnt).astype(np.float32)
+        d = (rows - mean).astype(np.float32)
+        return mean, (_seq_sum_f32((d * d).astype(np.float32)) / cnt).astype(np.float32)
+
+    eps = np.float32(np.float32(1e-9) * mean_var(x)[1].max())
+    classes = np.unique(y)
+    theta = np.zeros((len(classes), x.shape[1]))
+    var = np.zeros((len(classes), x.shape[1]))
+    count = np.zeros(len(classes))
+    for i, c in enumerate(classes):
+        rows = x[y == c]
+        theta[i], var[i] = mean_var(rows)
+        count[i] = rows.shape[0]
+    var += eps
+    return dict(classes=classes, theta=theta, var=var, prior=count / n, epsilon=eps)
+
+
+def gnb_joint_log_likelihood(model, x):
+    """`GaussianNB._joint_log_likelihood` in float64: log prior_c - 1/2 sum_f log(2 pi var_cf) - 1/2 sum_f (x_f - theta_cf)^2 / var_cf"""
+    x = np.asarray(x, np.float32)
+    out = []
+    for i in range(len(model["classes"])):
+        n_ij = -0.5 * np.sum(np.log(2.0 * np.pi * model["var"][i]))
+        n_ij = n_ij - 0.5 * np.sum(((x - model["theta"][i]) ** 2) / model["var"][i], 1)
+        out.append(np.log(model["prior"][i]) + n_ij)
+    return np.array(out).T
+
+
+def gnb_predict(model, x):
+    """`GaussianNB.predict`: classes[arg-max of the joint log likelihood] (the first maximum)"""
+    return model["classes"][np.argmax(gnb_joint_log_likelihood(model, x), axis=1)]
+
+
+def gnb_accuracies(x_feat, x_agg, labels, node_sets):
+    """The GNB branch of one call of classifier_based_performance_metric, epoch by epoch (utils/homophily_metrics.py:296-312):
+    fit on the raw and on the aggregated features of the epoch's train rows (ascending ids: the reference indexes with boolean
+    masks), predict its validation rows, mean hit rate.  -> (G_results, X_results) float64 [epochs]"""
+    labels = np.asarray(labels, np.int64)
+    g_res, x_res = [], []
+    for train, valid in node_sets:
+        train, valid = np.sort(np.asarray(train, np.int64)), np.sort(np.asarray(valid, np.int64))
+        accs = []
+        for m in (x_agg, x_feat):
+            pred = gnb_predict(gnb_fit(m[train], labels[train]), m[valid])
+            accs.append(float(np.mean((pred == labels[valid]).astype(np.float32))))
+        g_res.append(accs[0])
+        x_res.append(accs[1])
+    return np.array(g_res), np.array(x_res)

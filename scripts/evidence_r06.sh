@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 C=$ROOT/gpurun_out/r06_collect
 mkdir -p "$C"
-LEAN="--cold 0 --configs 0 --train 0 --projection 0 --whole 0"
+LEAN="--cold 0 --configs 0 --train 0 --projection 0 --whole 0 --gnb 0"
 bash scripts/profile_r02.sh r06_c3 $LEAN > gpurun_out/ev6_c3.log 2>&1                        # bench line + kernel stats + PMC passes, C3 headline
 cp gpurun_out/r06_c3/bench.json "$C/r06_c3_bench.json"; cp gpurun_out/r06_c3/kernel_stats.csv "$C/r06_c3_bench_kernel_stats.csv"
 cp gpurun_out/r06_c3/pmc/summary.txt "$C/r06_c3_pmc_summary.txt"; cp gpurun_out/r06_c3/pmc/summary.json "$C/r06_c3_pmc_summary.json"
@@ -22,7 +22,7 @@ cp gpurun_out/bench_detail.json "$C/r06_bench_driver_flags_detail.json"
 python3 scripts/bench_configs.py --out "$C/r06_configs.jsonl" > /dev/null 2> gpurun_out/r06_configs.err   # one line per BASELINE config (+ binding resource)
 cd /tmp && export TMPDIR=/tmp
 for part in train configs whole; do                                                            # kernel statistics of the other blocks of the line
-  flags="--steps 10 --warmup 2 --secondary 0 --full-metrics 0 --cpu-budget 0 --cold 0 --configs 0 --train 0 --projection 0 --whole 0"
+  flags="--steps 10 --warmup 2 --secondary 0 --full-metrics 0 --cpu-budget 0 --cold 0 --configs 0 --train 0 --projection 0 --whole 0 --gnb 0"
   flags=${flags/--$part 0/--$part 1}
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/r06_${part}_stats" -- python3 "$ROOT/bench.py" $flags > /dev/null 2>&1
   find "$ROOT/gpurun_out/r06_${part}_stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$C/r06_${part}_kernel_stats.csv"

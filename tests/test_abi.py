@@ -52,7 +52,7 @@ def test_struct_layout_matches_header(tmp_path):
     import wdg_amd._lib as L
     mirrors = {"wdg_spmm_job": L.SpmmJob, "wdg_spmm_item": L.SpmmItem, "wdg_stats_job": L.StatsJob, "wdg_las_job": L.LasJob,
                "wdg_gemm_job": L.GemmJob, "wdg_mlp2_job": L.Mlp2Job, "wdg_gram_job": L.GramJob, "wdg_kr_job": L.KrJob, "wdg_sell16_job": L.Sell16Job, "wdg_kr_sample_job": L.KrSampleJob,
-               "wdg_edge_gram_job": L.EdgeGramJob, "wdg_transpose_job": L.TransposeJob}
+               "wdg_edge_gram_job": L.EdgeGramJob, "wdg_transpose_job": L.TransposeJob, "wdg_row_rep_job": L.RowRepJob, "wdg_gnb_job": L.GnbJob}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wdg.h"', 'int main(void) {']
     for cname, mirror in mirrors.items():
         lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')

@@ -141,6 +141,8 @@ SIGNATURES = {
     "wdg_edge_gram_mean_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "wdg_kernel_regress_batched_f32": (c_int, [c_void_p, c_int32, c_void_p]),
     "wdg_row_rep_batched": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "wdg_gnb_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "wdg_gnb_batched_f32": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "wdg_sweep_pack_f64": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "wdg_kr_deflate_workspace_bytes": (c_size_t, [c_int32]),
     "wdg_kernel_regress_deflated_batched_f32": (c_int, [c_void_p, c_int32, c_void_p]),
@@ -183,6 +185,12 @@ class RowRepJob(ctypes.Structure):
     """mirror of `wdg_row_rep_job` (include/wdg.h)"""
     _fields_ = [("A", c_void_p), ("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p),
                 ("rep_out", c_void_p), ("hash_ws", c_void_p), ("lda", c_int64), ("a_group_stride", c_int64), ("n", c_int32), ("F", c_int32)]
+
+
+class GnbJob(ctypes.Structure):
+    """mirror of `wdg_gnb_job` (include/wdg.h)"""
+    _fields_ = [("X", c_void_p), ("train", c_void_p), ("val", c_void_p), ("labels", c_void_p), ("ws", c_void_p), ("correct", c_void_p),
+                ("pred", c_void_p), ("ldx", c_int64), ("n_train", c_int32), ("n_val", c_int32), ("F", c_int32), ("n_classes", c_int32)]
 
 
 class KrSampleJob(ctypes.Structure):

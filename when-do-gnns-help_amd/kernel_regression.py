@@ -399,3 +399,69 @@ class KrBatch:
         if self.n_jobs and bool((correct < 0).any().item()):
             raise _lib.WdgError("wdg_kernel_regress_batched_f32 refused a problem (shape outside the solver's limits)")
         return correct.to(torch.float32) / self.n_val
+
+
+# ------------------------------------------------------------------------------------------- Gaussian naive Bayes (the GNB classifier)
+_GNB_JOB_DTYPE = np.dtype([("X", "<u8"), ("train", "<u8"), ("val", "<u8"), ("labels", "<u8"), ("ws", "<u8"), ("correct", "<u8"),
+                           ("pred", "<u8"), ("ldx", "<i8"), ("n_train", "<i4"), ("n_val", "<i4"), ("F", "<i4"), ("n_classes", "<i4")])
+assert _GNB_JOB_DTYPE.itemsize == ctypes.sizeof(_lib.GnbJob)
+
+
+class GnbBatch:
+    """Job table for wdg_gnb_batched_f32: many (feature matrix, train rows, validation rows) Gaussian-naive-Bayes problems in one call -
+    the GNB branch of classifier_based_performance_metric (utils/homophily_metrics.py:296-312), scikit-learn's arithmetic (csrc/gnb.hip)."""
+
+    MAX_CLASSES = 16
+
+    def __init__(self, problems, n_classes, want_pred=False):
+        """problems: list of (X [n, F] fp32 device, row-major, train int32 device [nt], val int32 device [nv], labels int32 device [n]);
+        the statistics are summed over the train rows IN THE ORDER GIVEN (the reference's boolean masks: ascending ids).
+        -> self.correct [n_problems] int32 after launch(); want_pred: self.pred[i] int32 [nv] too.
+        Raises for what scikit-learn raises for or the kernel does not hold: no train rows, no features, more than 16 classes."""
+        dev = require_gpu()
+        self.keep = problems
+        n = self.n_jobs = len(problems)
+        self.n_classes = int(n_classes)
+        if n and not 1 <= self.n_classes <= self.MAX_CLASSES:
+            raise ValueError(f"GnbBatch: {n_classes} classes, the kernel holds 1..{self.MAX_CLASSES}")
+        for x, tr, va, lab in problems:
+            if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1 or not x.is_cuda:
+                raise ValueError("GnbBatch: X must be a row-major fp32 device matrix")
+            if tr.dtype != torch.int32 or va.dtype != torch.int32 or lab.dtype != torch.int32:
+                raise ValueError("GnbBatch: int32 node ids and labels expected")
+            if tr.shape[0] < 1 or x.shape[1] < 1:
+                raise ValueError("GnbBatch: a problem needs at least one train row and one feature")
+            if lab.shape[0] != x.shape[0]:
+                raise ValueError("GnbBatch: one label per row of X")
+        col = lambda f: np.fromiter((f(p_) for p_ in problems), np.int64, n)  # noqa: E731
+        feats, n_val = col(lambda p_: p_[0].shape[1]), col(lambda p_: p_[2].shape[0])
+        self.max_feat, self.max_val = int(feats.max(initial=0)), int(n_val.max(initial=0))
+        self.correct = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        self.n_val = n_val
+        ws_each = np.array([int(lib.wdg_gnb_workspace_bytes(int(f), self.n_classes)) for f in feats], np.int64)
+        ws_off = np.concatenate([[0], np.cumsum(ws_each)]).astype(np.int64)
+        self.ws = torch.empty(max(int(ws_off[-1]), 256), dtype=torch.uint8, device=dev)
+        self.pred = None
+        tab = np.zeros(n, _GNB_JOB_DTYPE)
+        tab["X"], tab["ldx"] = col(lambda p_: p_[0].data_ptr()), col(lambda p_: _ld(p_[0]))
+        tab["train"], tab["val"], tab["labels"] = col(lambda p_: p_[1].data_ptr()), col(lambda p_: p_[2].data_ptr()), col(lambda p_: p_[3].data_ptr())
+        tab["ws"] = self.ws.data_ptr() + ws_off[:-1]
+        tab["correct"] = self.correct.data_ptr() + 4 * np.arange(n, dtype=np.int64)
+        if want_pred:
+            v_off = np.concatenate([[0], np.cumsum(n_val)]).astype(np.int64)
+            pool = torch.full((max(int(v_off[-1]), 1),), -1, dtype=torch.int32, device=dev)
+            self.pred = [pool[int(v_off[i]):int(v_off[i + 1])] for i in range(n)]
+            tab["pred"] = pool.data_ptr() + 4 * v_off[:-1]
+        tab["n_train"], tab["n_val"], tab["F"], tab["n_classes"] = col(lambda p_: p_[1].shape[0]), n_val, feats, self.n_classes
+        self.table = _h2d(tab.view(np.uint8), dev) if n else torch.empty(0, dtype=torch.uint8)
+
+    def launch(self):
+        check(lib.wdg_gnb_batched_f32(_ptr(self.table), self.n_jobs, self.max_feat, self.max_val, self.n_classes, stream_handle()),
+              "wdg_gnb_batched_f32")
+
+    def accuracy(self):
+        """[n_problems] float32 (host): hits / validation rows, as `torch.mean(pred.eq(labels[idx_val]).float())` gives them
+        (utils/homophily_metrics.py:311-312); NaN for a problem without validation rows"""
+        hits = self.correct[:self.n_jobs].cpu().numpy().astype(np.float32)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return hits / self.n_val.astype(np.float32)

@@ -9,7 +9,7 @@ This module is the one namespace callers use (`from wdg_amd import ops`); the co
   aggregate.py          spmm, SpmmBatch (the quad-row kernel's tape and its cost cut), spmm_plan
   stats.py              edge / label statistics, LAS, per-edge cosine, their job tables
   gemm.py               gemm, gemm_skinny, GemmBatch, Mlp2Batch
-  kernel_regression.py  GramBatch, PropagatedGram, RowRepBatch, EdgeGramBatch, KrSets, KrBatch
+  kernel_regression.py  GramBatch, PropagatedGram, RowRepBatch, EdgeGramBatch, KrSets, KrBatch, GnbBatch
 (module-level switches - aggregate.ABLATE_BITS, aggregate.NARROW_MIN_ENTRIES - are set on the module that owns them)."""
 from ._lib import check, lib, require_gpu, stream_handle  # noqa: F401
 from ._rt import (  # noqa: F401
@@ -32,5 +32,5 @@ from .gemm import (  # noqa: F401
     gemm, gemm_skinny, GemmBatch, Mlp2Batch,
 )
 from .kernel_regression import (  # noqa: F401
-    deflation_enabled, EdgeGramBatch, GramBatch, kr_split_sizes, KrBatch, KrSets, PropagatedGram, RowRepBatch, _KR_JOB_DTYPE,
+    deflation_enabled, EdgeGramBatch, GnbBatch, GramBatch, kr_split_sizes, KrBatch, KrSets, PropagatedGram, RowRepBatch, _KR_JOB_DTYPE,
 )

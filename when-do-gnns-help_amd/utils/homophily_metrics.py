@@ -316,6 +316,42 @@ def _kernel_regression_on_device(features, adj, labels, sample_max, base_classif
     return p, time.time() - t_time
 
 
+LAST_GNB_ACCURACIES = None  # [epoch, (graph-aware, features only)] of the last device GNB call: diagnostics / tests
+
+
+def _gnb_on_device(features, adj, labels, sample_max, epochs):
+    """the GNB branch of classifier_based_performance_metric (utils/homophily_metrics.py:296-312) on the GPU -> (p_value, seconds),
+    or None when the kernel does not hold the labels (more than 16 classes: the caller then runs scikit-learn on the host like the
+    reference).  The epochs' node sets are drawn first - same generator, same order as the reference -, then every epoch's two fits
+    and predictions (aggregated features, raw features) run in ONE call of wdg_gnb_batched_f32, whose statistics are scikit-learn's
+    bit for bit (csrc/gnb.hip; tests/test_gpu_gnb.py checks kernel and scikit-learn against each other)."""
+    from .util_funcs import kernel_regression_epoch_indices
+    global LAST_GNB_ACCURACIES
+    t_time = time.time()
+    g = _graph(adj)
+    dev = g.device
+    features = features.to(dev, torch.float32).contiguous()
+    labels = labels.to(dev).flatten()
+    lab32 = labels.to(torch.int32)
+    n_cls = int(labels.max().item()) + 1
+    if n_cls > ops.GnbBatch.MAX_CLASSES or int(labels.min().item()) < 0 or features.shape[1] < 1:
+        return None  # (before the node sets are drawn: the host path draws them itself, from the same generator state)
+    node_sets = kernel_regression_epoch_indices(labels, sample_max, epochs)  # (the generator is consumed as in the reference)
+    h_agg = ops.spmm(g, features)
+    problems = []
+    for tr, va in node_sets:
+        tr, va = tr.to(dev, torch.int32), va.to(dev, torch.int32)
+        problems += [(h_agg, tr, va, lab32), (features, tr, va, lab32)]
+    gb = ops.GnbBatch(problems, n_cls)
+    gb.launch()
+    acc = torch.from_numpy(gb.accuracy()).reshape(epochs, 2)
+    LAST_GNB_ACCURACIES = acc.clone()
+    G_results, X_results = acc[:, 0], acc[:, 1]
+    _, p = ttest_ind(X_results, G_results, axis=0, equal_var=False, nan_policy='propagate')
+    p = p / 2 if torch.mean((G_results > X_results).float()) <= 0.5 else 1 - p / 2
+    return p, time.time() - t_time
+
+
 def classifier_based_performance_metric(features, adj, labels, sample_max, base_classifier='kernel_reg1', epochs=100,
                                         solver=None):
     """Classifier-based performance metric -> (p_value, seconds).  reference: utils/homophily_metrics.py:260-349.
@@ -323,7 +359,9 @@ def classifier_based_performance_metric(features, adj, labels, sample_max, base_
     GPU: the aggregation A X (hoisted out of the epoch loop - it is loop invariant), the sampled
     Gram products and the arc-cosine map (hoisted too when nnodes <= sample_max: the sample is then every node).
     Host, exactly as in the reference: split sampling from torch's CPU generator, `np.linalg.pinv` (the reference
-    moves the kernels to the CPU for it, :286-290), sklearn GNB/SVM, scipy's Welch t-test.
+    moves the kernels to the CPU for it, :286-290), sklearn SVM, scipy's Welch t-test.
+    base_classifier 'gnb' (round 6): all epochs' Gaussian-naive-Bayes fits and predictions in one call of wdg_gnb_batched_f32
+    (_gnb_on_device; scikit-learn's statistics bit for bit); WDG_GNB_SOLVER=host / solver="host" runs sklearn like the reference.
 
     solver="device" (the default for the kernel-regression classifiers when a train block fits the solver: <= 320 rows;
     WDG_KR_SOLVER=host restores the reference's host path) keeps the metric on the GPU: the kernels of
@@ -341,6 +379,10 @@ def classifier_based_performance_metric(features, adj, labels, sample_max, base_
         if res is not None:
             return res
         solver = "host"  # (a train block larger than the solver holds)
+    if base_classifier == 'gnb' and solver == "device" and os.environ.get("WDG_GNB_SOLVER", "device") != "host":
+        res = _gnb_on_device(features, adj, labels, sample_max, epochs)
+        if res is not None:
+            return res
     from sklearn import svm
     from sklearn.naive_bayes import GaussianNB
 
