@@ -112,3 +112,54 @@ def test_document_binding_reproduces_the_reference_on_cora(tag):
         ys[fn] = y
     # both kernel families sum a row's entries in CSR order in fp32 (fused or separate multiply-add): rounding-level agreement
     np.testing.assert_allclose(ys["spmm"], ys["spmm_band"], rtol=2e-6, atol=1e-6 * scale)
+
+
+def test_document_gnb_job_mirror_matches_the_header(tmp_path):
+    ns = _binding_namespace()
+    mirror = ns["GnbJob"]
+    names = [f for f, _ in mirror._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wdg.h"', 'int main(void) {', 'printf("size %zu\\n", sizeof(wdg_gnb_job));']
+    lines += [f'printf("{f} %zu\\n", offsetof(wdg_gnb_job, {f}));' for f in names]
+    lines += ["return 0;", "}"]
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(got["size"]) == ctypes.sizeof(mirror)
+    for f in names:
+        assert int(got[f]) == getattr(mirror, f).offset, f
+    import wdg_amd._lib as L
+    assert [(f, t) for f, t in L.GnbJob._fields_] == [(f, t) for f, t in mirror._fields_]
+
+
+@pytest.mark.gpu
+def test_document_gnb_binding_reproduces_scikit_learn_on_texas():
+    """the document's gnb_accuracies() on the texas fixture (raw features and a device aggregation of them) against the reference's
+    own computation for the branch: GaussianNB().fit(...).predict(...) per epoch and matrix, mean hit rate"""
+    from sklearn.naive_bayes import GaussianNB
+    ns = _binding_namespace()
+    g0 = load("real_texas")
+    x = torch.from_numpy(dense_features(g0, "featl1_data")).cuda()
+    n = x.shape[0]
+    labels = torch.from_numpy(np.asarray(g0["labels"]).reshape(-1).astype(np.int64))
+    idx = torch.from_numpy(np.stack([g0["large_rw_row"], g0["large_rw_col"]]).astype(np.int64)) if "large_rw_row" in g0 else None
+    if idx is None:
+        rng0 = np.random.default_rng(0)
+        idx = torch.from_numpy(rng0.integers(0, n, (2, 4 * n)).astype(np.int64))
+        adj = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (n, n)).cuda()
+    else:
+        adj = torch.sparse_coo_tensor(idx, torch.from_numpy(g0["large_rw_val"]), (n, n)).cuda()
+    x_agg = ns["spmm"](adj, x)
+    rng = np.random.default_rng(4)
+    sets = []
+    for _ in range(5):
+        perm = rng.permutation(n)
+        sets.append((torch.from_numpy(np.sort(perm[:110])), torch.from_numpy(np.sort(perm[110:]))))
+    c = int(labels.max()) + 1
+    got = ns["gnb_accuracies"]([x_agg, x], sets, labels, c).numpy()
+    torch.cuda.synchronize()
+    lab = labels.numpy()
+    for e, (tr, va) in enumerate(sets):
+        for k, m in enumerate((x_agg.cpu().numpy(), x.cpu().numpy())):
+            want = np.float32(np.mean(GaussianNB().fit(m[tr.numpy()], lab[tr.numpy()]).predict(m[va.numpy()]) == lab[va.numpy()]))
+            assert got[e, k] == want, (e, k, got[e, k], want)
