@@ -297,4 +297,7 @@ def test_reference_pattern_restatement_reproduces_the_references_scalars(name):
     adj = rp.normalised_dense_adjacency(d["adj_row"], d["adj_col"], n)
     got = rp.six_scalars(adj, torch.eye(int(lab.max()) + 1)[torch.as_tensor(lab)])
     want = [float(d["m_" + k]) for k in ("edge_homo", "node_homo", "class_homo", "adj_homo", "label_info", "soft_las")]
-    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+    # (label informativeness - index 4 - is a difference of fp32 logarithm sums of ~0.005: torch's CPU reductions order their sums by the
+    # host's vector width and threads, one fp32 rounding of the sums - 2.4e-7 absolute - is 5e-5 relative there: seen on a Zen 5 host)
+    np.testing.assert_allclose(np.delete(got, 4), np.delete(want, 4), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(got[4], want[4], rtol=1e-6, atol=1e-6)
