@@ -120,6 +120,19 @@ _H2D_RING_BYTES = int(float(os.environ.get("WDG_H2D_RING_MB", "512")) * (1 << 20
 _H2D_THREADS = int(os.environ.get("WDG_H2D_THREADS", "8"))
 
 
+def _arena_take(nbytes):
+    """-> (arena, handle, uint8 slice) of the process's page-locked upload ring (created on first use, under the lock: two threads'
+    first uploads must not pin a ring each).  The caller fills the slice, queues its copy and calls arena.issued(handle) - or
+    arena.abandon(handle) if either failed."""
+    global _ARENA
+    with _ARENA_LOCK:  # (sweep.run_shards uploads from a helper thread as well: the ring's bookkeeping under a lock, the copies not)
+        if _ARENA is None:
+            _ARENA = _PinnedArena(_H2D_RING_BYTES)
+        arena = _ARENA
+        handle, _start, piece = arena.take(nbytes)
+    return arena, handle, piece
+
+
 def _h2d(host, dev=None):
     """A host array (job table, offsets, labels, a feature matrix) -> device tensor WITHOUT blocking the host on what the stream
     has queued: through the page-locked arena and a non-blocking copy.  (`tensor.to(dev)` from pageable memory returns only when
@@ -128,7 +141,6 @@ def _h2d(host, dev=None):
     round 4 sent everything above 8 MB down the blocking pageable path because ONE thread's memcpy of the wide bases' 30-MB
     feature matrices cost more than it saved - and then every such upload waited for the stream's queued regressions: 5 ms a
     piece in the profile of a rank's share of the whole sweep); only arrays above WDG_H2D_MAX_MB (64) take the plain copy."""
-    global _ARENA
     dev = dev or require_gpu()
     t = torch.from_numpy(host) if isinstance(host, np.ndarray) else host
     t = t.contiguous()
@@ -137,11 +149,7 @@ def _h2d(host, dev=None):
         return torch.empty(t.shape, dtype=t.dtype, device=dev)
     if nbytes > _H2D_MAX_BYTES:
         return t.to(dev)
-    with _ARENA_LOCK:  # (sweep.run_shards uploads from a helper thread as well: the ring's bookkeeping under a lock, the copies not)
-        if _ARENA is None:  # (created under the lock: two threads' first uploads must not pin a ring each)
-            _ARENA = _PinnedArena(_H2D_RING_BYTES)
-        arena = _ARENA
-        handle, _start, piece = arena.take(nbytes)
+    arena, handle, piece = _arena_take(nbytes)
     try:
         p = piece.view(t.dtype).view(t.shape)
         # (numpy's memcpy / the library's threads, not Tensor.copy_: torch parallelises a host copy of a few MB over every hardware

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import c_void_p, check, lib, require_gpu, stream_handle
 from ._rt import *  # noqa: F401,F403  (the flag values of include/wdg.h)
-from ._rt import _dev, _h2d, _ld, _ptr, _table
+from ._rt import _arena_take, _dev, _h2d, _H2D_MAX_BYTES, _ld, _ptr, _table
 
 
 def quad_disabled():
@@ -255,9 +255,6 @@ class CsrGraph:
         return CsrGraph(self.rowptr, self.col, val, self.n_rows, self.n_cols)  # SELL copy (holds values) not shared
 
 
-_PACK_STAGING = {}  # device index -> a ring of page-locked int32 staging tensors, grown on demand, reused shard after shard
-
-
 def _host_pack_coo(coos, lens, node_ptr_h, e_total, dev):
     """-> (src, dst) int32 device tensors holding the shard's edge lists as ids of the block-diagonal union, or None when the
     inputs are not plain contiguous host arrays of one integer width (the caller then takes the torch path).  Raises IndexError
@@ -273,30 +270,38 @@ def _host_pack_coo(coos, lens, node_ptr_h, e_total, dev):
     if kind not in (np.dtype(np.int64), np.dtype(np.int32)):
         return None
     G = len(coos)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ring = _PACK_STAGING.setdefault(key, {"next": 0, "bufs": [None] * 3})  # (three: pipelined shards keep two uploads in flight)
-    slot = ring["next"]
-    ring["next"] = (slot + 1) % len(ring["bufs"])
-    stage = ring["bufs"][slot]
-    if stage is None or stage.numel() < 2 * e_total:
-        stage = ring["bufs"][slot] = torch.empty(int(2 * e_total * 1.25) + 1024, dtype=torch.int32).pin_memory()
-    elif getattr(stage, "_busy", None) is not None:
-        stage._busy.synchronize()  # the copy that last read this buffer (three shards ago) has left it
     ptrs = ctypes.c_void_p * G
     sp, dp = ptrs(*[a.ctypes.data for a, _b in arrs]), ptrs(*[b.ctypes.data for _a, b in arrs])
     lens_a = np.asarray(lens, np.int64)
     nptr = np.ascontiguousarray(node_ptr_h, np.int32)
     bad = ctypes.c_int32(0)
-    host = stage.numpy()
     threads = int(os.environ.get("WDG_HOST_PACK_THREADS", "8"))
+    nbytes = 8 * e_total
+    # packed straight into a slice of the process's page-locked upload ring (round 6: the staging tensors this function used to pin
+    # for itself cost a hipHostMalloc of 20 MB each inside a pipeline's first pass); arrays beyond the ring's share: a pinned tensor of
+    # their own, as before
+    if 0 < nbytes <= _H2D_MAX_BYTES:
+        arena, handle, piece = _arena_take(nbytes)
+        try:
+            host = piece[:nbytes].view(torch.int32)
+            base = host.data_ptr()
+            check(lib.wdg_host_pack_coo_i32(sp, dp, lens_a.ctypes.data, nptr.ctypes.data, G, kind.itemsize, ctypes.c_void_p(base),
+                                            ctypes.c_void_p(base + 4 * e_total), ctypes.byref(bad), threads), "wdg_host_pack_coo_i32")
+            if bad.value:
+                raise IndexError("edge index out of range for its graph")
+            both = host.to(dev, non_blocking=True)
+        except BaseException:
+            arena.abandon(handle)
+            raise
+        arena.issued(handle)
+        return both[:e_total], both[e_total:]
+    stage = torch.empty(max(2 * e_total, 1), dtype=torch.int32).pin_memory()
+    host = stage.numpy()
     check(lib.wdg_host_pack_coo_i32(sp, dp, lens_a.ctypes.data, nptr.ctypes.data, G, kind.itemsize, host[:e_total].ctypes.data,
                                     host[e_total:2 * e_total].ctypes.data, ctypes.byref(bad), threads), "wdg_host_pack_coo_i32")
     if bad.value:
         raise IndexError("edge index out of range for its graph")
-    both = stage[:2 * e_total].to(dev, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    stage._busy = ev  # the next shard may not overwrite the staging buffer before this copy has left it
+    both = stage[:2 * e_total].to(dev)  # (blocking: the staging tensor dies with this call)
     return both[:e_total], both[e_total:]
 
 
