@@ -162,7 +162,7 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     for _ in range(5):
         batch.step()
     untuned_ms = spmm_launch_ms(ROOFLINE_LAUNCHES)
-    batch.tune()  # (replayed `steps` times: the feedback-balanced tape cut pays; ~90 untimed steps)
+    batch.tune()  # (replayed `steps` times: the feedback-balanced tape cut pays; ~250 untimed steps, 55 ms)
 
     def sync_all():
         torch.cuda.synchronize()

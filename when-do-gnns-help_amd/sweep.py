@@ -395,7 +395,7 @@ class SweepBatch:
         build: "batched" (default; WDG_SWEEP_BUILD) - all graphs of the shard through ops.GraphBatch: one COO -> CSR build of
         their block-diagonal union, the SELL-16 copies in five launches, ONE host read-back; "per_graph" - round 2's
         CsrGraph.from_coo + ensure_quad per graph (~20 launches and two host syncs each), kept for A/B runs and tests.
-        tune: balance the aggregation's tape cut by feedback (tune() below: ~90 extra steps) - worth it for a batch that is
+        tune: balance the aggregation's tape cut by feedback (tune() below: ~250 extra steps) - worth it for a batch that is
         replayed many times (training, the replay benchmark); a one-pass sweep takes the modelled cut.
         graph_batch: the shard's ops.GraphBatch (A + I of every job, quad=True) when the caller has queued or finished the build
         already (run_bases builds the NEXT shard's graphs on a stream of their own while this shard's bases run).
@@ -644,21 +644,25 @@ class SweepBatch:
         self._y_rm.view(j, n, g, 16).copy_(self.y_pool.permute(0, 2, 1, 3))
         self._y_at = self.spmm.n_launches
 
-    def tune(self, rounds=6, steps=5, confirm=24):
+    def tune(self, rounds=10, steps=5, confirm=24, finalists=3):
         """Balance the aggregation's eight segments (one per XCD) by what they really cost INSIDE the step.  The modelled cut
         leaves the XCDs 25 - 40 % apart (a segment that holds two phase groups stages a second slab while the other XCDs' stores
         fill the write path: 10 - 55 us, depending on when), and the launch ends with the slowest.  The kernel can record
         every workgroup's start and end on the device clock (wdg_spmm_quad_batched_clocked_f32); here the step is run a few
         times, each segment's share of the modelled cost is scaled by (mean span / its span) ^ 0.7, the tape is cut again,
-        and the cut with the shortest launch (HIP events around the launch, median over `steps` steps) is kept.
-        rounds x (2 + steps) + 2 x (1 + confirm) steps, once per batch; every cut computes the same bits (a row's sum order is
-        fixed by the SELL-16 copy)."""
+        and the cuts with the shortest launches (HIP events around the launch, median over `steps` steps) go to a confirmation: the
+        modelled cut and the `finalists` best balanced ones are stepped `confirm` times back to back each, the fastest stays (round 6:
+        ten rounds and three finalists instead of six and one - with one finalist picked from five-step medians the tuned launch of
+        one box varied between 90 and 99 us from run to run).
+        rounds x (2 + steps) + confirm + (1 + finalists) x (1 + confirm) steps, once per batch; every cut computes the same bits (a row's sum
+        order is fixed by the SELL-16 copy)."""
         sp = self.spmm
         if not sp.quad or sp.n_segments != 8 or sp.n_items <= sp.n_segments or os.environ.get("WDG_QUAD_TUNE", "1") == "0":  # noqa: E501
             return None
         clock = sp.new_clock()
         shares = np.ones(8)
         best = None
+        cands = []  # (median launch ms, shares | None, spans) of every round
         for rnd in range(rounds):
             sp._set_segments(0, None if rnd == 0 else shares)
             for _ in range(2):
@@ -673,30 +677,34 @@ class SweepBatch:
                 torch.cuda.synchronize()
                 spans += sp.segment_spans(clock) / steps
             t = sorted(a.elapsed_time(b) for a, b in ev)[steps // 2]
-            if best is None or t < best[0]:
-                best = (t, None if rnd == 0 else shares.copy(), spans.copy())
+            cands.append((t, None if rnd == 0 else shares.copy(), spans.copy()))
             shares = shares * (spans.mean() / spans) ** 0.7
             shares /= shares.sum() / 8
+        best = min(cands, key=lambda c: c[0])
         # Confirmation in the regime the batch will run in: the rounds above synchronise after every step (they read the clocks
-        # back), a replay does not.  The modelled cut and the best balanced one are stepped `confirm` times back to back each; the
-        # faster stays.  (It also leaves the chip in its steady state: behind the tuner's stop-and-go the first ~30 steps of a
+        # back), a replay does not.  The modelled cut and the best balanced ones are stepped `confirm` times back to back each; the
+        # fastest stays.  (It also leaves the chip in its steady state: behind the tuner's stop-and-go the first ~30 steps of a
         # burst run 5 - 8 % slower - scripts/dev/step_transient.py.)
-        if best[1] is not None and confirm > 0:
-            burst = {}
-            for name, cut in (("modelled", None), ("balanced", best[1])):
-                sp._set_segments(0, cut)
+        balanced = sorted((c for c in cands if c[1] is not None), key=lambda c: c[0])[:max(int(finalists), 1)]
+        if balanced and confirm > 0:
+            runs = [("modelled", cands[0])] + [(f"balanced{i}", c) for i, c in enumerate(balanced)]
+            for _ in range(confirm):  # (an untimed burst first: the candidates are compared in the steady state ...
+                self.step()
+            burst = {name: 0.0 for name, _c in runs}
+            half = max(confirm // 2, 1)
+            for name, c in runs + runs[::-1]:  # ... and there and back again: a drift of the chip's state over the bursts cancels)
+                sp._set_segments(0, c[1])
                 self.step()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                for _ in range(confirm):
+                for _ in range(half):
                     self.step()
                 b.record()
                 torch.cuda.synchronize()
-                burst[name] = a.elapsed_time(b) / confirm
-            if burst["modelled"] < burst["balanced"]:
-                sp._set_segments(0, None)
-                best = (best[0], None, best[2])
-            best = best + (burst,)
+                burst[name] += a.elapsed_time(b) / (2 * half)
+            name, c = min(runs, key=lambda r: burst[r[0]])
+            sp._set_segments(0, c[1])
+            best = (c[0], c[1], c[2], burst)
         else:
             sp._set_segments(0, best[1])
         sp.tuned = best
