@@ -215,7 +215,10 @@ def measure(args, k, seeds, steps, warmup, world, rank, dev):
     if in_region < ROOFLINE_LAUNCHES:
         for _ in range(3):
             batch.step()
-        spmm_ms += spmm_launch_ms(ROOFLINE_LAUNCHES - in_region)
+        extra = spmm_launch_ms(ROOFLINE_LAUNCHES - in_region)
+        if os.environ.get("WDG_BENCH_DUMP_LAUNCHES"):
+            print("launch us behind the region:", " ".join(f"{v * 1e3:.0f}" for v in extra), file=sys.stderr)
+        spmm_ms += extra
     spmm_ms.sort()
     return dict(batch=batch, mine=mine, h_levels=h_levels, elapsed=elapsed, enqueue_s=enqueue_s, total_edges=total_edges,
                 n_graphs=sum(g.shape[0] for g in gathered), spmm_ms=spmm_ms, spmm_in_region=in_region, untuned_ms=untuned_ms,

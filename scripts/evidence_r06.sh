@@ -9,7 +9,7 @@ C=$ROOT/gpurun_out/r06_collect
 mkdir -p "$C"
 LEAN="--cold 0 --configs 0 --train 0 --projection 0 --whole 0 --gnb 0"
 bash scripts/profile_r02.sh r06_c3 $LEAN > gpurun_out/ev6_c3.log 2>&1                        # bench line + kernel stats + PMC passes, C3 headline
-cp gpurun_out/r06_c3/bench.json "$C/r06_c3_bench.json"; cp gpurun_out/r06_c3/kernel_stats.csv "$C/r06_c3_bench_kernel_stats.csv"
+cp gpurun_out/r06_c3/bench.json "$C/r06_c3_bench.json"; cp gpurun_out/r06_c3/kernel_stats.csv "$C/r06_c3_bench_kernel_stats.csv"; cp gpurun_out/r06_c3/trace_vs_events.txt "$C/r06_c3_trace_vs_events.txt"
 cp gpurun_out/r06_c3/pmc/summary.txt "$C/r06_c3_pmc_summary.txt"; cp gpurun_out/r06_c3/pmc/summary.json "$C/r06_c3_pmc_summary.json"
 bash scripts/profile_pmc.sh r06_c2/pmc --k 2 --seeds 10 --secondary 0 --full-metrics 0 $LEAN > gpurun_out/ev6_c2.log 2>&1    # C2: traffic of the `secondary` line
 cp gpurun_out/r06_c2/pmc/summary.txt "$C/r06_c2_pmc_summary.txt"; cp gpurun_out/r06_c2/pmc/summary.json "$C/r06_c2_pmc_summary.json"
