@@ -126,7 +126,7 @@ def test_gnb_refusals(ops):
     assert WdgError is not None
 
 
-@pytest.mark.parametrize("name", ["texas", "cora"])
+@pytest.mark.parametrize("name", ["texas", "cora", "citeseer", "film"])
 def test_gnb_metric_on_device_equals_the_host_path(name, monkeypatch):
     """classifier_based_performance_metric(base_classifier='gnb'): the device call against the reference's own route - scikit-learn
     on the host over the same aggregated features and the same node sets (same torch CPU generator stream): the per-epoch accuracies
