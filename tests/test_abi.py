@@ -47,6 +47,22 @@ def test_host_side_queries_need_no_gpu():
     assert L.lib.wdg_spmm_plan(1, 200000, 200000, 7, 0, ctypes.byref(slab), ctypes.byref(thr)) == 1  # row gather
 
 
+def test_argument_refusals_need_no_gpu():
+    """entry points refuse malformed arguments before they touch the device: an error code and a message, no launch (round 6's
+    new entries: the band plan with a named hub threshold, the GNB batch, the row representatives)"""
+    import wdg_amd._lib as L
+    null = ctypes.c_void_p(0)
+    assert L.lib.wdg_csr_band_plan_hub(null, 4, -1, null, null, null, 0, null) != 0          # negative hub threshold
+    assert L.lib.wdg_csr_band_plan_hub(null, -1, 0, null, null, null, 0, null) != 0          # negative row count
+    assert L.lib.wdg_gnb_batched_f32(null, 3, 8, 8, 2, null) != 0                            # null job table
+    assert L.lib.wdg_gnb_batched_f32(null, 0, 8, 8, 2, null) == 0                            # nothing to do
+    assert L.lib.wdg_gnb_batched_f32(null, 1, 8, 8, 17, null) != 0                           # more classes than the kernel holds
+    assert L.lib.wdg_gnb_batched_f32(null, 70000, 8, 8, 2, null) != 0                        # more problems than one launch takes
+    assert L.lib.wdg_row_rep_batched(null, 2, 8, 7, null) != 0                               # unknown source kind
+    assert L.lib.wdg_gnb_workspace_bytes(1433, 7) >= 512 + 2 * 7 * 1433 * 4 and L.lib.wdg_gnb_workspace_bytes(1433, 7) % 256 == 0
+    assert L.lib.wdg_gnb_workspace_bytes(-1, 2) == 0
+
+
 def test_struct_layout_matches_header(tmp_path):
     """every job / item struct of include/wdg.h: size and field offsets as gcc lays them out == the ctypes mirrors"""
     import wdg_amd._lib as L
